@@ -1,0 +1,48 @@
+"""Build the gfx950 shared library in-tree (feartracker_amd/libfear_hip.so) with hipcc.
+
+The `.so` is git-ignored but travels to the GPU box with the gpurun snapshot; nothing is
+JIT-compiled at run time.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(PKG_DIR, "csrc", "fear_engine.hip")
+DEPS = [SRC, os.path.join(PKG_DIR, "csrc", "fear_kernels.h"),
+        os.path.join(os.path.dirname(PKG_DIR), "include", "fear_hip.h"),
+        os.path.join(os.path.dirname(PKG_DIR), "include", "fearw_format.h")]
+LIB = os.path.join(PKG_DIR, "libfear_hip.so")
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: cannot build libfear_hip.so")
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in DEPS)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/fear_engine.hip for gfx950 (cross-compiles without a GPU)."""
+    if not force and not is_stale():
+        return LIB
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
+           "-o", LIB + ".tmp", SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force=True, verbose=True))

@@ -1,0 +1,765 @@
+// fear_engine.hip — host side of the MI355X FEAR engine: model-file parsing, weight packing,
+// launch-plan construction, workspace management and the C ABI of include/fear_hip.h.
+//
+// Reference behaviour reproduced (BN folded, inference only):
+//   FEARNet.get_features  model_training/model/fear_net.py:63-66  (Encoder.stages[:4] + AdjustLayer)
+//   FEARNet.track         model_training/model/fear_net.py:90-96  (+ BoxTower.forward, model/blocks.py:174-194)
+//   FEARBoxCoder.decode   model_training/dataset/box_coder.py:75-107
+// The launch plan is derived from the block table of the .fearw file (include/fearw_format.h), so any
+// FBNet-style trunk (stem + inverted-residual blocks) with the FEAR head runs, not only FEAR-XS.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/fear_hip.h"
+#include "../../include/fearw_format.h"
+#include "fear_kernels.h"
+
+namespace {
+
+using namespace fear;
+
+// ---------------------------------------------------------------------------------------------
+float half_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1f;
+    uint32_t man = h & 0x3ffu;
+    uint32_t bits;
+    if (exp == 0) {
+        if (man == 0) {
+            bits = sign;
+        } else {  // subnormal: normalise
+            int e = -1;
+            do { ++e; man <<= 1; } while (!(man & 0x400u));
+            bits = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3ffu) << 13);
+        }
+    } else if (exp == 31) {
+        bits = sign | 0x7f800000u | (man << 13);
+    } else {
+        bits = sign | ((exp + 127 - 15) << 23) | (man << 13);
+    }
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+
+struct Conv {
+    int cout, cin_g, groups, k, stride, pad, relu, has_bias;
+    std::vector<float> w;  // OIHW fp32
+    std::vector<float> b;
+    // device copies
+    float* d_w = nullptr;  // pointwise: [N][K]; depthwise: [k*k][C]; stem: [27][16]
+    float* d_b = nullptr;
+    bool is_dw() const { return groups == cout && cin_g == 1 && groups > 1; }
+    bool is_pw() const { return groups == 1 && k == 1; }
+};
+
+enum OpType { OP_STEM, OP_PW, OP_DW, OP_CORR, OP_PW_SMALL };
+
+struct Op {
+    OpType type;
+    int conv = -1;
+    // tensors: buffer id (-1 = external), channel offset inside the row, row stride (floats)
+    int in_buf = -1, in_ld = 0, in_off = 0;
+    int out_buf = -1, out_ld = 0, out_off = 0;
+    int res_buf = -1, res_ld = 0;
+    int H = 0, W = 0;         // input spatial size
+    int Ho = 0, Wo = 0;       // output spatial size
+    int C = 0, N = 0;         // input / output channels
+    int relu = 0, act = 0;
+    int out_external = 0;     // 1: features NCHW, 2: bbox, 3: cls
+    int tmpl_cls = 0;         // OP_CORR: use the classification template
+    char name[64];
+    double flops = 0, bytes = 0;  // per crop: algorithmic FLOPs, compulsory bytes (in + out + weights excluded)
+    // profiling
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    double prof_ms = 0;
+    int64_t prof_n = 0;
+};
+
+struct Plan {
+    int hw = 0;
+    bool with_head = false;
+    std::vector<Op> ops;
+    int n_bufs = 0;
+    size_t buf_floats_per_crop = 0;  // every pool buffer has this many floats per crop
+};
+
+}  // namespace
+
+struct fear_handle {
+    int device = 0;
+    std::vector<Conv> convs;
+    std::vector<FearwBlock> blocks;
+    bool has_head = false;
+    int feat_channels = 0;
+    int max_batch = 64;
+    int profile = 0;
+    int last_hip_error = 0;
+    std::map<std::pair<int, int>, std::unique_ptr<Plan>> plans;
+    float* workspace = nullptr;
+    size_t workspace_floats = 0;
+    std::vector<float*> weight_allocs;
+};
+
+namespace {
+
+#define HIP_TRY(h, expr)                                   \
+    do {                                                   \
+        hipError_t _e = (expr);                            \
+        if (_e != hipSuccess) {                            \
+            (h)->last_hip_error = (int)_e;                 \
+            return FEAR_ERR_HIP;                           \
+        }                                                  \
+    } while (0)
+
+int upload(fear_handle* h, const std::vector<float>& host, float** dev) {
+    *dev = nullptr;
+    if (host.empty()) return FEAR_OK;
+    float* p = nullptr;
+    if (hipMalloc(&p, host.size() * sizeof(float)) != hipSuccess) return FEAR_ERR_ALLOC;
+    h->weight_allocs.push_back(p);
+    HIP_TRY(h, hipMemcpy(p, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    *dev = p;
+    return FEAR_OK;
+}
+
+int parse_model(fear_handle* h, const uint8_t* blob, size_t nbytes) {
+    if (nbytes < sizeof(FearwHeader)) return FEAR_ERR_FORMAT;
+    FearwHeader hd;
+    memcpy(&hd, blob, sizeof(hd));
+    if (memcmp(hd.magic, FEARW_MAGIC, 8) != 0 || hd.version != FEARW_VERSION || hd.payload_dtype != 0)
+        return FEAR_ERR_FORMAT;
+    const size_t tables = sizeof(FearwHeader) + (size_t)hd.n_convs * sizeof(FearwConv) +
+                          (size_t)hd.n_blocks * sizeof(FearwBlock);
+    if (nbytes < tables + hd.payload_bytes) return FEAR_ERR_FORMAT;
+    const uint8_t* payload = blob + tables;
+    const FearwConv* ct = reinterpret_cast<const FearwConv*>(blob + sizeof(FearwHeader));
+    const FearwBlock* bt = reinterpret_cast<const FearwBlock*>(blob + sizeof(FearwHeader) +
+                                                               (size_t)hd.n_convs * sizeof(FearwConv));
+    h->convs.resize(hd.n_convs);
+    for (uint32_t i = 0; i < hd.n_convs; ++i) {
+        FearwConv fc;
+        memcpy(&fc, ct + i, sizeof(fc));
+        Conv& c = h->convs[i];
+        c.cout = fc.cout; c.cin_g = fc.cin_per_group; c.groups = fc.groups; c.k = fc.k;
+        c.stride = fc.stride; c.pad = fc.pad; c.relu = fc.relu; c.has_bias = fc.has_bias;
+        const size_t nw = (size_t)c.cout * c.cin_g * c.k * c.k;
+        if (fc.w_off + nw * 2 > hd.payload_bytes) return FEAR_ERR_FORMAT;
+        if (c.pad != c.k / 2 || (c.stride != 1 && c.stride != 2)) return FEAR_ERR_FORMAT;
+        c.w.resize(nw);
+        const uint16_t* src = reinterpret_cast<const uint16_t*>(payload + fc.w_off);
+        for (size_t j = 0; j < nw; ++j) c.w[j] = half_to_float(src[j]);
+        if (c.has_bias) {
+            if (fc.b_off + (size_t)c.cout * 2 > hd.payload_bytes) return FEAR_ERR_FORMAT;
+            c.b.resize(c.cout);
+            const uint16_t* bs = reinterpret_cast<const uint16_t*>(payload + fc.b_off);
+            for (int j = 0; j < c.cout; ++j) c.b[j] = half_to_float(bs[j]);
+        }
+    }
+    h->blocks.resize(hd.n_blocks);
+    for (uint32_t i = 0; i < hd.n_blocks; ++i) {
+        memcpy(&h->blocks[i], bt + i, sizeof(FearwBlock));
+        for (int j = 0; j < 3; ++j)
+            if (h->blocks[i].conv[j] >= (int)hd.n_convs) return FEAR_ERR_FORMAT;
+        if (h->blocks[i].kind == FEARW_SEP) h->has_head = true;
+        if (h->blocks[i].kind == FEARW_NECK) h->feat_channels = h->convs[h->blocks[i].conv[0]].cout;
+    }
+    if (h->blocks.empty() || h->blocks[0].kind != FEARW_STEM || h->feat_channels == 0) return FEAR_ERR_FORMAT;
+    return FEAR_OK;
+}
+
+// Re-lay-out and upload weights: pointwise [N][K] as is; depthwise -> [k*k][C]; stem -> [27][16].
+int pack_weights(fear_handle* h) {
+    for (Conv& c : h->convs) {
+        std::vector<float> packed;
+        if (c.is_pw()) {
+            if (c.cin_g % 4 != 0) return FEAR_ERR_FORMAT;
+            packed = c.w;
+        } else if (c.is_dw()) {
+            if (c.cout % 4 != 0 || (c.k != 3 && c.k != 5)) return FEAR_ERR_FORMAT;
+            const int kk = c.k * c.k;
+            packed.resize((size_t)kk * c.cout);
+            for (int ch = 0; ch < c.cout; ++ch)
+                for (int t = 0; t < kk; ++t) packed[(size_t)t * c.cout + ch] = c.w[(size_t)ch * kk + t];
+        } else {  // stem
+            if (c.cout != 16 || c.cin_g != 3 || c.k != 3 || c.stride != 2 || !c.has_bias) return FEAR_ERR_FORMAT;
+            packed.resize(27 * 16);
+            for (int o = 0; o < 16; ++o)
+                for (int t = 0; t < 27; ++t) packed[t * 16 + o] = c.w[o * 27 + t];
+        }
+        int st = upload(h, packed, &c.d_w);
+        if (st != FEAR_OK) return st;
+        st = upload(h, c.b, &c.d_b);
+        if (st != FEAR_OK) return st;
+    }
+    return FEAR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Plan construction.  Activation buffers come from a small pool of equally sized slabs
+// (per-crop size = the largest intermediate tensor) handed out by liveness, so consecutive layers
+// keep re-using the same few address ranges (friendly to the 256 MiB Infinity Cache).
+struct Pool {
+    std::vector<int> free_ids;
+    int count = 0;
+    int acquire() {
+        if (!free_ids.empty()) { int id = free_ids.back(); free_ids.pop_back(); return id; }
+        return count++;
+    }
+    void release(int id) { if (id >= 0) free_ids.push_back(id); }
+};
+
+struct T {  // tensor view inside the plan
+    int buf = -1, ld = 0, off = 0, C = 0, H = 0, W = 0;
+};
+
+void set_name(Op& op, const char* fmt, int a, int b, int c) { snprintf(op.name, sizeof(op.name), fmt, a, b, c); }
+
+int build_plan(fear_handle* h, int hw, bool with_head, Plan** out) {
+    auto key = std::make_pair(hw, with_head ? 1 : 0);
+    auto it = h->plans.find(key);
+    if (it != h->plans.end()) { *out = it->second.get(); return FEAR_OK; }
+    if (hw < 32 || hw % 32 != 0 || hw > 1024) return FEAR_ERR_SHAPE;
+    if (with_head && !h->has_head) return FEAR_ERR_NOHEAD;
+    std::unique_ptr<Plan> plan(new Plan);
+    plan->hw = hw;
+    plan->with_head = with_head;
+    Pool pool;
+    size_t max_elems = 0;
+    auto track = [&](const T& t) {
+        size_t e = (size_t)t.H * t.W * t.ld;
+        if (e > max_elems) max_elems = e;
+    };
+    std::vector<Op>& ops = plan->ops;
+
+    auto add_pw = [&](int conv, const T& in, T& outT, const T* res, int relu, int out_ld, int out_off, int out_buf) {
+        const Conv& c = h->convs[conv];
+        Op op{};
+        op.type = OP_PW; op.conv = conv;
+        op.in_buf = in.buf; op.in_ld = in.ld; op.in_off = in.off;
+        op.H = in.H; op.W = in.W; op.Ho = in.H; op.Wo = in.W; op.C = c.cin_g; op.N = c.cout;
+        op.relu = relu;
+        outT.buf = out_buf >= 0 ? out_buf : pool.acquire();
+        outT.ld = out_ld > 0 ? out_ld : c.cout; outT.off = out_off; outT.C = c.cout; outT.H = in.H; outT.W = in.W;
+        op.out_buf = outT.buf; op.out_ld = outT.ld; op.out_off = outT.off;
+        if (res) { op.res_buf = res->buf; op.res_ld = res->ld; }
+        set_name(op, "pw_%dx%d_hw%d", c.cin_g, c.cout, in.H);
+        const double px = (double)in.H * in.W;
+        op.flops = 2.0 * px * c.cin_g * c.cout;
+        op.bytes = 4.0 * px * (c.cin_g + c.cout + (res ? c.cout : 0));
+        ops.push_back(op);
+        track(outT);
+    };
+    auto add_dw = [&](int conv, const T& in, T& outT, int relu) {
+        const Conv& c = h->convs[conv];
+        Op op{};
+        op.type = OP_DW; op.conv = conv;
+        op.in_buf = in.buf; op.in_ld = in.ld; op.in_off = in.off;
+        op.H = in.H; op.W = in.W; op.Ho = in.H / c.stride; op.Wo = in.W / c.stride; op.C = c.cout; op.N = c.cout;
+        op.relu = relu;
+        outT.buf = pool.acquire(); outT.ld = c.cout; outT.off = 0; outT.C = c.cout; outT.H = op.Ho; outT.W = op.Wo;
+        op.out_buf = outT.buf; op.out_ld = outT.ld; op.out_off = 0;
+        set_name(op, "dw%d_c%d_hw%d", c.k * 10 + c.stride, c.cout, in.H);
+        op.flops = 2.0 * op.Ho * op.Wo * c.cout * c.k * c.k;
+        op.bytes = 4.0 * c.cout * ((double)in.H * in.W + (double)op.Ho * op.Wo);
+        ops.push_back(op);
+        track(outT);
+    };
+
+    T cur;
+    size_t bi = 0;
+    // ---- stem
+    {
+        const FearwBlock& b = h->blocks[0];
+        const Conv& c = h->convs[b.conv[0]];
+        Op op{};
+        op.type = OP_STEM; op.conv = b.conv[0];
+        op.H = hw; op.W = hw; op.Ho = hw / 2; op.Wo = hw / 2; op.C = 3; op.N = c.cout; op.relu = 1;
+        cur.buf = pool.acquire(); cur.ld = c.cout; cur.off = 0; cur.C = c.cout; cur.H = hw / 2; cur.W = hw / 2;
+        op.out_buf = cur.buf; op.out_ld = cur.ld;
+        set_name(op, "stem_3x%d_hw%d%.0d", c.cout, hw, 0);
+        op.flops = 2.0 * op.Ho * op.Wo * 27 * c.cout;
+        op.bytes = 4.0 * (3.0 * hw * hw + (double)op.Ho * op.Wo * c.cout);
+        ops.push_back(op);
+        track(cur);
+        bi = 1;
+    }
+    // ---- trunk + neck
+    for (; bi < h->blocks.size(); ++bi) {
+        const FearwBlock& b = h->blocks[bi];
+        if (b.kind == FEARW_IR) {
+            T x = cur, e = cur, d, o;
+            if (b.conv[0] >= 0) {
+                add_pw(b.conv[0], x, e, nullptr, 1, 0, 0, -1);
+            }
+            add_dw(b.conv[1], e, d, 1);
+            if (b.conv[0] >= 0) pool.release(e.buf);
+            add_pw(b.conv[2], d, o, b.residual ? &x : nullptr, 0, 0, 0, -1);
+            pool.release(d.buf);
+            pool.release(x.buf);
+            cur = o;
+        } else if (b.kind == FEARW_NECK) {
+            T o;
+            if (!with_head) {
+                // write the features straight to the caller's NCHW tensor
+                const Conv& c = h->convs[b.conv[0]];
+                Op op{};
+                op.type = OP_PW; op.conv = b.conv[0];
+                op.in_buf = cur.buf; op.in_ld = cur.ld; op.in_off = cur.off;
+                op.H = cur.H; op.W = cur.W; op.Ho = cur.H; op.Wo = cur.W; op.C = c.cin_g; op.N = c.cout;
+                op.out_external = 1;
+                set_name(op, "neck_%dx%d_hw%d", c.cin_g, c.cout, cur.H);
+                op.flops = 2.0 * cur.H * cur.W * c.cin_g * c.cout;
+                op.bytes = 4.0 * cur.H * cur.W * (c.cin_g + c.cout);
+                ops.push_back(op);
+                pool.release(cur.buf);
+                cur = T{};
+            } else {
+                add_pw(b.conv[0], cur, o, nullptr, 0, 0, 0, -1);
+                snprintf(ops.back().name, sizeof(ops.back().name), "neck_%dx%d_hw%d", ops.back().C, ops.back().N, cur.H);
+                pool.release(cur.buf);
+                cur = o;
+            }
+            ++bi;
+            break;
+        } else {
+            return FEAR_ERR_FORMAT;
+        }
+    }
+    // ---- head (BoxTower.forward, model/blocks.py:174-194)
+    if (with_head) {
+        const FearwBlock* role[9] = {nullptr};
+        std::vector<const FearwBlock*> bbox_tower, cls_tower;
+        for (; bi < h->blocks.size(); ++bi) {
+            const FearwBlock& b = h->blocks[bi];
+            if (b.kind != FEARW_SEP || b.role < 1 || b.role > 8) return FEAR_ERR_FORMAT;
+            if (b.role == FEARW_BBOX_TOWER) bbox_tower.push_back(&b);
+            else if (b.role == FEARW_CLS_TOWER) cls_tower.push_back(&b);
+            else role[b.role] = &b;
+        }
+        for (int r : {FEARW_CLS_ENCODE, FEARW_REG_ENCODE, FEARW_CLS_CORR, FEARW_REG_CORR, FEARW_BBOX_PRED, FEARW_CLS_PRED})
+            if (!role[r]) return FEAR_ERR_FORMAT;
+        const T feat = cur;
+        const int S = feat.H;               // 16 for a 256 search crop
+        const int tz = 64;                  // template positions: (128/16)^2, matches fear_track's tmpl shape
+        // one branch: encode -> correlation/concat -> corr sep -> towers -> pred
+        auto branch = [&](const FearwBlock* enc, const FearwBlock* corr, const std::vector<const FearwBlock*>& tower,
+                          const FearwBlock* pred, bool is_cls) -> int {
+            const Conv& enc_pw = h->convs[enc->conv[1]];
+            const Conv& corr_dw = h->convs[corr->conv[0]];
+            if (corr_dw.cout != enc_pw.cout + tz) return FEAR_ERR_FORMAT;
+            T d, cat;
+            add_dw(enc->conv[0], feat, d, 0);
+            // encode pointwise writes channels [0, C) of the concat buffer; correlation fills [C, C+64)
+            add_pw(enc->conv[1], d, cat, nullptr, 1, corr_dw.cout, 0, -1);
+            pool.release(d.buf);
+            {
+                Op op{};
+                op.type = OP_CORR;
+                op.in_buf = cat.buf; op.in_ld = cat.ld; op.in_off = 0;
+                op.out_buf = cat.buf; op.out_ld = cat.ld; op.out_off = enc_pw.cout;
+                op.H = S; op.W = S; op.Ho = S; op.Wo = S; op.C = enc_pw.cout; op.N = tz;
+                op.tmpl_cls = is_cls ? 1 : 0;
+                set_name(op, is_cls ? "corr_cls_%dx%d_hw%d" : "corr_reg_%dx%d_hw%d", op.C, tz, S);
+                op.flops = 2.0 * S * S * op.C * tz;
+                op.bytes = 4.0 * (S * S * (op.C + tz) + (double)op.C * tz);
+                ops.push_back(op);
+            }
+            T catv = cat;
+            catv.C = corr_dw.cout;
+            T x;
+            add_dw(corr->conv[0], catv, d, 0);
+            pool.release(cat.buf);
+            add_pw(corr->conv[1], d, x, nullptr, 1, 0, 0, -1);
+            pool.release(d.buf);
+            for (const FearwBlock* tb : tower) {
+                T y;
+                add_dw(tb->conv[0], x, d, 0);
+                pool.release(x.buf);
+                add_pw(tb->conv[1], d, y, nullptr, 1, 0, 0, -1);
+                pool.release(d.buf);
+                x = y;
+            }
+            add_dw(pred->conv[0], x, d, 0);
+            pool.release(x.buf);
+            {
+                const Conv& c = h->convs[pred->conv[1]];
+                if (c.cout != (is_cls ? 1 : 4)) return FEAR_ERR_FORMAT;
+                Op op{};
+                op.type = OP_PW_SMALL; op.conv = pred->conv[1];
+                op.in_buf = d.buf; op.in_ld = d.ld;
+                op.H = S; op.W = S; op.Ho = S; op.Wo = S; op.C = c.cin_g; op.N = c.cout;
+                op.act = pred->act;
+                op.out_external = is_cls ? 3 : 2;
+                set_name(op, is_cls ? "cls_pred_%dx%d_hw%d" : "bbox_pred_%dx%d_hw%d", c.cin_g, c.cout, S);
+                op.flops = 2.0 * S * S * c.cin_g * c.cout;
+                op.bytes = 4.0 * S * S * (c.cin_g + c.cout);
+                ops.push_back(op);
+            }
+            pool.release(d.buf);
+            return FEAR_OK;
+        };
+        int st = branch(role[FEARW_CLS_ENCODE], role[FEARW_CLS_CORR], cls_tower, role[FEARW_CLS_PRED], true);
+        if (st != FEAR_OK) return st;
+        st = branch(role[FEARW_REG_ENCODE], role[FEARW_REG_CORR], bbox_tower, role[FEARW_BBOX_PRED], false);
+        if (st != FEAR_OK) return st;
+        pool.release(feat.buf);
+    }
+    plan->n_bufs = pool.count;
+    plan->buf_floats_per_crop = (max_elems + 63) & ~(size_t)63;
+    *out = plan.get();
+    h->plans[key] = std::move(plan);
+    return FEAR_OK;
+}
+
+int ensure_workspace(fear_handle* h, const Plan& p) {
+    const size_t need = (size_t)p.n_bufs * p.buf_floats_per_crop * h->max_batch;
+    if (need <= h->workspace_floats) return FEAR_OK;
+    if (h->workspace) {
+        HIP_TRY(h, hipDeviceSynchronize());
+        HIP_TRY(h, hipFree(h->workspace));
+        h->workspace = nullptr;
+        h->workspace_floats = 0;
+    }
+    if (hipMalloc(&h->workspace, need * sizeof(float)) != hipSuccess) return FEAR_ERR_ALLOC;
+    h->workspace_floats = need;
+    return FEAR_OK;
+}
+
+template <int MT, bool WKN>
+void launch_pw_nt(int nt, dim3 grid, hipStream_t s, const PwArgs& a) {
+    switch (nt) {
+        case 1: hipLaunchKernelGGL((pw_mfma_kernel<MT, 1, WKN>), grid, dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((pw_mfma_kernel<MT, 2, WKN>), grid, dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL((pw_mfma_kernel<MT, 3, WKN>), grid, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((pw_mfma_kernel<MT, 4, WKN>), grid, dim3(256), 0, s, a); break;
+        case 6: hipLaunchKernelGGL((pw_mfma_kernel<MT, 6, WKN>), grid, dim3(256), 0, s, a); break;
+        case 7: hipLaunchKernelGGL((pw_mfma_kernel<MT, 7, WKN>), grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((pw_mfma_kernel<MT, 8, WKN>), grid, dim3(256), 0, s, a); break;
+    }
+}
+
+// channel tiles per pass: the largest of {8,7,6,4,3,2,1} that divides the tile count
+int pick_nt(int n_tiles) {
+    for (int nt : {8, 7, 6, 4, 3, 2, 1})
+        if (n_tiles % nt == 0) return nt;
+    return 1;
+}
+
+template <int KS, int S>
+void launch_dw(dim3 grid, hipStream_t s, const DwArgs& a) {
+    hipLaunchKernelGGL((dw_conv_kernel<KS, S, 4>), grid, dim3(256), 0, s, a);
+}
+
+struct Ext {
+    const float* img;      // NCHW input
+    const float* tmpl;     // template features
+    const float* tmpl_cls;
+    float* feat_out;
+    float* bbox_out;
+    float* cls_out;
+};
+
+int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s) {
+    const size_t slab = p.buf_floats_per_crop * h->max_batch;
+    auto buf = [&](int id) -> float* { return h->workspace + (size_t)id * slab; };
+    for (Op& op : p.ops) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (h->profile) {
+            HIP_TRY(h, hipEventCreate(&e0));
+            HIP_TRY(h, hipEventCreate(&e1));
+            HIP_TRY(h, hipEventRecord(e0, s));
+        }
+        const Conv* c = op.conv >= 0 ? &h->convs[op.conv] : nullptr;
+        switch (op.type) {
+            case OP_STEM: {
+                StemArgs a{ext.img, c->d_w, c->d_b, buf(op.out_buf), n, op.H, op.W, op.Ho, op.Wo};
+                const long total = (long)n * op.Ho * op.Wo;
+                hipLaunchKernelGGL(stem_conv_kernel, dim3((total + 255) / 256), dim3(256), 0, s, a);
+                break;
+            }
+            case OP_PW: {
+                PwArgs a{};
+                a.X = buf(op.in_buf) + op.in_off; a.ldx = op.in_ld;
+                a.W = c->d_w; a.bias = c->d_b;
+                a.R = op.res_buf >= 0 ? buf(op.res_buf) : nullptr; a.ldr = op.res_ld;
+                a.M = n * op.H * op.W; a.K = op.C; a.N = op.N; a.relu = op.relu;
+                if (op.out_external == 1) { a.Y = ext.feat_out; a.ldy = op.N; a.nchw_hw = op.H * op.W; }
+                else { a.Y = buf(op.out_buf) + op.out_off; a.ldy = op.out_ld; a.nchw_hw = 0; }
+                const int nt = pick_nt((op.N + 15) / 16);
+                const int rows_per_block = 4 * 2 * 16;
+                dim3 grid((a.M + rows_per_block - 1) / rows_per_block);
+                launch_pw_nt<2, false>(nt, grid, s, a);
+                break;
+            }
+            case OP_CORR: {
+                PwArgs a{};
+                a.X = buf(op.in_buf) + op.in_off; a.ldx = op.in_ld;
+                a.W = (op.tmpl_cls && ext.tmpl_cls) ? ext.tmpl_cls : ext.tmpl;
+                a.bias = nullptr; a.R = nullptr;
+                a.Y = buf(op.out_buf) + op.out_off; a.ldy = op.out_ld;
+                a.M = n * op.H * op.W; a.K = op.C; a.N = op.N; a.relu = 0; a.nchw_hw = 0;
+                a.rows_per_crop = op.H * op.W; a.w_crop_stride = (long)op.C * op.N;
+                const int rows_per_block = 4 * 2 * 16;
+                dim3 grid((a.M + rows_per_block - 1) / rows_per_block);
+                launch_pw_nt<2, true>(pick_nt(op.N / 16), grid, s, a);
+                break;
+            }
+            case OP_DW: {
+                DwArgs a{};
+                a.X = buf(op.in_buf) + op.in_off; a.ldx = op.in_ld;
+                a.Wt = c->d_w; a.bias = c->d_b;
+                a.Y = buf(op.out_buf); a.ldy = op.out_ld;
+                a.B = n; a.H = op.H; a.W = op.W; a.C = op.C; a.Ho = op.Ho; a.Wo = op.Wo; a.relu = op.relu;
+                const long strips = (op.Ho + 3) / 4;
+                const long total = (long)n * strips * op.Wo * (op.C / 4);
+                dim3 grid((total + 255) / 256);
+                if (c->k == 3 && c->stride == 1) launch_dw<3, 1>(grid, s, a);
+                else if (c->k == 3 && c->stride == 2) launch_dw<3, 2>(grid, s, a);
+                else if (c->k == 5 && c->stride == 1) launch_dw<5, 1>(grid, s, a);
+                else launch_dw<5, 2>(grid, s, a);
+                break;
+            }
+            case OP_PW_SMALL: {
+                PwSmallArgs a{};
+                a.X = buf(op.in_buf); a.ldx = op.in_ld; a.W = c->d_w; a.bias = c->d_b;
+                a.Y = op.out_external == 3 ? ext.cls_out : ext.bbox_out;
+                a.M = n * op.H * op.W; a.K = op.C; a.N = op.N; a.hw = op.H * op.W; a.act = op.act;
+                dim3 grid(((long)a.M * 16 + 255) / 256);
+                if (op.N == 1) hipLaunchKernelGGL((pw_small_kernel<1>), grid, dim3(256), 0, s, a);
+                else hipLaunchKernelGGL((pw_small_kernel<4>), grid, dim3(256), 0, s, a);
+                break;
+            }
+        }
+        if (h->profile) {
+            HIP_TRY(h, hipEventRecord(e1, s));
+            op.events.emplace_back(e0, e1);
+        }
+    }
+    HIP_TRY(h, hipGetLastError());
+    return FEAR_OK;
+}
+
+int drain_events(fear_handle* h) {
+    for (auto& kv : h->plans)
+        for (Op& op : kv.second->ops) {
+            for (auto& ev : op.events) {
+                HIP_TRY(h, hipEventSynchronize(ev.second));
+                float ms = 0.f;
+                HIP_TRY(h, hipEventElapsedTime(&ms, ev.first, ev.second));
+                op.prof_ms += ms;
+                op.prof_n += 1;
+                hipEventDestroy(ev.first);
+                hipEventDestroy(ev.second);
+            }
+            op.events.clear();
+        }
+    return FEAR_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char* fear_version(void) { return "feartracker_amd 0.1 (gfx950, fp32 MFMA)"; }
+
+const char* fear_strerror(int status) {
+    switch (status) {
+        case FEAR_OK: return "ok";
+        case FEAR_ERR_NULL: return "null handle or pointer";
+        case FEAR_ERR_SHAPE: return "unsupported shape or option value";
+        case FEAR_ERR_FORMAT: return "malformed or unsupported .fearw model";
+        case FEAR_ERR_HIP: return "HIP runtime error";
+        case FEAR_ERR_ALLOC: return "allocation failed";
+        case FEAR_ERR_NOHEAD: return "model has no correlation head";
+        default: return "unknown status";
+    }
+}
+
+int fear_create(const void* fearw_blob, size_t nbytes, int device, fear_handle** out) {
+    if (!fearw_blob || !out) return FEAR_ERR_NULL;
+    *out = nullptr;
+    std::unique_ptr<fear_handle> h(new (std::nothrow) fear_handle);
+    if (!h) return FEAR_ERR_ALLOC;
+    h->device = device;
+    int st = parse_model(h.get(), static_cast<const uint8_t*>(fearw_blob), nbytes);
+    if (st != FEAR_OK) return st;
+    if (hipSetDevice(device) != hipSuccess) return FEAR_ERR_HIP;
+    st = pack_weights(h.get());
+    if (st != FEAR_OK) {
+        for (float* p : h->weight_allocs) hipFree(p);
+        return st;
+    }
+    *out = h.release();
+    return FEAR_OK;
+}
+
+int fear_destroy(fear_handle* h) {
+    if (!h) return FEAR_ERR_NULL;
+    hipSetDevice(h->device);
+    hipDeviceSynchronize();
+    drain_events(h);
+    for (float* p : h->weight_allocs) hipFree(p);
+    if (h->workspace) hipFree(h->workspace);
+    delete h;
+    return FEAR_OK;
+}
+
+int fear_set_option(fear_handle* h, int option, int64_t value) {
+    if (!h) return FEAR_ERR_NULL;
+    switch (option) {
+        case FEAR_OPT_MAX_BATCH:
+            if (value < 1 || value > 65536) return FEAR_ERR_SHAPE;
+            h->max_batch = (int)value;
+            return FEAR_OK;
+        case FEAR_OPT_PROFILE:
+            h->profile = value ? 1 : 0;
+            return FEAR_OK;
+        default: return FEAR_ERR_SHAPE;
+    }
+}
+
+int64_t fear_get_option(fear_handle* h, int option) {
+    if (!h) return FEAR_ERR_NULL;
+    switch (option) {
+        case FEAR_OPT_MAX_BATCH: return h->max_batch;
+        case FEAR_OPT_PROFILE: return h->profile;
+        default: return FEAR_ERR_SHAPE;
+    }
+}
+
+int fear_features(fear_handle* h, const float* img, int n, int hw, float* out, void* stream) {
+    if (!h || !img || !out) return FEAR_ERR_NULL;
+    if (n < 0) return FEAR_ERR_SHAPE;
+    if (n == 0) return FEAR_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    Plan* p = nullptr;
+    int st = build_plan(h, hw, false, &p);
+    if (st != FEAR_OK) return st;
+    st = ensure_workspace(h, *p);
+    if (st != FEAR_OK) return st;
+    const int fhw = (hw / 16) * (hw / 16);
+    for (int b0 = 0; b0 < n; b0 += h->max_batch) {
+        const int nb = n - b0 < h->max_batch ? n - b0 : h->max_batch;
+        Ext ext{};
+        ext.img = img + (size_t)b0 * 3 * hw * hw;
+        ext.feat_out = out + (size_t)b0 * h->feat_channels * fhw;
+        st = run_plan(h, *p, nb, ext, static_cast<hipStream_t>(stream));
+        if (st != FEAR_OK) return st;
+    }
+    return FEAR_OK;
+}
+
+int fear_track(fear_handle* h, const float* search, const float* tmpl, const float* tmpl_cls, int n, float* bbox,
+               float* cls, void* stream) {
+    if (!h || !search || !tmpl || !bbox || !cls) return FEAR_ERR_NULL;
+    if (n < 0) return FEAR_ERR_SHAPE;
+    if (n == 0) return FEAR_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int hw = 256;
+    Plan* p = nullptr;
+    int st = build_plan(h, hw, true, &p);
+    if (st != FEAR_OK) return st;
+    st = ensure_workspace(h, *p);
+    if (st != FEAR_OK) return st;
+    const size_t tz = (size_t)h->feat_channels * 64;
+    for (int b0 = 0; b0 < n; b0 += h->max_batch) {
+        const int nb = n - b0 < h->max_batch ? n - b0 : h->max_batch;
+        Ext ext{};
+        ext.img = search + (size_t)b0 * 3 * hw * hw;
+        ext.tmpl = tmpl + (size_t)b0 * tz;
+        ext.tmpl_cls = tmpl_cls ? tmpl_cls + (size_t)b0 * tz : nullptr;
+        ext.bbox_out = bbox + (size_t)b0 * 4 * 256;
+        ext.cls_out = cls + (size_t)b0 * 256;
+        st = run_plan(h, *p, nb, ext, static_cast<hipStream_t>(stream));
+        if (st != FEAR_OK) return st;
+    }
+    return FEAR_OK;
+}
+
+int fear_decode(fear_handle* h, const float* cls, const float* bbox, int n, int score_size, int total_stride,
+                int instance_size, int32_t* rc, double* xywh, float* score, void* stream) {
+    if (!h || !cls || !bbox || !rc || !xywh || !score) return FEAR_ERR_NULL;
+    if (n < 0 || score_size < 1 || score_size > 64) return FEAR_ERR_SHAPE;
+    if (n == 0) return FEAR_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    DecodeArgs a{cls, bbox, rc, xywh, score, n, score_size, total_stride, instance_size};
+    hipLaunchKernelGGL(decode_kernel, dim3(n), dim3(64), 0, static_cast<hipStream_t>(stream), a);
+    HIP_TRY(h, hipGetLastError());
+    return FEAR_OK;
+}
+
+int fear_normalize_u8(fear_handle* h, const uint8_t* u8, int n, int hw, float* out, void* stream) {
+    if (!h || !u8 || !out) return FEAR_ERR_NULL;
+    if (n < 0 || hw < 1) return FEAR_ERR_SHAPE;
+    if (n == 0) return FEAR_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    NormArgs a{};
+    a.X = u8; a.Y = out; a.plane = hw * hw; a.pixels = (long)n * hw * hw;
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    for (int c = 0; c < 3; ++c) {
+        a.mean[c] = mean[c] * 255.0f;
+        a.inv_std[c] = 1.0f / (stdv[c] * 255.0f);
+    }
+    hipLaunchKernelGGL(normalize_kernel, dim3((a.pixels + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    HIP_TRY(h, hipGetLastError());
+    return FEAR_OK;
+}
+
+int fear_plan_size(fear_handle* h, int hw, int with_head) {
+    if (!h) return FEAR_ERR_NULL;
+    Plan* p = nullptr;
+    int st = build_plan(h, hw, with_head != 0, &p);
+    if (st != FEAR_OK) return st;
+    return (int)p->ops.size();
+}
+
+int fear_plan_op(fear_handle* h, int hw, int with_head, int i, char* name64, double* flops_per_crop,
+                 double* bytes_per_crop) {
+    if (!h) return FEAR_ERR_NULL;
+    Plan* p = nullptr;
+    int st = build_plan(h, hw, with_head != 0, &p);
+    if (st != FEAR_OK) return st;
+    if (i < 0 || i >= (int)p->ops.size()) return FEAR_ERR_SHAPE;
+    const Op& op = p->ops[i];
+    if (name64) { strncpy(name64, op.name, 63); name64[63] = 0; }
+    if (flops_per_crop) *flops_per_crop = op.flops;
+    if (bytes_per_crop) *bytes_per_crop = op.bytes;
+    return FEAR_OK;
+}
+
+int fear_profile_read(fear_handle* h, int hw, int with_head, int i, double* total_ms, int64_t* launches) {
+    if (!h) return FEAR_ERR_NULL;
+    Plan* p = nullptr;
+    int st = build_plan(h, hw, with_head != 0, &p);
+    if (st != FEAR_OK) return st;
+    if (i < 0 || i >= (int)p->ops.size()) return FEAR_ERR_SHAPE;
+    st = drain_events(h);
+    if (st != FEAR_OK) return st;
+    if (total_ms) *total_ms = p->ops[i].prof_ms;
+    if (launches) *launches = p->ops[i].prof_n;
+    return FEAR_OK;
+}
+
+int fear_profile_reset(fear_handle* h) {
+    if (!h) return FEAR_ERR_NULL;
+    int st = drain_events(h);
+    if (st != FEAR_OK) return st;
+    for (auto& kv : h->plans)
+        for (Op& op : kv.second->ops) { op.prof_ms = 0; op.prof_n = 0; }
+    return FEAR_OK;
+}
+
+size_t fear_workspace_bytes(fear_handle* h) { return h ? h->workspace_floats * sizeof(float) : 0; }
+
+int fear_last_hip_error(fear_handle* h) { return h ? h->last_hip_error : 0; }
+
+}  // extern "C"

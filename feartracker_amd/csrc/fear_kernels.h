@@ -1,0 +1,386 @@
+// fear_kernels.h — gfx950 (CDNA4, wave64) device kernels of the FEAR-XS inference path.
+//
+// Activations are fp32 NHWC ("pixel-major") inside the engine: a 1x1 convolution is then a
+// row-major GEMM  Y[m][n] = sum_k X[m][k] * W[n][k]  with m = pixel, k/n = channels, and both
+// operands K-contiguous, which is exactly the shape v_mfma_f32_16x16x4_f32 fragments want.
+//
+// Kernel inventory (reference operator each one replaces):
+//   stem_conv_kernel   3x3 s2 conv 3->16 + ReLU, NCHW in -> NHWC out   (fbnet_c stages[0], via model/blocks.py:29)
+//   pw_mfma_kernel     1x1 conv as MFMA GEMM + bias/ReLU/residual       (IR expand/project, AdjustLayer blocks.py:78-81,
+//                                                                        SepConv.pointwise blocks.py:67)
+//                      also the pixel-wise correlation z^T x            (MobileCorrelation, blocks.py:121-123)
+//   dw_conv_kernel     depthwise kxk (k=3/5, s=1/2) + bias/ReLU         (IR depthwise, SepConv.depthwise blocks.py:57-66)
+//   pw_small_kernel    1x1 conv with Cout<=4 (+exp), NCHW out           (bbox_pred / cls_pred, blocks.py:167-168,186-192)
+//   decode_kernel      sigmoid + arg-max + ltrb->xywh                   (FEARBoxCoder.decode, dataset/box_coder.py:75-107)
+//   normalize_kernel   uint8 HWC -> normalised fp32 NCHW                (Tracker._preprocess_image, base_tracker.py:97-103)
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace fear {
+
+// ------------------------------------------------------------------------------------------------
+// 1x1 convolution / correlation on the matrix cores.
+//
+// One wavefront owns MT pixel tiles (16 pixels each) and, per pass, NT channel tiles (16 output
+// channels each).  Fragments are loaded straight from global/L2 in MFMA order — no LDS staging:
+//   v_mfma_f32_16x16x4_f32: A-operand lane l = A[i = l&15][k = l>>4], B-operand lane l = B[k = l>>4][j = l&15]
+// We feed A := weights (i = output channel), B := activations (j = pixel).  A lane loads one float4
+//   W[n0 + (l&15)][kg*16 + 4*(l>>4) + 0..3]   and   X[m0 + (l&15)][kg*16 + 4*(l>>4) + 0..3]
+// and issues 4 MFMAs (one per float4 component); the k permutation is the same on both operands so
+// the sum is unchanged.  The accumulator lane then holds Y[m0 + (l&15)][n0 + 4*(l>>4) + 0..3]: four
+// consecutive output channels of one pixel -> one 16-byte store, 64 contiguous bytes per pixel row.
+//
+// WKN = true: weights are given K-major, W[k][n] (the template features z[c][j] of the correlation,
+// NCHW (256, 8x8) as handed over by the caller) with a per-crop stride.
+struct PwArgs {
+    const float* X;      // [M][ldx]
+    const float* W;      // [N][K]  (or [K][N] per crop when WKN)
+    const float* bias;   // [N] or nullptr
+    const float* R;      // residual [M][ldr] or nullptr
+    float* Y;            // [M][ldy]  (or NCHW when nchw_hw > 0)
+    int ldx, ldr, ldy;
+    int M, K, N;
+    int relu;
+    int nchw_hw;         // >0: store Y as [M / hw][N][hw] (NCHW), hw = pixels per crop
+    int rows_per_crop;   // WKN only: pixels per crop (selects the crop's weight matrix)
+    long w_crop_stride;  // WKN only: floats between consecutive crops' weights
+};
+
+template <int MT, int NT, bool WKN>
+__global__ __launch_bounds__(256) void pw_mfma_kernel(PwArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int li = lane & 15;
+    const int lk = lane >> 4;
+    const int m_wave = (blockIdx.x * 4 + wave) * (MT * 16);
+    if (m_wave >= a.M) return;
+
+    const float* Wp = a.W;
+    if (WKN) Wp += (long)(m_wave / a.rows_per_crop) * a.w_crop_stride;
+
+    const float* xrow[MT];
+    bool mvalid[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int m = m_wave + mt * 16 + li;
+        mvalid[mt] = m < a.M;
+        if (m >= a.M) m = a.M - 1;
+        xrow[mt] = a.X + (long)m * a.ldx;
+    }
+
+    const int n_tiles = (a.N + 15) >> 4;
+    for (int nc = 0; nc < n_tiles; nc += NT) {
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        int nrow[NT];
+        bool nvalid[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            int n = (nc + nt) * 16 + li;
+            nvalid[nt] = n < a.N;
+            nrow[nt] = nvalid[nt] ? n : (a.N - 1);
+        }
+
+        for (int kg = 0; kg < a.K; kg += 16) {
+            const int k = kg + lk * 4;
+            const bool kvalid = k < a.K;   // K is a multiple of 4 (asserted on the host)
+            f32x4 xf[MT], wf[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                xf[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (kvalid) xf[mt] = *reinterpret_cast<const f32x4*>(xrow[mt] + k);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                wf[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (kvalid && nvalid[nt]) {
+                    if (WKN) {
+                        const float* p = Wp + (long)k * a.N + nrow[nt];
+                        wf[nt] = (f32x4){p[0], p[a.N], p[2 * a.N], p[3 * a.N]};
+                    } else {
+                        wf[nt] = *reinterpret_cast<const f32x4*>(Wp + (long)nrow[nt] * a.K + k);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][i], xf[mt][i], acc[mt][nt], 0, 0, 0);
+        }
+
+        // epilogue: lane holds channels n0 + 4*lk + {0..3} of pixel m0 + li
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = (nc + nt) * 16 + lk * 4;
+            if (n >= a.N) continue;   // N is a multiple of 4
+            f32x4 b = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (a.bias) b = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if (!mvalid[mt]) continue;
+                const long m = m_wave + mt * 16 + li;
+                f32x4 v = acc[mt][nt] + b;
+                if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
+                if (a.relu) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+                if (a.nchw_hw > 0) {
+                    const long crop = m / a.nchw_hw, px = m % a.nchw_hw;
+                    float* y = a.Y + (crop * a.N + n) * a.nchw_hw + px;
+                    y[0] = v.x; y[a.nchw_hw] = v.y; y[2 * (long)a.nchw_hw] = v.z; y[3 * (long)a.nchw_hw] = v.w;
+                } else {
+                    *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Depthwise KSxKS convolution, stride S, pad KS/2, NHWC.  A thread owns 4 channels (one float4) of a
+// vertical strip of RO output pixels, so consecutive lanes walk (channel-group, x): every global
+// load/store instruction of a wavefront covers one contiguous 1 KiB run, and each input row is loaded
+// once per strip and reused by all output rows it contributes to.
+struct DwArgs {
+    const float* X;   // [B][H][W][ldx]
+    const float* Wt;  // [KS*KS][C]  (tap-major, channel-contiguous)
+    const float* bias;  // [C] or nullptr
+    float* Y;         // [B][Ho][Wo][ldy]
+    int ldx, ldy;
+    int B, H, W, C, Ho, Wo;
+    int relu;
+};
+
+template <int KS, int S, int RO>
+__global__ __launch_bounds__(256) void dw_conv_kernel(DwArgs a) {
+    constexpr int P = KS / 2;
+    constexpr int IR = (RO - 1) * S + KS;   // input rows touched by one strip
+    const int cgs = a.C >> 2;
+    const int strips = (a.Ho + RO - 1) / RO;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)a.B * strips * a.Wo * cgs;
+    if (idx >= total) return;
+    const int cg = idx % cgs; idx /= cgs;
+    const int ox = idx % a.Wo; idx /= a.Wo;
+    const int st = idx % strips;
+    const int b = idx / strips;
+    const int c = cg * 4;
+    const int oy0 = st * RO;
+
+    f32x4 w[KS * KS];
+#pragma unroll
+    for (int t = 0; t < KS * KS; ++t) w[t] = *reinterpret_cast<const f32x4*>(a.Wt + (long)t * a.C + c);
+    f32x4 acc[RO];
+    f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + c);
+#pragma unroll
+    for (int r = 0; r < RO; ++r) acc[r] = b4;
+
+    const float* xb = a.X + (long)b * a.H * a.W * a.ldx + c;
+    const int iy0 = oy0 * S - P;
+    const int ix0 = ox * S - P;
+#pragma unroll
+    for (int iy = 0; iy < IR; ++iy) {
+        const int y = iy0 + iy;
+        if (y < 0 || y >= a.H) continue;
+        const float* xr = xb + (long)y * a.W * a.ldx;
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+            const int x = ix0 + kx;
+            if (x < 0 || x >= a.W) continue;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xr + (long)x * a.ldx);
+#pragma unroll
+            for (int r = 0; r < RO; ++r) {
+                const int ky = iy - r * S;          // compile-time after unrolling
+                if (ky >= 0 && ky < KS) acc[r] += v * w[ky * KS + kx];
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RO; ++r) {
+        const int oy = oy0 + r;
+        if (oy >= a.Ho) break;
+        f32x4 v = acc[r];
+        if (a.relu) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        *reinterpret_cast<f32x4*>(a.Y + (((long)b * a.Ho + oy) * a.Wo + ox) * a.ldy + c) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stem: 3x3 stride-2 pad-1 convolution 3 -> 16 channels + ReLU.  Reads the caller's NCHW image,
+// writes NHWC.  One thread per output pixel; the 432 weights are wave-uniform (scalar loads).
+struct StemArgs {
+    const float* X;   // [B][3][H][W]
+    const float* Wt;  // [27][16]  ((ci*3+ky)*3+kx major, cout contiguous)
+    const float* bias;  // [16]
+    float* Y;         // [B][H/2][W/2][16]
+    int B, H, W, Ho, Wo;
+};
+
+__global__ __launch_bounds__(256) void stem_conv_kernel(StemArgs a) {
+    // weights + bias staged once per block; every lane reads the same LDS address (broadcast)
+    __shared__ __attribute__((aligned(16))) float sw[27 * 16 + 16];
+    for (int i = threadIdx.x; i < 27 * 16 + 16; i += 256) sw[i] = i < 27 * 16 ? a.Wt[i] : a.bias[i - 27 * 16];
+    __syncthreads();
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)a.B * a.Ho * a.Wo;
+    if (idx >= total) return;
+    const int ox = idx % a.Wo;
+    const int oy = (idx / a.Wo) % a.Ho;
+    const int b = idx / ((long)a.Wo * a.Ho);
+    f32x4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = *reinterpret_cast<const f32x4*>(sw + 27 * 16 + 4 * q);
+    const float* xb = a.X + (long)b * 3 * a.H * a.W;
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int y = oy * 2 - 1 + ky;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int x = ox * 2 - 1 + kx;
+                float v = 0.f;
+                if (y >= 0 && y < a.H && x >= 0 && x < a.W) v = xb[((long)ci * a.H + y) * a.W + x];
+                const f32x4* wt = reinterpret_cast<const f32x4*>(sw + ((ci * 3 + ky) * 3 + kx) * 16);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] += wt[q] * v;
+            }
+        }
+    f32x4* y = reinterpret_cast<f32x4*>(a.Y + idx * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        y[q] = (f32x4){fmaxf(acc[q].x, 0.f), fmaxf(acc[q].y, 0.f), fmaxf(acc[q].z, 0.f), fmaxf(acc[q].w, 0.f)};
+}
+
+// ------------------------------------------------------------------------------------------------
+// 1x1 convolution with a handful of output channels (bbox_pred: 4 + exp, cls_pred: 1): 16 lanes
+// cooperate on one pixel, each summing a K/16 slice with float4 loads, then a 4-step xor-shuffle
+// reduction inside the 16-lane group.  Writes NCHW (the layout of the reference's output maps).
+struct PwSmallArgs {
+    const float* X;   // [M][ldx]
+    const float* W;   // [N][K]
+    const float* bias;  // [N]
+    float* Y;         // [M/hw][N][hw]
+    int ldx, M, K, N, hw;
+    int act;          // 0 none, 2 exp
+};
+
+template <int N>
+__global__ __launch_bounds__(256) void pw_small_kernel(PwSmallArgs a) {
+    const int lane16 = threadIdx.x & 15;
+    const long m = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const bool valid = m < a.M;
+    const float* x = a.X + (valid ? m : 0) * a.ldx;
+    float acc[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) acc[n] = 0.f;
+    for (int k = lane16 * 4; k < a.K; k += 64) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + k);
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(a.W + (long)n * a.K + k);
+            acc[n] += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) acc[n] += __shfl_xor(acc[n], off, 16);
+    }
+    if (valid && lane16 == 0) {
+        const long crop = m / a.hw, px = m % a.hw;
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            float v = acc[n] + a.bias[n];
+            if (a.act == 2) v = expf(v);
+            a.Y[(crop * N + n) * a.hw + px] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// FEARBoxCoder.decode with use_sigmoid=True: one wavefront per crop.  Scores are sigmoid(cls) in
+// fp32 (ties after rounding resolve to the first cell, like torch.argmax); the box arithmetic runs
+// in float64 against the float64 grid, as in the reference.
+struct DecodeArgs {
+    const float* cls;   // [n][1][S][S]
+    const float* bbox;  // [n][4][S][S]
+    int32_t* rc;        // [n][2]
+    double* xywh;       // [n][4]
+    float* score;       // [n]
+    int n, S, stride, instance;
+};
+
+__global__ __launch_bounds__(64) void decode_kernel(DecodeArgs a) {
+    const int crop = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int cells = a.S * a.S;
+    const float* c = a.cls + (long)crop * cells;
+    float best = -1.f;
+    int best_i = 0x7fffffff;
+    for (int i = lane; i < cells; i += 64) {
+        const float s = 1.f / (1.f + expf(-c[i]));
+        if (s > best) { best = s; best_i = i; }   // strictly greater keeps the first index per lane
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ob = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(best_i, off, 64);
+        if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
+    }
+    if (lane == 0) {
+        const int r = best_i / a.S, col = best_i % a.S;
+        const double gx = (double)(col - a.S / 2) * a.stride + a.instance / 2;
+        const double gy = (double)(r - a.S / 2) * a.stride + a.instance / 2;
+        const float* bb = a.bbox + (long)crop * 4 * cells + best_i;
+        const double x0 = gx - (double)bb[0], y0 = gy - (double)bb[cells];
+        const double x1 = gx + (double)bb[2 * cells], y1 = gy + (double)bb[3 * cells];
+        a.rc[crop * 2] = r;
+        a.rc[crop * 2 + 1] = col;
+        a.xywh[crop * 4 + 0] = x0;
+        a.xywh[crop * 4 + 1] = y0;
+        a.xywh[crop * 4 + 2] = x1 - x0;
+        a.xywh[crop * 4 + 3] = y1 - y0;
+        a.score[crop] = best;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// uint8 HWC RGB -> normalised fp32 NCHW: (px - 255*mean) * (1/(255*std)), fp32 like albumentations.
+struct NormArgs {
+    const uint8_t* X;  // [n][hw][hw][3]
+    float* Y;          // [n][3][hw][hw]
+    long pixels;       // n*hw*hw
+    int plane;         // hw*hw
+    float mean[3], inv_std[3];
+};
+
+__global__ __launch_bounds__(256) void normalize_kernel(NormArgs a) {
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.pixels) return;
+    const long crop = p / a.plane, px = p % a.plane;
+    const uint8_t* s = a.X + p * 3;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        float v = (float)s[ch];
+        v -= a.mean[ch];
+        v *= a.inv_std[ch];
+        a.Y[(crop * 3 + ch) * a.plane + px] = v;
+    }
+}
+
+}  // namespace fear

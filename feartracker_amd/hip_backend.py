@@ -1,0 +1,270 @@
+"""ctypes binding of the C ABI in include/fear_hip.h and the drop-in model object.
+
+`FEARNetHIP` exposes the surface of the reference `FEARNet` that the tracker, the CoreML
+wrapper and the thop wrapper use (model_training/model/fear_net.py:58-96,
+evaluate/coreml_convert.py:55-57, evaluate/macs_params.py:15-17):
+`get_features(crop)`, `track(search, template_features)`, `forward((template, search))`,
+`connector(...)` is internal to the fused engine, `.eval()/.cuda()/.to()` are no-ops returning
+self.  All tensors are fp32 NCHW torch tensors on the handle's GPU; torch is only the
+allocator/stream provider here — every FLOP runs in the hand-written HIP kernels.
+
+There is NO fallback: if the shared library is missing or the GPU is absent the constructor
+raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Dict, Optional, Tuple
+
+import torch  # must be imported before the library so that both share one libamdhip64
+
+from .constants import TARGET_CLASSIFICATION_KEY, TARGET_REGRESSION_LABEL_KEY
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libfear_hip.so")
+DEFAULT_WEIGHTS = os.path.join(_PKG, "weights", "fear_xs_noembs.fearw")
+
+FEAR_OPT_MAX_BATCH = 1
+FEAR_OPT_PROFILE = 2
+
+_lib = None
+
+
+def load_library() -> ctypes.CDLL:
+    """dlopen libfear_hip.so and declare the prototypes of include/fear_hip.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found. Build it with `python -m feartracker_amd._build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    c = ctypes
+    vp, i32, i64, f32p = c.c_void_p, c.c_int, c.c_int64, c.c_void_p
+    lib.fear_create.argtypes = [vp, c.c_size_t, i32, c.POINTER(vp)]
+    lib.fear_create.restype = i32
+    lib.fear_destroy.argtypes = [vp]
+    lib.fear_destroy.restype = i32
+    lib.fear_features.argtypes = [vp, f32p, i32, i32, f32p, vp]
+    lib.fear_features.restype = i32
+    lib.fear_track.argtypes = [vp, f32p, f32p, f32p, i32, f32p, f32p, vp]
+    lib.fear_track.restype = i32
+    lib.fear_decode.argtypes = [vp, f32p, f32p, i32, i32, i32, i32, vp, vp, f32p, vp]
+    lib.fear_decode.restype = i32
+    lib.fear_normalize_u8.argtypes = [vp, vp, i32, i32, f32p, vp]
+    lib.fear_normalize_u8.restype = i32
+    lib.fear_set_option.argtypes = [vp, i32, i64]
+    lib.fear_set_option.restype = i32
+    lib.fear_get_option.argtypes = [vp, i32]
+    lib.fear_get_option.restype = i64
+    lib.fear_plan_size.argtypes = [vp, i32, i32]
+    lib.fear_plan_size.restype = i32
+    lib.fear_plan_op.argtypes = [vp, i32, i32, i32, c.c_char_p, c.POINTER(c.c_double), c.POINTER(c.c_double)]
+    lib.fear_plan_op.restype = i32
+    lib.fear_profile_read.argtypes = [vp, i32, i32, i32, c.POINTER(c.c_double), c.POINTER(i64)]
+    lib.fear_profile_read.restype = i32
+    lib.fear_profile_reset.argtypes = [vp]
+    lib.fear_profile_reset.restype = i32
+    lib.fear_workspace_bytes.argtypes = [vp]
+    lib.fear_workspace_bytes.restype = c.c_size_t
+    lib.fear_strerror.argtypes = [i32]
+    lib.fear_strerror.restype = c.c_char_p
+    lib.fear_last_hip_error.argtypes = [vp]
+    lib.fear_last_hip_error.restype = i32
+    lib.fear_version.argtypes = []
+    lib.fear_version.restype = c.c_char_p
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = (
+    "fear_create", "fear_destroy", "fear_features", "fear_track", "fear_decode", "fear_normalize_u8",
+    "fear_set_option", "fear_get_option", "fear_plan_size", "fear_plan_op", "fear_profile_read",
+    "fear_profile_reset", "fear_workspace_bytes", "fear_strerror", "fear_last_hip_error", "fear_version",
+)
+
+
+class FearError(RuntimeError):
+    pass
+
+
+class FEARNetHIP:
+    """FEAR network running on one MI355X through libfear_hip.so."""
+
+    def __init__(self, weights_path: str = DEFAULT_WEIGHTS, device: int = 0, max_batch: int = 64):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        if not torch.cuda.is_available():
+            raise RuntimeError("FEARNetHIP needs a ROCm GPU (torch.cuda.is_available() is False); no CPU fallback")
+        self.device = torch.device(f"cuda:{int(device)}")
+        torch.cuda.init()
+        with torch.cuda.device(self.device):
+            torch.zeros(1, device=self.device)  # make sure the HIP context exists before the engine uploads
+            with open(weights_path, "rb") as fh:
+                blob = fh.read()
+            self._check(self._lib.fear_create(blob, len(blob), int(device), ctypes.byref(self._h)))
+        self.weights_path = weights_path
+        self.set_max_batch(max_batch)
+        self.feat_channels = 256
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, status: int) -> None:
+        if status != 0:
+            hip = self._lib.fear_last_hip_error(self._h) if self._h else 0
+            raise FearError(f"libfear_hip: {self._lib.fear_strerror(status).decode()} (status {status}, hip {hip})")
+
+    def _stream(self) -> ctypes.c_void_p:
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _prep(self, t: torch.Tensor, name: str) -> torch.Tensor:
+        if not isinstance(t, torch.Tensor):
+            raise TypeError(f"{name} must be a torch.Tensor")
+        if t.device != self.device:
+            t = t.to(self.device)
+        if t.dtype != torch.float32:
+            t = t.float()
+        return t.contiguous()
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h:
+                self._lib.fear_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ nn.Module look-alikes
+    def eval(self):
+        return self
+
+    def cuda(self, device=None):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def set_max_batch(self, n: int) -> None:
+        self._check(self._lib.fear_set_option(self._h, FEAR_OPT_MAX_BATCH, int(n)))
+
+    def set_profile(self, on: bool) -> None:
+        self._check(self._lib.fear_set_option(self._h, FEAR_OPT_PROFILE, 1 if on else 0))
+
+    # ------------------------------------------------------------------ reference API
+    @torch.no_grad()
+    def get_features(self, crop: torch.Tensor) -> torch.Tensor:
+        """(N,3,H,H) normalised fp32 -> (N,256,H/16,H/16); fear_net.py:63-66."""
+        crop = self._prep(crop, "crop")
+        if crop.dim() != 4 or crop.shape[1] != 3 or crop.shape[2] != crop.shape[3]:
+            raise ValueError(f"crop must be (N,3,H,H), got {tuple(crop.shape)}")
+        n, hw = crop.shape[0], crop.shape[2]
+        out = torch.empty((n, self.feat_channels, hw // 16, hw // 16), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self._lib.fear_features(self._h, crop.data_ptr(), n, hw, out.data_ptr(), self._stream()))
+        return out
+
+    @torch.no_grad()
+    def track(self, search: torch.Tensor, template_features: torch.Tensor,
+              update: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """fear_net.py:90-96; `update` = optional cls-branch template (blocks.py:174-179)."""
+        bbox, cls = self.track_maps(search, template_features, update)
+        return {TARGET_REGRESSION_LABEL_KEY: bbox, TARGET_CLASSIFICATION_KEY: cls}
+
+    @torch.no_grad()
+    def track_maps(self, search, template_features, update=None, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+        search = self._prep(search, "search")
+        z = self._prep(template_features, "template_features")
+        n = search.shape[0]
+        if tuple(search.shape[1:]) != (3, 256, 256):
+            raise ValueError(f"search must be (N,3,256,256), got {tuple(search.shape)}")
+        if z.shape[0] == 1 and n > 1:
+            z = z.expand(n, -1, -1, -1).contiguous()
+        if tuple(z.shape) != (n, self.feat_channels, 8, 8):
+            raise ValueError(f"template_features must be ({n},256,8,8), got {tuple(z.shape)}")
+        zu_ptr = None
+        if update is not None:
+            zu = self._prep(update, "update")
+            if zu.shape[0] == 1 and n > 1:
+                zu = zu.expand(n, -1, -1, -1).contiguous()
+            if tuple(zu.shape) != tuple(z.shape):
+                raise ValueError("update template must have the shape of template_features")
+            zu_ptr = zu.data_ptr()
+        if out is None:
+            bbox = torch.empty((n, 4, 16, 16), dtype=torch.float32, device=self.device)
+            cls = torch.empty((n, 1, 16, 16), dtype=torch.float32, device=self.device)
+        else:
+            bbox, cls = out
+        with torch.cuda.device(self.device):
+            self._check(self._lib.fear_track(self._h, search.data_ptr(), z.data_ptr(), zu_ptr, n,
+                                             bbox.data_ptr(), cls.data_ptr(), self._stream()))
+        return bbox, cls
+
+    @torch.no_grad()
+    def forward(self, x: Tuple[torch.Tensor, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """fear_net.py:83-88: both branches through the trunk."""
+        template, search = x
+        return self.track(search, self.get_features(template))
+
+    __call__ = forward
+
+    # ------------------------------------------------------------------ device-side helpers
+    @torch.no_grad()
+    def decode(self, cls: torch.Tensor, bbox: torch.Tensor, score_size: int = 16, total_stride: int = 16,
+               instance_size: int = 256):
+        """Device arg-max decode (box_coder.py:75-107 with use_sigmoid=True).
+        Returns (rc int32 (N,2), xywh float64 (N,4), score fp32 (N,))."""
+        cls = self._prep(cls, "cls")
+        bbox = self._prep(bbox, "bbox")
+        n = cls.shape[0]
+        rc = torch.empty((n, 2), dtype=torch.int32, device=self.device)
+        xywh = torch.empty((n, 4), dtype=torch.float64, device=self.device)
+        score = torch.empty((n,), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self._lib.fear_decode(self._h, cls.data_ptr(), bbox.data_ptr(), n, score_size, total_stride,
+                                              instance_size, rc.data_ptr(), xywh.data_ptr(), score.data_ptr(),
+                                              self._stream()))
+        return rc, xywh, score
+
+    @torch.no_grad()
+    def normalize_u8(self, crops_u8_nhwc: torch.Tensor) -> torch.Tensor:
+        """uint8 (N,H,H,3) RGB -> normalised fp32 (N,3,H,H) on device (base_tracker.py:97-103)."""
+        x = crops_u8_nhwc
+        if x.dtype != torch.uint8 or x.dim() != 4 or x.shape[3] != 3 or x.shape[1] != x.shape[2]:
+            raise ValueError("expected uint8 (N,H,H,3)")
+        x = x.to(self.device).contiguous()
+        n, hw = x.shape[0], x.shape[1]
+        out = torch.empty((n, 3, hw, hw), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self._lib.fear_normalize_u8(self._h, x.data_ptr(), n, hw, out.data_ptr(), self._stream()))
+        return out
+
+    # ------------------------------------------------------------------ measurement
+    def plan(self, hw: int = 256, with_head: bool = True):
+        """[(name, flops_per_crop, bytes_per_crop)] for every kernel launch of the plan."""
+        n = self._lib.fear_plan_size(self._h, hw, int(with_head))
+        if n < 0:
+            self._check(n)
+        ops = []
+        for i in range(n):
+            name = ctypes.create_string_buffer(64)
+            fl, by = ctypes.c_double(), ctypes.c_double()
+            self._check(self._lib.fear_plan_op(self._h, hw, int(with_head), i, name, ctypes.byref(fl), ctypes.byref(by)))
+            ops.append((name.value.decode(), fl.value, by.value))
+        return ops
+
+    def profile_read(self, hw: int = 256, with_head: bool = True):
+        """[(total_ms, launches)] per op since the last reset (needs set_profile(True))."""
+        n = self._lib.fear_plan_size(self._h, hw, int(with_head))
+        res = []
+        for i in range(n):
+            ms, cnt = ctypes.c_double(), ctypes.c_int64()
+            self._check(self._lib.fear_profile_read(self._h, hw, int(with_head), i, ctypes.byref(ms), ctypes.byref(cnt)))
+            res.append((ms.value, cnt.value))
+        return res
+
+    def profile_reset(self) -> None:
+        self._check(self._lib.fear_profile_reset(self._h))
+
+    def workspace_bytes(self) -> int:
+        return int(self._lib.fear_workspace_bytes(self._h))

@@ -1,0 +1,104 @@
+/*
+ * fear_hip.h — C ABI of the MI355X (gfx950) FEAR per-frame inference engine.
+ *
+ * This is the drop-in boundary for the reference's hot path: the two methods of
+ * `FEARNet` that `FEARTracker.initialize()/update()` call
+ *     model_training/model/fear_net.py:63-66   get_features(crop)
+ *     model_training/model/fear_net.py:90-96   track(search, template_features)
+ * plus the arg-max box decode of `FEARBoxCoder.decode`
+ *     model_training/dataset/box_coder.py:75-107
+ * Everything else of the reference (Hydra config, Lightning training, datasets, CoreML export,
+ * iOS apps) is out of scope.
+ *
+ * Conventions
+ *   - plain C, no torch/HIP types in signatures; `stream` is a `hipStream_t` passed as void*
+ *     (NULL = the null stream).  Calls are asynchronous on that stream.
+ *   - every tensor pointer is a DEVICE pointer owned by the caller, contiguous, in the
+ *     reference's layouts: fp32 NCHW in and out.  Internal NHWC buffers are private.
+ *   - no exceptions cross the ABI: 0 on success, negative FEAR_ERR_* otherwise;
+ *     `fear_strerror` maps a status to text.
+ *   - a handle is bound to one device, owns the packed weights and a workspace, and is not
+ *     thread-safe; use one handle per device (one process per GPU for multi-GPU).
+ */
+#ifndef FEAR_HIP_H
+#define FEAR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FEAR_OK 0
+#define FEAR_ERR_NULL (-1)      /* null handle / pointer                                   */
+#define FEAR_ERR_SHAPE (-2)     /* unsupported n / hw / option value                       */
+#define FEAR_ERR_FORMAT (-3)    /* malformed or unsupported .fearw model blob              */
+#define FEAR_ERR_HIP (-4)       /* a HIP runtime call failed (see fear_last_hip_error)     */
+#define FEAR_ERR_ALLOC (-5)     /* device/host allocation failed                           */
+#define FEAR_ERR_NOHEAD (-6)    /* model blob has no correlation head (trunk-only file)    */
+
+typedef struct fear_handle fear_handle;
+
+/* Parse a `.fearw` model blob (host memory, layout include/fearw_format.h), upload the weights
+ * (fp16 -> fp32, re-laid-out for the kernels) to `device` and build the launch plans.
+ * Replaces: FEARNet.__init__ + load_from_lighting (model/fear_net.py:15-56, utils/torch.py:11-24). */
+int fear_create(const void* fearw_blob, size_t nbytes, int device, fear_handle** out);
+
+int fear_destroy(fear_handle* h);
+
+/* FEARNet.get_features (fear_net.py:63-66): trunk + 1x1 neck.
+ *   img   : (n, 3, hw, hw) fp32 NCHW, already normalised; hw a multiple of 32 (128 template / 256 search)
+ *   out   : (n, 256, hw/16, hw/16) fp32 NCHW                                                  */
+int fear_features(fear_handle* h, const float* img, int n, int hw, float* out, void* stream);
+
+/* FEARNet.track (fear_net.py:90-96) == get_features(search) + BoxTower (model/blocks.py:174-194).
+ *   search   : (n, 3, 256, 256) fp32 NCHW, normalised
+ *   tmpl     : (n, 256, 8, 8)   template features of each crop (as returned by fear_features)
+ *   tmpl_cls : optional second template used by the classification branch only
+ *              (`update` argument of BoxTower.forward, blocks.py:174-179); NULL = tmpl
+ *   bbox     : (n, 4, 16, 16) ltrb distances in search-crop pixels (exp already applied)
+ *   cls      : (n, 1, 16, 16) classification logits (0.1 factor already applied)              */
+int fear_track(fear_handle* h, const float* search, const float* tmpl, const float* tmpl_cls, int n,
+               float* bbox, float* cls, void* stream);
+
+/* FEARBoxCoder.decode (box_coder.py:75-107) with use_sigmoid=True on device, one wavefront per crop:
+ *   rc    : (n, 2) int32   arg-max cell (row, col), first maximum
+ *   xywh  : (n, 4) float64 box in search-crop pixels (float64 like the reference's grids)
+ *   score : (n)    fp32    sigmoid(cls) at the arg-max cell
+ * score_size / total_stride / instance_size are the tracker config values (16 / 16 / 256).      */
+int fear_decode(fear_handle* h, const float* cls, const float* bbox, int n, int score_size, int total_stride,
+                int instance_size, int32_t* rc, double* xywh, float* score, void* stream);
+
+/* Tracker._preprocess_image (base_tracker.py:97-103) on device: uint8 HWC RGB crops ->
+ * normalised fp32 NCHW, (px - 255*mean) * (1/(255*std)).
+ *   u8  : (n, hw, hw, 3) uint8     out : (n, 3, hw, hw) fp32                                    */
+int fear_normalize_u8(fear_handle* h, const uint8_t* u8, int n, int hw, float* out, void* stream);
+
+/* ---- engine options ------------------------------------------------------------------------- */
+#define FEAR_OPT_MAX_BATCH 1   /* crops processed per internal pass (workspace is sized for it)  */
+#define FEAR_OPT_PROFILE 2     /* 1: bracket every kernel launch with hipEvents (fear_profile_*) */
+int fear_set_option(fear_handle* h, int option, int64_t value);
+int64_t fear_get_option(fear_handle* h, int option);
+
+/* ---- introspection / measurement ------------------------------------------------------------- */
+/* Number of kernel launches ("ops") in the plan for input size hw (with_head: track vs features). */
+int fear_plan_size(fear_handle* h, int hw, int with_head);
+/* Describe op `i` of that plan: name (<=63 chars), algorithmic FLOPs and compulsory bytes per crop. */
+int fear_plan_op(fear_handle* h, int hw, int with_head, int i, char* name64, double* flops_per_crop,
+                 double* bytes_per_crop);
+/* With FEAR_OPT_PROFILE=1: synchronise and return the accumulated device time (ms) and launch count of
+ * op `i` since the last fear_profile_reset; events are recorded on the stream the op was launched on. */
+int fear_profile_read(fear_handle* h, int hw, int with_head, int i, double* total_ms, int64_t* launches);
+int fear_profile_reset(fear_handle* h);
+
+size_t fear_workspace_bytes(fear_handle* h);
+const char* fear_strerror(int status);
+/* hipError_t (as int) of the last failing HIP call on this handle, 0 if none. */
+int fear_last_hip_error(fear_handle* h);
+const char* fear_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FEAR_HIP_H */
