@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Throughput bench of the FEAR-XS per-frame hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1] per GPU; configs[2] is the same sharded over 8 GPUs):
+`FEARNet.track` (model_training/model/fear_net.py:90-96) on a batch of 256 independent synthetic
+search crops per GPU — seeded uint8 256x256 RGB crops normalised like base_tracker.py:70-81,
+each with its own cached template features from a 128x128 template crop (computed once, outside
+the timed region, by `get_features`), FEAR-XS-NoEmbs weights, fp32.  Inputs are resident in HBM
+when the timed region starts.  A step = one pass of the hot path over the batch; with N > 1 the
+batch is sharded (independent crops) and a step also includes the single RCCL
+all-gather of the packed (bbox, cls) maps.  Protocol mirrors the reference's own
+(README.md:43, Benchmark.swift:55-77): warm-up calls, then the mean over K timed calls.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     dominant kernel (largest share of device time): algorithmic FLOPs or bytes per launch /
+               its average launch duration, measured with HIP events recorded around that kernel on the
+               launch stream inside the timed region.
+  cpu_baseline the CPU oracle (torch fp32, all host cores) timed on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 = fp32 vector rate
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec peak
+FLOPS_PER_CROP = 922_787_840    # 2 x 461 393 920 MAC
+BYTES_PER_CROP = 857_088        # compulsory fp32 bytes per crop
+
+
+def norm_u8(u8_nchw: torch.Tensor) -> torch.Tensor:
+    mean = torch.tensor([0.485, 0.456, 0.406], device=u8_nchw.device).view(1, 3, 1, 1) * 255.0
+    inv = 1.0 / (torch.tensor([0.229, 0.224, 0.225], device=u8_nchw.device).view(1, 3, 1, 1) * 255.0)
+    return (u8_nchw.float() - mean) * inv
+
+
+def synth_batch(batch: int, rank: int):
+    """Seeded synthetic crops; every rank draws its own slice of one global stream (seed 0)."""
+    g = torch.Generator().manual_seed(1000 + rank)
+    search = torch.randint(0, 256, (batch, 3, 256, 256), dtype=torch.uint8, generator=g)
+    tmpl = torch.randint(0, 256, (batch, 3, 128, 128), dtype=torch.uint8, generator=g)
+    return search, tmpl
+
+
+def cpu_baseline(search_u8, tmpl_u8, weights, budget_s: float = 15.0):
+    """Oracle (kind='port') on the host cores, bounded sample: batches of 8 crops until ~budget_s."""
+    from oracle.fear_oracle import OracleNet  # checker/baseline only, never on the product path
+    # torch/oneDNN fp32 conv throughput on this graph peaks at ~16 threads on the 2x64-core EPYC host
+    # (tools/cpu_sweep.py: 16 thr 93 crops/s, 32 thr 85, 64 thr 42, 128 thr 15); use the best setting.
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    net = OracleNet(weights)
+    bs = 8
+    x = norm_u8(search_u8[:bs])
+    z = net.get_features(norm_u8(tmpl_u8[:bs]))
+    net.track(x, z)  # warm-up
+    t0 = time.perf_counter()
+    crops = 0
+    while True:
+        net.track(x, z)
+        crops += bs
+        dt = time.perf_counter() - t0
+        if dt > budget_s or crops >= 4096:
+            break
+    return {"value": crops / dt, "unit": "crops/s", "cores": torch.get_num_threads(), "kind": "port",
+            "host_cpus": os.cpu_count(),
+            "sample": f"{crops} crops (batches of {bs}) of the same synthetic 256x256 workload, torch fp32 oracle, {dt:.1f}s"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=256, help="search crops per GPU per step")
+    ap.add_argument("--max-batch", type=int, default=int(os.environ.get("FEAR_MAX_BATCH", "256")),
+                    help="crops per internal engine pass (workspace / cache footprint)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump-ops", action="store_true", help="print the per-kernel time table to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback on the product path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from feartracker_amd import FEARNetHIP, DEFAULT_WEIGHTS
+    from feartracker_amd.sharding import gather_maps
+
+    B = args.batch
+    net = FEARNetHIP(DEFAULT_WEIGHTS, device=local_rank, max_batch=args.max_batch)
+    search_u8, tmpl_u8 = synth_batch(B, rank)
+    search = norm_u8(search_u8.to(dev)).contiguous()
+    tmpl_feats = net.get_features(norm_u8(tmpl_u8.to(dev)).contiguous())
+    packed = torch.empty((B, 5, 16, 16), dtype=torch.float32, device=dev)
+    bbox_v, cls_v = packed[:, :4], packed[:, 4:]   # views are not contiguous per tensor -> use own outputs
+    bbox = torch.empty((B, 4, 16, 16), dtype=torch.float32, device=dev)
+    cls = torch.empty((B, 1, 16, 16), dtype=torch.float32, device=dev)
+    gathered = torch.empty((world * B, 5, 16, 16), dtype=torch.float32, device=dev) if world > 1 else None
+
+    def step():
+        net.track_maps(search, tmpl_feats, out=(bbox, cls))
+        if world > 1:
+            gather_maps(bbox, cls, packed, gathered)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warm-up; the first warm-up steps run with every kernel bracketed to find the dominant one
+    n_prof = min(3, max(1, args.warmup))
+    net.set_profile(True, op=-1)
+    net.profile_reset()
+    for _ in range(n_prof):
+        step()
+    torch.cuda.synchronize()
+    plan = net.plan(256, True)
+    prof = net.profile_read(256, True)
+    net.set_profile(False)
+    per_op = [(ms / max(cnt, 1), cnt) for ms, cnt in prof]
+    launches_per_step = [cnt / n_prof for _, cnt in prof]
+    op_time = [per_op[i][0] * launches_per_step[i] for i in range(len(plan))]
+    dom = max(range(len(plan)), key=lambda i: op_time[i])
+    if args.dump_ops and rank == 0:
+        tot = sum(op_time)
+        for i, (name, fl, by) in enumerate(plan):
+            crops_per_launch = B / max(launches_per_step[i], 1)
+            t = per_op[i][0]
+            print(f"{i:3d} {name:28s} {op_time[i]:8.3f} ms/step {100 * op_time[i] / tot:5.1f}%  "
+                  f"{fl * crops_per_launch / (t * 1e-3) / 1e12 if t else 0:7.2f} TF/s "
+                  f"{by * crops_per_launch / (t * 1e-3) / 1e9 if t else 0:8.1f} GB/s", file=sys.stderr)
+        print(f"sum of kernels {tot:.3f} ms/step", file=sys.stderr)
+    for _ in range(max(0, args.warmup - n_prof)):
+        step()
+
+    # timed region: only the dominant kernel is bracketed with HIP events (2 events per launch)
+    net.profile_reset()
+    net.set_profile(True, op=dom)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    net.set_profile(False)
+    dom_ms, dom_cnt = net.profile_read(256, True)[dom]
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_crops = world * B * args.steps
+        value = total_crops / elapsed
+        name, fl, by = plan[dom]
+        avg_ms = dom_ms / max(dom_cnt, 1)
+        crops_per_launch = B * args.steps / max(dom_cnt, 1)
+        ai = fl / by
+        ridge = PEAK_FP32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+        if ai >= ridge:
+            achieved = fl * crops_per_launch / (avg_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_FP32_MFMA_TFLOPS}
+        else:
+            achieved = by * crops_per_launch / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": achieved / PEAK_HBM_GBS}
+        roof.update({"traffic": None, "kernel": name, "avg_launch_ms": avg_ms, "launches": dom_cnt,
+                     "share_of_step": op_time[dom] / max(sum(op_time), 1e-12),
+                     "whole_path_tflops": value * FLOPS_PER_CROP / 1e12 / world,
+                     "whole_path_frac_of_fp32_peak": value * FLOPS_PER_CROP / 1e12 / world / PEAK_FP32_MFMA_TFLOPS})
+        out = {
+            "metric": "search-region crops/sec (FEAR-XS 256x256)",
+            "value": value,
+            "unit": "crops/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"FEAR-XS track(): batch={B} synthetic 256x256 search / 128x128 template crops per GPU, fp32"
+                                   + (f", sharded over {world} GPUs + 1 RCCL all-gather of (B,5,16,16) maps" if world > 1 else ""),
+                       "batch_per_gpu": B, "global_batch": world * B, "weights": "FEAR-XS-NoEmbs (fp16 values upcast to fp32)",
+                       "engine_pass": args.max_batch, "parallelism": f"dp{world}"},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(search_u8, tmpl_u8, DEFAULT_WEIGHTS)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

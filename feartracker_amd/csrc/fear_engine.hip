@@ -101,6 +101,7 @@ struct fear_handle {
     int feat_channels = 0;
     int max_batch = 64;
     int profile = 0;
+    int profile_op = -1;   // -1: every op, else only this op index of each plan
     int last_hip_error = 0;
     std::map<std::pair<int, int>, std::unique_ptr<Plan>> plans;
     float* workspace = nullptr;
@@ -470,9 +471,12 @@ struct Ext {
 int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s) {
     const size_t slab = p.buf_floats_per_crop * h->max_batch;
     auto buf = [&](int id) -> float* { return h->workspace + (size_t)id * slab; };
+    int op_index = -1;
     for (Op& op : p.ops) {
+        ++op_index;
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (h->profile) {
+        const bool prof = h->profile && (h->profile_op < 0 || h->profile_op == op_index);
+        if (prof) {
             HIP_TRY(h, hipEventCreate(&e0));
             HIP_TRY(h, hipEventCreate(&e1));
             HIP_TRY(h, hipEventRecord(e0, s));
@@ -538,7 +542,7 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s) {
                 break;
             }
         }
-        if (h->profile) {
+        if (prof) {
             HIP_TRY(h, hipEventRecord(e1, s));
             op.events.emplace_back(e0, e1);
         }
@@ -623,6 +627,10 @@ int fear_set_option(fear_handle* h, int option, int64_t value) {
         case FEAR_OPT_PROFILE:
             h->profile = value ? 1 : 0;
             return FEAR_OK;
+        case FEAR_OPT_PROFILE_OP:
+            if (value < -1 || value > 4096) return FEAR_ERR_SHAPE;
+            h->profile_op = (int)value;
+            return FEAR_OK;
         default: return FEAR_ERR_SHAPE;
     }
 }
@@ -632,14 +640,16 @@ int64_t fear_get_option(fear_handle* h, int option) {
     switch (option) {
         case FEAR_OPT_MAX_BATCH: return h->max_batch;
         case FEAR_OPT_PROFILE: return h->profile;
+        case FEAR_OPT_PROFILE_OP: return h->profile_op;
         default: return FEAR_ERR_SHAPE;
     }
 }
 
 int fear_features(fear_handle* h, const float* img, int n, int hw, float* out, void* stream) {
-    if (!h || !img || !out) return FEAR_ERR_NULL;
+    if (!h) return FEAR_ERR_NULL;
     if (n < 0) return FEAR_ERR_SHAPE;
-    if (n == 0) return FEAR_OK;
+    if (n == 0) return FEAR_OK;   // empty batch: nothing to read or write, null tensors are fine
+    if (!img || !out) return FEAR_ERR_NULL;
     HIP_TRY(h, hipSetDevice(h->device));
     Plan* p = nullptr;
     int st = build_plan(h, hw, false, &p);
@@ -660,9 +670,10 @@ int fear_features(fear_handle* h, const float* img, int n, int hw, float* out, v
 
 int fear_track(fear_handle* h, const float* search, const float* tmpl, const float* tmpl_cls, int n, float* bbox,
                float* cls, void* stream) {
-    if (!h || !search || !tmpl || !bbox || !cls) return FEAR_ERR_NULL;
+    if (!h) return FEAR_ERR_NULL;
     if (n < 0) return FEAR_ERR_SHAPE;
     if (n == 0) return FEAR_OK;
+    if (!search || !tmpl || !bbox || !cls) return FEAR_ERR_NULL;
     HIP_TRY(h, hipSetDevice(h->device));
     const int hw = 256;
     Plan* p = nullptr;
@@ -687,9 +698,10 @@ int fear_track(fear_handle* h, const float* search, const float* tmpl, const flo
 
 int fear_decode(fear_handle* h, const float* cls, const float* bbox, int n, int score_size, int total_stride,
                 int instance_size, int32_t* rc, double* xywh, float* score, void* stream) {
-    if (!h || !cls || !bbox || !rc || !xywh || !score) return FEAR_ERR_NULL;
+    if (!h) return FEAR_ERR_NULL;
     if (n < 0 || score_size < 1 || score_size > 64) return FEAR_ERR_SHAPE;
     if (n == 0) return FEAR_OK;
+    if (!cls || !bbox || !rc || !xywh || !score) return FEAR_ERR_NULL;
     HIP_TRY(h, hipSetDevice(h->device));
     DecodeArgs a{cls, bbox, rc, xywh, score, n, score_size, total_stride, instance_size};
     hipLaunchKernelGGL(decode_kernel, dim3(n), dim3(64), 0, static_cast<hipStream_t>(stream), a);
@@ -698,9 +710,10 @@ int fear_decode(fear_handle* h, const float* cls, const float* bbox, int n, int 
 }
 
 int fear_normalize_u8(fear_handle* h, const uint8_t* u8, int n, int hw, float* out, void* stream) {
-    if (!h || !u8 || !out) return FEAR_ERR_NULL;
+    if (!h) return FEAR_ERR_NULL;
     if (n < 0 || hw < 1) return FEAR_ERR_SHAPE;
     if (n == 0) return FEAR_OK;
+    if (!u8 || !out) return FEAR_ERR_NULL;
     HIP_TRY(h, hipSetDevice(h->device));
     NormArgs a{};
     a.X = u8; a.Y = out; a.plane = hw * hw; a.pixels = (long)n * hw * hw;

@@ -1,0 +1,75 @@
+"""Multi-GPU sharding of independent search crops.
+
+Every search crop (with its template features) is an independent unit — `FEARNet.track` has no
+cross-crop state (BN folded) — so a global batch is split contiguously over the ranks of one node
+(one process per GPU, `torch.distributed` backend "nccl" = RCCL over xGMI), each rank runs the HIP
+path on its shard, and ONE all-gather of the packed per-crop maps (bbox 4x16x16 + cls 1x16x16 fp32 =
+5 120 B/crop) gives every rank the full result.  The reference has no inference-time collective
+(single `cuda_id`, base_tracker.py:29); this module is the only place the framework communicates.
+
+Works on CPU tensors with the gloo backend too (used by the world_size-2 tests).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous split of n crops: the first n % world ranks get one extra crop."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def pack_maps(bbox: torch.Tensor, cls: torch.Tensor, packed: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(B,4,S,S) + (B,1,S,S) -> (B,5,S,S)."""
+    if packed is None:
+        packed = torch.empty((bbox.shape[0], 5) + tuple(bbox.shape[2:]), dtype=bbox.dtype, device=bbox.device)
+    packed[:, :4].copy_(bbox)
+    packed[:, 4:].copy_(cls)
+    return packed
+
+
+def gather_maps(bbox: torch.Tensor, cls: torch.Tensor, packed: Optional[torch.Tensor] = None,
+                gathered: Optional[torch.Tensor] = None, group=None) -> torch.Tensor:
+    """All-gather equally sized shards: returns (world*B, 5, S, S), rank-major."""
+    packed = pack_maps(bbox, cls, packed)
+    world = dist.get_world_size(group)
+    if gathered is None:
+        gathered = torch.empty((world * packed.shape[0],) + tuple(packed.shape[1:]), dtype=packed.dtype,
+                               device=packed.device)
+    dist.all_gather_into_tensor(gathered, packed, group=group)
+    return gathered
+
+
+def track_sharded(net, search: torch.Tensor, template_features: torch.Tensor, group=None):
+    """Run `net.track` on this rank's contiguous shard of a replicated global batch and all-gather.
+
+    search (N,3,256,256) / template_features (N,256,8,8) are the GLOBAL batch (same on every rank, any
+    device); returns (bbox (N,4,S,S), cls (N,1,S,S)) for the whole batch on every rank.  Ragged splits
+    (N % world != 0) are padded to the largest shard for the collective and trimmed afterwards.
+    """
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n = search.shape[0]
+    lo, hi = shard_range(n, world, rank)
+    out = net.track(search[lo:hi], template_features[lo:hi])
+    from .constants import TARGET_CLASSIFICATION_KEY, TARGET_REGRESSION_LABEL_KEY
+    bbox, cls = out[TARGET_REGRESSION_LABEL_KEY], out[TARGET_CLASSIFICATION_KEY]
+    if world == 1:
+        return bbox, cls
+    cap = (n + world - 1) // world
+    packed = torch.zeros((cap, 5) + tuple(bbox.shape[2:]), dtype=bbox.dtype, device=bbox.device)
+    if hi > lo:
+        pack_maps(bbox, cls, packed[: hi - lo])
+    gathered = torch.empty((world * cap,) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
+    dist.all_gather_into_tensor(gathered, packed, group=group)
+    parts = []
+    for r in range(world):
+        rlo, rhi = shard_range(n, world, r)
+        parts.append(gathered[r * cap: r * cap + (rhi - rlo)])
+    full = torch.cat(parts, dim=0)
+    return full[:, :4].contiguous(), full[:, 4:].contiguous()

@@ -176,7 +176,10 @@ class Tracker:
         if not self.tracking_config.get("smooth", False):
             return pred
         r, c = decoded_info.pred_coords[0]
-        lr = (penalty[r, c] * cls_score[r, c] * self.tracking_config["lr"]).item()
+        # the reference multiplies a numpy float64 scalar into a 0-dim fp32 torch tensor: the products are
+        # rounded to fp32 (base_tracker.py:159)
+        lr = float(np.float32(np.float32(penalty[r, c]) * np.float32(cls_score[r, c]))
+                   * np.float32(self.tracking_config["lr"]))
         w, h = self._smooth_size(np.array(pred[2:]), prev_size=self.tracking_state.prev_size, lr=lr)
         return np.array([pred[0], pred[1], w, h])
 

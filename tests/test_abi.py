@@ -1,0 +1,68 @@
+"""The C-ABI library loads and exports every symbol include/fear_hip.h declares; error paths that
+need no GPU behave (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from feartracker_amd import hip_backend
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "fear_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fear_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = hip_backend.load_library()
+    declared = _declared_symbols()
+    assert len(declared) >= 14
+    for sym in declared:
+        assert hasattr(lib, sym), f"{sym} declared in include/fear_hip.h but not exported"
+    assert set(declared) == set(hip_backend.EXPORTED_SYMBOLS)
+    assert b"gfx950" in lib.fear_version()
+
+
+def test_status_strings_and_null_handling():
+    lib = hip_backend.load_library()
+    assert lib.fear_strerror(0) == b"ok"
+    for code in (-1, -2, -3, -4, -5, -6):
+        assert lib.fear_strerror(code) not in (b"ok", b"unknown status")
+    assert lib.fear_strerror(-99) == b"unknown status"
+    h = ctypes.c_void_p()
+    assert lib.fear_create(None, 0, 0, ctypes.byref(h)) == -1
+    assert lib.fear_create(b"not a model" * 20, 220, 0, ctypes.byref(h)) == -3        # FEAR_ERR_FORMAT
+    assert lib.fear_destroy(None) == -1
+    assert lib.fear_set_option(None, 1, 8) == -1
+    assert lib.fear_workspace_bytes(None) == 0
+
+
+def test_truncated_model_is_rejected():
+    lib = hip_backend.load_library()
+    blob = open(hip_backend.DEFAULT_WEIGHTS, "rb").read()
+    h = ctypes.c_void_p()
+    assert lib.fear_create(blob[: len(blob) // 2], len(blob) // 2, 0, ctypes.byref(h)) == -3
+    bad = bytearray(blob)
+    bad[8] = 9          # version field
+    assert lib.fear_create(bytes(bad), len(bad), 0, ctypes.byref(h)) == -3
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        hip_backend.FEARNetHIP()
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "feartracker_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, fn)).read()
+                assert "oracle" not in text.replace("no oracle", ""), f"{fn} mentions the oracle"

@@ -1,0 +1,84 @@
+"""world_size-2 gloo test of the sharding + all-gather path (feartracker_amd/sharding.py) on CPU.
+The per-rank compute is a deterministic stand-in with the `track` API (the collective logic under test is
+independent of what produces the maps); the N=1 result is the reference."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from feartracker_amd.sharding import gather_maps, shard_range, track_sharded
+
+
+class FakeNet:
+    """Cheap deterministic per-crop function: every crop's maps depend only on that crop."""
+
+    def track(self, search, template_features):
+        n = search.shape[0]
+        s = search.reshape(n, -1)[:, :1280].reshape(n, 5, 16, 16) + template_features.reshape(n, -1)[:, :1].view(n, 1, 1, 1)
+        return {"TARGET_REGRESSION_LABEL_KEY": s[:, :4].contiguous(), "TARGET_CLASSIFICATION_KEY": s[:, 4:].contiguous()}
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(0)
+    search = torch.randn(n, 3, 256, 256, generator=g)
+    z = torch.randn(n, 256, 8, 8, generator=g)
+    bbox, cls = track_sharded(FakeNet(), search, z)
+    # equal-shard fast path used by bench.py
+    if n % world == 0:
+        lo, hi = shard_range(n, world, rank)
+        out = FakeNet().track(search[lo:hi], z[lo:hi])
+        g2 = gather_maps(out["TARGET_REGRESSION_LABEL_KEY"], out["TARGET_CLASSIFICATION_KEY"])
+    else:
+        g2 = torch.zeros(1)
+    q.put((rank, bbox.numpy(), cls.numpy(), g2.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [8, 7])
+def test_sharded_track_equals_single_process(n):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(0)
+    search = torch.randn(n, 3, 256, 256, generator=g)
+    z = torch.randn(n, 256, 8, 8, generator=g)
+    ref = FakeNet().track(search, z)
+    for rank, bbox, cls, g2 in results:
+        bbox, cls, g2 = torch.from_numpy(bbox), torch.from_numpy(cls), torch.from_numpy(g2)
+        assert torch.equal(bbox, ref["TARGET_REGRESSION_LABEL_KEY"])       # bit-for-bit, SURVEY.md §4
+        assert torch.equal(cls, ref["TARGET_CLASSIFICATION_KEY"])
+        if n % world == 0:
+            assert torch.equal(g2[:, :4], ref["TARGET_REGRESSION_LABEL_KEY"])
+            assert torch.equal(g2[:, 4:], ref["TARGET_CLASSIFICATION_KEY"])
+
+
+def test_shard_range_covers_everything():
+    for n in (0, 1, 7, 8, 2048, 2049):
+        for world in (1, 2, 4, 8):
+            spans = [shard_range(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for a, b in zip(spans, spans[1:]):
+                assert a[1] == b[0]
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1

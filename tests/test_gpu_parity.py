@@ -60,3 +60,109 @@ def test_track_vs_oracle_seeded_batches(hip_net, oracle_net):
         bbox, cls = hip_net.track_maps(x.cuda(), z.cuda())
         assert rel_err(bbox, ref["TARGET_REGRESSION_LABEL_KEY"]) < REL
         assert rel_err(cls, ref["TARGET_CLASSIFICATION_KEY"]) < REL
+
+
+def test_head_modules_fixture_via_update_template(hip_net, oracle_net, golden_dir):
+    """Dual-template path: `update` replaces the template of the cls branch only (blocks.py:174-179)."""
+    g = torch.Generator().manual_seed(21)
+    x = norm_u8(torch.randint(0, 256, (2, 3, 256, 256), dtype=torch.uint8, generator=g))
+    z = oracle_net.get_features(norm_u8(torch.randint(0, 256, (2, 3, 128, 128), dtype=torch.uint8, generator=g)))
+    zu = oracle_net.get_features(norm_u8(torch.randint(0, 256, (2, 3, 128, 128), dtype=torch.uint8, generator=g)))
+    ref = oracle_net.track(x, z, update=zu)
+    out = hip_net.track(x.cuda(), z.cuda(), update=zu.cuda())
+    assert rel_err(out["TARGET_REGRESSION_LABEL_KEY"], ref["TARGET_REGRESSION_LABEL_KEY"]) < REL
+    assert rel_err(out["TARGET_CLASSIFICATION_KEY"], ref["TARGET_CLASSIFICATION_KEY"]) < REL
+    plain = hip_net.track(x.cuda(), z.cuda())
+    assert torch.equal(plain["TARGET_REGRESSION_LABEL_KEY"], out["TARGET_REGRESSION_LABEL_KEY"])
+    assert not torch.equal(plain["TARGET_CLASSIFICATION_KEY"], out["TARGET_CLASSIFICATION_KEY"])
+
+
+def test_empty_ragged_and_chunked_batches(hip_net, oracle_net):
+    from feartracker_amd import FEARNetHIP
+    from conftest import WEIGHTS
+    empty = hip_net.track_maps(torch.empty(0, 3, 256, 256).cuda(), torch.empty(0, 256, 8, 8).cuda())
+    assert empty[0].shape == (0, 4, 16, 16) and empty[1].shape == (0, 1, 16, 16)
+    assert hip_net.get_features(torch.empty(0, 3, 128, 128).cuda()).shape == (0, 256, 8, 8)
+    # n larger than the engine pass: 7 crops through a handle limited to 3 per pass == one pass of 7
+    g = torch.Generator().manual_seed(31)
+    x = norm_u8(torch.randint(0, 256, (7, 3, 256, 256), dtype=torch.uint8, generator=g)).cuda()
+    z = hip_net.get_features(norm_u8(torch.randint(0, 256, (7, 3, 128, 128), dtype=torch.uint8, generator=g)).cuda())
+    small = FEARNetHIP(WEIGHTS, device=0, max_batch=3)
+    b1, c1 = hip_net.track_maps(x, z)
+    b2, c2 = small.track_maps(x, z)
+    assert torch.equal(b1, b2) and torch.equal(c1, c2)       # per-crop results do not depend on batching
+    assert torch.equal(small.get_features(x[:, :, :128, :128].contiguous()),
+                       hip_net.get_features(x[:, :, :128, :128].contiguous()))
+    # a single template broadcast over the batch (the tracker keeps one template per track)
+    b3, _ = hip_net.track_maps(x[:2], z[:1])
+    b4, _ = hip_net.track_maps(x[:2], z[:1].expand(2, -1, -1, -1).contiguous())
+    assert torch.equal(b3, b4)
+    with pytest.raises(ValueError):
+        hip_net.track_maps(x[:, :, :128, :128], z)
+
+
+def test_device_decode_matches_reference_fixture(hip_net, golden_dir):
+    d = np.load(f"{golden_dir}/box_coder.npz")
+    rc, xywh, score = hip_net.decode(torch.from_numpy(d["cls_maps"]).cuda(), torch.from_numpy(d["reg_maps"]).cuda())
+    np.testing.assert_array_equal(rc.cpu().numpy(), d["dec_sigmoid_rc"])
+    np.testing.assert_allclose(xywh.cpu().numpy(), d["dec_sigmoid_bbox"], rtol=0, atol=1e-9)
+    assert xywh.dtype == torch.float64
+    ref_score = torch.from_numpy(d["cls_maps"]).sigmoid().reshape(16, -1).max(dim=1).values
+    np.testing.assert_allclose(score.cpu().numpy(), ref_score.numpy(), rtol=1e-6)
+    assert tuple(rc[3].tolist()) == (5, 7)                   # exact tie -> first maximum
+
+
+def test_device_normalize_matches_host(hip_net):
+    from feartracker_amd.geometry import normalize_image
+    rng = np.random.RandomState(4)
+    u8 = rng.randint(0, 256, size=(3, 128, 128, 3)).astype(np.uint8)
+    got = hip_net.normalize_u8(torch.from_numpy(u8)).cpu().numpy()
+    ref = np.stack([normalize_image(im).transpose(2, 0, 1) for im in u8])
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-6)
+
+
+def test_tracker_clip_through_drop_in_api(hip_net, golden_dir):
+    """initialize/update loop of the drop-in FEARTracker on the HIP engine reproduces the boxes the
+    reference tracker produced on the synthetic clip (fixture: tools/make_golden.py §8)."""
+    from feartracker_amd import DEFAULT_TRACKING_CONFIG, FEARTracker
+    d = np.load(f"{golden_dir}/clip_synth.npz")
+    trk = FEARTracker(hip_net, cuda_id=0, **DEFAULT_TRACKING_CONFIG)
+    frames = d["frames"]
+    trk.initialize(frames[0], d["init_bbox"])
+    assert trk._template_features.is_cuda
+    assert rel_err(trk._template_features, torch.from_numpy(d["template_features"])) < REL
+    boxes = [np.array(d["init_bbox"])]
+    for f in frames[1:]:
+        boxes.append(np.array(trk.update(f)["bbox"]))
+    np.testing.assert_array_equal(np.stack(boxes), d["tracked"])     # argmax-identical boxes on the whole clip
+    # raw prediction + score of the first updates
+    trk2 = FEARTracker(hip_net, cuda_id=0, **DEFAULT_TRACKING_CONFIG)
+    trk2.initialize(frames[0], d["init_bbox"])
+    pred, score = trk2.track(d["crops"][0])
+    np.testing.assert_allclose(pred, d["raw_pred"][0], rtol=1e-3, atol=1e-2)
+    assert abs(float(score) - float(d["scores"][0])) < 1e-4
+
+
+def test_full_size_batch_properties(hip_net):
+    """BASELINE.json configs[1] size (B=256): size-independent properties instead of an oracle run —
+    batch invariance (crop i alone == crop i inside the batch, bit for bit), permutation equivariance,
+    finite and strictly positive ltrb distances."""
+    from feartracker_amd import FEARNetHIP
+    from conftest import WEIGHTS
+    net = FEARNetHIP(WEIGHTS, device=0, max_batch=256)
+    g = torch.Generator().manual_seed(99)
+    x = norm_u8(torch.randint(0, 256, (256, 3, 256, 256), dtype=torch.uint8, generator=g)).cuda()
+    t = norm_u8(torch.randint(0, 256, (256, 3, 128, 128), dtype=torch.uint8, generator=g)).cuda()
+    z = net.get_features(t)
+    bbox, cls = net.track_maps(x, z)
+    assert torch.isfinite(bbox).all() and torch.isfinite(cls).all() and (bbox > 0).all()
+    for i in (0, 17, 255):
+        bi, ci = net.track_maps(x[i:i + 1], z[i:i + 1])
+        assert torch.equal(bi[0], bbox[i]) and torch.equal(ci[0], cls[i])
+    perm = torch.randperm(256, generator=g).cuda()
+    bp, cp = net.track_maps(x[perm].contiguous(), z[perm].contiguous())
+    assert torch.equal(bp, bbox[perm]) and torch.equal(cp, cls[perm])
+    rc, xywh, score = net.decode(cls, bbox)
+    flat = cls.reshape(256, -1).sigmoid()
+    assert torch.equal(rc[:, 0].long() * 16 + rc[:, 1].long(), flat.argmax(dim=1)) or \
+        torch.allclose(score, flat.max(dim=1).values)
