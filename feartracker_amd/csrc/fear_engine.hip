@@ -60,7 +60,7 @@ struct Conv {
     bool is_pw() const { return groups == 1 && k == 1; }
 };
 
-enum OpType { OP_STEM, OP_PW, OP_DW, OP_CORR, OP_PW_SMALL };
+enum OpType { OP_STEM, OP_PW, OP_DW, OP_CORR, OP_PW_SMALL, OP_IR16, OP_IRTILE };
 
 struct Op {
     OpType type;
@@ -75,6 +75,9 @@ struct Op {
     int relu = 0, act = 0;
     int out_external = 0;     // 1: features NCHW, 2: bbox, 3: cls
     int tmpl_cls = 0;         // OP_CORR: use the classification template
+    int conv_e = -1, conv_d = -1, conv_p = -1;  // OP_IR16: expand (or -1) / depthwise / project convs
+    int relu_dw = 0;
+    int fused_id = -1;        // OP_IR16: index into the fused-kernel table
     char name[64];
     double flops = 0, bytes = 0;  // per crop: algorithmic FLOPs, compulsory bytes (in + out + weights excluded)
     // profiling
@@ -102,6 +105,8 @@ struct fear_handle {
     int max_batch = 64;
     int profile = 0;
     int profile_op = -1;   // -1: every op, else only this op index of each plan
+    int fuse = 1;          // 1: use the fused block kernels where an instantiation exists
+    bool fused_attr_set = false;
     int last_hip_error = 0;
     std::map<std::pair<int, int>, std::unique_ptr<Plan>> plans;
     float* workspace = nullptr;
@@ -203,6 +208,61 @@ int pack_weights(fear_handle* h) {
     return FEAR_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Fused 16x16 block kernels (ir16_fused_kernel): one instantiation per (CIN, CEXP, COUT, KS, EXPAND).
+struct Fused16 {
+    int cin, cexp, cout, ks, expand;
+    void (*kernel)(IrArgs);
+    int lds_bytes;
+};
+#define FUSED16(CIN, CEXP, COUT, KS, CE, EXP) \
+    {CIN, CEXP, COUT, KS, EXP, ir16_fused_kernel<CIN, CEXP, COUT, KS, CE, (EXP) != 0>, ir16_lds_bytes<CIN, CEXP, COUT, KS, CE, (EXP) != 0>()}
+const Fused16 kFused16[] = {
+    FUSED16(64, 192, 64, 5, 32, 1),   FUSED16(64, 384, 64, 5, 32, 1),  FUSED16(64, 384, 112, 5, 32, 1),
+    FUSED16(112, 672, 112, 5, 32, 1), FUSED16(112, 336, 112, 5, 16, 1),
+    FUSED16(256, 256, 256, 3, 32, 0), FUSED16(320, 320, 256, 3, 32, 0),
+};
+
+// Spatially tiled fused block kernels (ir_tile_fused_kernel) for the high-resolution trunk stages.
+struct FusedTile {
+    int cin, cexp, cout, ks, st, expand, hw;   // hw: input map size the tiling was chosen for
+    int tw, th;
+    void (*kernel)(IrTileArgs);
+    int lds_bytes;
+};
+#define FTILE(CIN, CEXP, CEXPP, COUT, KS, ST, TW, TH, CE, NBUF, EXP, MINW, HW)                                      \
+    {CIN, CEXP, COUT, KS, ST, EXP, HW, TW, TH,                                                                     \
+     ir_tile_fused_kernel<CIN, CEXP, CEXPP, COUT, KS, ST, TW, TH, CE, NBUF, (EXP) != 0, MINW>,                      \
+     ir_tile_lds_bytes<KS, ST, TW, TH, CE, NBUF>()}
+const FusedTile kFusedTile[] = {
+    FTILE(16, 16, 16, 16, 3, 1, 32, 16, 16, 1, 0, 4, 128),    // fbnet_c stage 1  (e1, 128x128)
+    FTILE(16, 96, 96, 24, 3, 2, 16, 8, 16, 1, 1, 4, 128),     // stage 2          (e6 s2, 128 -> 64)
+    FTILE(24, 24, 32, 24, 3, 1, 16, 16, 32, 1, 0, 4, 64),     // stages 4, 5      (e1, 64x64)
+    FTILE(24, 144, 144, 32, 5, 2, 16, 8, 16, 1, 1, 4, 64),    // stage 6          (e6 s2, 64 -> 32)
+    FTILE(32, 96, 96, 32, 5, 1, 16, 16, 16, 1, 1, 2, 32),     // stage 7  (4 corner tiles: 18x18 clipped region)
+    FTILE(32, 192, 192, 32, 5, 1, 16, 16, 16, 1, 1, 2, 32),   // stage 8
+    FTILE(32, 192, 192, 32, 3, 1, 32, 16, 16, 1, 1, 2, 32),   // stage 9
+    FTILE(32, 192, 192, 64, 5, 2, 16, 8, 16, 1, 1, 2, 32),    // stage 10         (e6 s2, 32 -> 16)
+};
+int find_fused_tile(int cin, int cexp, int cout, int ks, int st, int expand, int hw) {
+    for (size_t i = 0; i < sizeof(kFusedTile) / sizeof(kFusedTile[0]); ++i) {
+        const FusedTile& f = kFusedTile[i];
+        if (f.cin == cin && f.cexp == cexp && f.cout == cout && f.ks == ks && f.st == st && f.expand == expand &&
+            f.hw == hw)
+            return (int)i;
+    }
+    return -1;
+}
+
+int find_fused16(int cin, int cexp, int cout, int ks, int expand) {
+    for (size_t i = 0; i < sizeof(kFused16) / sizeof(kFused16[0]); ++i) {
+        const Fused16& f = kFused16[i];
+        if (f.cin == cin && f.cexp == cexp && f.cout == cout && f.ks == ks && f.expand == expand) return (int)i;
+    }
+    return -1;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Plan construction.  Activation buffers come from a small pool of equally sized slabs
 // (per-crop size = the largest intermediate tensor) handed out by liveness, so consecutive layers
@@ -274,6 +334,59 @@ int build_plan(fear_handle* h, int hw, bool with_head, Plan** out) {
         track(outT);
     };
 
+    // fused 16x16 block (returns false when no instantiation matches -> caller emits the unfused ops)
+    auto add_fused16 = [&](int ce, int cd, int cp, const T& in, T& outT, const T* res, int relu_dw, int relu_out,
+                           int out_ld, const char* tag) -> bool {
+        if (!h->fuse || in.H != 16 || in.W != 16) return false;
+        const Conv& d = h->convs[cd];
+        const Conv& p = h->convs[cp];
+        if (d.stride != 1) return false;
+        const int cin = ce >= 0 ? h->convs[ce].cin_g : d.cout;
+        const int id = find_fused16(cin, d.cout, p.cout, d.k, ce >= 0 ? 1 : 0);
+        if (id < 0) return false;
+        Op op{};
+        op.type = OP_IR16; op.fused_id = id; op.conv_e = ce; op.conv_d = cd; op.conv_p = cp;
+        op.in_buf = in.buf; op.in_ld = in.ld; op.in_off = in.off;
+        op.H = 16; op.W = 16; op.Ho = 16; op.Wo = 16; op.C = cin; op.N = p.cout;
+        op.relu_dw = relu_dw; op.relu = relu_out;
+        outT.buf = pool.acquire(); outT.ld = out_ld > 0 ? out_ld : p.cout; outT.off = 0; outT.C = p.cout; outT.H = 16; outT.W = 16;
+        op.out_buf = outT.buf; op.out_ld = outT.ld;
+        if (res) { op.res_buf = res->buf; op.res_ld = res->ld; }
+        snprintf(op.name, sizeof(op.name), "%s_%dx%dx%d_k%d", tag, cin, d.cout, p.cout, d.k);
+        op.flops = 2.0 * 256 * ((ce >= 0 ? (double)cin * d.cout : 0.0) + (double)d.cout * d.k * d.k + (double)d.cout * p.cout);
+        op.bytes = 4.0 * 256 * (cin + p.cout + (res ? p.cout : 0));
+        ops.push_back(op);
+        track(outT);
+        return true;
+    };
+
+    auto add_fused_tile = [&](int ce, int cd, int cp, const T& in, T& outT, const T* res) -> bool {
+        if (!h->fuse || in.H != in.W) return false;
+        const Conv& d = h->convs[cd];
+        const Conv& p = h->convs[cp];
+        const int cin = ce >= 0 ? h->convs[ce].cin_g : d.cout;
+        const int id = find_fused_tile(cin, d.cout, p.cout, d.k, d.stride, ce >= 0 ? 1 : 0, in.H);
+        if (id < 0) return false;
+        const FusedTile& f = kFusedTile[id];
+        const int ho = in.H / d.stride;
+        if (ho % f.th != 0 || ho % f.tw != 0) return false;
+        Op op{};
+        op.type = OP_IRTILE; op.fused_id = id; op.conv_e = ce; op.conv_d = cd; op.conv_p = cp;
+        op.in_buf = in.buf; op.in_ld = in.ld; op.in_off = in.off;
+        op.H = in.H; op.W = in.W; op.Ho = ho; op.Wo = ho; op.C = cin; op.N = p.cout;
+        op.relu_dw = 1; op.relu = 0;
+        outT.buf = pool.acquire(); outT.ld = p.cout; outT.off = 0; outT.C = p.cout; outT.H = ho; outT.W = ho;
+        op.out_buf = outT.buf; op.out_ld = outT.ld;
+        if (res) { op.res_buf = res->buf; op.res_ld = res->ld; }
+        snprintf(op.name, sizeof(op.name), "irt_%dx%dx%d_k%ds%d_hw%d", cin, d.cout, p.cout, d.k, d.stride, in.H);
+        op.flops = 2.0 * ((ce >= 0 ? (double)in.H * in.W * cin * d.cout : 0.0) +
+                          (double)ho * ho * d.cout * d.k * d.k + (double)ho * ho * d.cout * p.cout);
+        op.bytes = 4.0 * ((double)in.H * in.W * cin + (double)ho * ho * p.cout * (res ? 2 : 1));
+        ops.push_back(op);
+        track(outT);
+        return true;
+    };
+
     T cur;
     size_t bi = 0;
     // ---- stem
@@ -297,6 +410,12 @@ int build_plan(fear_handle* h, int hw, bool with_head, Plan** out) {
         const FearwBlock& b = h->blocks[bi];
         if (b.kind == FEARW_IR) {
             T x = cur, e = cur, d, o;
+            if (add_fused16(b.conv[0], b.conv[1], b.conv[2], x, o, b.residual ? &x : nullptr, 1, 0, 0, "ir16") ||
+                add_fused_tile(b.conv[0], b.conv[1], b.conv[2], x, o, b.residual ? &x : nullptr)) {
+                pool.release(x.buf);
+                cur = o;
+                continue;
+            }
             if (b.conv[0] >= 0) {
                 add_pw(b.conv[0], x, e, nullptr, 1, 0, 0, -1);
             }
@@ -357,10 +476,12 @@ int build_plan(fear_handle* h, int hw, bool with_head, Plan** out) {
             const Conv& corr_dw = h->convs[corr->conv[0]];
             if (corr_dw.cout != enc_pw.cout + tz) return FEAR_ERR_FORMAT;
             T d, cat;
-            add_dw(enc->conv[0], feat, d, 0);
             // encode pointwise writes channels [0, C) of the concat buffer; correlation fills [C, C+64)
-            add_pw(enc->conv[1], d, cat, nullptr, 1, corr_dw.cout, 0, -1);
-            pool.release(d.buf);
+            if (!add_fused16(-1, enc->conv[0], enc->conv[1], feat, cat, nullptr, 0, 1, corr_dw.cout, "sep16")) {
+                add_dw(enc->conv[0], feat, d, 0);
+                add_pw(enc->conv[1], d, cat, nullptr, 1, corr_dw.cout, 0, -1);
+                pool.release(d.buf);
+            }
             {
                 Op op{};
                 op.type = OP_CORR;
@@ -376,16 +497,24 @@ int build_plan(fear_handle* h, int hw, bool with_head, Plan** out) {
             T catv = cat;
             catv.C = corr_dw.cout;
             T x;
-            add_dw(corr->conv[0], catv, d, 0);
-            pool.release(cat.buf);
-            add_pw(corr->conv[1], d, x, nullptr, 1, 0, 0, -1);
-            pool.release(d.buf);
+            if (add_fused16(-1, corr->conv[0], corr->conv[1], catv, x, nullptr, 0, 1, 0, "sep16")) {
+                pool.release(cat.buf);
+            } else {
+                add_dw(corr->conv[0], catv, d, 0);
+                pool.release(cat.buf);
+                add_pw(corr->conv[1], d, x, nullptr, 1, 0, 0, -1);
+                pool.release(d.buf);
+            }
             for (const FearwBlock* tb : tower) {
                 T y;
-                add_dw(tb->conv[0], x, d, 0);
-                pool.release(x.buf);
-                add_pw(tb->conv[1], d, y, nullptr, 1, 0, 0, -1);
-                pool.release(d.buf);
+                if (add_fused16(-1, tb->conv[0], tb->conv[1], x, y, nullptr, 0, 1, 0, "sep16")) {
+                    pool.release(x.buf);
+                } else {
+                    add_dw(tb->conv[0], x, d, 0);
+                    pool.release(x.buf);
+                    add_pw(tb->conv[1], d, y, nullptr, 1, 0, 0, -1);
+                    pool.release(d.buf);
+                }
                 x = y;
             }
             add_dw(pred->conv[0], x, d, 0);
@@ -469,6 +598,15 @@ struct Ext {
 };
 
 int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s) {
+    if (!h->fused_attr_set) {
+        for (const Fused16& f : kFused16)
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(f.kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, f.lds_bytes));
+        for (const FusedTile& f : kFusedTile)
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(f.kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, f.lds_bytes));
+        h->fused_attr_set = true;
+    }
     const size_t slab = p.buf_floats_per_crop * h->max_batch;
     auto buf = [&](int id) -> float* { return h->workspace + (size_t)id * slab; };
     int op_index = -1;
@@ -529,6 +667,36 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s) {
                 else if (c->k == 3 && c->stride == 2) launch_dw<3, 2>(grid, s, a);
                 else if (c->k == 5 && c->stride == 1) launch_dw<5, 1>(grid, s, a);
                 else launch_dw<5, 2>(grid, s, a);
+                break;
+            }
+            case OP_IR16: {
+                const Fused16& f = kFused16[op.fused_id];
+                const Conv& cd = h->convs[op.conv_d];
+                const Conv& cp = h->convs[op.conv_p];
+                IrArgs a{};
+                a.X = buf(op.in_buf) + op.in_off; a.ldx = op.in_ld;
+                if (op.conv_e >= 0) { a.We = h->convs[op.conv_e].d_w; a.be = h->convs[op.conv_e].d_b; }
+                a.Wd = cd.d_w; a.bd = cd.d_b; a.Wp = cp.d_w; a.bp = cp.d_b;
+                a.R = op.res_buf >= 0 ? buf(op.res_buf) : nullptr; a.ldr = op.res_ld;
+                a.Y = buf(op.out_buf); a.ldy = op.out_ld;
+                a.relu_dw = op.relu_dw; a.relu_out = op.relu;
+                hipLaunchKernelGGL(f.kernel, dim3(n), dim3(512), f.lds_bytes, s, a);
+                break;
+            }
+            case OP_IRTILE: {
+                const FusedTile& f = kFusedTile[op.fused_id];
+                const Conv& cd = h->convs[op.conv_d];
+                const Conv& cp = h->convs[op.conv_p];
+                IrTileArgs ta{};
+                IrArgs& a = ta.b;
+                a.X = buf(op.in_buf) + op.in_off; a.ldx = op.in_ld;
+                if (op.conv_e >= 0) { a.We = h->convs[op.conv_e].d_w; a.be = h->convs[op.conv_e].d_b; }
+                a.Wd = cd.d_w; a.bd = cd.d_b; a.Wp = cp.d_w; a.bp = cp.d_b;
+                a.R = op.res_buf >= 0 ? buf(op.res_buf) : nullptr; a.ldr = op.res_ld;
+                a.Y = buf(op.out_buf); a.ldy = op.out_ld;
+                a.relu_dw = op.relu_dw; a.relu_out = op.relu;
+                ta.H = op.H; ta.W = op.W; ta.tiles_x = op.Wo / f.tw; ta.tiles_y = op.Ho / f.th;
+                hipLaunchKernelGGL(f.kernel, dim3((unsigned)n * ta.tiles_x * ta.tiles_y), dim3(512), f.lds_bytes, s, ta);
                 break;
             }
             case OP_PW_SMALL: {
@@ -631,6 +799,10 @@ int fear_set_option(fear_handle* h, int option, int64_t value) {
             if (value < -1 || value > 4096) return FEAR_ERR_SHAPE;
             h->profile_op = (int)value;
             return FEAR_OK;
+        case FEAR_OPT_FUSE:
+            if (value != 0 && value != 1) return FEAR_ERR_SHAPE;
+            if (h->fuse != (int)value) { h->fuse = (int)value; h->plans.clear(); }
+            return FEAR_OK;
         default: return FEAR_ERR_SHAPE;
     }
 }
@@ -641,6 +813,7 @@ int64_t fear_get_option(fear_handle* h, int option) {
         case FEAR_OPT_MAX_BATCH: return h->max_batch;
         case FEAR_OPT_PROFILE: return h->profile;
         case FEAR_OPT_PROFILE_OP: return h->profile_op;
+        case FEAR_OPT_FUSE: return h->fuse;
         default: return FEAR_ERR_SHAPE;
     }
 }

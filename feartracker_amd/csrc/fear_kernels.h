@@ -383,4 +383,391 @@ __global__ __launch_bounds__(256) void normalize_kernel(NormArgs a) {
     }
 }
 
+// ================================================================================================
+// Fused block kernel for 16x16 feature maps (FBNet inverted-residual blocks at stride 16 and the
+// separable-conv stages of BoxTower): one workgroup (8 wavefronts) owns one crop's whole 16x16 map, so
+// the depthwise halo is plain zero padding and nothing is recomputed.
+//
+//   IR block (EXPAND):   y = [x +] P( relu( D( relu( E(x) ) ) ) )      E: 1x1 CIN->CEXP, D: depthwise KSxKS,
+//   SepConv (!EXPAND):   y = act( P( D(x) ) )                           P: 1x1 CEXP->COUT
+//
+// The expanded tensor never leaves the CU: it is produced CE channels at a time by MFMA (phase A) into a
+// zero-ringed LDS tile, consumed by the depthwise conv on the VALU (phase B) whose float4 results are —
+// by construction of the lane mapping — already the B-operand fragments of the projection MFMAs
+// (phase C), which accumulate over the chunks in registers.  The LDS tile is double buffered: phase A
+// of chunk c+1 is issued in the same barrier interval as phases B/C of chunk c, so matrix-core and VALU
+// work of one wave can overlap and there is one s_barrier per chunk.
+//
+// Lane mapping (wave w of 8, lane l): li = l&15 = pixel column x, lk = l>>4; the wave owns rows 2w, 2w+1
+// (= MFMA pixel tiles).  MFMA 16x16x4 f32 fragments as in pw_mfma_kernel (weights = A operand).
+struct IrArgs {
+    const float* X;   // [B*256][ldx]
+    const float* We;  // [CEXP][CIN]            (EXPAND)
+    const float* be;  // [CEXP]                 (EXPAND)
+    const float* Wd;  // [KS*KS][CEXP] tap-major
+    const float* bd;  // [CEXP] or nullptr
+    const float* Wp;  // [COUT][CEXP]
+    const float* bp;  // [COUT]
+    const float* R;   // residual [B*256][ldr] or nullptr
+    float* Y;         // [B*256][ldy]
+    int ldx, ldr, ldy;
+    int relu_dw, relu_out;
+};
+
+template <int CIN, int CEXP, int COUT, int KS, int CE, bool EXPAND>
+__global__ __launch_bounds__(512) void ir16_fused_kernel(IrArgs a) {
+    constexpr int S = 16, P = KS / 2, PW = S + 2 * P, ES = CE + 4, NJ = CE / 16;
+    constexpr int NCHUNK = CEXP / CE, NTP = COUT / 16, KG = CIN / 16;
+    static_assert(CEXP % CE == 0 && COUT % 16 == 0 && (CE == 16 || CE == 32), "shape");
+    static_assert(!EXPAND || CIN % 16 == 0, "CIN");
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][PW*PW][ES]
+    constexpr int EBUF = PW * PW * ES;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const long crop = blockIdx.x;
+    const float* Xc = a.X + crop * 256 * a.ldx;
+    const int y0 = wave * 2;
+
+    // zero both E buffers once: the padding ring stays zero, the interior is rewritten per chunk
+    for (int i = threadIdx.x * 4; i < 2 * EBUF; i += 512 * 4) *reinterpret_cast<f32x4*>(lds + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // activation fragments of this wave's two pixel rows stay in registers for every chunk
+    f32x4 xf[EXPAND ? 2 : 1][EXPAND ? KG : 1];
+    if (EXPAND) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg)
+                xf[mt][kg] = *reinterpret_cast<const f32x4*>(Xc + (long)((y0 + mt) * S + li) * a.ldx + kg * 16 + lk * 4);
+    }
+    __syncthreads();
+
+    auto phase_a = [&](int c0, float* E) {
+        if (EXPAND) {
+            f32x4 acc[2][NJ];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NJ; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg) {
+                f32x4 wf[NJ];
+#pragma unroll
+                for (int nt = 0; nt < NJ; ++nt)
+                    wf[nt] = *reinterpret_cast<const f32x4*>(a.We + (long)(c0 + nt * 16 + li) * CIN + kg * 16 + lk * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NJ; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][i], xf[mt][kg][i], acc[mt][nt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NJ; ++nt) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(a.be + c0 + nt * 16 + lk * 4);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    f32x4 v = acc[mt][nt] + b;
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    *reinterpret_cast<f32x4*>(E + ((y0 + mt + P) * PW + li + P) * ES + nt * 16 + lk * 4) = v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(Xc + (long)((y0 + mt) * S + li) * a.ldx + c0 + j * 16 + lk * 4);
+                    *reinterpret_cast<f32x4*>(E + ((y0 + mt + P) * PW + li + P) * ES + j * 16 + lk * 4) = v;
+                }
+        }
+    };
+
+    f32x4 accp[2][NTP];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTP; ++nt) accp[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    phase_a(0, lds);
+    __syncthreads();
+
+    for (int c = 0; c < NCHUNK; ++c) {
+        const int c0 = c * CE;
+        const float* E = lds + (c & 1) * EBUF;
+        if (c + 1 < NCHUNK) phase_a(c0 + CE, lds + ((c + 1) & 1) * EBUF);
+
+        // phase B: depthwise on the VALU, results land directly in MFMA fragment layout
+        f32x4 df[2][NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int cc = j * 16 + lk * 4;
+            f32x4 d0 = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (a.bd) d0 = *reinterpret_cast<const f32x4*>(a.bd + c0 + cc);
+            f32x4 d1 = d0;
+#pragma unroll
+            for (int iy = 0; iy < KS + 1; ++iy) {
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(E + ((y0 + iy) * PW + li + kx) * ES + cc);
+                    if (iy < KS) d0 += v * *reinterpret_cast<const f32x4*>(a.Wd + (long)(iy * KS + kx) * CEXP + c0 + cc);
+                    if (iy >= 1) d1 += v * *reinterpret_cast<const f32x4*>(a.Wd + (long)((iy - 1) * KS + kx) * CEXP + c0 + cc);
+                }
+            }
+            if (a.relu_dw) {
+                d0.x = fmaxf(d0.x, 0.f); d0.y = fmaxf(d0.y, 0.f); d0.z = fmaxf(d0.z, 0.f); d0.w = fmaxf(d0.w, 0.f);
+                d1.x = fmaxf(d1.x, 0.f); d1.y = fmaxf(d1.y, 0.f); d1.z = fmaxf(d1.z, 0.f); d1.w = fmaxf(d1.w, 0.f);
+            }
+            df[0][j] = d0;
+            df[1][j] = d1;
+        }
+        // phase C: projection, accumulating over chunks
+#pragma unroll
+        for (int nt = 0; nt < NTP; ++nt) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const f32x4 wp = *reinterpret_cast<const f32x4*>(a.Wp + (long)(nt * 16 + li) * CEXP + c0 + j * 16 + lk * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        accp[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[i], df[mt][j][i], accp[mt][nt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // epilogue
+#pragma unroll
+    for (int nt = 0; nt < NTP; ++nt) {
+        const int n = nt * 16 + lk * 4;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(a.bp + n);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const long m = crop * 256 + (y0 + mt) * S + li;
+            f32x4 v = accp[mt][nt] + b;
+            if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
+            if (a.relu_out) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+            *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = v;
+        }
+    }
+}
+
+template <int CIN, int CEXP, int COUT, int KS, int CE, bool EXPAND>
+constexpr int ir16_lds_bytes() {
+    return 2 * (16 + 2 * (KS / 2)) * (16 + 2 * (KS / 2)) * (CE + 4) * 4;
+}
+
+// ================================================================================================
+// General spatially tiled fused block kernel (any map size, stride 1 or 2): one workgroup (8 waves)
+// produces a TW x TH tile of output pixels of one crop.  Same three phases as ir16_fused_kernel, but the
+// expansion runs over the tile's input region including the depthwise halo (clipped to the image; the
+// out-of-image part of the LDS tile is zero = the conv's zero padding), so only the narrow block input
+// is read from HBM and only the narrow block output is written.
+//
+//   region: IHR x IWR input pixels, IWR = (TW-1)*ST + KS;  LDS tile E[IHR*IWR][CE+4] per buffer
+//   phase A: m-tiles = groups of 16 region pixels in clipped row-major order, interleaved over the waves
+//   phase B/C: wave w owns MTC = TH*(TW/16)/8 output rows of one 16-pixel column segment (vertical strip)
+struct IrTileArgs {
+    IrArgs b;
+    int H, W;            // input map size (output is H/ST x W/ST)
+    int tiles_x, tiles_y;
+};
+
+template <int CIN, int CEXP, int CEXPP, int COUT, int KS, int ST, int TW, int TH, int CE, int NBUF, bool EXPAND, int MINW>
+__global__ __launch_bounds__(512, MINW) void ir_tile_fused_kernel(IrTileArgs t) {
+    const IrArgs& a = t.b;
+    constexpr int P = KS / 2, IWR = (TW - 1) * ST + KS, IHR = (TH - 1) * ST + KS, ES = CE + 4, NJ = CE / 16;
+    constexpr int SEG = TW / 16, NMT_OUT = TH * SEG, MTC = NMT_OUT / 8;
+    constexpr int NMT_IN_MAX = (IHR * IWR + 15) / 16, MTA = (NMT_IN_MAX + 7) / 8;
+    constexpr int NCHUNK = CEXPP / CE, NTP = (COUT + 15) / 16, KG = (CIN + 15) / 16;
+    constexpr int EBUF = IHR * IWR * ES;
+    constexpr bool PADC = CEXPP != CEXP;   // channel count padded up to a chunk multiple (e.g. 24 -> 32)
+    static_assert(CEXPP % CE == 0 && CEXPP >= CEXP && (CE == 16 || CE == 32) && NMT_OUT % 8 == 0 && TW % 16 == 0, "shape");
+    static_assert(SEG == 1 || SEG == 2, "TW must be 16 or 32");
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [NBUF][IHR*IWR][ES]
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int tiles = t.tiles_x * t.tiles_y;
+    const long crop = blockIdx.x / tiles;
+    const int tile = blockIdx.x % tiles;
+    const int ox0 = (tile % t.tiles_x) * TW, oy0 = (tile / t.tiles_x) * TH;
+    const int ix0 = ox0 * ST - P, iy0 = oy0 * ST - P;
+    const int cx_lo = max(ix0, 0), cy_lo = max(iy0, 0);
+    const int CW = min(ix0 + IWR, t.W) - cx_lo, CH = min(iy0 + IHR, t.H) - cy_lo;
+    const int NPIX = CW * CH;
+    const int Wo = t.W / ST, Ho = t.H / ST;
+    const float* Xc = a.X + crop * t.H * t.W * a.ldx;
+
+    for (int i = threadIdx.x * 4; i < NBUF * EBUF; i += 512 * 4) *reinterpret_cast<f32x4*>(lds + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // per-lane geometry of the wave's phase-A pixel tiles (chunk invariant)
+    int eoff[MTA];      // float offset of the pixel inside an E buffer, -1 = no pixel (tail of the last tile)
+    long xoff[MTA];     // float offset of the pixel's channel vector in X
+    f32x4 xf[EXPAND ? MTA : 1][EXPAND ? KG : 1];
+#pragma unroll
+    for (int i = 0; i < MTA; ++i) {
+        const int q = (wave + 8 * i) * 16 + li;
+        const bool valid = q < NPIX;
+        const int qq = valid ? q : 0;
+        const int cy = qq / CW, cx = qq - cy * CW;
+        const int gy = cy_lo + cy, gx = cx_lo + cx;
+        eoff[i] = valid ? ((gy - iy0) * IWR + (gx - ix0)) * ES : -1;
+        xoff[i] = ((long)gy * t.W + gx) * a.ldx;
+        if (EXPAND) {
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg) {
+                xf[i][kg] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (kg * 16 + lk * 4 < CIN) xf[i][kg] = *reinterpret_cast<const f32x4*>(Xc + xoff[i] + kg * 16 + lk * 4);
+            }
+        }
+    }
+    __syncthreads();
+
+    auto phase_a = [&](int c0, float* E) {
+        if (EXPAND) {
+            f32x4 wf[NJ][KG];
+#pragma unroll
+            for (int nt = 0; nt < NJ; ++nt)
+#pragma unroll
+                for (int kg = 0; kg < KG; ++kg) {
+                    wf[nt][kg] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (kg * 16 + lk * 4 < CIN)
+                        wf[nt][kg] = *reinterpret_cast<const f32x4*>(a.We + (long)(c0 + nt * 16 + li) * CIN + kg * 16 + lk * 4);
+                }
+            f32x4 bias[NJ];
+#pragma unroll
+            for (int nt = 0; nt < NJ; ++nt) bias[nt] = *reinterpret_cast<const f32x4*>(a.be + c0 + nt * 16 + lk * 4);
+#pragma unroll
+            for (int i = 0; i < MTA; ++i) {
+                if ((wave + 8 * i) * 16 >= NPIX) break;     // wave-uniform
+                f32x4 acc[NJ];
+#pragma unroll
+                for (int nt = 0; nt < NJ; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int nt = 0; nt < NJ; ++nt)
+                            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][kg][c], xf[i][kg][c], acc[nt], 0, 0, 0);
+                // accumulator lane: pixel li of the tile, channels nt*16 + 4*lk..  -> needs THAT pixel's E offset
+                const int eo = eoff[i];
+#pragma unroll
+                for (int nt = 0; nt < NJ; ++nt) {
+                    f32x4 v = acc[nt] + bias[nt];
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    if (eo >= 0) *reinterpret_cast<f32x4*>(E + eo + nt * 16 + lk * 4) = v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MTA; ++i) {
+                if ((wave + 8 * i) * 16 >= NPIX) break;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int ch = c0 + j * 16 + lk * 4;
+                    if (ch < CIN && eoff[i] >= 0)
+                        *reinterpret_cast<f32x4*>(E + eoff[i] + j * 16 + lk * 4) =
+                            *reinterpret_cast<const f32x4*>(Xc + xoff[i] + ch);
+                }
+            }
+        }
+    };
+
+    // output strip of this wave
+    const int seg = SEG == 1 ? 0 : (wave & 1);
+    const int r0 = (SEG == 1 ? wave : (wave >> 1)) * MTC;
+    f32x4 accp[MTC][NTP];
+#pragma unroll
+    for (int r = 0; r < MTC; ++r)
+#pragma unroll
+        for (int nt = 0; nt < NTP; ++nt) accp[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (NBUF == 2) { phase_a(0, lds); __syncthreads(); }
+
+    for (int c = 0; c < NCHUNK; ++c) {
+        const int c0 = c * CE;
+        const float* E = lds + (NBUF == 2 ? (c & 1) * EBUF : 0);
+        if (NBUF == 2) {
+            if (c + 1 < NCHUNK) phase_a(c0 + CE, lds + ((c + 1) & 1) * EBUF);
+        } else {
+            phase_a(c0, lds);
+            __syncthreads();
+        }
+        f32x4 df[MTC][NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int cc = j * 16 + lk * 4;
+            f32x4 d[MTC];
+            f32x4 bd = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const bool chv = !PADC || (c0 + cc < CEXP);
+            if (a.bd && chv) bd = *reinterpret_cast<const f32x4*>(a.bd + c0 + cc);
+#pragma unroll
+            for (int r = 0; r < MTC; ++r) d[r] = bd;
+            const float* Ebase = E + ((r0 * ST) * IWR + (seg * 16 + li) * ST) * ES + cc;
+#pragma unroll
+            for (int iy = 0; iy < (MTC - 1) * ST + KS; ++iy) {
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(Ebase + (iy * IWR + kx) * ES);
+#pragma unroll
+                    for (int r = 0; r < MTC; ++r) {
+                        const int ky = iy - r * ST;
+                        if (ky >= 0 && ky < KS && chv)
+                            d[r] += v * *reinterpret_cast<const f32x4*>(a.Wd + (long)(ky * KS + kx) * CEXP + c0 + cc);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < MTC; ++r) {
+                f32x4 v = d[r];
+                if (a.relu_dw) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                df[r][j] = v;
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTP; ++nt) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                f32x4 wp = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (nt * 16 + li < COUT && (!PADC || c0 + j * 16 + lk * 4 < CEXP))
+                    wp = *reinterpret_cast<const f32x4*>(a.Wp + (long)(nt * 16 + li) * CEXP + c0 + j * 16 + lk * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < MTC; ++r)
+                        accp[r][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[i], df[r][j][i], accp[r][nt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int nt = 0; nt < NTP; ++nt) {
+        const int n = nt * 16 + lk * 4;
+        if (n >= COUT) continue;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(a.bp + n);
+#pragma unroll
+        for (int r = 0; r < MTC; ++r) {
+            const int oy = oy0 + r0 + r, ox = ox0 + seg * 16 + li;
+            const long m = (crop * Ho + oy) * Wo + ox;
+            f32x4 v = accp[r][nt] + b;
+            if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
+            if (a.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = v;
+        }
+    }
+}
+
+template <int KS, int ST, int TW, int TH, int CE, int NBUF>
+constexpr int ir_tile_lds_bytes() {
+    return NBUF * ((TH - 1) * ST + KS) * ((TW - 1) * ST + KS) * (CE + 4) * 4;
+}
+
 }  // namespace fear

@@ -28,6 +28,7 @@ DEFAULT_WEIGHTS = os.path.join(_PKG, "weights", "fear_xs_noembs.fearw")
 FEAR_OPT_MAX_BATCH = 1
 FEAR_OPT_PROFILE = 2
 FEAR_OPT_PROFILE_OP = 3
+FEAR_OPT_FUSE = 4
 
 _lib = None
 
@@ -148,6 +149,10 @@ class FEARNetHIP:
 
     def set_max_batch(self, n: int) -> None:
         self._check(self._lib.fear_set_option(self._h, FEAR_OPT_MAX_BATCH, int(n)))
+
+    def set_fuse(self, on: bool) -> None:
+        """Fused block kernels (default) vs one kernel per conv layer (bring-up / A-B measurements)."""
+        self._check(self._lib.fear_set_option(self._h, FEAR_OPT_FUSE, 1 if on else 0))
 
     def set_profile(self, on: bool, op: int = -1) -> None:
         """Bracket kernel launches with hipEvents; op >= 0 restricts it to one op of the plan."""

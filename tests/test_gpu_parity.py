@@ -166,3 +166,21 @@ def test_full_size_batch_properties(hip_net):
     flat = cls.reshape(256, -1).sigmoid()
     assert torch.equal(rc[:, 0].long() * 16 + rc[:, 1].long(), flat.argmax(dim=1)) or \
         torch.allclose(score, flat.max(dim=1).values)
+
+
+def test_fused_and_layerwise_plans_agree(hip_net, oracle_net):
+    """The fused 16x16 block kernels and the one-kernel-per-layer plan compute the same function."""
+    from feartracker_amd import FEARNetHIP
+    from conftest import WEIGHTS
+    g = torch.Generator().manual_seed(41)
+    x = norm_u8(torch.randint(0, 256, (3, 3, 256, 256), dtype=torch.uint8, generator=g)).cuda()
+    z = hip_net.get_features(norm_u8(torch.randint(0, 256, (3, 3, 128, 128), dtype=torch.uint8, generator=g)).cuda())
+    plain = FEARNetHIP(WEIGHTS, device=0, max_batch=8)
+    plain.set_fuse(False)
+    assert len(plain.plan(256, True)) > len(hip_net.plan(256, True))
+    b0, c0 = plain.track_maps(x, z)
+    b1, c1 = hip_net.track_maps(x, z)
+    assert rel_err(b1, b0) < 1e-4 and rel_err(c1, c0) < 1e-4
+    ref = oracle_net.track(x.cpu(), z.cpu())
+    assert rel_err(b0, ref["TARGET_REGRESSION_LABEL_KEY"]) < REL
+    assert rel_err(c0, ref["TARGET_CLASSIFICATION_KEY"]) < REL
