@@ -55,6 +55,7 @@ struct Conv {
     std::vector<float> b;
     // device copies
     float* d_w = nullptr;  // pointwise: [N][K]; depthwise: [k*k][C]; stem: [27][16]
+    float* d_w2 = nullptr; // stem only: [16][32] zero-padded rows for the implicit-GEMM kernel
     float* d_b = nullptr;
     bool is_dw() const { return groups == cout && cin_g == 1 && groups > 1; }
     bool is_pw() const { return groups == 1 && k == 1; }
@@ -78,6 +79,7 @@ struct Op {
     int conv_e = -1, conv_d = -1, conv_p = -1;  // OP_IR16: expand (or -1) / depthwise / project convs
     int relu_dw = 0;
     int fused_id = -1;        // OP_IR16: index into the fused-kernel table
+    float* d_packed = nullptr; // OP_IR16: per-chunk packed weights (Ir2Geom layout), owned by the handle
     char name[64];
     double flops = 0, bytes = 0;  // per crop: algorithmic FLOPs, compulsory bytes (in + out + weights excluded)
     // profiling
@@ -199,6 +201,11 @@ int pack_weights(fear_handle* h) {
             packed.resize(27 * 16);
             for (int o = 0; o < 16; ++o)
                 for (int t = 0; t < 27; ++t) packed[t * 16 + o] = c.w[o * 27 + t];
+            std::vector<float> rows(16 * 32, 0.f);
+            for (int o = 0; o < 16; ++o)
+                for (int t = 0; t < 27; ++t) rows[o * 32 + t] = c.w[o * 27 + t];
+            int st2 = upload(h, rows, &c.d_w2);
+            if (st2 != FEAR_OK) return st2;
         }
         int st = upload(h, packed, &c.d_w);
         if (st != FEAR_OK) return st;
@@ -213,15 +220,15 @@ int pack_weights(fear_handle* h) {
 // Fused 16x16 block kernels (ir16_fused_kernel): one instantiation per (CIN, CEXP, COUT, KS, EXPAND).
 struct Fused16 {
     int cin, cexp, cout, ks, expand;
-    void (*kernel)(IrArgs);
+    void (*kernel)(Ir2Args);
     int lds_bytes;
 };
-#define FUSED16(CIN, CEXP, COUT, KS, CE, EXP) \
-    {CIN, CEXP, COUT, KS, EXP, ir16_fused_kernel<CIN, CEXP, COUT, KS, CE, (EXP) != 0>, ir16_lds_bytes<CIN, CEXP, COUT, KS, CE, (EXP) != 0>()}
+#define FUSED16(CIN, CEXP, COUT, KS, EXP) \
+    {CIN, CEXP, COUT, KS, EXP, ir16v2_fused_kernel<CIN, CEXP, COUT, KS, (EXP) != 0>, Ir2Geom<CIN, CEXP, COUT, KS, (EXP) != 0>::LDS_BYTES}
 const Fused16 kFused16[] = {
-    FUSED16(64, 192, 64, 5, 32, 1),   FUSED16(64, 384, 64, 5, 32, 1),  FUSED16(64, 384, 112, 5, 32, 1),
-    FUSED16(112, 672, 112, 5, 32, 1), FUSED16(112, 336, 112, 5, 16, 1),
-    FUSED16(256, 256, 256, 3, 32, 0), FUSED16(320, 320, 256, 3, 32, 0),
+    FUSED16(64, 192, 64, 5, 1),   FUSED16(64, 384, 64, 5, 1),  FUSED16(64, 384, 112, 5, 1),
+    FUSED16(112, 672, 112, 5, 1), FUSED16(112, 336, 112, 5, 1),
+    FUSED16(256, 256, 256, 3, 0), FUSED16(320, 320, 256, 3, 0),
 };
 
 // Spatially tiled fused block kernels (ir_tile_fused_kernel) for the high-resolution trunk stages.
@@ -261,6 +268,37 @@ int find_fused16(int cin, int cexp, int cout, int ks, int expand) {
         if (f.cin == cin && f.cexp == cexp && f.cout == cout && f.ks == ks && f.expand == expand) return (int)i;
     }
     return -1;
+}
+
+
+// Pack the weights of one fused 16x16 block per 16-channel chunk in the order ir16v2_fused_kernel stages them:
+//   [A-part: KG fragments x 256 | be[16]] [BC-part: NTP fragments x 256 | Wd[k*k][16] | bd[16]]
+// (fragment lane l holds W[row0 + (l&15)][col0 + 4*(l>>4) + 0..3]).
+int pack_fused16(fear_handle* h, int ce, int cd, int cp, float** out) {
+    const Conv& d = h->convs[cd];
+    const Conv& p = h->convs[cp];
+    const Conv* e = ce >= 0 ? &h->convs[ce] : nullptr;
+    const int cexp = d.cout, cout = p.cout, kk = d.k * d.k;
+    const int cin = e ? e->cin_g : cexp;
+    const int kg_n = e ? cin / 16 : 0, ntp = cout / 16;
+    std::vector<float> buf;
+    for (int c0 = 0; c0 < cexp; c0 += 16) {
+        if (e) {
+            for (int kg = 0; kg < kg_n; ++kg)
+                for (int l = 0; l < 64; ++l)
+                    for (int i = 0; i < 4; ++i)
+                        buf.push_back(e->w[(size_t)(c0 + (l & 15)) * cin + kg * 16 + (l >> 4) * 4 + i]);
+            for (int ch = 0; ch < 16; ++ch) buf.push_back(e->has_bias ? e->b[c0 + ch] : 0.f);
+        }
+        for (int nt = 0; nt < ntp; ++nt)
+            for (int l = 0; l < 64; ++l)
+                for (int i = 0; i < 4; ++i)
+                    buf.push_back(p.w[(size_t)(nt * 16 + (l & 15)) * cexp + c0 + (l >> 4) * 4 + i]);
+        for (int t = 0; t < kk; ++t)
+            for (int ch = 0; ch < 16; ++ch) buf.push_back(d.w[(size_t)(c0 + ch) * kk + t]);
+        for (int ch = 0; ch < 16; ++ch) buf.push_back(d.has_bias ? d.b[c0 + ch] : 0.f);
+    }
+    return upload(h, buf, out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -344,8 +382,10 @@ int build_plan(fear_handle* h, int hw, bool with_head, Plan** out) {
         const int cin = ce >= 0 ? h->convs[ce].cin_g : d.cout;
         const int id = find_fused16(cin, d.cout, p.cout, d.k, ce >= 0 ? 1 : 0);
         if (id < 0) return false;
+        if (!p.has_bias) return false;
         Op op{};
         op.type = OP_IR16; op.fused_id = id; op.conv_e = ce; op.conv_d = cd; op.conv_p = cp;
+        if (pack_fused16(h, ce, cd, cp, &op.d_packed) != FEAR_OK) return false;
         op.in_buf = in.buf; op.in_ld = in.ld; op.in_off = in.off;
         op.H = 16; op.W = 16; op.Ho = 16; op.Wo = 16; op.C = cin; op.N = p.cout;
         op.relu_dw = relu_dw; op.relu = relu_out;
@@ -622,9 +662,15 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s) {
         const Conv* c = op.conv >= 0 ? &h->convs[op.conv] : nullptr;
         switch (op.type) {
             case OP_STEM: {
-                StemArgs a{ext.img, c->d_w, c->d_b, buf(op.out_buf), n, op.H, op.W, op.Ho, op.Wo};
-                const long total = (long)n * op.Ho * op.Wo;
-                hipLaunchKernelGGL(stem_conv_kernel, dim3((total + 255) / 256), dim3(256), 0, s, a);
+                if (h->fuse && op.Wo % 16 == 0) {
+                    StemMfmaArgs a{ext.img, c->d_w2, c->d_b, buf(op.out_buf), n, op.H, op.W, op.Ho, op.Wo};
+                    const long rows = (long)n * op.Ho;
+                    hipLaunchKernelGGL(stem_mfma_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, a);
+                } else {
+                    StemArgs a{ext.img, c->d_w, c->d_b, buf(op.out_buf), n, op.H, op.W, op.Ho, op.Wo};
+                    const long total = (long)n * op.Ho * op.Wo;
+                    hipLaunchKernelGGL(stem_conv_kernel, dim3((total + 255) / 256), dim3(256), 0, s, a);
+                }
                 break;
             }
             case OP_PW: {
@@ -671,12 +717,9 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s) {
             }
             case OP_IR16: {
                 const Fused16& f = kFused16[op.fused_id];
-                const Conv& cd = h->convs[op.conv_d];
-                const Conv& cp = h->convs[op.conv_p];
-                IrArgs a{};
+                Ir2Args a{};
                 a.X = buf(op.in_buf) + op.in_off; a.ldx = op.in_ld;
-                if (op.conv_e >= 0) { a.We = h->convs[op.conv_e].d_w; a.be = h->convs[op.conv_e].d_b; }
-                a.Wd = cd.d_w; a.bd = cd.d_b; a.Wp = cp.d_w; a.bp = cp.d_b;
+                a.Wpk = op.d_packed; a.bp = h->convs[op.conv_p].d_b;
                 a.R = op.res_buf >= 0 ? buf(op.res_buf) : nullptr; a.ldr = op.res_ld;
                 a.Y = buf(op.out_buf); a.ldy = op.out_ld;
                 a.relu_dw = op.relu_dw; a.relu_out = op.relu;

@@ -267,6 +267,62 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Stem on the matrix cores: the 3x3 stride-2 conv is an implicit GEMM with K = 27 (padded to 32):
+// per 16-pixel row segment 8 MFMA 16x16x4 (A = weights [16][32], B = im2col gather straight from the
+// caller's NCHW image), ReLU, one 16-byte NHWC store per lane.  One wavefront walks one output row.
+struct StemMfmaArgs {
+    const float* X;     // [B][3][H][W]
+    const float* Wp;    // [16][32]  k = (ci*3+ky)*3+kx, zero padded 27..31
+    const float* bias;  // [16]
+    float* Y;           // [B][H/2][W/2][16]
+    int B, H, W, Ho, Wo;
+};
+
+__global__ __launch_bounds__(256) void stem_mfma_kernel(StemMfmaArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const long row = (long)blockIdx.x * 4 + wave;          // (crop, oy)
+    if (row >= (long)a.B * a.Ho) return;
+    const int oy = row % a.Ho;
+    const long b = row / a.Ho;
+    f32x4 wf[2];
+    wf[0] = *reinterpret_cast<const f32x4*>(a.Wp + li * 32 + lk * 4);
+    wf[1] = *reinterpret_cast<const f32x4*>(a.Wp + li * 32 + 16 + lk * 4);
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bias + lk * 4);
+    // the 8 taps this lane gathers: k = kg*16 + 4*lk + i
+    int toff[8], tky[8], tkx[8];
+    bool tval[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int k = (t >> 2) * 16 + lk * 4 + (t & 3);
+        tval[t] = k < 27;
+        const int kk = tval[t] ? k : 0;
+        const int ci = kk / 9, ky = (kk % 9) / 3, kx = kk % 3;
+        tky[t] = ky; tkx[t] = kx;
+        toff[t] = (ci * a.H + ky) * a.W + kx;
+    }
+    const float* xb = a.X + b * 3 * a.H * a.W + (long)(2 * oy - 1) * a.W - 1;
+    float* yb = a.Y + row * a.Wo * 16;
+#pragma unroll 2
+    for (int ox0 = 0; ox0 < a.Wo; ox0 += 16) {
+        const int ox = ox0 + li;
+        const float* xp = xb + 2 * ox;
+        float v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const bool ok = tval[t] && (2 * oy - 1 + tky[t] >= 0) && (2 * ox - 1 + tkx[t] >= 0);
+            v[t] = ok ? xp[toff[t]] : 0.f;
+        }
+        f32x4 acc = bias;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t >> 2][t & 3], v[t], acc, 0, 0, 0);
+        acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+        *reinterpret_cast<f32x4*>(yb + (long)ox * 16 + lk * 4) = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // 1x1 convolution with a handful of output channels (bbox_pred: 4 + exp, cls_pred: 1): 16 lanes
 // cooperate on one pixel, each summing a K/16 slice with float4 loads, then a 4-step xor-shuffle
 // reduction inside the 16-lane group.  Writes NCHW (the layout of the reference's output maps).
@@ -414,7 +470,9 @@ struct IrArgs {
     int relu_dw, relu_out;
 };
 
-template <int CIN, int CEXP, int COUT, int KS, int CE, bool EXPAND>
+// ABL: ablation bits for tools/kbench.hip only (0 in the product): 1 skip expand MFMAs, 2 skip depthwise math,
+// 4 skip projection MFMAs, 8 skip the weight/activation global loads of phase A/C (use constants).
+template <int CIN, int CEXP, int COUT, int KS, int CE, bool EXPAND, int ABL = 0>
 __global__ __launch_bounds__(512) void ir16_fused_kernel(IrArgs a) {
     constexpr int S = 16, P = KS / 2, PW = S + 2 * P, ES = CE + 4, NJ = CE / 16;
     constexpr int NCHUNK = CEXP / CE, NTP = COUT / 16, KG = CIN / 16;
@@ -454,8 +512,15 @@ __global__ __launch_bounds__(512) void ir16_fused_kernel(IrArgs a) {
             for (int kg = 0; kg < KG; ++kg) {
                 f32x4 wf[NJ];
 #pragma unroll
-                for (int nt = 0; nt < NJ; ++nt)
-                    wf[nt] = *reinterpret_cast<const f32x4*>(a.We + (long)(c0 + nt * 16 + li) * CIN + kg * 16 + lk * 4);
+                for (int nt = 0; nt < NJ; ++nt) {
+                    if (ABL & 8) wf[nt] = (f32x4){0.5f, 0.25f, 0.125f, 1.f};
+                    else wf[nt] = *reinterpret_cast<const f32x4*>(a.We + (long)(c0 + nt * 16 + li) * CIN + kg * 16 + lk * 4);
+                }
+                if (ABL & 1) {
+#pragma unroll
+                    for (int nt = 0; nt < NJ; ++nt) asm volatile("" :: "v"(wf[nt]));
+                    continue;
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -494,11 +559,7 @@ __global__ __launch_bounds__(512) void ir16_fused_kernel(IrArgs a) {
     phase_a(0, lds);
     __syncthreads();
 
-    for (int c = 0; c < NCHUNK; ++c) {
-        const int c0 = c * CE;
-        const float* E = lds + (c & 1) * EBUF;
-        if (c + 1 < NCHUNK) phase_a(c0 + CE, lds + ((c + 1) & 1) * EBUF);
-
+    auto phase_bc = [&](int c0, const float* E) {
         // phase B: depthwise on the VALU, results land directly in MFMA fragment layout
         f32x4 df[2][NJ];
 #pragma unroll
@@ -507,6 +568,10 @@ __global__ __launch_bounds__(512) void ir16_fused_kernel(IrArgs a) {
             f32x4 d0 = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (a.bd) d0 = *reinterpret_cast<const f32x4*>(a.bd + c0 + cc);
             f32x4 d1 = d0;
+            if (ABL & 2) {
+                d0 += *reinterpret_cast<const f32x4*>(E + ((y0 + P) * PW + li + P) * ES + cc);
+                d1 += *reinterpret_cast<const f32x4*>(E + ((y0 + 1 + P) * PW + li + P) * ES + cc);
+            } else {
 #pragma unroll
             for (int iy = 0; iy < KS + 1; ++iy) {
 #pragma unroll
@@ -515,6 +580,7 @@ __global__ __launch_bounds__(512) void ir16_fused_kernel(IrArgs a) {
                     if (iy < KS) d0 += v * *reinterpret_cast<const f32x4*>(a.Wd + (long)(iy * KS + kx) * CEXP + c0 + cc);
                     if (iy >= 1) d1 += v * *reinterpret_cast<const f32x4*>(a.Wd + (long)((iy - 1) * KS + kx) * CEXP + c0 + cc);
                 }
+            }
             }
             if (a.relu_dw) {
                 d0.x = fmaxf(d0.x, 0.f); d0.y = fmaxf(d0.y, 0.f); d0.z = fmaxf(d0.z, 0.f); d0.w = fmaxf(d0.w, 0.f);
@@ -528,13 +594,35 @@ __global__ __launch_bounds__(512) void ir16_fused_kernel(IrArgs a) {
         for (int nt = 0; nt < NTP; ++nt) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const f32x4 wp = *reinterpret_cast<const f32x4*>(a.Wp + (long)(nt * 16 + li) * CEXP + c0 + j * 16 + lk * 4);
+                f32x4 wp;
+                if (ABL & 8) wp = (f32x4){0.5f, 0.25f, 0.125f, 1.f};
+                else wp = *reinterpret_cast<const f32x4*>(a.Wp + (long)(nt * 16 + li) * CEXP + c0 + j * 16 + lk * 4);
+                if (ABL & 4) {
+                    asm volatile("" :: "v"(wp), "v"(df[0][j]), "v"(df[1][j]));
+                    continue;
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt)
                         accp[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[i], df[mt][j][i], accp[mt][nt], 0, 0, 0);
             }
+        }
+    };
+
+    // The two waves sharing a SIMD (w and w+4) run the phases of one barrier interval in opposite order, so
+    // one is on the matrix pipe (phase A / C) while the other is on the VALU + LDS (phase B).
+    const bool a_first = wave < 4;
+    for (int c = 0; c < NCHUNK; ++c) {
+        const int c0 = c * CE;
+        const float* E = lds + (c & 1) * EBUF;
+        float* En = lds + ((c + 1) & 1) * EBUF;
+        if (a_first) {
+            if (c + 1 < NCHUNK) phase_a(c0 + CE, En);
+            phase_bc(c0, E);
+        } else {
+            phase_bc(c0, E);
+            if (c + 1 < NCHUNK) phase_a(c0 + CE, En);
         }
         __syncthreads();
     }
@@ -768,6 +856,228 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_fused_kernel(IrTileArgs t) 
 template <int KS, int ST, int TW, int TH, int CE, int NBUF>
 constexpr int ir_tile_lds_bytes() {
     return NBUF * ((TH - 1) * ST + KS) * ((TW - 1) * ST + KS) * (CE + 4) * 4;
+}
+
+// ================================================================================================
+// ir16v2: same block as ir16_fused_kernel, re-engineered around what the ablation (tools/kbench.hip)
+// showed — the per-chunk global weight loads (expand / depthwise / projection weights, identical for
+// all 8 waves) were exposed latency, ~40 % of the kernel.  Now every weight a chunk needs is
+//   * pre-packed on the host per chunk, MFMA fragments in lane order (one contiguous 1 KiB ds_read_b128
+//     per fragment, conflict free),
+//   * prefetched global -> registers at the START of a barrier interval and written to a double-buffered
+//     LDS stage at its END (1-3 float4 per thread), so the HBM/L2 latency hides behind a whole interval of
+//     MFMA + VALU work,
+//   * read from LDS by every wave.
+// CE = 16 channels per chunk (one k-group), E double buffered, A-part of the weights prefetched two
+// chunks ahead, B/C-part one chunk ahead.  Packed layout per chunk (floats):
+//   A-part  (EXPAND): KG fragments x 256 (lane l: We[c0 + l&15][kg*16 + 4*(l>>4) + 0..3]) | be[16]
+//   BC-part          : NTP fragments x 256 (lane l: Wp[nt*16 + l&15][c0 + 4*(l>>4) + 0..3]) | Wd[KS*KS][16] | bd[16]
+struct Ir2Args {
+    const float* X;    // [B*256][ldx]
+    const float* Wpk;  // packed per-chunk weights (layout above), chunk stride = AP + BP floats
+    const float* bp;   // [COUT]
+    const float* R;    // residual or nullptr
+    float* Y;
+    int ldx, ldr, ldy;
+    int relu_dw, relu_out;
+};
+
+template <int CIN, int CEXP, int COUT, int KS, bool EXPAND>
+struct Ir2Geom {
+    static constexpr int CE = 16, S = 16, P = KS / 2, PW = S + 2 * P, ES = CE + 4;
+    static constexpr int NCHUNK = CEXP / CE, NTP = COUT / 16, KG = EXPAND ? CIN / 16 : 0;
+    static constexpr int AP = EXPAND ? KG * 256 + 16 : 0;
+    static constexpr int BP = NTP * 256 + KS * KS * 16 + 16;
+    static constexpr int EBUF = PW * PW * ES;
+    static constexpr int LDS_FLOATS = 2 * EBUF + 2 * AP + 2 * BP;
+    static constexpr int LDS_BYTES = LDS_FLOATS * 4;
+};
+
+template <int CIN, int CEXP, int COUT, int KS, bool EXPAND>
+__global__ __launch_bounds__(512) void ir16v2_fused_kernel(Ir2Args a) {
+    using G = Ir2Geom<CIN, CEXP, COUT, KS, EXPAND>;
+    constexpr int S = G::S, P = G::P, PW = G::PW, ES = G::ES, NCHUNK = G::NCHUNK, NTP = G::NTP, KG = G::KG;
+    constexpr int AP = G::AP, BP = G::BP, EBUF = G::EBUF, CST = AP + BP;
+    constexpr int AP4 = AP / 4, BP4 = BP / 4;                 // float4 counts
+    constexpr int NRA = (AP4 + 511) / 512, NRB = (BP4 + 511) / 512;
+    static_assert(CEXP % 16 == 0 && COUT % 16 == 0 && (!EXPAND || CIN % 16 == 0), "shape");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const Ebuf = lds;                    // [2][EBUF]
+    float* const WA = lds + 2 * EBUF;           // [2][AP]
+    float* const WB = WA + 2 * AP;              // [2][BP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const long crop = blockIdx.x;
+    const float* Xc = a.X + crop * 256 * a.ldx;
+    const int y0 = wave * 2;
+
+    for (int i = tid * 4; i < 2 * EBUF; i += 512 * 4) *reinterpret_cast<f32x4*>(lds + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 xf[EXPAND ? 2 : 1][EXPAND ? KG : 1];
+    if (EXPAND) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg)
+                xf[mt][kg] = *reinterpret_cast<const f32x4*>(Xc + (long)((y0 + mt) * S + li) * a.ldx + kg * 16 + lk * 4);
+    }
+
+    // ---- staging helpers: global -> regs (issue early), regs -> LDS (commit late)
+    f32x4 ra[EXPAND ? NRA : 2], rb[NRB];
+    auto load_a = [&](int c) {      // EXPAND: A-part of chunk c; !EXPAND: the X channels of chunk c for this lane's 2 pixels
+        if (EXPAND) {
+#pragma unroll
+            for (int r = 0; r < NRA; ++r) {
+                const int idx = tid + r * 512;
+                if (idx < AP4) ra[r] = *reinterpret_cast<const f32x4*>(a.Wpk + (long)c * CST + idx * 4);
+            }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                ra[mt] = *reinterpret_cast<const f32x4*>(Xc + (long)((y0 + mt) * S + li) * a.ldx + c * 16 + lk * 4);
+        }
+    };
+    auto store_a = [&](int c) {
+        if (EXPAND) {
+            float* dst = WA + (c & 1) * AP;
+#pragma unroll
+            for (int r = 0; r < NRA; ++r) {
+                const int idx = tid + r * 512;
+                if (idx < AP4) *reinterpret_cast<f32x4*>(dst + idx * 4) = ra[r];
+            }
+        } else {
+            float* E = Ebuf + (c & 1) * EBUF;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                *reinterpret_cast<f32x4*>(E + ((y0 + mt + P) * PW + li + P) * ES + lk * 4) = ra[mt];
+        }
+    };
+    auto load_b = [&](int c) {
+#pragma unroll
+        for (int r = 0; r < NRB; ++r) {
+            const int idx = tid + r * 512;
+            if (idx < BP4) rb[r] = *reinterpret_cast<const f32x4*>(a.Wpk + (long)c * CST + AP + idx * 4);
+        }
+    };
+    auto store_b = [&](int c) {
+        float* dst = WB + (c & 1) * BP;
+#pragma unroll
+        for (int r = 0; r < NRB; ++r) {
+            const int idx = tid + r * 512;
+            if (idx < BP4) *reinterpret_cast<f32x4*>(dst + idx * 4) = rb[r];
+        }
+    };
+
+    // phase A (EXPAND): E[c] <- relu(We_chunk . x + be) on the matrix cores, weights from LDS stage c&1
+    auto phase_a = [&](int c) {
+        const float* wa = WA + (c & 1) * AP;
+        float* E = Ebuf + (c & 1) * EBUF;
+        f32x4 acc[2];
+        acc[0] = acc[1] = *reinterpret_cast<const f32x4*>(wa + KG * 256 + lk * 4);   // bias
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) {
+            const f32x4 wf = *reinterpret_cast<const f32x4*>(wa + kg * 256 + lane * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i], xf[mt][kg][i], acc[mt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            f32x4 v = acc[mt];
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            *reinterpret_cast<f32x4*>(E + ((y0 + mt + P) * PW + li + P) * ES + lk * 4) = v;
+        }
+    };
+
+    f32x4 accp[2][NTP];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTP; ++nt) accp[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // phases B + C of chunk c: depthwise on the VALU from E[c&1], projection MFMAs, weights from WB[c&1]
+    auto phase_bc = [&](int c) {
+        const float* E = Ebuf + (c & 1) * EBUF;
+        const float* wb = WB + (c & 1) * BP;
+        const float* wd = wb + NTP * 256 + lk * 4;
+        f32x4 d0 = *reinterpret_cast<const f32x4*>(wd + KS * KS * 16);
+        f32x4 d1 = d0;
+        const float* e0 = E + (y0 * PW + li) * ES + lk * 4;
+#pragma unroll
+        for (int iy = 0; iy < KS + 1; ++iy) {
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(e0 + (iy * PW + kx) * ES);
+                if (iy < KS) d0 += v * *reinterpret_cast<const f32x4*>(wd + (iy * KS + kx) * 16);
+                if (iy >= 1) d1 += v * *reinterpret_cast<const f32x4*>(wd + ((iy - 1) * KS + kx) * 16);
+            }
+        }
+        if (a.relu_dw) {
+            d0.x = fmaxf(d0.x, 0.f); d0.y = fmaxf(d0.y, 0.f); d0.z = fmaxf(d0.z, 0.f); d0.w = fmaxf(d0.w, 0.f);
+            d1.x = fmaxf(d1.x, 0.f); d1.y = fmaxf(d1.y, 0.f); d1.z = fmaxf(d1.z, 0.f); d1.w = fmaxf(d1.w, 0.f);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTP; ++nt) {
+            const f32x4 wp = *reinterpret_cast<const f32x4*>(wb + nt * 256 + lane * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                accp[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[i], d0[i], accp[0][nt], 0, 0, 0);
+                accp[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[i], d1[i], accp[1][nt], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- prologue: stage A(0), A(1), BC(0); produce E[0]
+    load_a(0);
+    load_b(0);
+    __syncthreads();                       // zero fill done before the first E / stage writes
+    store_a(0);
+    store_b(0);
+    if (EXPAND) {
+        if (NCHUNK > 1) { load_a(1); store_a(1); }
+        __syncthreads();
+        phase_a(0);
+    }
+    __syncthreads();
+
+    const bool a_first = wave < 4;
+    for (int c = 0; c < NCHUNK; ++c) {
+        // prefetch (registers only): EXPAND: A-part two chunks ahead; !EXPAND: next chunk's activations
+        const int ca = EXPAND ? c + 2 : c + 1;
+        if (ca < NCHUNK) load_a(ca);
+        if (c + 1 < NCHUNK) load_b(c + 1);
+        if (EXPAND) {
+            if (a_first) {
+                if (c + 1 < NCHUNK) phase_a(c + 1);
+                phase_bc(c);
+            } else {
+                phase_bc(c);
+                if (c + 1 < NCHUNK) phase_a(c + 1);
+            }
+        } else {
+            phase_bc(c);
+        }
+        if (ca < NCHUNK) store_a(ca);
+        if (c + 1 < NCHUNK) store_b(c + 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int nt = 0; nt < NTP; ++nt) {
+        const int n = nt * 16 + lk * 4;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(a.bp + n);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const long m = crop * 256 + (y0 + mt) * S + li;
+            f32x4 v = accp[mt][nt] + b;
+            if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
+            if (a.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = v;
+        }
+    }
 }
 
 }  // namespace fear
