@@ -235,22 +235,21 @@ const Fused16 kFused16[] = {
 struct FusedTile {
     int cin, cexp, cout, ks, st, expand, hw;   // hw: input map size the tiling was chosen for
     int tw, th;
-    void (*kernel)(IrTileArgs);
+    void (*kernel)(IrT2Args);
     int lds_bytes;
 };
-#define FTILE(CIN, CEXP, CEXPP, COUT, KS, ST, TW, TH, CE, NBUF, EXP, MINW, HW)                                      \
-    {CIN, CEXP, COUT, KS, ST, EXP, HW, TW, TH,                                                                     \
-     ir_tile_fused_kernel<CIN, CEXP, CEXPP, COUT, KS, ST, TW, TH, CE, NBUF, (EXP) != 0, MINW>,                      \
-     ir_tile_lds_bytes<KS, ST, TW, TH, CE, NBUF>()}
+#define FTILE(CIN, CEXP, CEXPP, COUT, KS, ST, TW, TH, EXP, MINW, HW)                                             \
+    {CIN, CEXP, COUT, KS, ST, EXP, HW, TW, TH, ir_tile_v2_kernel<CIN, CEXPP, COUT, KS, ST, TW, TH, (EXP) != 0, MINW>, \
+     IrT2Geom<CIN, CEXPP, COUT, KS, ST, TW, TH, (EXP) != 0>::LDS_BYTES}
 const FusedTile kFusedTile[] = {
-    FTILE(16, 16, 16, 16, 3, 1, 32, 16, 16, 1, 0, 4, 128),    // fbnet_c stage 1  (e1, 128x128)
-    FTILE(16, 96, 96, 24, 3, 2, 16, 8, 16, 1, 1, 4, 128),     // stage 2          (e6 s2, 128 -> 64)
-    FTILE(24, 24, 32, 24, 3, 1, 16, 16, 32, 1, 0, 4, 64),     // stages 4, 5      (e1, 64x64)
-    FTILE(24, 144, 144, 32, 5, 2, 16, 8, 16, 1, 1, 4, 64),    // stage 6          (e6 s2, 64 -> 32)
-    FTILE(32, 96, 96, 32, 5, 1, 16, 16, 16, 1, 1, 2, 32),     // stage 7  (4 corner tiles: 18x18 clipped region)
-    FTILE(32, 192, 192, 32, 5, 1, 16, 16, 16, 1, 1, 2, 32),   // stage 8
-    FTILE(32, 192, 192, 32, 3, 1, 32, 16, 16, 1, 1, 2, 32),   // stage 9
-    FTILE(32, 192, 192, 64, 5, 2, 16, 8, 16, 1, 1, 2, 32),    // stage 10         (e6 s2, 32 -> 16)
+    FTILE(16, 16, 16, 16, 3, 1, 32, 16, 0, 4, 128),    // fbnet_c stage 1  (e1, 128x128)
+    FTILE(16, 96, 96, 24, 3, 2, 16, 8, 1, 4, 128),     // stage 2          (e6 s2, 128 -> 64)
+    FTILE(24, 24, 32, 24, 3, 1, 16, 16, 0, 4, 64),     // stages 4, 5      (e1, 64x64; 24 channels padded to 32)
+    FTILE(24, 144, 144, 32, 5, 2, 16, 8, 1, 4, 64),    // stage 6          (e6 s2, 64 -> 32)
+    FTILE(32, 96, 96, 32, 5, 1, 16, 16, 1, 2, 32),     // stage 7  (4 corner tiles: 18x18 clipped region)
+    FTILE(32, 192, 192, 32, 5, 1, 16, 16, 1, 2, 32),   // stage 8
+    FTILE(32, 192, 192, 32, 3, 1, 32, 16, 1, 2, 32),   // stage 9
+    FTILE(32, 192, 192, 64, 5, 2, 16, 8, 1, 2, 32),    // stage 10         (e6 s2, 32 -> 16)
 };
 int find_fused_tile(int cin, int cexp, int cout, int ks, int st, int expand, int hw) {
     for (size_t i = 0; i < sizeof(kFusedTile) / sizeof(kFusedTile[0]); ++i) {
@@ -280,23 +279,28 @@ int pack_fused16(fear_handle* h, int ce, int cd, int cp, float** out) {
     const Conv* e = ce >= 0 ? &h->convs[ce] : nullptr;
     const int cexp = d.cout, cout = p.cout, kk = d.k * d.k;
     const int cin = e ? e->cin_g : cexp;
-    const int kg_n = e ? cin / 16 : 0, ntp = cout / 16;
+    const int kg_n = e ? (cin + 15) / 16 : 0, ntp = (cout + 15) / 16;
+    const int cexpp = (cexp + 15) / 16 * 16;       // channels / rows beyond the real extent are packed as zeros
     std::vector<float> buf;
-    for (int c0 = 0; c0 < cexp; c0 += 16) {
+    for (int c0 = 0; c0 < cexpp; c0 += 16) {
         if (e) {
             for (int kg = 0; kg < kg_n; ++kg)
                 for (int l = 0; l < 64; ++l)
-                    for (int i = 0; i < 4; ++i)
-                        buf.push_back(e->w[(size_t)(c0 + (l & 15)) * cin + kg * 16 + (l >> 4) * 4 + i]);
-            for (int ch = 0; ch < 16; ++ch) buf.push_back(e->has_bias ? e->b[c0 + ch] : 0.f);
+                    for (int i = 0; i < 4; ++i) {
+                        const int n = c0 + (l & 15), k = kg * 16 + (l >> 4) * 4 + i;
+                        buf.push_back(n < cexp && k < cin ? e->w[(size_t)n * cin + k] : 0.f);
+                    }
+            for (int ch = 0; ch < 16; ++ch) buf.push_back(e->has_bias && c0 + ch < cexp ? e->b[c0 + ch] : 0.f);
         }
         for (int nt = 0; nt < ntp; ++nt)
             for (int l = 0; l < 64; ++l)
-                for (int i = 0; i < 4; ++i)
-                    buf.push_back(p.w[(size_t)(nt * 16 + (l & 15)) * cexp + c0 + (l >> 4) * 4 + i]);
+                for (int i = 0; i < 4; ++i) {
+                    const int n = nt * 16 + (l & 15), k = c0 + (l >> 4) * 4 + i;
+                    buf.push_back(n < cout && k < cexp ? p.w[(size_t)n * cexp + k] : 0.f);
+                }
         for (int t = 0; t < kk; ++t)
-            for (int ch = 0; ch < 16; ++ch) buf.push_back(d.w[(size_t)(c0 + ch) * kk + t]);
-        for (int ch = 0; ch < 16; ++ch) buf.push_back(d.has_bias ? d.b[c0 + ch] : 0.f);
+            for (int ch = 0; ch < 16; ++ch) buf.push_back(c0 + ch < cexp ? d.w[(size_t)(c0 + ch) * kk + t] : 0.f);
+        for (int ch = 0; ch < 16; ++ch) buf.push_back(d.has_bias && c0 + ch < cexp ? d.b[c0 + ch] : 0.f);
     }
     return upload(h, buf, out);
 }
@@ -410,8 +414,10 @@ int build_plan(fear_handle* h, int hw, bool with_head, Plan** out) {
         const FusedTile& f = kFusedTile[id];
         const int ho = in.H / d.stride;
         if (ho % f.th != 0 || ho % f.tw != 0) return false;
+        if (!p.has_bias) return false;
         Op op{};
         op.type = OP_IRTILE; op.fused_id = id; op.conv_e = ce; op.conv_d = cd; op.conv_p = cp;
+        if (pack_fused16(h, ce, cd, cp, &op.d_packed) != FEAR_OK) return false;
         op.in_buf = in.buf; op.in_ld = in.ld; op.in_off = in.off;
         op.H = in.H; op.W = in.W; op.Ho = ho; op.Wo = ho; op.C = cin; op.N = p.cout;
         op.relu_dw = 1; op.relu = 0;
@@ -728,13 +734,10 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s) {
             }
             case OP_IRTILE: {
                 const FusedTile& f = kFusedTile[op.fused_id];
-                const Conv& cd = h->convs[op.conv_d];
-                const Conv& cp = h->convs[op.conv_p];
-                IrTileArgs ta{};
-                IrArgs& a = ta.b;
+                IrT2Args ta{};
+                Ir2Args& a = ta.b;
                 a.X = buf(op.in_buf) + op.in_off; a.ldx = op.in_ld;
-                if (op.conv_e >= 0) { a.We = h->convs[op.conv_e].d_w; a.be = h->convs[op.conv_e].d_b; }
-                a.Wd = cd.d_w; a.bd = cd.d_b; a.Wp = cp.d_w; a.bp = cp.d_b;
+                a.Wpk = op.d_packed; a.bp = h->convs[op.conv_p].d_b;
                 a.R = op.res_buf >= 0 ? buf(op.res_buf) : nullptr; a.ldr = op.res_ld;
                 a.Y = buf(op.out_buf); a.ldy = op.out_ld;
                 a.relu_dw = op.relu_dw; a.relu_out = op.relu;

@@ -1080,4 +1080,205 @@ __global__ __launch_bounds__(512) void ir16v2_fused_kernel(Ir2Args a) {
     }
 }
 
+// ================================================================================================
+// Tiled fused block kernel, v2: ir_tile_fused_kernel with the ir16v2 weight path — per-chunk host-packed
+// fragments (zero padded where CIN / COUT / CEXP are not multiples of 16), prefetched global -> registers
+// during chunk c and committed to the alternate LDS stage before the chunk's last barrier.  CE = 16,
+// single E tile (so several workgroups fit a CU and overlap each other's phases and HBM traffic).
+template <int CIN, int CEXPP, int COUT, int KS, int ST, int TW, int TH, bool EXPAND>
+struct IrT2Geom {
+    static constexpr int CE = 16, P = KS / 2, IWR = (TW - 1) * ST + KS, IHR = (TH - 1) * ST + KS, ES = CE + 4;
+    static constexpr int SEG = TW / 16, NMT_OUT = TH * SEG, MTC = NMT_OUT / 8;
+    static constexpr int NMT_IN_MAX = (IHR * IWR + 15) / 16, MTA = (NMT_IN_MAX + 7) / 8;
+    static constexpr int NCHUNK = CEXPP / CE, NTP = (COUT + 15) / 16, KG = EXPAND ? (CIN + 15) / 16 : 0;
+    static constexpr int AP = EXPAND ? KG * 256 + 16 : 0;
+    static constexpr int BP = NTP * 256 + KS * KS * 16 + 16;
+    static constexpr int EBUF = IHR * IWR * ES;
+    static constexpr int LDS_BYTES = (EBUF + 2 * (AP + BP)) * 4;
+};
+
+struct IrT2Args {
+    Ir2Args b;
+    int H, W, tiles_x, tiles_y;
+};
+
+template <int CIN, int CEXPP, int COUT, int KS, int ST, int TW, int TH, bool EXPAND, int MINW>
+__global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
+    using G = IrT2Geom<CIN, CEXPP, COUT, KS, ST, TW, TH, EXPAND>;
+    const Ir2Args& a = t.b;
+    constexpr int P = G::P, IWR = G::IWR, IHR = G::IHR, ES = G::ES, SEG = G::SEG, MTC = G::MTC, MTA = G::MTA;
+    constexpr int NCHUNK = G::NCHUNK, NTP = G::NTP, KG = G::KG, AP = G::AP, BP = G::BP, EBUF = G::EBUF;
+    constexpr int CST = AP + BP, W4 = CST / 4, NRW = (W4 + 511) / 512;
+    static_assert(G::NMT_OUT % 8 == 0 && (SEG == 1 || SEG == 2), "tile shape");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const E = lds;               // [EBUF]
+    float* const WS = lds + EBUF;       // [2][AP + BP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int tiles = t.tiles_x * t.tiles_y;
+    const long crop = blockIdx.x / tiles;
+    const int tile = blockIdx.x % tiles;
+    const int ox0 = (tile % t.tiles_x) * TW, oy0 = (tile / t.tiles_x) * TH;
+    const int ix0 = ox0 * ST - P, iy0 = oy0 * ST - P;
+    const int cx_lo = max(ix0, 0), cy_lo = max(iy0, 0);
+    const int CW = min(ix0 + IWR, t.W) - cx_lo, CH = min(iy0 + IHR, t.H) - cy_lo;
+    const int NPIX = CW * CH;
+    const int Wo = t.W / ST, Ho = t.H / ST;
+    const float* Xc = a.X + crop * t.H * t.W * a.ldx;
+
+    for (int i = tid * 4; i < EBUF; i += 512 * 4) *reinterpret_cast<f32x4*>(E + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // weights of chunk 0 -> registers (committed after the zero-fill barrier)
+    f32x4 rw[NRW];
+    auto load_w = [&](int c) {
+#pragma unroll
+        for (int r = 0; r < NRW; ++r) {
+            const int idx = tid + r * 512;
+            if (idx < W4) rw[r] = *reinterpret_cast<const f32x4*>(a.Wpk + (long)c * CST + idx * 4);
+        }
+    };
+    auto store_w = [&](int c) {
+        float* dst = WS + (c & 1) * CST;
+#pragma unroll
+        for (int r = 0; r < NRW; ++r) {
+            const int idx = tid + r * 512;
+            if (idx < W4) *reinterpret_cast<f32x4*>(dst + idx * 4) = rw[r];
+        }
+    };
+    load_w(0);
+
+    int eoff[MTA];
+    long xoff[MTA];
+    f32x4 xf[EXPAND ? MTA : 1][EXPAND ? KG : 1];
+#pragma unroll
+    for (int i = 0; i < MTA; ++i) {
+        const int q = (wave + 8 * i) * 16 + li;
+        const bool valid = q < NPIX;
+        const int qq = valid ? q : 0;
+        const int cy = qq / CW, cx = qq - cy * CW;
+        const int gy = cy_lo + cy, gx = cx_lo + cx;
+        eoff[i] = valid ? ((gy - iy0) * IWR + (gx - ix0)) * ES : -1;
+        xoff[i] = ((long)gy * t.W + gx) * a.ldx;
+        if (EXPAND) {
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg) {
+                xf[i][kg] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (kg * 16 + lk * 4 < CIN) xf[i][kg] = *reinterpret_cast<const f32x4*>(Xc + xoff[i] + kg * 16 + lk * 4);
+            }
+        }
+    }
+    // !EXPAND: activations of the next chunk are prefetched into registers as well
+    f32x4 rx[EXPAND ? 1 : MTA];
+    auto load_x = [&](int c) {
+        if (!EXPAND) {
+#pragma unroll
+            for (int i = 0; i < MTA; ++i) {
+                rx[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (c * 16 + lk * 4 < CIN) rx[i] = *reinterpret_cast<const f32x4*>(Xc + xoff[i] + c * 16 + lk * 4);
+            }
+        }
+    };
+    load_x(0);
+    __syncthreads();
+    store_w(0);
+
+    const int seg = SEG == 1 ? 0 : (wave & 1);
+    const int r0 = (SEG == 1 ? wave : (wave >> 1)) * MTC;
+    f32x4 accp[MTC][NTP];
+#pragma unroll
+    for (int r = 0; r < MTC; ++r)
+#pragma unroll
+        for (int nt = 0; nt < NTP; ++nt) accp[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int c = 0; c < NCHUNK; ++c) {
+        const float* wa = WS + (c & 1) * CST;
+        const float* wb = wa + AP;
+        if (EXPAND) __syncthreads();          // stage c&1 committed (first chunk: by store_w(0) above)
+        // ---- phase A: E <- relu(expand) (or the raw activations)
+        if (EXPAND) {
+            f32x4 wf[KG > 0 ? KG : 1];
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg) wf[kg] = *reinterpret_cast<const f32x4*>(wa + kg * 256 + lane * 4);
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(wa + KG * 256 + lk * 4);
+#pragma unroll
+            for (int i = 0; i < MTA; ++i) {
+                if ((wave + 8 * i) * 16 >= NPIX) break;
+                f32x4 acc = bias;
+#pragma unroll
+                for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kg][q], xf[i][kg][q], acc, 0, 0, 0);
+                acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+                if (eoff[i] >= 0) *reinterpret_cast<f32x4*>(E + eoff[i] + lk * 4) = acc;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MTA; ++i) {
+                if ((wave + 8 * i) * 16 >= NPIX) break;
+                if (eoff[i] >= 0) *reinterpret_cast<f32x4*>(E + eoff[i] + lk * 4) = rx[i];
+            }
+        }
+        // prefetch the next chunk's weights (and activations) while this chunk computes
+        if (c + 1 < NCHUNK) { load_w(c + 1); load_x(c + 1); }
+        __syncthreads();
+        // ---- phase B: depthwise from E, weights from the LDS stage
+        f32x4 d[MTC];
+        {
+            const float* wd = wb + NTP * 256 + lk * 4;
+            const f32x4 bd = *reinterpret_cast<const f32x4*>(wd + KS * KS * 16);
+#pragma unroll
+            for (int r = 0; r < MTC; ++r) d[r] = bd;
+            const float* Ebase = E + ((r0 * ST) * IWR + (seg * 16 + li) * ST) * ES + lk * 4;
+#pragma unroll
+            for (int iy = 0; iy < (MTC - 1) * ST + KS; ++iy) {
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(Ebase + (iy * IWR + kx) * ES);
+#pragma unroll
+                    for (int r = 0; r < MTC; ++r) {
+                        const int ky = iy - r * ST;
+                        if (ky >= 0 && ky < KS) d[r] += v * *reinterpret_cast<const f32x4*>(wd + (ky * KS + kx) * 16);
+                    }
+                }
+            }
+            if (a.relu_dw) {
+#pragma unroll
+                for (int r = 0; r < MTC; ++r) {
+                    d[r].x = fmaxf(d[r].x, 0.f); d[r].y = fmaxf(d[r].y, 0.f); d[r].z = fmaxf(d[r].z, 0.f); d[r].w = fmaxf(d[r].w, 0.f);
+                }
+            }
+        }
+        // ---- phase C: projection
+#pragma unroll
+        for (int nt = 0; nt < NTP; ++nt) {
+            const f32x4 wp = *reinterpret_cast<const f32x4*>(wb + nt * 256 + lane * 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < MTC; ++r)
+                    accp[r][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[q], d[r][q], accp[r][nt], 0, 0, 0);
+        }
+        if (c + 1 < NCHUNK) store_w(c + 1);
+        if (!EXPAND || c + 1 == NCHUNK) __syncthreads();   // E is rewritten next chunk (EXPAND syncs at loop top)
+    }
+
+#pragma unroll
+    for (int nt = 0; nt < NTP; ++nt) {
+        const int n = nt * 16 + lk * 4;
+        if (n >= COUT) continue;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(a.bp + n);
+#pragma unroll
+        for (int r = 0; r < MTC; ++r) {
+            const int oy = oy0 + r0 + r, ox = ox0 + seg * 16 + li;
+            const long m = (crop * Ho + oy) * Wo + ox;
+            f32x4 v = accp[r][nt] + b;
+            if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
+            if (a.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = v;
+        }
+    }
+}
+
 }  // namespace fear
