@@ -79,6 +79,27 @@ def cpu_baseline(search_u8, tmpl_u8, weights, budget_s: float = 15.0):
             "sample": f"{crops} crops (batches of {bs}) of the same synthetic 256x256 workload, torch fp32 oracle, {dt:.1f}s"}
 
 
+def pmc_traffic(op_name: str):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
+    command (profiles/rNN_traffic.json via tools/pmc_to_traffic.py; op -> kernel symbol via rNN_per_op.csv).
+    PMC counters cannot be collected from inside the timed run, so this is the offline measurement or null."""
+    import csv
+    import glob
+    try:
+        per_op = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_per_op.csv")))[-1]
+        traffic = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]
+        sym = None
+        with open(per_op) as fh:
+            for r in csv.DictReader(fh):
+                if r["name"] == op_name:
+                    sym = r["kernel"]
+                    break
+        t = json.load(open(traffic))
+        return t[sym]["traffic_bytes_per_launch"] if sym in t else None
+    except Exception:
+        return None
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,7 +162,14 @@ def main() -> None:
     per_op = [(ms / max(cnt, 1), cnt) for ms, cnt in prof]
     launches_per_step = [cnt / n_prof for _, cnt in prof]
     op_time = [per_op[i][0] * launches_per_step[i] for i in range(len(plan))]
-    dom = max(range(len(plan)), key=lambda i: op_time[i])
+    # ops with the same name run the same kernel symbol on the same shape (what rocprofv3 --stats groups):
+    # the dominant kernel is the name group with the largest share of the step
+    group_time = {}
+    for i, (nm, _, _) in enumerate(plan):
+        group_time[nm] = group_time.get(nm, 0.0) + op_time[i]
+    dom_name = max(group_time, key=group_time.get)
+    dom_ops = [i for i, (nm, _, _) in enumerate(plan) if nm == dom_name]
+    dom = dom_ops[0]
     if args.dump_ops and rank == 0:
         tot = sum(op_time)
         for i, (name, fl, by) in enumerate(plan):
@@ -164,7 +192,9 @@ def main() -> None:
     barrier()
     elapsed = time.perf_counter() - t0
     net.set_profile(False)
-    dom_ms, dom_cnt = net.profile_read(256, True)[dom]
+    reads = net.profile_read(256, True)
+    dom_ms = sum(reads[i][0] for i in dom_ops)
+    dom_cnt = sum(reads[i][1] for i in dom_ops)
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -176,7 +206,7 @@ def main() -> None:
         value = total_crops / elapsed
         name, fl, by = plan[dom]
         avg_ms = dom_ms / max(dom_cnt, 1)
-        crops_per_launch = B * args.steps / max(dom_cnt, 1)
+        crops_per_launch = B * args.steps * len(dom_ops) / max(dom_cnt, 1)
         ai = fl / by
         ridge = PEAK_FP32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
         if ai >= ridge:
@@ -187,8 +217,9 @@ def main() -> None:
             achieved = by * crops_per_launch / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": achieved / PEAK_HBM_GBS}
-        roof.update({"traffic": None, "kernel": name, "avg_launch_ms": avg_ms, "launches": dom_cnt,
-                     "share_of_step": op_time[dom] / max(sum(op_time), 1e-12),
+        roof.update({"traffic": pmc_traffic(name), "kernel": name, "avg_launch_ms": avg_ms, "launches": dom_cnt,
+                     "launches_per_step": len(dom_ops) * max(1, -(-B // args.max_batch)),
+                     "share_of_step": group_time[dom_name] / max(sum(op_time), 1e-12),
                      "whole_path_tflops": value * FLOPS_PER_CROP / 1e12 / world,
                      "whole_path_frac_of_fp32_peak": value * FLOPS_PER_CROP / 1e12 / world / PEAK_FP32_MFMA_TFLOPS})
         out = {

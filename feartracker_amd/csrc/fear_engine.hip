@@ -659,7 +659,9 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s) {
     for (Op& op : p.ops) {
         ++op_index;
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        const bool prof = h->profile && (h->profile_op < 0 || h->profile_op == op_index);
+        // a selected op also selects every op with the same name (= same kernel symbol and shape)
+        const bool prof = h->profile && (h->profile_op < 0 || h->profile_op == op_index ||
+                                         (h->profile_op < (int)p.ops.size() && !strcmp(p.ops[h->profile_op].name, op.name)));
         if (prof) {
             HIP_TRY(h, hipEventCreate(&e0));
             HIP_TRY(h, hipEventCreate(&e1));

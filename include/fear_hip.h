@@ -78,7 +78,7 @@ int fear_normalize_u8(fear_handle* h, const uint8_t* u8, int n, int hw, float* o
 /* ---- engine options ------------------------------------------------------------------------- */
 #define FEAR_OPT_MAX_BATCH 1   /* crops processed per internal pass (workspace is sized for it)  */
 #define FEAR_OPT_PROFILE 2     /* 1: bracket kernel launches with hipEvents (fear_profile_*)     */
-#define FEAR_OPT_PROFILE_OP 3  /* -1: profile every op of a plan; i >= 0: only op i             */
+#define FEAR_OPT_PROFILE_OP 3  /* -1: every op of a plan; i >= 0: op i and all ops sharing its name */
 #define FEAR_OPT_FUSE 4        /* 1 (default): fused block kernels; 0: one kernel per conv layer  */
 int fear_set_option(fear_handle* h, int option, int64_t value);
 int64_t fear_get_option(fear_handle* h, int option);
