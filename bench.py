@@ -108,6 +108,8 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=256, help="search crops per GPU per step")
     ap.add_argument("--max-batch", type=int, default=int(os.environ.get("FEAR_MAX_BATCH", "256")),
                     help="crops per internal engine pass (workspace / cache footprint)")
+    ap.add_argument("--math", type=int, default=int(os.environ.get("FEAR_MATH", "0")), choices=[0, 1],
+                    help="0: fp32 MFMA (exact fp32, default); 1: fp16 hi+lo split operands on the matrix pipe, fp32 accumulate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump-ops", action="store_true", help="print the per-kernel time table to stderr")
     args = ap.parse_args()
@@ -130,6 +132,7 @@ def main() -> None:
 
     B = args.batch
     net = FEARNetHIP(DEFAULT_WEIGHTS, device=local_rank, max_batch=args.max_batch)
+    net.set_math(args.math)
     search_u8, tmpl_u8 = synth_batch(B, rank)
     search = norm_u8(search_u8.to(dev)).contiguous()
     tmpl_feats = net.get_features(norm_u8(tmpl_u8.to(dev)).contiguous())
@@ -238,7 +241,10 @@ def main() -> None:
             "config": {"workload": f"FEAR-XS track(): batch={B} synthetic 256x256 search / 128x128 template crops per GPU, fp32"
                                    + (f", sharded over {world} GPUs + 1 RCCL all-gather of (B,5,16,16) maps" if world > 1 else ""),
                        "batch_per_gpu": B, "global_batch": world * B, "weights": "FEAR-XS-NoEmbs (fp16 values upcast to fp32)",
-                       "engine_pass": args.max_batch, "parallelism": f"dp{world}"},
+                       "engine_pass": args.max_batch, "parallelism": f"dp{world}",
+                       "math": ("fp32 MFMA (v_mfma_f32_16x16x4_f32), exact fp32" if args.math == 0 else
+                                "pointwise convs of the fused 16x16 blocks: fp32 activations split into fp16 hi+lo, exact-fp16 "
+                                "weights, v_mfma_f32_16x16x32_f16, fp32 accumulate; everything else fp32")},
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:

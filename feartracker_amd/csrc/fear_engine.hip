@@ -49,6 +49,29 @@ float half_to_float(uint16_t h) {
     return f;
 }
 
+uint16_t float_to_half(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    const int32_t e = (int32_t)((x >> 23) & 0xff) - 127 + 15;
+    uint32_t man = x & 0x7fffffu;
+    if (((x >> 23) & 0xff) == 0xff) return (uint16_t)(sign | 0x7c00u | (man ? 0x200u : 0));
+    if (e >= 31) return (uint16_t)(sign | 0x7c00u);
+    if (e <= 0) {
+        if (e < -10) return (uint16_t)sign;
+        man |= 0x800000u;
+        const int shift = 14 - e;
+        uint32_t h = man >> shift;
+        const uint32_t rem = man & ((1u << shift) - 1), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (h & 1))) ++h;
+        return (uint16_t)(sign | h);
+    }
+    uint32_t h = ((uint32_t)e << 10) | (man >> 13);
+    const uint32_t rem = man & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1))) ++h;
+    return (uint16_t)(sign | h);
+}
+
 struct Conv {
     int cout, cin_g, groups, k, stride, pad, relu, has_bias;
     std::vector<float> w;  // OIHW fp32
@@ -80,6 +103,7 @@ struct Op {
     int relu_dw = 0;
     int fused_id = -1;        // OP_IR16: index into the fused-kernel table
     float* d_packed = nullptr; // OP_IR16: per-chunk packed weights (Ir2Geom layout), owned by the handle
+    int math = 0;              // OP_IR16: 1 = fp16-split matrix-pipe kernel
     char name[64];
     double flops = 0, bytes = 0;  // per crop: algorithmic FLOPs, compulsory bytes (in + out + weights excluded)
     // profiling
@@ -108,6 +132,7 @@ struct fear_handle {
     int profile = 0;
     int profile_op = -1;   // -1: every op, else only this op index of each plan
     int fuse = 1;          // 1: use the fused block kernels where an instantiation exists
+    int math = 0;          // 0: fp32 MFMA everywhere; 1: fp16-split operands on the matrix pipe in the fused 16x16 blocks
     bool fused_attr_set = false;
     int last_hip_error = 0;
     std::map<std::pair<int, int>, std::unique_ptr<Plan>> plans;
@@ -261,6 +286,16 @@ int find_fused_tile(int cin, int cexp, int cout, int ks, int st, int expand, int
     return -1;
 }
 
+#define FUSED16H(CIN, CEXP, COUT, KS, EXP) \
+    {CIN, CEXP, COUT, KS, EXP, ir16h_fused_kernel<CIN, CEXP, COUT, KS, (EXP) != 0>, IrHGeom<CIN, CEXP, COUT, KS, (EXP) != 0>::LDS_BYTES}
+// same shapes as kFused16, fp16-split operands on the matrix pipe (FEAR_OPT_MATH = 1)
+const Fused16 kFused16H[] = {
+    FUSED16H(64, 192, 64, 5, 1),   FUSED16H(64, 384, 64, 5, 1),  FUSED16H(64, 384, 112, 5, 1),
+    FUSED16H(112, 672, 112, 5, 1), FUSED16H(112, 336, 112, 5, 1),
+    FUSED16H(256, 256, 256, 3, 0), FUSED16H(320, 320, 256, 3, 0),
+};
+static_assert(sizeof(kFused16H) == sizeof(kFused16), "the two tables must list the same shapes in the same order");
+
 int find_fused16(int cin, int cexp, int cout, int ks, int expand) {
     for (size_t i = 0; i < sizeof(kFused16) / sizeof(kFused16[0]); ++i) {
         const Fused16& f = kFused16[i];
@@ -301,6 +336,46 @@ int pack_fused16(fear_handle* h, int ce, int cd, int cp, float** out) {
         for (int t = 0; t < kk; ++t)
             for (int ch = 0; ch < 16; ++ch) buf.push_back(c0 + ch < cexp ? d.w[(size_t)(c0 + ch) * kk + t] : 0.f);
         for (int ch = 0; ch < 16; ++ch) buf.push_back(d.has_bias && c0 + ch < cexp ? d.b[c0 + ch] : 0.f);
+    }
+    return upload(h, buf, out);
+}
+
+
+// Packed weights for the matrix-pipe (fp16-split) fused kernels, per 32-channel chunk (IrHGeom layout):
+//   [A-part: 2 n-tiles x KG32 fragments of 64 lanes x 8 halfs | be[32] fp32]
+//   [BC-part: NTP fragments | Wd[k*k][32] fp32 | bd[32] fp32]
+// The model's weights are fp16 values, so the fp32 -> fp16 conversion here is exact.
+int pack_fused_h(fear_handle* h, int ce, int cd, int cp, float** out) {
+    const Conv& d = h->convs[cd];
+    const Conv& p = h->convs[cp];
+    const Conv* e = ce >= 0 ? &h->convs[ce] : nullptr;
+    const int cexp = d.cout, cout = p.cout, kk = d.k * d.k;
+    const int cin = e ? e->cin_g : cexp;
+    const int kg_n = e ? (cin + 31) / 32 : 0, ntp = (cout + 15) / 16;
+    const int cexpp = (cexp + 31) / 32 * 32;
+    std::vector<float> buf;
+    auto push_frag = [&](const std::vector<float>& w, int rows, int cols, int row0, int col0) {
+        for (int l = 0; l < 64; ++l) {
+            uint16_t hv[8];
+            for (int j = 0; j < 8; ++j) {
+                const int r = row0 + (l & 15), c = col0 + (l >> 4) * 8 + j;
+                hv[j] = float_to_half(r < rows && c < cols ? w[(size_t)r * cols + c] : 0.f);
+            }
+            float f4[4];
+            memcpy(f4, hv, 16);
+            buf.insert(buf.end(), f4, f4 + 4);
+        }
+    };
+    for (int c0 = 0; c0 < cexpp; c0 += 32) {
+        if (e) {
+            for (int nt = 0; nt < 2; ++nt)
+                for (int kg = 0; kg < kg_n; ++kg) push_frag(e->w, cexp, cin, c0 + nt * 16, kg * 32);
+            for (int ch = 0; ch < 32; ++ch) buf.push_back(e->has_bias && c0 + ch < cexp ? e->b[c0 + ch] : 0.f);
+        }
+        for (int nt = 0; nt < ntp; ++nt) push_frag(p.w, cout, cexp, nt * 16, c0);
+        for (int t = 0; t < kk; ++t)
+            for (int ch = 0; ch < 32; ++ch) buf.push_back(c0 + ch < cexp ? d.w[(size_t)(c0 + ch) * kk + t] : 0.f);
+        for (int ch = 0; ch < 32; ++ch) buf.push_back(d.has_bias && c0 + ch < cexp ? d.b[c0 + ch] : 0.f);
     }
     return upload(h, buf, out);
 }
@@ -389,7 +464,9 @@ int build_plan(fear_handle* h, int hw, bool with_head, Plan** out) {
         if (!p.has_bias) return false;
         Op op{};
         op.type = OP_IR16; op.fused_id = id; op.conv_e = ce; op.conv_d = cd; op.conv_p = cp;
-        if (pack_fused16(h, ce, cd, cp, &op.d_packed) != FEAR_OK) return false;
+        op.math = h->math;
+        if ((h->math ? pack_fused_h(h, ce, cd, cp, &op.d_packed) : pack_fused16(h, ce, cd, cp, &op.d_packed)) != FEAR_OK)
+            return false;
         op.in_buf = in.buf; op.in_ld = in.ld; op.in_off = in.off;
         op.H = 16; op.W = 16; op.Ho = 16; op.Wo = 16; op.C = cin; op.N = p.cout;
         op.relu_dw = relu_dw; op.relu = relu_out;
@@ -648,6 +725,9 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s) {
         for (const Fused16& f : kFused16)
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(f.kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, f.lds_bytes));
+        for (const Fused16& f : kFused16H)
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(f.kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, f.lds_bytes));
         for (const FusedTile& f : kFusedTile)
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(f.kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, f.lds_bytes));
@@ -724,7 +804,7 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s) {
                 break;
             }
             case OP_IR16: {
-                const Fused16& f = kFused16[op.fused_id];
+                const Fused16& f = op.math ? kFused16H[op.fused_id] : kFused16[op.fused_id];
                 Ir2Args a{};
                 a.X = buf(op.in_buf) + op.in_off; a.ldx = op.in_ld;
                 a.Wpk = op.d_packed; a.bp = h->convs[op.conv_p].d_b;
@@ -851,6 +931,10 @@ int fear_set_option(fear_handle* h, int option, int64_t value) {
             if (value != 0 && value != 1) return FEAR_ERR_SHAPE;
             if (h->fuse != (int)value) { h->fuse = (int)value; h->plans.clear(); }
             return FEAR_OK;
+        case FEAR_OPT_MATH:
+            if (value != 0 && value != 1) return FEAR_ERR_SHAPE;
+            if (h->math != (int)value) { h->math = (int)value; h->plans.clear(); }
+            return FEAR_OK;
         default: return FEAR_ERR_SHAPE;
     }
 }
@@ -862,6 +946,7 @@ int64_t fear_get_option(fear_handle* h, int option) {
         case FEAR_OPT_PROFILE: return h->profile;
         case FEAR_OPT_PROFILE_OP: return h->profile_op;
         case FEAR_OPT_FUSE: return h->fuse;
+        case FEAR_OPT_MATH: return h->math;
         default: return FEAR_ERR_SHAPE;
     }
 }

@@ -440,426 +440,23 @@ __global__ __launch_bounds__(256) void normalize_kernel(NormArgs a) {
 }
 
 // ================================================================================================
-// Fused block kernel for 16x16 feature maps (FBNet inverted-residual blocks at stride 16 and the
-// separable-conv stages of BoxTower): one workgroup (8 wavefronts) owns one crop's whole 16x16 map, so
-// the depthwise halo is plain zero padding and nothing is recomputed.
+// Fused block kernels.  (The first generation — ir16_fused_kernel / ir_tile_fused_kernel, weights loaded from
+// global per chunk — was replaced by the v2 kernels below after the tools/kbench.hip ablation; see DESIGN.md.)
 //
 //   IR block (EXPAND):   y = [x +] P( relu( D( relu( E(x) ) ) ) )      E: 1x1 CIN->CEXP, D: depthwise KSxKS,
 //   SepConv (!EXPAND):   y = act( P( D(x) ) )                           P: 1x1 CEXP->COUT
 //
-// The expanded tensor never leaves the CU: it is produced CE channels at a time by MFMA (phase A) into a
+// The expanded tensor never leaves the CU: it is produced 16 channels at a time by MFMA (phase A) into a
 // zero-ringed LDS tile, consumed by the depthwise conv on the VALU (phase B) whose float4 results are —
 // by construction of the lane mapping — already the B-operand fragments of the projection MFMAs
-// (phase C), which accumulate over the chunks in registers.  The LDS tile is double buffered: phase A
-// of chunk c+1 is issued in the same barrier interval as phases B/C of chunk c, so matrix-core and VALU
-// work of one wave can overlap and there is one s_barrier per chunk.
+// (phase C), which accumulate over the chunks in registers.
 //
-// Lane mapping (wave w of 8, lane l): li = l&15 = pixel column x, lk = l>>4; the wave owns rows 2w, 2w+1
-// (= MFMA pixel tiles).  MFMA 16x16x4 f32 fragments as in pw_mfma_kernel (weights = A operand).
-struct IrArgs {
-    const float* X;   // [B*256][ldx]
-    const float* We;  // [CEXP][CIN]            (EXPAND)
-    const float* be;  // [CEXP]                 (EXPAND)
-    const float* Wd;  // [KS*KS][CEXP] tap-major
-    const float* bd;  // [CEXP] or nullptr
-    const float* Wp;  // [COUT][CEXP]
-    const float* bp;  // [COUT]
-    const float* R;   // residual [B*256][ldr] or nullptr
-    float* Y;         // [B*256][ldy]
-    int ldx, ldr, ldy;
-    int relu_dw, relu_out;
-};
-
-// ABL: ablation bits for tools/kbench.hip only (0 in the product): 1 skip expand MFMAs, 2 skip depthwise math,
-// 4 skip projection MFMAs, 8 skip the weight/activation global loads of phase A/C (use constants).
-template <int CIN, int CEXP, int COUT, int KS, int CE, bool EXPAND, int ABL = 0>
-__global__ __launch_bounds__(512) void ir16_fused_kernel(IrArgs a) {
-    constexpr int S = 16, P = KS / 2, PW = S + 2 * P, ES = CE + 4, NJ = CE / 16;
-    constexpr int NCHUNK = CEXP / CE, NTP = COUT / 16, KG = CIN / 16;
-    static_assert(CEXP % CE == 0 && COUT % 16 == 0 && (CE == 16 || CE == 32), "shape");
-    static_assert(!EXPAND || CIN % 16 == 0, "CIN");
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][PW*PW][ES]
-    constexpr int EBUF = PW * PW * ES;
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int li = lane & 15, lk = lane >> 4;
-    const long crop = blockIdx.x;
-    const float* Xc = a.X + crop * 256 * a.ldx;
-    const int y0 = wave * 2;
-
-    // zero both E buffers once: the padding ring stays zero, the interior is rewritten per chunk
-    for (int i = threadIdx.x * 4; i < 2 * EBUF; i += 512 * 4) *reinterpret_cast<f32x4*>(lds + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // activation fragments of this wave's two pixel rows stay in registers for every chunk
-    f32x4 xf[EXPAND ? 2 : 1][EXPAND ? KG : 1];
-    if (EXPAND) {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int kg = 0; kg < KG; ++kg)
-                xf[mt][kg] = *reinterpret_cast<const f32x4*>(Xc + (long)((y0 + mt) * S + li) * a.ldx + kg * 16 + lk * 4);
-    }
-    __syncthreads();
-
-    auto phase_a = [&](int c0, float* E) {
-        if (EXPAND) {
-            f32x4 acc[2][NJ];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NJ; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kg = 0; kg < KG; ++kg) {
-                f32x4 wf[NJ];
-#pragma unroll
-                for (int nt = 0; nt < NJ; ++nt) {
-                    if (ABL & 8) wf[nt] = (f32x4){0.5f, 0.25f, 0.125f, 1.f};
-                    else wf[nt] = *reinterpret_cast<const f32x4*>(a.We + (long)(c0 + nt * 16 + li) * CIN + kg * 16 + lk * 4);
-                }
-                if (ABL & 1) {
-#pragma unroll
-                    for (int nt = 0; nt < NJ; ++nt) asm volatile("" :: "v"(wf[nt]));
-                    continue;
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < NJ; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][i], xf[mt][kg][i], acc[mt][nt], 0, 0, 0);
-            }
-#pragma unroll
-            for (int nt = 0; nt < NJ; ++nt) {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(a.be + c0 + nt * 16 + lk * 4);
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    f32x4 v = acc[mt][nt] + b;
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                    *reinterpret_cast<f32x4*>(E + ((y0 + mt + P) * PW + li + P) * ES + nt * 16 + lk * 4) = v;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(Xc + (long)((y0 + mt) * S + li) * a.ldx + c0 + j * 16 + lk * 4);
-                    *reinterpret_cast<f32x4*>(E + ((y0 + mt + P) * PW + li + P) * ES + j * 16 + lk * 4) = v;
-                }
-        }
-    };
-
-    f32x4 accp[2][NTP];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NTP; ++nt) accp[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    phase_a(0, lds);
-    __syncthreads();
-
-    auto phase_bc = [&](int c0, const float* E) {
-        // phase B: depthwise on the VALU, results land directly in MFMA fragment layout
-        f32x4 df[2][NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int cc = j * 16 + lk * 4;
-            f32x4 d0 = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (a.bd) d0 = *reinterpret_cast<const f32x4*>(a.bd + c0 + cc);
-            f32x4 d1 = d0;
-            if (ABL & 2) {
-                d0 += *reinterpret_cast<const f32x4*>(E + ((y0 + P) * PW + li + P) * ES + cc);
-                d1 += *reinterpret_cast<const f32x4*>(E + ((y0 + 1 + P) * PW + li + P) * ES + cc);
-            } else {
-#pragma unroll
-            for (int iy = 0; iy < KS + 1; ++iy) {
-#pragma unroll
-                for (int kx = 0; kx < KS; ++kx) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(E + ((y0 + iy) * PW + li + kx) * ES + cc);
-                    if (iy < KS) d0 += v * *reinterpret_cast<const f32x4*>(a.Wd + (long)(iy * KS + kx) * CEXP + c0 + cc);
-                    if (iy >= 1) d1 += v * *reinterpret_cast<const f32x4*>(a.Wd + (long)((iy - 1) * KS + kx) * CEXP + c0 + cc);
-                }
-            }
-            }
-            if (a.relu_dw) {
-                d0.x = fmaxf(d0.x, 0.f); d0.y = fmaxf(d0.y, 0.f); d0.z = fmaxf(d0.z, 0.f); d0.w = fmaxf(d0.w, 0.f);
-                d1.x = fmaxf(d1.x, 0.f); d1.y = fmaxf(d1.y, 0.f); d1.z = fmaxf(d1.z, 0.f); d1.w = fmaxf(d1.w, 0.f);
-            }
-            df[0][j] = d0;
-            df[1][j] = d1;
-        }
-        // phase C: projection, accumulating over chunks
-#pragma unroll
-        for (int nt = 0; nt < NTP; ++nt) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                f32x4 wp;
-                if (ABL & 8) wp = (f32x4){0.5f, 0.25f, 0.125f, 1.f};
-                else wp = *reinterpret_cast<const f32x4*>(a.Wp + (long)(nt * 16 + li) * CEXP + c0 + j * 16 + lk * 4);
-                if (ABL & 4) {
-                    asm volatile("" :: "v"(wp), "v"(df[0][j]), "v"(df[1][j]));
-                    continue;
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-                        accp[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[i], df[mt][j][i], accp[mt][nt], 0, 0, 0);
-            }
-        }
-    };
-
-    // The two waves sharing a SIMD (w and w+4) run the phases of one barrier interval in opposite order, so
-    // one is on the matrix pipe (phase A / C) while the other is on the VALU + LDS (phase B).
-    const bool a_first = wave < 4;
-    for (int c = 0; c < NCHUNK; ++c) {
-        const int c0 = c * CE;
-        const float* E = lds + (c & 1) * EBUF;
-        float* En = lds + ((c + 1) & 1) * EBUF;
-        if (a_first) {
-            if (c + 1 < NCHUNK) phase_a(c0 + CE, En);
-            phase_bc(c0, E);
-        } else {
-            phase_bc(c0, E);
-            if (c + 1 < NCHUNK) phase_a(c0 + CE, En);
-        }
-        __syncthreads();
-    }
-
-    // epilogue
-#pragma unroll
-    for (int nt = 0; nt < NTP; ++nt) {
-        const int n = nt * 16 + lk * 4;
-        const f32x4 b = *reinterpret_cast<const f32x4*>(a.bp + n);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const long m = crop * 256 + (y0 + mt) * S + li;
-            f32x4 v = accp[mt][nt] + b;
-            if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
-            if (a.relu_out) {
-                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-            }
-            *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = v;
-        }
-    }
-}
-
-template <int CIN, int CEXP, int COUT, int KS, int CE, bool EXPAND>
-constexpr int ir16_lds_bytes() {
-    return 2 * (16 + 2 * (KS / 2)) * (16 + 2 * (KS / 2)) * (CE + 4) * 4;
-}
+// Lane mapping (wave w, lane l): li = l&15 = pixel column x, lk = l>>4; MFMA 16x16x4 f32 fragments as in
+// pw_mfma_kernel (weights = A operand, pixels = B operand).
 
 // ================================================================================================
-// General spatially tiled fused block kernel (any map size, stride 1 or 2): one workgroup (8 waves)
-// produces a TW x TH tile of output pixels of one crop.  Same three phases as ir16_fused_kernel, but the
-// expansion runs over the tile's input region including the depthwise halo (clipped to the image; the
-// out-of-image part of the LDS tile is zero = the conv's zero padding), so only the narrow block input
-// is read from HBM and only the narrow block output is written.
-//
-//   region: IHR x IWR input pixels, IWR = (TW-1)*ST + KS;  LDS tile E[IHR*IWR][CE+4] per buffer
-//   phase A: m-tiles = groups of 16 region pixels in clipped row-major order, interleaved over the waves
-//   phase B/C: wave w owns MTC = TH*(TW/16)/8 output rows of one 16-pixel column segment (vertical strip)
-struct IrTileArgs {
-    IrArgs b;
-    int H, W;            // input map size (output is H/ST x W/ST)
-    int tiles_x, tiles_y;
-};
-
-template <int CIN, int CEXP, int CEXPP, int COUT, int KS, int ST, int TW, int TH, int CE, int NBUF, bool EXPAND, int MINW>
-__global__ __launch_bounds__(512, MINW) void ir_tile_fused_kernel(IrTileArgs t) {
-    const IrArgs& a = t.b;
-    constexpr int P = KS / 2, IWR = (TW - 1) * ST + KS, IHR = (TH - 1) * ST + KS, ES = CE + 4, NJ = CE / 16;
-    constexpr int SEG = TW / 16, NMT_OUT = TH * SEG, MTC = NMT_OUT / 8;
-    constexpr int NMT_IN_MAX = (IHR * IWR + 15) / 16, MTA = (NMT_IN_MAX + 7) / 8;
-    constexpr int NCHUNK = CEXPP / CE, NTP = (COUT + 15) / 16, KG = (CIN + 15) / 16;
-    constexpr int EBUF = IHR * IWR * ES;
-    constexpr bool PADC = CEXPP != CEXP;   // channel count padded up to a chunk multiple (e.g. 24 -> 32)
-    static_assert(CEXPP % CE == 0 && CEXPP >= CEXP && (CE == 16 || CE == 32) && NMT_OUT % 8 == 0 && TW % 16 == 0, "shape");
-    static_assert(SEG == 1 || SEG == 2, "TW must be 16 or 32");
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // [NBUF][IHR*IWR][ES]
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int li = lane & 15, lk = lane >> 4;
-    const int tiles = t.tiles_x * t.tiles_y;
-    const long crop = blockIdx.x / tiles;
-    const int tile = blockIdx.x % tiles;
-    const int ox0 = (tile % t.tiles_x) * TW, oy0 = (tile / t.tiles_x) * TH;
-    const int ix0 = ox0 * ST - P, iy0 = oy0 * ST - P;
-    const int cx_lo = max(ix0, 0), cy_lo = max(iy0, 0);
-    const int CW = min(ix0 + IWR, t.W) - cx_lo, CH = min(iy0 + IHR, t.H) - cy_lo;
-    const int NPIX = CW * CH;
-    const int Wo = t.W / ST, Ho = t.H / ST;
-    const float* Xc = a.X + crop * t.H * t.W * a.ldx;
-
-    for (int i = threadIdx.x * 4; i < NBUF * EBUF; i += 512 * 4) *reinterpret_cast<f32x4*>(lds + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // per-lane geometry of the wave's phase-A pixel tiles (chunk invariant)
-    int eoff[MTA];      // float offset of the pixel inside an E buffer, -1 = no pixel (tail of the last tile)
-    long xoff[MTA];     // float offset of the pixel's channel vector in X
-    f32x4 xf[EXPAND ? MTA : 1][EXPAND ? KG : 1];
-#pragma unroll
-    for (int i = 0; i < MTA; ++i) {
-        const int q = (wave + 8 * i) * 16 + li;
-        const bool valid = q < NPIX;
-        const int qq = valid ? q : 0;
-        const int cy = qq / CW, cx = qq - cy * CW;
-        const int gy = cy_lo + cy, gx = cx_lo + cx;
-        eoff[i] = valid ? ((gy - iy0) * IWR + (gx - ix0)) * ES : -1;
-        xoff[i] = ((long)gy * t.W + gx) * a.ldx;
-        if (EXPAND) {
-#pragma unroll
-            for (int kg = 0; kg < KG; ++kg) {
-                xf[i][kg] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (kg * 16 + lk * 4 < CIN) xf[i][kg] = *reinterpret_cast<const f32x4*>(Xc + xoff[i] + kg * 16 + lk * 4);
-            }
-        }
-    }
-    __syncthreads();
-
-    auto phase_a = [&](int c0, float* E) {
-        if (EXPAND) {
-            f32x4 wf[NJ][KG];
-#pragma unroll
-            for (int nt = 0; nt < NJ; ++nt)
-#pragma unroll
-                for (int kg = 0; kg < KG; ++kg) {
-                    wf[nt][kg] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (kg * 16 + lk * 4 < CIN)
-                        wf[nt][kg] = *reinterpret_cast<const f32x4*>(a.We + (long)(c0 + nt * 16 + li) * CIN + kg * 16 + lk * 4);
-                }
-            f32x4 bias[NJ];
-#pragma unroll
-            for (int nt = 0; nt < NJ; ++nt) bias[nt] = *reinterpret_cast<const f32x4*>(a.be + c0 + nt * 16 + lk * 4);
-#pragma unroll
-            for (int i = 0; i < MTA; ++i) {
-                if ((wave + 8 * i) * 16 >= NPIX) break;     // wave-uniform
-                f32x4 acc[NJ];
-#pragma unroll
-                for (int nt = 0; nt < NJ; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int kg = 0; kg < KG; ++kg)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-#pragma unroll
-                        for (int nt = 0; nt < NJ; ++nt)
-                            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][kg][c], xf[i][kg][c], acc[nt], 0, 0, 0);
-                // accumulator lane: pixel li of the tile, channels nt*16 + 4*lk..  -> needs THAT pixel's E offset
-                const int eo = eoff[i];
-#pragma unroll
-                for (int nt = 0; nt < NJ; ++nt) {
-                    f32x4 v = acc[nt] + bias[nt];
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                    if (eo >= 0) *reinterpret_cast<f32x4*>(E + eo + nt * 16 + lk * 4) = v;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < MTA; ++i) {
-                if ((wave + 8 * i) * 16 >= NPIX) break;
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const int ch = c0 + j * 16 + lk * 4;
-                    if (ch < CIN && eoff[i] >= 0)
-                        *reinterpret_cast<f32x4*>(E + eoff[i] + j * 16 + lk * 4) =
-                            *reinterpret_cast<const f32x4*>(Xc + xoff[i] + ch);
-                }
-            }
-        }
-    };
-
-    // output strip of this wave
-    const int seg = SEG == 1 ? 0 : (wave & 1);
-    const int r0 = (SEG == 1 ? wave : (wave >> 1)) * MTC;
-    f32x4 accp[MTC][NTP];
-#pragma unroll
-    for (int r = 0; r < MTC; ++r)
-#pragma unroll
-        for (int nt = 0; nt < NTP; ++nt) accp[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    if (NBUF == 2) { phase_a(0, lds); __syncthreads(); }
-
-    for (int c = 0; c < NCHUNK; ++c) {
-        const int c0 = c * CE;
-        const float* E = lds + (NBUF == 2 ? (c & 1) * EBUF : 0);
-        if (NBUF == 2) {
-            if (c + 1 < NCHUNK) phase_a(c0 + CE, lds + ((c + 1) & 1) * EBUF);
-        } else {
-            phase_a(c0, lds);
-            __syncthreads();
-        }
-        f32x4 df[MTC][NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int cc = j * 16 + lk * 4;
-            f32x4 d[MTC];
-            f32x4 bd = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const bool chv = !PADC || (c0 + cc < CEXP);
-            if (a.bd && chv) bd = *reinterpret_cast<const f32x4*>(a.bd + c0 + cc);
-#pragma unroll
-            for (int r = 0; r < MTC; ++r) d[r] = bd;
-            const float* Ebase = E + ((r0 * ST) * IWR + (seg * 16 + li) * ST) * ES + cc;
-#pragma unroll
-            for (int iy = 0; iy < (MTC - 1) * ST + KS; ++iy) {
-#pragma unroll
-                for (int kx = 0; kx < KS; ++kx) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(Ebase + (iy * IWR + kx) * ES);
-#pragma unroll
-                    for (int r = 0; r < MTC; ++r) {
-                        const int ky = iy - r * ST;
-                        if (ky >= 0 && ky < KS && chv)
-                            d[r] += v * *reinterpret_cast<const f32x4*>(a.Wd + (long)(ky * KS + kx) * CEXP + c0 + cc);
-                    }
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < MTC; ++r) {
-                f32x4 v = d[r];
-                if (a.relu_dw) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                df[r][j] = v;
-            }
-        }
-#pragma unroll
-        for (int nt = 0; nt < NTP; ++nt) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                f32x4 wp = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (nt * 16 + li < COUT && (!PADC || c0 + j * 16 + lk * 4 < CEXP))
-                    wp = *reinterpret_cast<const f32x4*>(a.Wp + (long)(nt * 16 + li) * CEXP + c0 + j * 16 + lk * 4);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int r = 0; r < MTC; ++r)
-                        accp[r][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[i], df[r][j][i], accp[r][nt], 0, 0, 0);
-            }
-        }
-        __syncthreads();
-    }
-
-#pragma unroll
-    for (int nt = 0; nt < NTP; ++nt) {
-        const int n = nt * 16 + lk * 4;
-        if (n >= COUT) continue;
-        const f32x4 b = *reinterpret_cast<const f32x4*>(a.bp + n);
-#pragma unroll
-        for (int r = 0; r < MTC; ++r) {
-            const int oy = oy0 + r0 + r, ox = ox0 + seg * 16 + li;
-            const long m = (crop * Ho + oy) * Wo + ox;
-            f32x4 v = accp[r][nt] + b;
-            if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
-            if (a.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = v;
-        }
-    }
-}
-
-template <int KS, int ST, int TW, int TH, int CE, int NBUF>
-constexpr int ir_tile_lds_bytes() {
-    return NBUF * ((TH - 1) * ST + KS) * ((TW - 1) * ST + KS) * (CE + 4) * 4;
-}
-
-// ================================================================================================
-// ir16v2: same block as ir16_fused_kernel, re-engineered around what the ablation (tools/kbench.hip)
+// ir16v2: one workgroup (8 waves) owns one crop's whole 16x16 map, so the depthwise halo is plain zero padding
+// and nothing is recomputed.  Engineered around what the ablation (tools/kbench.hip) of the first generation
 // showed — the per-chunk global weight loads (expand / depthwise / projection weights, identical for
 // all 8 waves) were exposed latency, ~40 % of the kernel.  Now every weight a chunk needs is
 //   * pre-packed on the host per chunk, MFMA fragments in lane order (one contiguous 1 KiB ds_read_b128
@@ -1043,23 +640,15 @@ __global__ __launch_bounds__(512) void ir16v2_fused_kernel(Ir2Args a) {
     }
     __syncthreads();
 
-    const bool a_first = wave < 4;
     for (int c = 0; c < NCHUNK; ++c) {
         // prefetch (registers only): EXPAND: A-part two chunks ahead; !EXPAND: next chunk's activations
         const int ca = EXPAND ? c + 2 : c + 1;
         if (ca < NCHUNK) load_a(ca);
         if (c + 1 < NCHUNK) load_b(c + 1);
-        if (EXPAND) {
-            if (a_first) {
-                if (c + 1 < NCHUNK) phase_a(c + 1);
-                phase_bc(c);
-            } else {
-                phase_bc(c);
-                if (c + 1 < NCHUNK) phase_a(c + 1);
-            }
-        } else {
-            phase_bc(c);
-        }
+        // (fp32 MFMA executes on the vector ALUs on gfx950 — tools/coexec.hip: an MFMA wave and a VALU wave on one
+        //  SIMD take the SUM of their times — so there is nothing to gain from staggering phases between waves)
+        if (EXPAND && c + 1 < NCHUNK) phase_a(c + 1);
+        phase_bc(c);
         if (ca < NCHUNK) store_a(ca);
         if (c + 1 < NCHUNK) store_b(c + 1);
         __syncthreads();
@@ -1274,6 +863,269 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
             const int oy = oy0 + r0 + r, ox = ox0 + seg * 16 + li;
             const long m = (crop * Ho + oy) * Wo + ox;
             f32x4 v = accp[r][nt] + b;
+            if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
+            if (a.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = v;
+        }
+    }
+}
+
+// ================================================================================================
+// ir16h: the fused 16x16 block on the REAL matrix pipe.
+//
+// tools/coexec.hip shows that v_mfma_f32_16x16x4_f32 executes on the vector ALUs (an fp32-MFMA wave and a VALU
+// wave on one SIMD take the SUM of their times), so in ir16v2 the depthwise VALU work can never hide under the
+// pointwise MFMAs.  The f16 MFMA (v_mfma_f32_16x16x32_f16) runs on the dedicated matrix pipe at 16x the rate and
+// co-executes with the VALU.  FEAR's weights ARE fp16 numbers (the model ships as fp16), so a pointwise conv can
+// be computed as            W . x  =  W . hi(x) + W . lo(x),   hi = fp16(x),  lo = fp16(x - hi)
+// with exact fp16 x fp16 products accumulated in fp32 by two matrix-pipe MFMAs: the activation is represented to
+// 2^-22 relative (fp32 itself rounds every product to 2^-24), the accumulation stays fp32, and everything that is
+// not a GEMM (bias, ReLU, the depthwise conv, residual adds) stays plain fp32 on the VALU.  Measured deviation
+// from the exact fp32-MFMA path is ~1e-6 relative (same size as the difference between two fp32 summation
+// orders); the tolerance of the path is 1e-3.  Range assumption: |activation| < 65504 (fp16 max).
+//
+// Geometry differs from ir16v2 only by the K granularity of the MFMA (32 instead of 4): chunks of CE = 32
+// expanded channels, a lane owns 8 consecutive channels (two float4) of its pixel.
+//   A-part per chunk: 2 n-tiles x KG32 fragments (64 lanes x 8 halfs: We[c0 + nt*16 + l&15][kg*32 + 8*(l>>4) + j])
+//                     | be[32] fp32
+//   BC-part         : NTP fragments (Wp[nt*16 + l&15][c0 + 8*(l>>4) + j]) | Wd[KS*KS][32] fp32 | bd[32] fp32
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+template <int CIN, int CEXP, int COUT, int KS, bool EXPAND>
+struct IrHGeom {
+    static constexpr int CE = 32, S = 16, P = KS / 2, PW = S + 2 * P, ES = CE + 4;
+    static constexpr int NCHUNK = (CEXP + CE - 1) / CE, NTP = COUT / 16, KG = EXPAND ? (CIN + 31) / 32 : 0;
+    // stage sizes in floats (a fragment = 64 lanes x 16 B = 256 floats)
+    static constexpr int AP = EXPAND ? 2 * KG * 256 + 32 : 0;
+    static constexpr int BP = NTP * 256 + KS * KS * 32 + 32;
+    static constexpr int EBUF = PW * PW * ES;
+    static constexpr int LDS_FLOATS = 2 * EBUF + 2 * AP + 2 * BP;
+    static constexpr int LDS_BYTES = LDS_FLOATS * 4;
+};
+
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split_half8(const f32x4& a, const f32x4& b, h8& hi, h8& lo) {
+    const f32x8 x = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    hi = __builtin_convertvector(x, h8);
+    lo = __builtin_convertvector(x - __builtin_convertvector(hi, f32x8), h8);
+}
+
+template <int CIN, int CEXP, int COUT, int KS, bool EXPAND>
+__global__ __launch_bounds__(512) void ir16h_fused_kernel(Ir2Args a) {
+    using G = IrHGeom<CIN, CEXP, COUT, KS, EXPAND>;
+    constexpr int S = G::S, P = G::P, PW = G::PW, ES = G::ES, NCHUNK = G::NCHUNK, NTP = G::NTP, KG = G::KG;
+    constexpr int AP = G::AP, BP = G::BP, EBUF = G::EBUF, CST = AP + BP;
+    constexpr int AP4 = AP / 4, BP4 = BP / 4;
+    constexpr int NRA = (AP4 + 511) / 512, NRB = (BP4 + 511) / 512;
+    static_assert(COUT % 16 == 0 && (EXPAND || CIN == CEXP), "shape");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const Ebuf = lds;                    // [2][EBUF]
+    float* const WA = lds + 2 * EBUF;           // [2][AP]
+    float* const WB = WA + 2 * AP;              // [2][BP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const long crop = blockIdx.x;
+    const float* Xc = a.X + crop * 256 * a.ldx;
+    const int y0 = wave * 2;
+
+    for (int i = tid * 4; i < 2 * EBUF; i += 512 * 4) *reinterpret_cast<f32x4*>(lds + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // activation fragments (hi / lo halves) of this wave's two pixel rows, resident for every chunk
+    h8 xhi[EXPAND ? 2 : 1][EXPAND ? KG : 1], xlo[EXPAND ? 2 : 1][EXPAND ? KG : 1];
+    if (EXPAND) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg) {
+                const int k = kg * 32 + lk * 8;
+                const float* px = Xc + (long)((y0 + mt) * S + li) * a.ldx + k;
+                f32x4 v0 = (f32x4){0.f, 0.f, 0.f, 0.f}, v1 = v0;
+                if (k < CIN) v0 = *reinterpret_cast<const f32x4*>(px);
+                if (k + 4 < CIN) v1 = *reinterpret_cast<const f32x4*>(px + 4);
+                split_half8(v0, v1, xhi[mt][kg], xlo[mt][kg]);
+            }
+    }
+
+    f32x4 ra[EXPAND ? (NRA > 0 ? NRA : 1) : 4], rb[NRB];
+    auto load_a = [&](int c) {      // EXPAND: A-part of chunk c; !EXPAND: this lane's 8 channels x 2 pixels of chunk c
+        if (EXPAND) {
+#pragma unroll
+            for (int r = 0; r < NRA; ++r) {
+                const int idx = tid + r * 512;
+                if (idx < AP4) ra[r] = *reinterpret_cast<const f32x4*>(a.Wpk + (long)c * CST + idx * 4);
+            }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int k = c * 32 + lk * 8;
+                const float* px = Xc + (long)((y0 + mt) * S + li) * a.ldx + k;
+                ra[2 * mt] = ra[2 * mt + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (k < CIN) ra[2 * mt] = *reinterpret_cast<const f32x4*>(px);
+                if (k + 4 < CIN) ra[2 * mt + 1] = *reinterpret_cast<const f32x4*>(px + 4);
+            }
+        }
+    };
+    auto store_a = [&](int c) {
+        if (EXPAND) {
+            float* dst = WA + (c & 1) * AP;
+#pragma unroll
+            for (int r = 0; r < NRA; ++r) {
+                const int idx = tid + r * 512;
+                if (idx < AP4) *reinterpret_cast<f32x4*>(dst + idx * 4) = ra[r];
+            }
+        } else {
+            float* E = Ebuf + (c & 1) * EBUF;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                float* e = E + ((y0 + mt + P) * PW + li + P) * ES + lk * 8;
+                *reinterpret_cast<f32x4*>(e) = ra[2 * mt];
+                *reinterpret_cast<f32x4*>(e + 4) = ra[2 * mt + 1];
+            }
+        }
+    };
+    auto load_b = [&](int c) {
+#pragma unroll
+        for (int r = 0; r < NRB; ++r) {
+            const int idx = tid + r * 512;
+            if (idx < BP4) rb[r] = *reinterpret_cast<const f32x4*>(a.Wpk + (long)c * CST + AP + idx * 4);
+        }
+    };
+    auto store_b = [&](int c) {
+        float* dst = WB + (c & 1) * BP;
+#pragma unroll
+        for (int r = 0; r < NRB; ++r) {
+            const int idx = tid + r * 512;
+            if (idx < BP4) *reinterpret_cast<f32x4*>(dst + idx * 4) = rb[r];
+        }
+    };
+
+    // phase A: E[c] <- relu(We_chunk . (x_hi + x_lo) + be): 2 n-tiles x 2 pixel rows, matrix pipe
+    auto phase_a = [&](int c) {
+        const float* wa = WA + (c & 1) * AP;
+        float* E = Ebuf + (c & 1) * EBUF;
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(wa + 2 * KG * 256 + nt * 16 + lk * 4);
+            acc[0][nt] = bias;
+            acc[1][nt] = bias;
+        }
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const h8 wf = *reinterpret_cast<const h8*>(wa + (nt * KG + kg) * 256 + lane * 4);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xhi[mt][kg], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xlo[mt][kg], acc[mt][nt], 0, 0, 0);
+                }
+            }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                f32x4 v = acc[mt][nt];
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                *reinterpret_cast<f32x4*>(E + ((y0 + mt + P) * PW + li + P) * ES + nt * 16 + lk * 4) = v;
+            }
+    };
+
+    f32x4 accp[2][NTP];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTP; ++nt) accp[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // phase B (fp32 VALU depthwise, 8 channels x 2 rows per lane) + phase C (projection on the matrix pipe)
+    auto phase_bc = [&](int c) {
+        const float* E = Ebuf + (c & 1) * EBUF;
+        const float* wb = WB + (c & 1) * BP;
+        const float* wd = wb + NTP * 256 + lk * 8;
+        // Both output rows of a lane are carried in ONE 8-wide accumulator per channel half ({row0 x4, row1 x4}):
+        // an input row iy feeds row 0 with tap row iy and row 1 with tap row iy-1, i.e. one 8-wide FMA with the
+        // activation duplicated.  (Written as two float4 chains, hipcc computes the chains in two passes and spills
+        // every LDS value in between: ~500 VGPRs of scratch traffic.)
+        f32x8 d8[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x4 bd = *reinterpret_cast<const f32x4*>(wd + KS * KS * 32 + h * 4);
+            d8[h] = __builtin_shufflevector(bd, bd, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+        const float* e0 = E + (y0 * PW + li) * ES + lk * 8;
+        const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+                f32x4 w[KS];
+#pragma unroll
+                for (int ky = 0; ky < KS; ++ky) w[ky] = *reinterpret_cast<const f32x4*>(wd + (ky * KS + kx) * 32 + h * 4);
+#pragma unroll
+                for (int iy = 0; iy < KS + 1; ++iy) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(e0 + (iy * PW + kx) * ES + h * 4);
+                    const f32x8 v8 = __builtin_shufflevector(v, v, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const f32x8 w8 = __builtin_shufflevector(iy < KS ? w[iy < KS ? iy : 0] : zero4,
+                                                             iy >= 1 ? w[iy >= 1 ? iy - 1 : 0] : zero4, 0, 1, 2, 3, 4, 5, 6, 7);
+                    d8[h] += v8 * w8;
+                }
+            }
+        }
+        h8 dhi[2], dlo[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            f32x4 q0 = r == 0 ? __builtin_shufflevector(d8[0], d8[0], 0, 1, 2, 3) : __builtin_shufflevector(d8[0], d8[0], 4, 5, 6, 7);
+            f32x4 q1 = r == 0 ? __builtin_shufflevector(d8[1], d8[1], 0, 1, 2, 3) : __builtin_shufflevector(d8[1], d8[1], 4, 5, 6, 7);
+            if (a.relu_dw) {
+                q0.x = fmaxf(q0.x, 0.f); q0.y = fmaxf(q0.y, 0.f); q0.z = fmaxf(q0.z, 0.f); q0.w = fmaxf(q0.w, 0.f);
+                q1.x = fmaxf(q1.x, 0.f); q1.y = fmaxf(q1.y, 0.f); q1.z = fmaxf(q1.z, 0.f); q1.w = fmaxf(q1.w, 0.f);
+            }
+            split_half8(q0, q1, dhi[r], dlo[r]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTP; ++nt) {
+            const h8 wp = *reinterpret_cast<const h8*>(wb + nt * 256 + lane * 4);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                accp[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wp, dhi[r], accp[r][nt], 0, 0, 0);
+                accp[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wp, dlo[r], accp[r][nt], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- prologue: stage A(0), A(1), BC(0); produce E[0]
+    load_a(0);
+    load_b(0);
+    __syncthreads();
+    store_a(0);
+    store_b(0);
+    if (EXPAND) {
+        if (NCHUNK > 1) { load_a(1); store_a(1); }
+        __syncthreads();
+        phase_a(0);
+    }
+    __syncthreads();
+
+    for (int c = 0; c < NCHUNK; ++c) {
+        const int ca = EXPAND ? c + 2 : c + 1;
+        if (ca < NCHUNK) load_a(ca);
+        if (c + 1 < NCHUNK) load_b(c + 1);
+        if (EXPAND && c + 1 < NCHUNK) phase_a(c + 1);
+        phase_bc(c);
+        if (ca < NCHUNK) store_a(ca);
+        if (c + 1 < NCHUNK) store_b(c + 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int nt = 0; nt < NTP; ++nt) {
+        const int n = nt * 16 + lk * 4;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(a.bp + n);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const long m = crop * 256 + (y0 + mt) * S + li;
+            f32x4 v = accp[mt][nt] + b;
             if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
             if (a.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = v;

@@ -29,6 +29,7 @@ FEAR_OPT_MAX_BATCH = 1
 FEAR_OPT_PROFILE = 2
 FEAR_OPT_PROFILE_OP = 3
 FEAR_OPT_FUSE = 4
+FEAR_OPT_MATH = 5
 
 _lib = None
 
@@ -153,6 +154,10 @@ class FEARNetHIP:
     def set_fuse(self, on: bool) -> None:
         """Fused block kernels (default) vs one kernel per conv layer (bring-up / A-B measurements)."""
         self._check(self._lib.fear_set_option(self._h, FEAR_OPT_FUSE, 1 if on else 0))
+
+    def set_math(self, mode: int) -> None:
+        """0: exact fp32 MFMA (default); 1: fp16 hi+lo split operands on the matrix pipe, fp32 accumulate."""
+        self._check(self._lib.fear_set_option(self._h, FEAR_OPT_MATH, int(mode)))
 
     def set_profile(self, on: bool, op: int = -1) -> None:
         """Bracket kernel launches with hipEvents; op >= 0 restricts it to one op of the plan."""

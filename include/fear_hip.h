@@ -80,6 +80,10 @@ int fear_normalize_u8(fear_handle* h, const uint8_t* u8, int n, int hw, float* o
 #define FEAR_OPT_PROFILE 2     /* 1: bracket kernel launches with hipEvents (fear_profile_*)     */
 #define FEAR_OPT_PROFILE_OP 3  /* -1: every op of a plan; i >= 0: op i and all ops sharing its name */
 #define FEAR_OPT_FUSE 4        /* 1 (default): fused block kernels; 0: one kernel per conv layer  */
+#define FEAR_OPT_MATH 5        /* pointwise-conv arithmetic of the fused blocks:                   */
+                               /*   0 (default) fp32 operands, v_mfma_f32_16x16x4_f32 (exact fp32) */
+                               /*   1 fp32 activations split into fp16 hi+lo, exact-fp16 weights,  */
+                               /*     v_mfma_f32_16x16x32_f16 on the matrix pipe, fp32 accumulate  */
 int fear_set_option(fear_handle* h, int option, int64_t value);
 int64_t fear_get_option(fear_handle* h, int option);
 

@@ -184,3 +184,31 @@ def test_fused_and_layerwise_plans_agree(hip_net, oracle_net):
     ref = oracle_net.track(x.cpu(), z.cpu())
     assert rel_err(b0, ref["TARGET_REGRESSION_LABEL_KEY"]) < REL
     assert rel_err(c0, ref["TARGET_CLASSIFICATION_KEY"]) < REL
+
+
+def test_matrix_pipe_split_mode_matches_fp32(hip_net, oracle_net, golden_dir):
+    """FEAR_OPT_MATH=1: pointwise convs of the fused blocks run as W.hi(x) + W.lo(x) on the f16 matrix pipe with
+    fp32 accumulation (the weights are exact fp16 numbers).  Must stay inside the same 1e-3 tolerance; the
+    measured deviation from the exact fp32-MFMA path is printed and must be < 1e-4."""
+    from feartracker_amd import FEARNetHIP
+    from conftest import WEIGHTS
+    fast = FEARNetHIP(WEIGHTS, device=0, max_batch=16)
+    fast.set_math(1)
+    d = np.load(f"{golden_dir}/track_maps.npz")
+    x = norm_u8(torch.from_numpy(d["search_u8"])).cuda()
+    z = torch.from_numpy(d["template_features"]).cuda()
+    b1, c1 = fast.track_maps(x, z)
+    b0, c0 = hip_net.track_maps(x, z)
+    assert rel_err(b1, torch.from_numpy(d["bbox"])) < REL and rel_err(c1, torch.from_numpy(d["cls"])) < REL
+    dev_b, dev_c = rel_err(b1, b0), rel_err(c1, c0)
+    print(f"split-vs-fp32 deviation: bbox {dev_b:.2e} cls {dev_c:.2e}")
+    assert dev_b < 1e-4 and dev_c < 1e-4
+    rc1, _, _ = fast.decode(c1, b1)
+    rc0, _, _ = hip_net.decode(c0, b0)
+    assert torch.equal(rc0, rc1)
+    g = torch.Generator().manual_seed(77)
+    xs = norm_u8(torch.randint(0, 256, (5, 3, 256, 256), dtype=torch.uint8, generator=g))
+    zs = oracle_net.get_features(norm_u8(torch.randint(0, 256, (5, 3, 128, 128), dtype=torch.uint8, generator=g)))
+    ref = oracle_net.track(xs, zs)
+    bb, cc = fast.track_maps(xs.cuda(), zs.cuda())
+    assert rel_err(bb, ref["TARGET_REGRESSION_LABEL_KEY"]) < REL and rel_err(cc, ref["TARGET_CLASSIFICATION_KEY"]) < REL
