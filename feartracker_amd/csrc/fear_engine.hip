@@ -262,10 +262,11 @@ struct FusedTile {
     int tw, th;
     void (*kernel)(IrT2Args);
     int lds_bytes;
+    int nw;                                     // waves per workgroup
 };
 #define FTILE(CIN, CEXP, CEXPP, COUT, KS, ST, TW, TH, EXP, MINW, HW)                                             \
     {CIN, CEXP, COUT, KS, ST, EXP, HW, TW, TH, ir_tile_v2_kernel<CIN, CEXPP, COUT, KS, ST, TW, TH, (EXP) != 0, MINW>, \
-     IrT2Geom<CIN, CEXPP, COUT, KS, ST, TW, TH, (EXP) != 0>::LDS_BYTES}
+     IrT2Geom<CIN, CEXPP, COUT, KS, ST, TW, TH, (EXP) != 0>::LDS_BYTES, 8}
 const FusedTile kFusedTile[] = {
     FTILE(16, 16, 16, 16, 3, 1, 32, 16, 0, 4, 128),    // fbnet_c stage 1  (e1, 128x128)
     FTILE(16, 96, 96, 24, 3, 2, 16, 8, 1, 4, 128),     // stage 2          (e6 s2, 128 -> 64)
@@ -276,6 +277,23 @@ const FusedTile kFusedTile[] = {
     FTILE(32, 192, 192, 32, 3, 1, 32, 16, 1, 2, 32),   // stage 9
     FTILE(32, 192, 192, 64, 5, 2, 16, 8, 1, 2, 32),    // stage 10         (e6 s2, 32 -> 16)
 };
+#define FTILEH(CIN, CEXP, CEXPP, COUT, KS, ST, TW, TH, EXP, NW, MINW, HW)                                             \
+    {CIN, CEXP, COUT, KS, ST, EXP, HW, TW, TH,                                                                        \
+     ir_tile_h_kernel<CIN, CEXPP, COUT, KS, ST, TW, TH, (EXP) != 0, NW, MINW>,                                         \
+     IrTHGeom<CIN, CEXPP, COUT, KS, ST, TW, TH, (EXP) != 0, NW>::LDS_BYTES, NW}
+// same blocks, fp16-split operands on the matrix pipe (FEAR_OPT_MATH = 1); tiles sized for the 144 B/pixel LDS tile
+const FusedTile kFusedTileH[] = {
+    FTILEH(16, 16, 32, 16, 3, 1, 32, 8, 0, 8, 2, 128),     // stage 1
+    FTILEH(16, 96, 96, 24, 3, 2, 16, 4, 1, 4, 2, 128),     // stage 2
+    FTILEH(24, 24, 32, 24, 3, 1, 16, 16, 0, 8, 2, 64),     // stages 4, 5
+    FTILEH(24, 144, 160, 32, 5, 2, 16, 4, 1, 4, 2, 64),    // stage 6   (144 -> 160 padded channels)
+    FTILEH(32, 96, 96, 32, 5, 1, 16, 16, 1, 8, 2, 32),     // stage 7
+    FTILEH(32, 192, 192, 32, 5, 1, 16, 16, 1, 8, 2, 32),   // stage 8
+    FTILEH(32, 192, 192, 32, 3, 1, 16, 16, 1, 8, 2, 32),   // stage 9
+    FTILEH(32, 192, 192, 64, 5, 2, 16, 4, 1, 4, 2, 32),    // stage 10
+};
+static_assert(sizeof(kFusedTileH) == sizeof(kFusedTile), "the two tile tables must list the same blocks in the same order");
+
 int find_fused_tile(int cin, int cexp, int cout, int ks, int st, int expand, int hw) {
     for (size_t i = 0; i < sizeof(kFusedTile) / sizeof(kFusedTile[0]); ++i) {
         const FusedTile& f = kFusedTile[i];
@@ -488,13 +506,16 @@ int build_plan(fear_handle* h, int hw, bool with_head, Plan** out) {
         const int cin = ce >= 0 ? h->convs[ce].cin_g : d.cout;
         const int id = find_fused_tile(cin, d.cout, p.cout, d.k, d.stride, ce >= 0 ? 1 : 0, in.H);
         if (id < 0) return false;
-        const FusedTile& f = kFusedTile[id];
+        const int use_h = h->math && ce >= 0;   // e1 blocks (no expand GEMM) stay on the fp32 kernel
+        const FusedTile& f = use_h ? kFusedTileH[id] : kFusedTile[id];
         const int ho = in.H / d.stride;
         if (ho % f.th != 0 || ho % f.tw != 0) return false;
         if (!p.has_bias) return false;
         Op op{};
         op.type = OP_IRTILE; op.fused_id = id; op.conv_e = ce; op.conv_d = cd; op.conv_p = cp;
-        if (pack_fused16(h, ce, cd, cp, &op.d_packed) != FEAR_OK) return false;
+        op.math = use_h;
+        if ((use_h ? pack_fused_h(h, ce, cd, cp, &op.d_packed) : pack_fused16(h, ce, cd, cp, &op.d_packed)) != FEAR_OK)
+            return false;
         op.in_buf = in.buf; op.in_ld = in.ld; op.in_off = in.off;
         op.H = in.H; op.W = in.W; op.Ho = ho; op.Wo = ho; op.C = cin; op.N = p.cout;
         op.relu_dw = 1; op.relu = 0;
@@ -731,6 +752,9 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s) {
         for (const FusedTile& f : kFusedTile)
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(f.kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, f.lds_bytes));
+        for (const FusedTile& f : kFusedTileH)
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(f.kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, f.lds_bytes));
         h->fused_attr_set = true;
     }
     const size_t slab = p.buf_floats_per_crop * h->max_batch;
@@ -815,7 +839,7 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s) {
                 break;
             }
             case OP_IRTILE: {
-                const FusedTile& f = kFusedTile[op.fused_id];
+                const FusedTile& f = op.math ? kFusedTileH[op.fused_id] : kFusedTile[op.fused_id];
                 IrT2Args ta{};
                 Ir2Args& a = ta.b;
                 a.X = buf(op.in_buf) + op.in_off; a.ldx = op.in_ld;
@@ -824,7 +848,7 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s) {
                 a.Y = buf(op.out_buf); a.ldy = op.out_ld;
                 a.relu_dw = op.relu_dw; a.relu_out = op.relu;
                 ta.H = op.H; ta.W = op.W; ta.tiles_x = op.Wo / f.tw; ta.tiles_y = op.Ho / f.th;
-                hipLaunchKernelGGL(f.kernel, dim3((unsigned)n * ta.tiles_x * ta.tiles_y), dim3(512), f.lds_bytes, s, ta);
+                hipLaunchKernelGGL(f.kernel, dim3((unsigned)n * ta.tiles_x * ta.tiles_y), dim3(64 * f.nw), f.lds_bytes, s, ta);
                 break;
             }
             case OP_PW_SMALL: {

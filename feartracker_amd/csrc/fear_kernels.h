@@ -1133,4 +1133,248 @@ __global__ __launch_bounds__(512) void ir16h_fused_kernel(Ir2Args a) {
     }
 }
 
+// ================================================================================================
+// ir_tile_h: the spatially tiled fused block (ir_tile_v2_kernel) on the f16 matrix pipe with hi+lo split
+// activations (see ir16h_fused_kernel for the arithmetic).  CE = 32 channels per chunk, a lane owns 8 channels
+// of its pixel; NW waves per workgroup (4 or 8) so that small tiles keep the LDS tile small enough for several
+// workgroups per CU.  Stride-2 blocks use one output row per wave (MTC = 1); stride-1 blocks process output
+// rows in pairs with the 8-wide accumulator formulation.
+template <int CIN, int CEXPP, int COUT, int KS, int ST, int TW, int TH, bool EXPAND, int NW>
+struct IrTHGeom {
+    static constexpr int CE = 32, P = KS / 2, IWR = (TW - 1) * ST + KS, IHR = (TH - 1) * ST + KS, ES = CE + 4;
+    static constexpr int SEG = TW / 16, NMT_OUT = TH * SEG, MTC = NMT_OUT / NW;
+    static constexpr int NMT_IN_MAX = (IHR * IWR + 15) / 16, MTA = (NMT_IN_MAX + NW - 1) / NW;
+    static constexpr int NCHUNK = CEXPP / CE, NTP = (COUT + 15) / 16, KG = EXPAND ? (CIN + 31) / 32 : 0;
+    static constexpr int AP = EXPAND ? 2 * KG * 256 + 32 : 0;
+    static constexpr int BP = NTP * 256 + KS * KS * 32 + 32;
+    static constexpr int EBUF = IHR * IWR * ES;
+    static constexpr int LDS_BYTES = (EBUF + 2 * (AP + BP)) * 4;
+};
+
+template <int CIN, int CEXPP, int COUT, int KS, int ST, int TW, int TH, bool EXPAND, int NW, int MINW>
+__global__ __launch_bounds__(64 * NW, MINW) void ir_tile_h_kernel(IrT2Args t) {
+    using G = IrTHGeom<CIN, CEXPP, COUT, KS, ST, TW, TH, EXPAND, NW>;
+    const Ir2Args& a = t.b;
+    constexpr int P = G::P, IWR = G::IWR, IHR = G::IHR, ES = G::ES, SEG = G::SEG, MTC = G::MTC, MTA = G::MTA;
+    constexpr int NCHUNK = G::NCHUNK, NTP = G::NTP, KG = G::KG, AP = G::AP, BP = G::BP, EBUF = G::EBUF;
+    constexpr int NT = 64 * NW, CST = AP + BP, W4 = CST / 4, NRW = (W4 + NT - 1) / NT;
+    static_assert(CEXPP % 32 == 0 && G::NMT_OUT % NW == 0 && (SEG == 1 || SEG == 2) && NW % SEG == 0, "tile shape");
+    static_assert(ST == 1 ? (MTC % 2 == 0) : (MTC == 1), "stride-1: row pairs; stride-2: one row per wave");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const E = lds;               // [EBUF]
+    float* const WS = lds + EBUF;       // [2][AP + BP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int tiles = t.tiles_x * t.tiles_y;
+    const long crop = blockIdx.x / tiles;
+    const int tile = blockIdx.x % tiles;
+    const int ox0 = (tile % t.tiles_x) * TW, oy0 = (tile / t.tiles_x) * TH;
+    const int ix0 = ox0 * ST - P, iy0 = oy0 * ST - P;
+    const int cx_lo = max(ix0, 0), cy_lo = max(iy0, 0);
+    const int CW = min(ix0 + IWR, t.W) - cx_lo, CH = min(iy0 + IHR, t.H) - cy_lo;
+    const int NPIX = CW * CH;
+    const int Wo = t.W / ST, Ho = t.H / ST;
+    const float* Xc = a.X + crop * t.H * t.W * a.ldx;
+
+    for (int i = tid * 4; i < EBUF; i += NT * 4) *reinterpret_cast<f32x4*>(E + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 rw[NRW];
+    auto load_w = [&](int c) {
+#pragma unroll
+        for (int r = 0; r < NRW; ++r) {
+            const int idx = tid + r * NT;
+            if (idx < W4) rw[r] = *reinterpret_cast<const f32x4*>(a.Wpk + (long)c * CST + idx * 4);
+        }
+    };
+    auto store_w = [&](int c) {
+        float* dst = WS + (c & 1) * CST;
+#pragma unroll
+        for (int r = 0; r < NRW; ++r) {
+            const int idx = tid + r * NT;
+            if (idx < W4) *reinterpret_cast<f32x4*>(dst + idx * 4) = rw[r];
+        }
+    };
+    load_w(0);
+
+    int eoff[MTA];
+    long xoff[MTA];
+    h8 xhi[EXPAND ? MTA : 1][EXPAND ? KG : 1], xlo[EXPAND ? MTA : 1][EXPAND ? KG : 1];
+#pragma unroll
+    for (int i = 0; i < MTA; ++i) {
+        const int q = (wave + NW * i) * 16 + li;
+        const bool valid = q < NPIX;
+        const int qq = valid ? q : 0;
+        const int cy = qq / CW, cx = qq - cy * CW;
+        const int gy = cy_lo + cy, gx = cx_lo + cx;
+        eoff[i] = valid ? ((gy - iy0) * IWR + (gx - ix0)) * ES : -1;
+        xoff[i] = ((long)gy * t.W + gx) * a.ldx;
+        if (EXPAND) {
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg) {
+                const int k = kg * 32 + lk * 8;
+                f32x4 v0 = (f32x4){0.f, 0.f, 0.f, 0.f}, v1 = v0;
+                if (k < CIN) v0 = *reinterpret_cast<const f32x4*>(Xc + xoff[i] + k);
+                if (k + 4 < CIN) v1 = *reinterpret_cast<const f32x4*>(Xc + xoff[i] + k + 4);
+                split_half8(v0, v1, xhi[i][kg], xlo[i][kg]);
+            }
+        }
+    }
+    f32x4 rx[EXPAND ? 1 : 2 * MTA];
+    auto load_x = [&](int c) {
+        if (!EXPAND) {
+#pragma unroll
+            for (int i = 0; i < MTA; ++i) {
+                const int k = c * 32 + lk * 8;
+                rx[2 * i] = rx[2 * i + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (k < CIN) rx[2 * i] = *reinterpret_cast<const f32x4*>(Xc + xoff[i] + k);
+                if (k + 4 < CIN) rx[2 * i + 1] = *reinterpret_cast<const f32x4*>(Xc + xoff[i] + k + 4);
+            }
+        }
+    };
+    load_x(0);
+    __syncthreads();
+    store_w(0);
+
+    const int seg = SEG == 1 ? 0 : (wave & 1);
+    const int r0 = (SEG == 1 ? wave : (wave >> 1)) * MTC;
+    f32x4 accp[MTC][NTP];
+#pragma unroll
+    for (int r = 0; r < MTC; ++r)
+#pragma unroll
+        for (int nt = 0; nt < NTP; ++nt) accp[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int c = 0; c < NCHUNK; ++c) {
+        const float* wa = WS + (c & 1) * CST;
+        const float* wb = wa + AP;
+        if (EXPAND) __syncthreads();
+        // ---- phase A
+        if (EXPAND) {
+            h8 wf[2][KG > 0 ? KG : 1];
+            f32x4 bias[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                bias[nt] = *reinterpret_cast<const f32x4*>(wa + 2 * KG * 256 + nt * 16 + lk * 4);
+#pragma unroll
+                for (int kg = 0; kg < KG; ++kg) wf[nt][kg] = *reinterpret_cast<const h8*>(wa + (nt * KG + kg) * 256 + lane * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < MTA; ++i) {
+                if ((wave + NW * i) * 16 >= NPIX) break;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    f32x4 acc = bias[nt];
+#pragma unroll
+                    for (int kg = 0; kg < KG; ++kg) {
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt][kg], xhi[i][kg], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt][kg], xlo[i][kg], acc, 0, 0, 0);
+                    }
+                    acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+                    if (eoff[i] >= 0) *reinterpret_cast<f32x4*>(E + eoff[i] + nt * 16 + lk * 4) = acc;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MTA; ++i) {
+                if ((wave + NW * i) * 16 >= NPIX) break;
+                if (eoff[i] >= 0) {
+                    *reinterpret_cast<f32x4*>(E + eoff[i] + lk * 8) = rx[2 * i];
+                    *reinterpret_cast<f32x4*>(E + eoff[i] + lk * 8 + 4) = rx[2 * i + 1];
+                }
+            }
+        }
+        if (c + 1 < NCHUNK) { load_w(c + 1); load_x(c + 1); }
+        __syncthreads();
+        // ---- phase B: fp32 depthwise, 8 channels per lane
+        const float* wd = wb + NTP * 256 + lk * 8;
+        const float* Ebase = E + ((r0 * ST) * IWR + (seg * 16 + li) * ST) * ES + lk * 8;
+        h8 dhi[MTC], dlo[MTC];
+        if (ST == 1) {
+#pragma unroll
+            for (int pr = 0; pr < MTC / 2; ++pr) {        // output rows 2pr, 2pr+1 in one 8-wide accumulator per half
+                f32x8 d8[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 bd = *reinterpret_cast<const f32x4*>(wd + KS * KS * 32 + h * 4);
+                    d8[h] = __builtin_shufflevector(bd, bd, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+                const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int kx = 0; kx < KS; ++kx) {
+                        f32x4 w[KS];
+#pragma unroll
+                        for (int ky = 0; ky < KS; ++ky) w[ky] = *reinterpret_cast<const f32x4*>(wd + (ky * KS + kx) * 32 + h * 4);
+#pragma unroll
+                        for (int iy = 0; iy < KS + 1; ++iy) {
+                            const f32x4 v = *reinterpret_cast<const f32x4*>(Ebase + ((2 * pr + iy) * IWR + kx) * ES + h * 4);
+                            const f32x8 v8 = __builtin_shufflevector(v, v, 0, 1, 2, 3, 4, 5, 6, 7);
+                            const f32x8 w8 = __builtin_shufflevector(iy < KS ? w[iy < KS ? iy : 0] : zero4,
+                                                                     iy >= 1 ? w[iy >= 1 ? iy - 1 : 0] : zero4, 0, 1, 2, 3, 4, 5, 6, 7);
+                            d8[h] += v8 * w8;
+                        }
+                    }
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    f32x4 q0 = rr == 0 ? __builtin_shufflevector(d8[0], d8[0], 0, 1, 2, 3) : __builtin_shufflevector(d8[0], d8[0], 4, 5, 6, 7);
+                    f32x4 q1 = rr == 0 ? __builtin_shufflevector(d8[1], d8[1], 0, 1, 2, 3) : __builtin_shufflevector(d8[1], d8[1], 4, 5, 6, 7);
+                    if (a.relu_dw) {
+                        q0.x = fmaxf(q0.x, 0.f); q0.y = fmaxf(q0.y, 0.f); q0.z = fmaxf(q0.z, 0.f); q0.w = fmaxf(q0.w, 0.f);
+                        q1.x = fmaxf(q1.x, 0.f); q1.y = fmaxf(q1.y, 0.f); q1.z = fmaxf(q1.z, 0.f); q1.w = fmaxf(q1.w, 0.f);
+                    }
+                    split_half8(q0, q1, dhi[2 * pr + rr], dlo[2 * pr + rr]);
+                }
+            }
+        } else {
+            f32x4 d[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) d[h] = *reinterpret_cast<const f32x4*>(wd + KS * KS * 32 + h * 4);
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        d[h] += *reinterpret_cast<const f32x4*>(Ebase + (ky * IWR + kx) * ES + h * 4) *
+                                *reinterpret_cast<const f32x4*>(wd + (ky * KS + kx) * 32 + h * 4);
+            if (a.relu_dw) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    d[h].x = fmaxf(d[h].x, 0.f); d[h].y = fmaxf(d[h].y, 0.f); d[h].z = fmaxf(d[h].z, 0.f); d[h].w = fmaxf(d[h].w, 0.f);
+                }
+            }
+            split_half8(d[0], d[1], dhi[0], dlo[0]);
+        }
+        // ---- phase C
+#pragma unroll
+        for (int nt = 0; nt < NTP; ++nt) {
+            const h8 wp = *reinterpret_cast<const h8*>(wb + nt * 256 + lane * 4);
+#pragma unroll
+            for (int r = 0; r < MTC; ++r) {
+                accp[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wp, dhi[r], accp[r][nt], 0, 0, 0);
+                accp[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wp, dlo[r], accp[r][nt], 0, 0, 0);
+            }
+        }
+        if (c + 1 < NCHUNK) store_w(c + 1);
+        if (!EXPAND || c + 1 == NCHUNK) __syncthreads();
+    }
+
+#pragma unroll
+    for (int nt = 0; nt < NTP; ++nt) {
+        const int n = nt * 16 + lk * 4;
+        if (n >= COUT) continue;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(a.bp + n);
+#pragma unroll
+        for (int r = 0; r < MTC; ++r) {
+            const int oy = oy0 + r0 + r, ox = ox0 + seg * 16 + li;
+            const long m = (crop * Ho + oy) * Wo + ox;
+            f32x4 v = accp[r][nt] + b;
+            if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
+            if (a.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = v;
+        }
+    }
+}
+
 }  // namespace fear
