@@ -204,6 +204,23 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the same K steps in the other arithmetic mode (supplementary number, same protocol)
+    other = 1 - args.math
+    net.set_math(other)
+    for _ in range(max(3, args.warmup // 2)):
+        step()
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed_other = time.perf_counter() - t1
+    if world > 1:
+        t = torch.tensor([elapsed_other], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed_other = float(t.item())
+    net.set_math(args.math)
+
     if rank == 0:
         total_crops = world * B * args.steps
         value = total_crops / elapsed
@@ -246,6 +263,12 @@ def main() -> None:
                                 "pointwise convs of the fused 16x16 blocks: fp32 activations split into fp16 hi+lo, exact-fp16 "
                                 "weights, v_mfma_f32_16x16x32_f16, fp32 accumulate; everything else fp32")},
             "roofline": roof,
+            "other_math_mode": {
+                "math": ("fp16 hi+lo split activations x exact-fp16 weights on the f16 matrix pipe, fp32 accumulate "
+                         "(deviation from the fp32-MFMA path ~1e-6 rel, tests/test_gpu_parity.py)" if other == 1 else
+                         "fp32 MFMA (exact fp32)"),
+                "value": world * B * args.steps / elapsed_other, "unit": "crops/s",
+                "ms_per_step": 1e3 * elapsed_other / args.steps},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(search_u8, tmpl_u8, DEFAULT_WEIGHTS)

@@ -139,6 +139,7 @@ struct fear_handle {
     float* workspace = nullptr;
     size_t workspace_floats = 0;
     std::vector<float*> weight_allocs;
+    std::vector<hipEvent_t> event_pool;   // recycled profiling events (creation is slow enough to perturb timing)
 };
 
 namespace {
@@ -767,8 +768,10 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s) {
         const bool prof = h->profile && (h->profile_op < 0 || h->profile_op == op_index ||
                                          (h->profile_op < (int)p.ops.size() && !strcmp(p.ops[h->profile_op].name, op.name)));
         if (prof) {
-            HIP_TRY(h, hipEventCreate(&e0));
-            HIP_TRY(h, hipEventCreate(&e1));
+            for (hipEvent_t* e : {&e0, &e1}) {
+                if (!h->event_pool.empty()) { *e = h->event_pool.back(); h->event_pool.pop_back(); }
+                else HIP_TRY(h, hipEventCreate(e));
+            }
             HIP_TRY(h, hipEventRecord(e0, s));
         }
         const Conv* c = op.conv >= 0 ? &h->convs[op.conv] : nullptr;
@@ -880,8 +883,8 @@ int drain_events(fear_handle* h) {
                 HIP_TRY(h, hipEventElapsedTime(&ms, ev.first, ev.second));
                 op.prof_ms += ms;
                 op.prof_n += 1;
-                hipEventDestroy(ev.first);
-                hipEventDestroy(ev.second);
+                h->event_pool.push_back(ev.first);
+                h->event_pool.push_back(ev.second);
             }
             op.events.clear();
         }
@@ -931,6 +934,7 @@ int fear_destroy(fear_handle* h) {
     hipSetDevice(h->device);
     hipDeviceSynchronize();
     drain_events(h);
+    for (hipEvent_t e : h->event_pool) hipEventDestroy(e);
     for (float* p : h->weight_allocs) hipFree(p);
     if (h->workspace) hipFree(h->workspace);
     delete h;

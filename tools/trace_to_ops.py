@@ -7,7 +7,9 @@ dispatches in order, keeps the `fear::` kernels of the bench's timed steps (the 
 dispatches of the track plan) and averages by position inside the plan.  Op names come from the
 `--dump-ops` table bench.py prints to stderr.
 
-usage: trace_to_ops.py <kernel_trace.csv> <bench_stderr.log> <steps> > per_op.csv
+usage: trace_to_ops.py <kernel_trace.csv> <bench_stderr.log> <steps> [tail_iters] > per_op.csv
+(tail_iters = plan executions AFTER the timed loop to skip: bench.py re-runs the steps in the other arithmetic
+mode afterwards, max(3, warmup//2) warm-ups + steps)
 """
 import csv
 import re
@@ -16,6 +18,7 @@ import sys
 
 def main():
     trace, log, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    tail = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     names = []
     for line in open(log):
         m = re.match(r"\s*(\d+)\s+(\S+)\s+([\d.]+) ms/step", line)
@@ -29,6 +32,8 @@ def main():
                 rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"],
                              int(r["Grid_Size_X"]), int(r["VGPR_Count"])))
     rows.sort()
+    if tail:
+        rows = rows[:-tail * plan_len]
     rows = rows[-steps * plan_len:]
     assert len(rows) == steps * plan_len, (len(rows), steps, plan_len)
     w = csv.writer(sys.stdout)
