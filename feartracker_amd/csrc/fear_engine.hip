@@ -104,6 +104,7 @@ struct Op {
     int fused_id = -1;        // OP_IR16: index into the fused-kernel table
     float* d_packed = nullptr; // OP_IR16: per-chunk packed weights (Ir2Geom layout), owned by the handle
     int math = 0;              // OP_IR16: 1 = fp16-split matrix-pipe kernel
+    int pred_cout = 0;         // OP_IR16 prediction head: real output channels (4 / 1), NCHW external output
     char name[64];
     double flops = 0, bytes = 0;  // per crop: algorithmic FLOPs, compulsory bytes (in + out + weights excluded)
     // profiling
@@ -255,6 +256,7 @@ const Fused16 kFused16[] = {
     FUSED16(64, 192, 64, 5, 1),   FUSED16(64, 384, 64, 5, 1),  FUSED16(64, 384, 112, 5, 1),
     FUSED16(112, 672, 112, 5, 1), FUSED16(112, 336, 112, 5, 1),
     FUSED16(256, 256, 256, 3, 0), FUSED16(320, 320, 256, 3, 0),
+    FUSED16(256, 256, 16, 3, 0),    // bbox_pred / cls_pred: 4 / 1 output channels padded to one 16-channel tile
 };
 
 // Spatially tiled fused block kernels (ir_tile_fused_kernel) for the high-resolution trunk stages.
@@ -312,10 +314,12 @@ const Fused16 kFused16H[] = {
     FUSED16H(64, 192, 64, 5, 1),   FUSED16H(64, 384, 64, 5, 1),  FUSED16H(64, 384, 112, 5, 1),
     FUSED16H(112, 672, 112, 5, 1), FUSED16H(112, 336, 112, 5, 1),
     FUSED16H(256, 256, 256, 3, 0), FUSED16H(320, 320, 256, 3, 0),
+    FUSED16H(256, 256, 16, 3, 0),
 };
 static_assert(sizeof(kFused16H) == sizeof(kFused16), "the two tables must list the same shapes in the same order");
 
 int find_fused16(int cin, int cexp, int cout, int ks, int expand) {
+    if (cout <= 4) cout = 16;     // prediction heads run on the one-tile instantiation
     for (size_t i = 0; i < sizeof(kFused16) / sizeof(kFused16[0]); ++i) {
         const Fused16& f = kFused16[i];
         if (f.cin == cin && f.cexp == cexp && f.cout == cout && f.ks == ks && f.expand == expand) return (int)i;
@@ -500,6 +504,29 @@ int build_plan(fear_handle* h, int hw, bool with_head, Plan** out) {
         return true;
     };
 
+    // prediction head (dw3x3 + 1x1 to 4 / 1 channels [+ exp]) as a fused 16x16 block writing the caller's NCHW map
+    auto add_fused_pred = [&](int cd, int cp, const T& in, int act, int ext) -> bool {
+        if (!h->fuse || in.H != 16 || in.W != 16) return false;
+        const Conv& d = h->convs[cd];
+        const Conv& p = h->convs[cp];
+        if (d.stride != 1 || p.cout > 4 || !p.has_bias) return false;
+        const int id = find_fused16(d.cout, d.cout, p.cout, d.k, 0);
+        if (id < 0) return false;
+        Op op{};
+        op.type = OP_IR16; op.fused_id = id; op.conv_e = -1; op.conv_d = cd; op.conv_p = cp;
+        op.math = h->math;
+        if ((h->math ? pack_fused_h(h, -1, cd, cp, &op.d_packed) : pack_fused16(h, -1, cd, cp, &op.d_packed)) != FEAR_OK)
+            return false;
+        op.in_buf = in.buf; op.in_ld = in.ld; op.in_off = in.off;
+        op.H = 16; op.W = 16; op.Ho = 16; op.Wo = 16; op.C = d.cout; op.N = p.cout;
+        op.pred_cout = p.cout; op.act = act; op.out_external = ext;
+        snprintf(op.name, sizeof(op.name), "%s_%dx%d_k%d", ext == 3 ? "cls_pred16" : "bbox_pred16", d.cout, p.cout, d.k);
+        op.flops = 2.0 * 256 * ((double)d.cout * d.k * d.k + (double)d.cout * p.cout);
+        op.bytes = 4.0 * 256 * (d.cout + p.cout);
+        ops.push_back(op);
+        return true;
+    };
+
     auto add_fused_tile = [&](int ce, int cd, int cp, const T& in, T& outT, const T* res) -> bool {
         if (!h->fuse || in.H != in.W) return false;
         const Conv& d = h->convs[cd];
@@ -661,6 +688,11 @@ int build_plan(fear_handle* h, int hw, bool with_head, Plan** out) {
                     pool.release(d.buf);
                 }
                 x = y;
+            }
+            if (h->convs[pred->conv[1]].cout != (is_cls ? 1 : 4)) return FEAR_ERR_FORMAT;
+            if (add_fused_pred(pred->conv[0], pred->conv[1], x, pred->act, is_cls ? 3 : 2)) {
+                pool.release(x.buf);
+                return FEAR_OK;
             }
             add_dw(pred->conv[0], x, d, 0);
             pool.release(x.buf);
@@ -836,8 +868,12 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s) {
                 a.X = buf(op.in_buf) + op.in_off; a.ldx = op.in_ld;
                 a.Wpk = op.d_packed; a.bp = h->convs[op.conv_p].d_b;
                 a.R = op.res_buf >= 0 ? buf(op.res_buf) : nullptr; a.ldr = op.res_ld;
-                a.Y = buf(op.out_buf); a.ldy = op.out_ld;
+                a.Y = op.out_buf >= 0 ? buf(op.out_buf) : nullptr; a.ldy = op.out_ld;
                 a.relu_dw = op.relu_dw; a.relu_out = op.relu;
+                if (op.pred_cout > 0) {
+                    a.pred_cout = op.pred_cout; a.pred_act = op.act;
+                    a.Y = op.out_external == 3 ? ext.cls_out : ext.bbox_out;
+                }
                 hipLaunchKernelGGL(f.kernel, dim3(n), dim3(512), f.lds_bytes, s, a);
                 break;
             }

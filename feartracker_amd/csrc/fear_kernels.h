@@ -477,6 +477,9 @@ struct Ir2Args {
     float* Y;
     int ldx, ldr, ldy;
     int relu_dw, relu_out;
+    // prediction heads (bbox_pred / cls_pred): COUT is padded to 16 in the kernel, only the first pred_cout channels
+    // are real; they are written NCHW ([crop][pred_cout][256]) with optional exp (pred_act == 2)
+    int pred_cout, pred_act;
 };
 
 template <int CIN, int CEXP, int COUT, int KS, bool EXPAND>
@@ -654,6 +657,25 @@ __global__ __launch_bounds__(512) void ir16v2_fused_kernel(Ir2Args a) {
         __syncthreads();
     }
 
+    if (a.pred_cout > 0) {          // prediction head: lanes lk == 0 hold channels 0..3 of their pixel
+        if (lk == 0) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int px = (y0 + mt) * S + li;
+                const f32x4 v = accp[mt][0];
+                const float vals[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    if (n < a.pred_cout) {
+                        float o = vals[n] + a.bp[n];
+                        if (a.pred_act == 2) o = expf(o);
+                        a.Y[(crop * a.pred_cout + n) * 256 + px] = o;
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int nt = 0; nt < NTP; ++nt) {
         const int n = nt * 16 + lk * 4;
@@ -1055,19 +1077,22 @@ __global__ __launch_bounds__(512) void ir16h_fused_kernel(Ir2Args a) {
         }
         const float* e0 = E + (y0 * PW + li) * ES + lk * 8;
         const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // column-outer; the two channel halves are two independent 8-wide chains interleaved for ILP
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int kx = 0; kx < KS; ++kx) {
+            f32x4 w[2][KS];
 #pragma unroll
-            for (int kx = 0; kx < KS; ++kx) {
-                f32x4 w[KS];
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int ky = 0; ky < KS; ++ky) w[ky] = *reinterpret_cast<const f32x4*>(wd + (ky * KS + kx) * 32 + h * 4);
+                for (int ky = 0; ky < KS; ++ky) w[h][ky] = *reinterpret_cast<const f32x4*>(wd + (ky * KS + kx) * 32 + h * 4);
 #pragma unroll
-                for (int iy = 0; iy < KS + 1; ++iy) {
+            for (int iy = 0; iy < KS + 1; ++iy) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
                     const f32x4 v = *reinterpret_cast<const f32x4*>(e0 + (iy * PW + kx) * ES + h * 4);
                     const f32x8 v8 = __builtin_shufflevector(v, v, 0, 1, 2, 3, 4, 5, 6, 7);
-                    const f32x8 w8 = __builtin_shufflevector(iy < KS ? w[iy < KS ? iy : 0] : zero4,
-                                                             iy >= 1 ? w[iy >= 1 ? iy - 1 : 0] : zero4, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const f32x8 w8 = __builtin_shufflevector(iy < KS ? w[h][iy < KS ? iy : 0] : zero4,
+                                                             iy >= 1 ? w[h][iy >= 1 ? iy - 1 : 0] : zero4, 0, 1, 2, 3, 4, 5, 6, 7);
                     d8[h] += v8 * w8;
                 }
             }
@@ -1118,6 +1143,25 @@ __global__ __launch_bounds__(512) void ir16h_fused_kernel(Ir2Args a) {
         __syncthreads();
     }
 
+    if (a.pred_cout > 0) {          // prediction head: lanes lk == 0 hold channels 0..3 of their pixel
+        if (lk == 0) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int px = (y0 + mt) * S + li;
+                const f32x4 v = accp[mt][0];
+                const float vals[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    if (n < a.pred_cout) {
+                        float o = vals[n] + a.bp[n];
+                        if (a.pred_act == 2) o = expf(o);
+                        a.Y[(crop * a.pred_cout + n) * 256 + px] = o;
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int nt = 0; nt < NTP; ++nt) {
         const int n = nt * 16 + lk * 4;
