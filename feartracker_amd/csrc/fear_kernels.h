@@ -484,7 +484,9 @@ struct Ir2Args {
 
 template <int CIN, int CEXP, int COUT, int KS, bool EXPAND>
 struct Ir2Geom {
-    static constexpr int CE = 16, S = 16, P = KS / 2, PW = S + 2 * P, ES = CE + 4;
+    // ES = 24 floats (6 x 16 B) per pixel: with lane stride = one pixel and lk stride = one 16-B unit every
+    // 16-lane service group of ds_read_b128 hits 16 distinct 16-B slots (conflict free; ES = 20 was 2-way)
+    static constexpr int CE = 16, S = 16, P = KS / 2, PW = S + 2 * P, ES = 24;
     static constexpr int NCHUNK = CEXP / CE, NTP = COUT / 16, KG = EXPAND ? CIN / 16 : 0;
     static constexpr int AP = EXPAND ? KG * 256 + 16 : 0;
     static constexpr int BP = NTP * 256 + KS * KS * 16 + 16;
@@ -915,14 +917,20 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 template <int CIN, int CEXP, int COUT, int KS, bool EXPAND>
 struct IrHGeom {
-    static constexpr int CE = 32, S = 16, P = KS / 2, PW = S + 2 * P, ES = CE + 4;
+    // LDS tile of the expanded activations: pixel (y, x) of the 16x16 map lives at index (y + P) * RW + x + P with
+    // RW = 16 + P: ONE zero gutter of P columns per row serves as the right padding of row y and the left padding of
+    // row y + 1 (a tap that runs off the right edge lands in the next row's gutter).  Per pixel 40 floats =
+    // [h = channel half][lk = owning lane group][4] (+8 pad): a lane's two 16-B reads per tap are a channel-half
+    // plane apart, which makes every ds_read_b128 service group conflict free (pixel stride 10 units, lk stride 1).
+    static constexpr int CE = 32, S = 16, P = KS / 2, RW = S + P, ES = 40;
     static constexpr int NCHUNK = (CEXP + CE - 1) / CE, NTP = COUT / 16, KG = EXPAND ? (CIN + 31) / 32 : 0;
     // stage sizes in floats (a fragment = 64 lanes x 16 B = 256 floats)
     static constexpr int AP = EXPAND ? 2 * KG * 256 + 32 : 0;
     static constexpr int BP = NTP * 256 + KS * KS * 32 + 32;
-    static constexpr int EBUF = PW * PW * ES;
+    static constexpr int EBUF = ((S + 2 * P) * RW + P) * ES;
     static constexpr int LDS_FLOATS = 2 * EBUF + 2 * AP + 2 * BP;
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
 typedef float f32x8 __attribute__((ext_vector_type(8)));
@@ -935,7 +943,7 @@ __device__ __forceinline__ void split_half8(const f32x4& a, const f32x4& b, h8& 
 template <int CIN, int CEXP, int COUT, int KS, bool EXPAND>
 __global__ __launch_bounds__(512) void ir16h_fused_kernel(Ir2Args a) {
     using G = IrHGeom<CIN, CEXP, COUT, KS, EXPAND>;
-    constexpr int S = G::S, P = G::P, PW = G::PW, ES = G::ES, NCHUNK = G::NCHUNK, NTP = G::NTP, KG = G::KG;
+    constexpr int S = G::S, P = G::P, PW = G::RW, ES = G::ES, NCHUNK = G::NCHUNK, NTP = G::NTP, KG = G::KG;
     constexpr int AP = G::AP, BP = G::BP, EBUF = G::EBUF, CST = AP + BP;
     constexpr int AP4 = AP / 4, BP4 = BP / 4;
     constexpr int NRA = (AP4 + 511) / 512, NRB = (BP4 + 511) / 512;
@@ -1000,9 +1008,9 @@ __global__ __launch_bounds__(512) void ir16h_fused_kernel(Ir2Args a) {
             float* E = Ebuf + (c & 1) * EBUF;
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
-                float* e = E + ((y0 + mt + P) * PW + li + P) * ES + lk * 8;
+                float* e = E + ((y0 + mt + P) * PW + li + P) * ES + lk * 4;      // [h][lk][4]: h = 0 | h = 1 at +16
                 *reinterpret_cast<f32x4*>(e) = ra[2 * mt];
-                *reinterpret_cast<f32x4*>(e + 4) = ra[2 * mt + 1];
+                *reinterpret_cast<f32x4*>(e + 16) = ra[2 * mt + 1];
             }
         }
     };
@@ -1050,7 +1058,7 @@ __global__ __launch_bounds__(512) void ir16h_fused_kernel(Ir2Args a) {
             for (int nt = 0; nt < 2; ++nt) {
                 f32x4 v = acc[mt][nt];
                 v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                *reinterpret_cast<f32x4*>(E + ((y0 + mt + P) * PW + li + P) * ES + nt * 16 + lk * 4) = v;
+                *reinterpret_cast<f32x4*>(E + ((y0 + mt + P) * PW + li + P) * ES + (lk & 1) * 16 + (2 * nt + (lk >> 1)) * 4) = v;
             }
     };
 
@@ -1075,7 +1083,7 @@ __global__ __launch_bounds__(512) void ir16h_fused_kernel(Ir2Args a) {
             const f32x4 bd = *reinterpret_cast<const f32x4*>(wd + KS * KS * 32 + h * 4);
             d8[h] = __builtin_shufflevector(bd, bd, 0, 1, 2, 3, 4, 5, 6, 7);
         }
-        const float* e0 = E + (y0 * PW + li) * ES + lk * 8;
+        const float* e0 = E + (y0 * PW + li) * ES + lk * 4;
         const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
         // column-outer; the two channel halves are two independent 8-wide chains interleaved for ILP
 #pragma unroll
@@ -1089,7 +1097,7 @@ __global__ __launch_bounds__(512) void ir16h_fused_kernel(Ir2Args a) {
             for (int iy = 0; iy < KS + 1; ++iy) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(e0 + (iy * PW + kx) * ES + h * 4);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(e0 + (iy * PW + kx) * ES + h * 16);
                     const f32x8 v8 = __builtin_shufflevector(v, v, 0, 1, 2, 3, 4, 5, 6, 7);
                     const f32x8 w8 = __builtin_shufflevector(iy < KS ? w[h][iy < KS ? iy : 0] : zero4,
                                                              iy >= 1 ? w[h][iy >= 1 ? iy - 1 : 0] : zero4, 0, 1, 2, 3, 4, 5, 6, 7);

@@ -1,6 +1,6 @@
-// kbench — standalone ablation micro-bench for the fused block kernels (development tool, not product).
+// kbench — standalone micro-bench for the fused 16x16 block kernels (development tool, not product).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/kbench tools/kbench.hip
-// Run on the GPU box: tools/kbench [crops=256] [iters=20]
+// Run on the GPU box: tools/kbench [crops=256] [iters=20]   (weights are random: timing only)
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -22,59 +22,58 @@ static float* dev_rand(size_t n, float scale) {
     return d;
 }
 
-template <int CIN, int CEXP, int COUT, int KS, int CE, bool EXPAND, int ABL>
-static double run(const char* tag, int crops, int iters, IrArgs a) {
-    auto k = ir16_fused_kernel<CIN, CEXP, COUT, KS, CE, EXPAND, ABL>;
-    const int lds = ir16_lds_bytes<CIN, CEXP, COUT, KS, CE, EXPAND>();
+template <typename K>
+static double time_kernel(K k, int lds, int crops, int iters, Ir2Args a, int threads = 512) {
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(crops), dim3(512), lds, 0, a);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(crops), dim3(threads), lds, 0, a);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k, dim3(crops), dim3(512), lds, 0, a);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k, dim3(crops), dim3(threads), lds, 0, a);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
-    const double us = 1e3 * ms / iters;
-    const double flops = 2.0 * 256 * ((EXPAND ? (double)CIN * CEXP : 0.0) + (double)CEXP * KS * KS + (double)CEXP * COUT) * crops;
-    printf("%-34s abl=%2d  %8.1f us  %6.1f TF/s\n", tag, ABL, us, flops / us * 1e-6);
-    return us;
+    return 1e3 * ms / iters;
 }
 
-template <int CIN, int CEXP, int COUT, int KS, int CE, bool EXPAND>
-static void suite(const char* tag, int crops, int iters) {
-    IrArgs a{};
+template <int CIN, int COUT>
+static Ir2Args make_args(int crops, size_t packed_floats) {
+    Ir2Args a{};
     a.ldx = CIN; a.ldr = COUT; a.ldy = COUT;
     a.X = dev_rand((size_t)crops * 256 * CIN, 2.f);
-    a.We = EXPAND ? dev_rand((size_t)CEXP * CIN, 0.2f) : nullptr;
-    a.be = EXPAND ? dev_rand(CEXP, 0.2f) : nullptr;
-    a.Wd = dev_rand((size_t)KS * KS * CEXP, 0.4f);
-    a.bd = dev_rand(CEXP, 0.2f);
-    a.Wp = dev_rand((size_t)COUT * CEXP, 0.2f);
+    a.Wpk = dev_rand(packed_floats, 0.01f);
     a.bp = dev_rand(COUT, 0.2f);
-    a.R = nullptr;
     float* y;
     CK(hipMalloc(&y, (size_t)crops * 256 * COUT * sizeof(float)));
-    a.Y = y;
-    a.relu_dw = 1; a.relu_out = 0;
-    run<CIN, CEXP, COUT, KS, CE, EXPAND, 0>(tag, crops, iters, a);
-    run<CIN, CEXP, COUT, KS, CE, EXPAND, 1>(tag, crops, iters, a);
-    run<CIN, CEXP, COUT, KS, CE, EXPAND, 2>(tag, crops, iters, a);
-    run<CIN, CEXP, COUT, KS, CE, EXPAND, 4>(tag, crops, iters, a);
-    run<CIN, CEXP, COUT, KS, CE, EXPAND, 5>(tag, crops, iters, a);
-    run<CIN, CEXP, COUT, KS, CE, EXPAND, 7>(tag, crops, iters, a);
-    run<CIN, CEXP, COUT, KS, CE, EXPAND, 8>(tag, crops, iters, a);
-    run<CIN, CEXP, COUT, KS, CE, EXPAND, 10>(tag, crops, iters, a);
+    a.Y = y; a.relu_dw = 1; a.relu_out = 0;
+    return a;
+}
+
+template <int CIN, int CEXP, int COUT, int KS, bool EXPAND>
+static void bench(const char* tag, int crops, int iters) {
+    const double flops = 2.0 * 256 * ((EXPAND ? (double)CIN * CEXP : 0.0) + (double)CEXP * KS * KS + (double)CEXP * COUT) * crops;
+    {
+        using G = Ir2Geom<CIN, CEXP, COUT, KS, EXPAND>;
+        Ir2Args a = make_args<CIN, COUT>(crops, (size_t)G::NCHUNK * (G::AP + G::BP));
+        const double us = time_kernel(ir16v2_fused_kernel<CIN, CEXP, COUT, KS, EXPAND>, G::LDS_BYTES, crops, iters, a);
+        printf("%-24s fp32-mfma  %8.1f us  %6.1f TF/s\n", tag, us, flops / us * 1e-6);
+    }
+    {
+        using G = IrHGeom<CIN, CEXP, COUT, KS, EXPAND>;
+        Ir2Args a = make_args<CIN, COUT>(crops, (size_t)G::NCHUNK * (G::AP + G::BP));
+        const double us = time_kernel(ir16h_fused_kernel<CIN, CEXP, COUT, KS, EXPAND>, G::LDS_BYTES, crops, iters, a);
+        printf("%-24s f16-split  %8.1f us  %6.1f TF/s\n", tag, us, flops / us * 1e-6);
+    }
 }
 
 int main(int argc, char** argv) {
     const int crops = argc > 1 ? atoi(argv[1]) : 256;
     const int iters = argc > 2 ? atoi(argv[2]) : 20;
-    suite<112, 672, 112, 5, 32, true>("ir16_112x672x112_k5", crops, iters);
-    suite<64, 384, 64, 5, 32, true>("ir16_64x384x64_k5", crops, iters);
-    suite<256, 256, 256, 3, 32, false>("sep16_256x256x256_k3", crops, iters);
+    bench<112, 672, 112, 5, true>("ir16_112x672x112_k5", crops, iters);
+    bench<64, 384, 64, 5, true>("ir16_64x384x64_k5", crops, iters);
+    bench<256, 256, 256, 3, false>("sep16_256x256x256_k3", crops, iters);
     return 0;
 }
