@@ -36,12 +36,30 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
-           "-o", LIB + ".tmp", SRC]
+           "-Rpass-analysis=kernel-resource-usage", "-o", LIB + ".tmp", SRC]
     if verbose:
         print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    res = subprocess.run(cmd, check=True, capture_output=True, text=True)
     os.replace(LIB + ".tmp", LIB)
+    spills = check_spills(res.stderr)
+    for name, n in spills:
+        print(f"WARNING: {name} spills {n} VGPRs to scratch (hipcc scheduling is fragile around the fused kernels; "
+              "a spilling build is several times slower)")
     return LIB
+
+
+def check_spills(remarks: str):
+    """Parse hipcc's kernel-resource-usage remarks: [(kernel symbol, spilled VGPRs)] for kernels that spill."""
+    import re
+    out, name = [], None
+    for line in remarks.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"VGPRs Spill: (\d+)", line)
+        if m and name and int(m.group(1)) > 0:
+            out.append((name, int(m.group(1))))
+    return out
 
 
 if __name__ == "__main__":

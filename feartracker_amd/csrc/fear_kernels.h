@@ -737,6 +737,7 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
     const int cx_lo = max(ix0, 0), cy_lo = max(iy0, 0);
     const int CW = min(ix0 + IWR, t.W) - cx_lo, CH = min(iy0 + IHR, t.H) - cy_lo;
     const int NPIX = CW * CH;
+    const float inv_cw = 1.0f / (float)CW;
     const int Wo = t.W / ST, Ho = t.H / ST;
     const float* Xc = a.X + crop * t.H * t.W * a.ldx;
 
@@ -769,7 +770,7 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
         const int q = (wave + 8 * i) * 16 + li;
         const bool valid = q < NPIX;
         const int qq = valid ? q : 0;
-        const int cy = qq / CW, cx = qq - cy * CW;
+        const int cy = (int)(((float)qq + 0.5f) * inv_cw), cx = qq - cy * CW;   // exact for qq < 2^16, CW <= 64
         const int gy = cy_lo + cy, gx = cx_lo + cx;
         eoff[i] = valid ? ((gy - iy0) * IWR + (gx - ix0)) * ES : -1;
         xoff[i] = ((long)gy * t.W + gx) * a.ldx;
@@ -1226,6 +1227,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ir_tile_h_kernel(IrT2Args t) {
     const int cx_lo = max(ix0, 0), cy_lo = max(iy0, 0);
     const int CW = min(ix0 + IWR, t.W) - cx_lo, CH = min(iy0 + IHR, t.H) - cy_lo;
     const int NPIX = CW * CH;
+    const float inv_cw = 1.0f / (float)CW;
     const int Wo = t.W / ST, Ho = t.H / ST;
     const float* Xc = a.X + crop * t.H * t.W * a.ldx;
 
@@ -1257,7 +1259,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ir_tile_h_kernel(IrT2Args t) {
         const int q = (wave + NW * i) * 16 + li;
         const bool valid = q < NPIX;
         const int qq = valid ? q : 0;
-        const int cy = qq / CW, cx = qq - cy * CW;
+        const int cy = (int)(((float)qq + 0.5f) * inv_cw), cx = qq - cy * CW;   // exact for qq < 2^16, CW <= 64
         const int gy = cy_lo + cy, gx = cx_lo + cx;
         eoff[i] = valid ? ((gy - iy0) * IWR + (gx - ix0)) * ES : -1;
         xoff[i] = ((long)gy * t.W + gx) * a.ldx;
