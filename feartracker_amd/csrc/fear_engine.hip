@@ -105,6 +105,7 @@ struct Op {
     float* d_packed = nullptr; // OP_IR16: per-chunk packed weights (Ir2Geom layout), owned by the handle
     int math = 0;              // OP_IR16: 1 = fp16-split matrix-pipe kernel
     int pred_cout = 0;         // OP_IR16 prediction head: real output channels (4 / 1), NCHW external output
+    int stem = 0;              // OP_IRTILE: stem conv fused in front (reads the caller's NCHW image)
     char name[64];
     double flops = 0, bytes = 0;  // per crop: algorithmic FLOPs, compulsory bytes (in + out + weights excluded)
     // profiling
@@ -297,6 +298,11 @@ const FusedTile kFusedTileH[] = {
 };
 static_assert(sizeof(kFusedTileH) == sizeof(kFusedTile), "the two tile tables must list the same blocks in the same order");
 
+// stem (3x3 s2, 3 -> 16) fused in front of the first e1 block: one entry, keyed by the block's shape and map size
+const FusedTile kStemTile = {16, 16, 16, 3, 1, 0, 128, 32, 16,
+                             ir_tile_v2_kernel<27, 16, 16, 3, 1, 32, 16, true, 4, true>,
+                             IrT2Geom<27, 16, 16, 3, 1, 32, 16, true>::LDS_BYTES, 8};
+
 int find_fused_tile(int cin, int cexp, int cout, int ks, int st, int expand, int hw) {
     for (size_t i = 0; i < sizeof(kFusedTile) / sizeof(kFusedTile[0]); ++i) {
         const FusedTile& f = kFusedTile[i];
@@ -336,7 +342,7 @@ int pack_fused16(fear_handle* h, int ce, int cd, int cp, float** out) {
     const Conv& p = h->convs[cp];
     const Conv* e = ce >= 0 ? &h->convs[ce] : nullptr;
     const int cexp = d.cout, cout = p.cout, kk = d.k * d.k;
-    const int cin = e ? e->cin_g : cexp;
+    const int cin = e ? e->cin_g * e->k * e->k : cexp;   // 27 for the stem conv used as the 'expand' of a fused stem tile
     const int kg_n = e ? (cin + 15) / 16 : 0, ntp = (cout + 15) / 16;
     const int cexpp = (cexp + 15) / 16 * 16;       // channels / rows beyond the real extent are packed as zeros
     std::vector<float> buf;
@@ -561,8 +567,36 @@ int build_plan(fear_handle* h, int hw, bool with_head, Plan** out) {
 
     T cur;
     size_t bi = 0;
+    // ---- stem fused with the first inverted-residual block (e1, residual) when the shapes match the instantiation
+    bool stem_fused = false;
+    if (h->fuse && h->blocks.size() > 1 && h->blocks[1].kind == FEARW_IR && h->blocks[1].conv[0] < 0 && h->blocks[1].residual) {
+        const Conv& cs = h->convs[h->blocks[0].conv[0]];
+        const Conv& d = h->convs[h->blocks[1].conv[1]];
+        const Conv& p = h->convs[h->blocks[1].conv[2]];
+        const FusedTile& f = kStemTile;
+        const int ho = hw / 2;
+        if (cs.cout == 16 && d.cout == f.cexp && p.cout == f.cout && d.k == f.ks && d.stride == 1 && ho == f.hw &&
+            p.has_bias && d.relu && !p.relu) {
+            Op op{};
+            op.type = OP_IRTILE; op.fused_id = -1; op.stem = 1;
+            op.conv_e = h->blocks[0].conv[0]; op.conv_d = h->blocks[1].conv[1]; op.conv_p = h->blocks[1].conv[2];
+            if (pack_fused16(h, op.conv_e, op.conv_d, op.conv_p, &op.d_packed) == FEAR_OK) {
+                op.H = ho; op.W = ho; op.Ho = ho; op.Wo = ho; op.C = 3; op.N = p.cout;
+                op.relu_dw = 1; op.relu = 0;
+                cur.buf = pool.acquire(); cur.ld = p.cout; cur.off = 0; cur.C = p.cout; cur.H = ho; cur.W = ho;
+                op.out_buf = cur.buf; op.out_ld = cur.ld;
+                snprintf(op.name, sizeof(op.name), "stem_irt_3x16x16_k3_hw%d", hw);
+                op.flops = 2.0 * ho * ho * (27.0 * 16 + 16.0 * 9 + 16.0 * 16);
+                op.bytes = 4.0 * (3.0 * hw * hw + (double)ho * ho * 16);
+                ops.push_back(op);
+                track(cur);
+                stem_fused = true;
+                bi = 2;
+            }
+        }
+    }
     // ---- stem
-    {
+    if (!stem_fused) {
         const FearwBlock& b = h->blocks[0];
         const Conv& c = h->convs[b.conv[0]];
         Op op{};
@@ -788,6 +822,8 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s) {
         for (const FusedTile& f : kFusedTileH)
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(f.kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, f.lds_bytes));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kStemTile.kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kStemTile.lds_bytes));
         h->fused_attr_set = true;
     }
     const size_t slab = p.buf_floats_per_crop * h->max_batch;
@@ -878,10 +914,11 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s) {
                 break;
             }
             case OP_IRTILE: {
-                const FusedTile& f = op.math ? kFusedTileH[op.fused_id] : kFusedTile[op.fused_id];
+                const FusedTile& f = op.stem ? kStemTile : (op.math ? kFusedTileH[op.fused_id] : kFusedTile[op.fused_id]);
                 IrT2Args ta{};
                 Ir2Args& a = ta.b;
-                a.X = buf(op.in_buf) + op.in_off; a.ldx = op.in_ld;
+                if (op.stem) { a.X = ext.img; a.ldx = 0; }
+                else { a.X = buf(op.in_buf) + op.in_off; a.ldx = op.in_ld; }
                 a.Wpk = op.d_packed; a.bp = h->convs[op.conv_p].d_b;
                 a.R = op.res_buf >= 0 ? buf(op.res_buf) : nullptr; a.ldr = op.res_ld;
                 a.Y = buf(op.out_buf); a.ldy = op.out_ld;

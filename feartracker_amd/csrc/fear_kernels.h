@@ -715,8 +715,12 @@ struct IrT2Args {
     int H, W, tiles_x, tiles_y;
 };
 
-template <int CIN, int CEXPP, int COUT, int KS, int ST, int TW, int TH, bool EXPAND, int MINW>
+// STEM = true fuses the network stem in front of an e1 block: phase A is then the stem's 3x3 stride-2 conv as an
+// implicit GEMM (K = 27 -> 32) gathered straight from the caller's NCHW image (a.X), producing the stem output
+// (= the block input) only in LDS; the block's residual is read back from that LDS tile.  CIN must be 27.
+template <int CIN, int CEXPP, int COUT, int KS, int ST, int TW, int TH, bool EXPAND, int MINW, bool STEM = false>
 __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
+    static_assert(!STEM || (EXPAND && CIN == 27 && ST == 1 && CEXPP == 16), "stem mode");
     using G = IrT2Geom<CIN, CEXPP, COUT, KS, ST, TW, TH, EXPAND>;
     const Ir2Args& a = t.b;
     constexpr int P = G::P, IWR = G::IWR, IHR = G::IHR, ES = G::ES, SEG = G::SEG, MTC = G::MTC, MTA = G::MTA;
@@ -739,7 +743,7 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
     const int NPIX = CW * CH;
     const float inv_cw = 1.0f / (float)CW;
     const int Wo = t.W / ST, Ho = t.H / ST;
-    const float* Xc = a.X + crop * t.H * t.W * a.ldx;
+    const float* Xc = STEM ? a.X + crop * 3 * (2 * t.H) * (2 * t.W) : a.X + crop * t.H * t.W * a.ldx;
 
     for (int i = tid * 4; i < EBUF; i += 512 * 4) *reinterpret_cast<f32x4*>(E + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -765,6 +769,19 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
     int eoff[MTA];
     long xoff[MTA];
     f32x4 xf[EXPAND ? MTA : 1][EXPAND ? KG : 1];
+    // stem mode: the 8 im2col taps this lane gathers (k = kg*16 + 4*lk + j)
+    int s_off[STEM ? 8 : 1], s_ky[STEM ? 8 : 1], s_kx[STEM ? 8 : 1];
+    if (STEM) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = (j >> 2) * 16 + lk * 4 + (j & 3);
+            const int kk = k < 27 ? k : 0;
+            const int ci = kk / 9, ky = (kk % 9) / 3, kx = kk % 3;
+            s_ky[j] = k < 27 ? ky : -100000;           // invalid taps fail the bounds test below
+            s_kx[j] = kx;
+            s_off[j] = (ci * 2 * t.H + ky) * 2 * t.W + kx;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MTA; ++i) {
         const int q = (wave + 8 * i) * 16 + li;
@@ -774,7 +791,17 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
         const int gy = cy_lo + cy, gx = cx_lo + cx;
         eoff[i] = valid ? ((gy - iy0) * IWR + (gx - ix0)) * ES : -1;
         xoff[i] = ((long)gy * t.W + gx) * a.ldx;
-        if (EXPAND) {
+        if (STEM) {
+            const float* pimg = Xc + (long)(2 * gy - 1) * 2 * t.W + 2 * gx - 1;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool ok = (2 * gy - 1 + s_ky[j] >= 0) && (2 * gx - 1 + s_kx[j] >= 0);
+                v[j] = ok ? pimg[s_off[j]] : 0.f;
+            }
+            xf[i][0] = (f32x4){v[0], v[1], v[2], v[3]};
+            xf[i][KG > 1 ? 1 : 0] = (f32x4){v[4], v[5], v[6], v[7]};
+        } else if (EXPAND) {
 #pragma unroll
             for (int kg = 0; kg < KG; ++kg) {
                 xf[i][kg] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -888,7 +915,8 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
             const int oy = oy0 + r0 + r, ox = ox0 + seg * 16 + li;
             const long m = (crop * Ho + oy) * Wo + ox;
             f32x4 v = accp[r][nt] + b;
-            if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
+            if (STEM) v += *reinterpret_cast<const f32x4*>(E + ((r0 + r + P) * IWR + seg * 16 + li + P) * ES + n);
+            else if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
             if (a.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = v;
         }
