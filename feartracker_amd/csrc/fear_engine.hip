@@ -1134,6 +1134,28 @@ int fear_normalize_u8(fear_handle* h, const uint8_t* u8, int n, int hw, float* o
     return FEAR_OK;
 }
 
+int fear_crop_normalize(fear_handle* h, const uint8_t* frame_u8, int frame_h, int frame_w, const int32_t* ctx_xywh,
+                        const uint8_t* pad_rgb, int n, int out_hw, float* out, void* stream) {
+    if (!h) return FEAR_ERR_NULL;
+    if (n < 0 || frame_h < 1 || frame_w < 1 || out_hw < 1 || out_hw > 4096) return FEAR_ERR_SHAPE;
+    if (n == 0) return FEAR_OK;
+    if (!frame_u8 || !ctx_xywh || !pad_rgb || !out) return FEAR_ERR_NULL;
+    HIP_TRY(h, hipSetDevice(h->device));
+    CropArgs a{};
+    a.frame = frame_u8; a.ctx = ctx_xywh; a.pad = pad_rgb; a.out = out;
+    a.H = frame_h; a.W = frame_w; a.S = out_hw; a.n = n;
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    for (int c = 0; c < 3; ++c) {
+        a.mean[c] = mean[c] * 255.0f;
+        a.inv_std[c] = 1.0f / (stdv[c] * 255.0f);
+    }
+    const long total = (long)n * out_hw * out_hw;
+    hipLaunchKernelGGL(crop_resize_normalize_kernel, dim3((total + 255) / 256), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), a);
+    HIP_TRY(h, hipGetLastError());
+    return FEAR_OK;
+}
+
 int fear_plan_size(fear_handle* h, int hw, int with_head) {
     if (!h) return FEAR_ERR_NULL;
     Plan* p = nullptr;

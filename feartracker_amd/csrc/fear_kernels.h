@@ -439,6 +439,68 @@ __global__ __launch_bounds__(256) void normalize_kernel(NormArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// get_extended_crop + normalise on device: context box -> constant border with the (saturate-
+// cast) mean colour -> cv2.INTER_LINEAR uint8 resize (11-bit fixed point, half-pixel centres) -> ImageNet
+// normalisation -> fp32 NCHW.  Reference: model_training/utils/utils.py:215-253 (cv2.copyMakeBorder + A.Resize)
+// and tracker/base_tracker.py:70-103.  Bit-exact against the host restatement feartracker_amd/geometry.py
+// (crop parity against real cv2 is unpinned in this image).  One thread per output pixel.
+struct CropArgs {
+    const uint8_t* frame;   // [H][W][3] RGB
+    const int* ctx;         // [n][4] context box x, y, w, h (frame coordinates, may leave the frame)
+    const uint8_t* pad;     // [n][3] border colour (already saturate-cast)
+    float* out;             // [n][3][S][S]
+    int H, W, S, n;
+    float mean[3], inv_std[3];
+};
+
+__device__ __forceinline__ void linear_tap(int d, int dst, int src, int& i0, int& i1, int& w0, int& w1) {
+    const double scale = (double)src / (double)dst;
+    const double pos = ((double)d + 0.5) * scale - 0.5;
+    int idx = (int)floor(pos);
+    float frac = (float)(pos - (double)idx);
+    if (idx < 0) { frac = 0.f; idx = 0; }
+    if (idx >= src - 1) { frac = 0.f; idx = src - 1; }
+    w1 = (int)rint((double)frac * 2048.0);
+    w0 = (int)rint((double)(1.0f - frac) * 2048.0);
+    i0 = idx;
+    i1 = min(idx + 1, src - 1);
+}
+
+__global__ __launch_bounds__(256) void crop_resize_normalize_kernel(CropArgs a) {
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int plane = a.S * a.S;
+    if (p >= (long)a.n * plane) return;
+    const int crop = p / plane, px = p % plane;
+    const int dy = px / a.S, dx = px % a.S;
+    const int cx = a.ctx[crop * 4], cy = a.ctx[crop * 4 + 1], cw = a.ctx[crop * 4 + 2], ch = a.ctx[crop * 4 + 3];
+    int x0, x1, ax0, ax1, y0, y1, ay0, ay1;
+    linear_tap(dx, a.S, cw, x0, x1, ax0, ax1);
+    linear_tap(dy, a.S, ch, y0, y1, ay0, ay1);
+    const bool same = (cw == a.S) && (ch == a.S);      // the reference's resize is the identity then
+    auto sample = [&](int sx, int sy, int c) -> int {
+        const int fx = cx + sx, fy = cy + sy;
+        if (fx < 0 || fx >= a.W || fy < 0 || fy >= a.H) return a.pad[crop * 3 + c];
+        return a.frame[((long)fy * a.W + fx) * 3 + c];
+    };
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        int v;
+        if (same) {
+            v = sample(dx, dy, c);
+        } else {
+            const int r0 = sample(x0, y0, c) * ax0 + sample(x1, y0, c) * ax1;
+            const int r1 = sample(x0, y1, c) * ax0 + sample(x1, y1, c) * ax1;
+            v = (((ay0 * (r0 >> 4)) >> 16) + ((ay1 * (r1 >> 4)) >> 16) + 2) >> 2;
+            v = min(max(v, 0), 255);
+        }
+        float f = (float)v;
+        f -= a.mean[c];
+        f *= a.inv_std[c];
+        a.out[((long)crop * 3 + c) * plane + px] = f;
+    }
+}
+
 // ================================================================================================
 // Fused block kernels.  (The first generation — ir16_fused_kernel / ir_tile_fused_kernel, weights loaded from
 // global per chunk — was replaced by the v2 kernels below after the tools/kbench.hip ablation; see DESIGN.md.)

@@ -131,6 +131,25 @@ def resize_bilinear_u8(img: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
     return np.clip(out, 0, 255).astype(np.uint8)
 
 
+def crop_geometry(image_shape: Tuple[int, ...], bbox: Sequence[float], crop_size: int,
+                  offset: float) -> Tuple[np.ndarray, np.ndarray]:
+    """The pixel-free part of `get_extended_crop`: (context box int32 xywh in frame coordinates, bbox inside the
+    resized crop).  Used by the device crop path (`FEARNetHIP.crop_normalize`), which does the pixel work on the GPU."""
+    img_h, img_w = image_shape[0], image_shape[1]
+    ctx = extend_bbox(bbox, offset)
+    cx, cy, cw, ch = (int(v) for v in ctx)
+    box_in_pad = ensure_bbox_boundaries(
+        np.array([bbox[0] - ctx[0], bbox[1] - ctx[1], bbox[2], bbox[3]]), img_shape=(ch, cw))
+    sx, sy = crop_size / float(cw), crop_size / float(ch)
+    box_in_crop = np.array([box_in_pad[0] * sx, box_in_pad[1] * sy, box_in_pad[2] * sx, box_in_pad[3] * sy])
+    return ctx, box_in_crop
+
+
+def border_color_u8(padding_value: Sequence[float]) -> np.ndarray:
+    """The uint8 colour cv2.copyMakeBorder writes for a float border value (round half to even, saturate)."""
+    return _saturate_u8(np.asarray(padding_value, dtype=np.float64).reshape(-1)[:3])
+
+
 def get_extended_crop(image: np.ndarray, bbox: Sequence[float], crop_size: int, offset: float,
                       padding_value: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """Context crop around `bbox`, padded with `padding_value`, resized to crop_size x crop_size.

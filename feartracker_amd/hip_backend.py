@@ -58,6 +58,8 @@ def load_library() -> ctypes.CDLL:
     lib.fear_decode.restype = i32
     lib.fear_normalize_u8.argtypes = [vp, vp, i32, i32, f32p, vp]
     lib.fear_normalize_u8.restype = i32
+    lib.fear_crop_normalize.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, f32p, vp]
+    lib.fear_crop_normalize.restype = i32
     lib.fear_set_option.argtypes = [vp, i32, i64]
     lib.fear_set_option.restype = i32
     lib.fear_get_option.argtypes = [vp, i32]
@@ -84,6 +86,7 @@ def load_library() -> ctypes.CDLL:
 
 EXPORTED_SYMBOLS = (
     "fear_create", "fear_destroy", "fear_features", "fear_track", "fear_decode", "fear_normalize_u8",
+    "fear_crop_normalize",
     "fear_set_option", "fear_get_option", "fear_plan_size", "fear_plan_op", "fear_profile_read",
     "fear_profile_reset", "fear_workspace_bytes", "fear_strerror", "fear_last_hip_error", "fear_version",
 )
@@ -250,6 +253,25 @@ class FEARNetHIP:
         out = torch.empty((n, 3, hw, hw), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             self._check(self._lib.fear_normalize_u8(self._h, x.data_ptr(), n, hw, out.data_ptr(), self._stream()))
+        return out
+
+    @torch.no_grad()
+    def crop_normalize(self, frame_u8: torch.Tensor, ctx_xywh, pad_rgb_u8, out_hw: int) -> torch.Tensor:
+        """Device get_extended_crop + normalise (utils.py:215-253 + base_tracker.py:97-103): frame (H,W,3) uint8 on
+        the GPU, ctx_xywh (n,4) int context boxes, pad_rgb_u8 (n,3) uint8 border colours -> (n,3,out_hw,out_hw) fp32."""
+        if frame_u8.dtype != torch.uint8 or frame_u8.dim() != 3 or frame_u8.shape[2] != 3:
+            raise ValueError("frame must be uint8 (H,W,3)")
+        frame_u8 = frame_u8.to(self.device).contiguous()
+        ctx = torch.as_tensor(ctx_xywh, dtype=torch.int32).reshape(-1, 4).to(self.device).contiguous()
+        pad = torch.as_tensor(pad_rgb_u8, dtype=torch.uint8).reshape(-1, 3).to(self.device).contiguous()
+        n = ctx.shape[0]
+        if pad.shape[0] != n:
+            raise ValueError("one border colour per context box")
+        out = torch.empty((n, 3, out_hw, out_hw), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self._lib.fear_crop_normalize(self._h, frame_u8.data_ptr(), frame_u8.shape[0], frame_u8.shape[1],
+                                                      ctx.data_ptr(), pad.data_ptr(), n, int(out_hw), out.data_ptr(),
+                                                      self._stream()))
         return out
 
     # ------------------------------------------------------------------ measurement

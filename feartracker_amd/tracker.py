@@ -24,7 +24,7 @@ import torch
 
 from .box_coder import FEARBoxCoder, TrackerDecodeResult
 from .constants import TARGET_CLASSIFICATION_KEY, TARGET_REGRESSION_LABEL_KEY
-from .geometry import clamp_bbox, get_extended_crop, normalize_image
+from .geometry import border_color_u8, clamp_bbox, crop_geometry, get_extended_crop, normalize_image
 
 
 def _resolve_device(cuda_id: Union[int, str, torch.device]) -> torch.device:
@@ -199,14 +199,35 @@ class FEARTracker(Tracker):
         st.mean_color = np.mean(image, axis=(0, 1))
         self._template_features = self.get_template_features(image, rect)
 
+    def _device_crop(self) -> bool:
+        """`device_crop=True` in the tracking config moves crop + border + resize + normalise to the GPU
+        (`fear_crop_normalize`); bit-identical to the host path, not part of the reference config."""
+        return bool(self.tracking_config.get("device_crop", False)) and hasattr(self.net, "crop_normalize")
+
     def get_template_features(self, image: np.ndarray, rect: np.ndarray):
         cfg = self.tracking_config
+        if self._device_crop():
+            ctx, _ = crop_geometry(image.shape, rect, cfg["template_size"], cfg["template_bbox_offset"])
+            pad = border_color_u8(np.mean(image, axis=(0, 1)))
+            x = self.net.crop_normalize(torch.from_numpy(np.ascontiguousarray(image[:, :, :3])), ctx, pad, cfg["template_size"])
+            return self.net.get_features(x)
         crop, _, _ = get_extended_crop(image=image, bbox=rect, offset=cfg["template_bbox_offset"],
                                        crop_size=cfg["template_size"])
         return self.net.get_features(self._preprocess_image(crop, self._template_transform))
 
     def update(self, image: np.ndarray, *kw) -> Dict[str, Any]:
         cfg, st = self.tracking_config, self.tracking_state
+        if self._device_crop():
+            context, box_in_crop = crop_geometry(image.shape, st.bbox, cfg["instance_size"], cfg["search_context"])
+            st.mapping = context
+            st.prev_size = box_in_crop[2:]
+            search = self.net.crop_normalize(torch.from_numpy(np.ascontiguousarray(image[:, :, :3])), context,
+                                             border_color_u8(st.mean_color), cfg["instance_size"])
+            pred, _ = self._postprocess(track_result=self.net.track(search, self._template_features))
+            pred = clamp_bbox(self._rescale_bbox(pred, st.mapping), image.shape)
+            st.bbox = pred
+            st.paths.append(pred)
+            return dict(bbox=pred)
         crop, box_in_crop, context = get_extended_crop(
             image=image, bbox=st.bbox, crop_size=cfg["instance_size"], offset=cfg["search_context"],
             padding_value=st.mean_color)

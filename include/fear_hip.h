@@ -75,6 +75,14 @@ int fear_decode(fear_handle* h, const float* cls, const float* bbox, int n, int 
  *   u8  : (n, hw, hw, 3) uint8     out : (n, 3, hw, hw) fp32                                    */
 int fear_normalize_u8(fear_handle* h, const uint8_t* u8, int n, int hw, float* out, void* stream);
 
+/* get_extended_crop + _preprocess_image on device (utils/utils.py:215-253, base_tracker.py:97-103):
+ * for each of n context boxes (x, y, w, h in frame pixels, as returned by extend_bbox; may leave the frame) cut the
+ * box out of ONE uint8 RGB frame, fill what lies outside the frame with pad_rgb (the saturate-cast mean colour),
+ * resize to out_hw x out_hw like cv2.INTER_LINEAR on uint8 and normalise -> (n, 3, out_hw, out_hw) fp32 NCHW.
+ *   frame_u8 : (frame_h, frame_w, 3) uint8, device     ctx_xywh : (n, 4) int32, device     pad_rgb : (n, 3) uint8, device */
+int fear_crop_normalize(fear_handle* h, const uint8_t* frame_u8, int frame_h, int frame_w, const int32_t* ctx_xywh,
+                        const uint8_t* pad_rgb, int n, int out_hw, float* out, void* stream);
+
 /* ---- engine options ------------------------------------------------------------------------- */
 #define FEAR_OPT_MAX_BATCH 1   /* crops processed per internal pass (workspace is sized for it)  */
 #define FEAR_OPT_PROFILE 2     /* 1: bracket kernel launches with hipEvents (fear_profile_*)     */

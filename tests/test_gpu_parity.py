@@ -212,3 +212,41 @@ def test_matrix_pipe_split_mode_matches_fp32(hip_net, oracle_net, golden_dir):
     ref = oracle_net.track(xs, zs)
     bb, cc = fast.track_maps(xs.cuda(), zs.cuda())
     assert rel_err(bb, ref["TARGET_REGRESSION_LABEL_KEY"]) < REL and rel_err(cc, ref["TARGET_CLASSIFICATION_KEY"]) < REL
+
+
+def test_device_crop_is_bit_identical_to_host_crop(hip_net, golden_dir):
+    """fear_crop_normalize (crop + constant border + cv2-style uint8 bilinear resize + normalise on device) against
+    the host restatement get_extended_crop + normalize_image: identical floats for boxes inside, across and
+    outside the frame, up- and down-scaling, and the identity size."""
+    from feartracker_amd import geometry as geo
+    d = np.load(f"{golden_dir}/clip_synth.npz")
+    frame = d["frames"][3]
+    mean = np.mean(frame, axis=(0, 1))
+    fr = torch.from_numpy(frame).cuda()
+    cases = [([68, 46, 44, 68], 256, 2.0), ([68, 46, 44, 68], 128, 0.2), ([0, 0, 30, 40], 256, 2.0),
+             ([300, 170, 40, 30], 256, 2.0), ([150, 90, 7, 5], 256, 2.0), ([100, 60, 128, 128], 128, 0.0),
+             ([10, 10, 300, 180], 256, 0.1), ([-20, -10, 50, 60], 128, 0.2)]
+    for box, size, off in cases:
+        crop, box_in_crop, ctx = geo.get_extended_crop(frame, np.array(box), size, off, padding_value=mean)
+        ref = np.transpose(geo.normalize_image(crop), (2, 0, 1))
+        ctx2, box2 = geo.crop_geometry(frame.shape, np.array(box), size, off)
+        np.testing.assert_array_equal(ctx, ctx2)
+        np.testing.assert_allclose(box_in_crop, box2, rtol=0, atol=1e-12)
+        got = hip_net.crop_normalize(fr, ctx, geo.border_color_u8(mean), size)[0].cpu().numpy()
+        np.testing.assert_array_equal(got, ref)
+    # batched: two boxes of one frame at once
+    ctxs = np.stack([geo.extend_bbox(np.array(c[0]), 2.0) for c in cases[:2]])
+    pads = np.stack([geo.border_color_u8(mean)] * 2)
+    both = hip_net.crop_normalize(fr, ctxs, pads, 256)
+    for i in range(2):
+        crop, _, _ = geo.get_extended_crop(frame, np.array(cases[i][0]), 256, 2.0, padding_value=mean)
+        np.testing.assert_array_equal(both[i].cpu().numpy(), np.transpose(geo.normalize_image(crop), (2, 0, 1)))
+
+
+def test_tracker_clip_with_device_crop(hip_net, golden_dir):
+    from feartracker_amd import DEFAULT_TRACKING_CONFIG, FEARTracker
+    d = np.load(f"{golden_dir}/clip_synth.npz")
+    trk = FEARTracker(hip_net, cuda_id=0, device_crop=True, **DEFAULT_TRACKING_CONFIG)
+    trk.initialize(d["frames"][0], d["init_bbox"])
+    boxes = [np.array(d["init_bbox"])] + [np.array(trk.update(f)["bbox"]) for f in d["frames"][1:]]
+    np.testing.assert_array_equal(np.stack(boxes), d["tracked"])
