@@ -250,3 +250,28 @@ def test_tracker_clip_with_device_crop(hip_net, golden_dir):
     trk.initialize(d["frames"][0], d["init_bbox"])
     boxes = [np.array(d["init_bbox"])] + [np.array(trk.update(f)["bbox"]) for f in d["frames"][1:]]
     np.testing.assert_array_equal(np.stack(boxes), d["tracked"])
+
+
+def test_other_sizes_and_second_weight_set(oracle_net):
+    """`fear_features` accepts any multiple of 32 (maps without a fused instantiation fall back to the layer-wise
+    kernels), and the engine is weight-file driven: the iOS demo's Tracker.mlmodel weights give their own maps."""
+    from feartracker_amd import FEARNetHIP
+    from oracle.fear_oracle import OracleNet
+    from conftest import WEIGHTS, WEIGHTS_DEMO
+    net = FEARNetHIP(WEIGHTS, device=0, max_batch=4)
+    g = torch.Generator().manual_seed(123)
+    for hw in (32, 96, 192, 320):
+        x = torch.randn(2, 3, hw, hw, generator=g)
+        assert rel_err(net.get_features(x.cuda()), oracle_net.get_features(x)) < REL
+    with pytest.raises(Exception):
+        net.get_features(torch.randn(1, 3, 100, 100).cuda())          # not a multiple of 32
+    demo, demo_ref = FEARNetHIP(WEIGHTS_DEMO, device=0, max_batch=4), OracleNet(WEIGHTS_DEMO)
+    x = norm_u8(torch.randint(0, 256, (2, 3, 256, 256), dtype=torch.uint8, generator=g))
+    z = demo_ref.get_features(norm_u8(torch.randint(0, 256, (2, 3, 128, 128), dtype=torch.uint8, generator=g)))
+    ref = demo_ref.track(x, z)
+    for mode in (0, 1):
+        demo.set_math(mode)
+        b, c = demo.track_maps(x.cuda(), z.cuda())
+        assert rel_err(b, ref["TARGET_REGRESSION_LABEL_KEY"]) < REL and rel_err(c, ref["TARGET_CLASSIFICATION_KEY"]) < REL
+    other = oracle_net.track(x, oracle_net.get_features(torch.zeros(2, 3, 128, 128)))
+    assert rel_err(b, other["TARGET_REGRESSION_LABEL_KEY"]) > 1e-2     # different trained weights, different maps
