@@ -110,6 +110,7 @@ def main() -> None:
                     help="crops per internal engine pass (workspace / cache footprint)")
     ap.add_argument("--math", type=int, default=int(os.environ.get("FEAR_MATH", "0")), choices=[0, 1],
                     help="0: fp32 MFMA (exact fp32, default); 1: fp16 hi+lo split operands on the matrix pipe, fp32 accumulate")
+    ap.add_argument("--no-chain", action="store_true", help="A/B: one fused kernel per stride-16 block instead of the chain kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump-ops", action="store_true", help="print the per-kernel time table to stderr")
     args = ap.parse_args()
@@ -133,6 +134,8 @@ def main() -> None:
     B = args.batch
     net = FEARNetHIP(DEFAULT_WEIGHTS, device=local_rank, max_batch=args.max_batch)
     net.set_math(args.math)
+    if args.no_chain:
+        net.set_chain(False)
     search_u8, tmpl_u8 = synth_batch(B, rank)
     search = norm_u8(search_u8.to(dev)).contiguous()
     tmpl_feats = net.get_features(norm_u8(tmpl_u8.to(dev)).contiguous())
@@ -220,6 +223,8 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed_other = float(t.item())
     net.set_math(args.math)
+    if args.no_chain:
+        net.set_chain(False)
 
     if rank == 0:
         total_crops = world * B * args.steps

@@ -84,7 +84,7 @@ struct Conv {
     bool is_pw() const { return groups == 1 && k == 1; }
 };
 
-enum OpType { OP_STEM, OP_PW, OP_DW, OP_CORR, OP_PW_SMALL, OP_IR16, OP_IRTILE };
+enum OpType { OP_STEM, OP_PW, OP_DW, OP_CORR, OP_PW_SMALL, OP_IR16, OP_IRTILE, OP_CHAIN16 };
 
 struct Op {
     OpType type;
@@ -106,6 +106,11 @@ struct Op {
     int math = 0;              // OP_IR16: 1 = fp16-split matrix-pipe kernel
     int pred_cout = 0;         // OP_IR16 prediction head: real output channels (4 / 1), NCHW external output
     int stem = 0;              // OP_IRTILE: stem conv fused in front (reads the caller's NCHW image)
+    // OP_CHAIN16: per-block packed weights / projection convs, neck fragments
+    float* chain_pk[8] = {nullptr};
+    int chain_cp[8] = {0};
+    float* neck_pk = nullptr;
+    int neck_conv = -1;
     char name[64];
     double flops = 0, bytes = 0;  // per crop: algorithmic FLOPs, compulsory bytes (in + out + weights excluded)
     // profiling
@@ -134,6 +139,7 @@ struct fear_handle {
     int profile = 0;
     int profile_op = -1;   // -1: every op, else only this op index of each plan
     int fuse = 1;          // 1: use the fused block kernels where an instantiation exists
+    int chain = 1;         // 1: run the stride-16 trunk stage as one register-resident chain kernel (fp32 mode)
     int math = 0;          // 0: fp32 MFMA everywhere; 1: fp16-split operands on the matrix pipe in the fused 16x16 blocks
     bool fused_attr_set = false;
     int last_hip_error = 0;
@@ -409,6 +415,32 @@ int pack_fused_h(fear_handle* h, int ce, int cd, int cp, float** out) {
     return upload(h, buf, out);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The stride-16 trunk stage of FEAR-XS (fbnet_c stages 11-17 + AdjustLayer) as one register-resident chain kernel.
+struct ChainShape { int cin, cexp, cout, ks, res; };
+const ChainShape kChainXS[7] = {{64, 192, 64, 5, 1},   {64, 384, 64, 5, 1},   {64, 384, 64, 5, 1}, {64, 384, 112, 5, 0},
+                                {112, 672, 112, 5, 1}, {112, 672, 112, 5, 1}, {112, 336, 112, 5, 1}};
+constexpr int kChainNeckOut = 256;
+auto* const kChainXSKernel =
+    chain16_kernel<ChainBlk<64, 192, 64, 5, true>, ChainBlk<64, 384, 64, 5, true>, ChainBlk<64, 384, 64, 5, true>,
+                   ChainBlk<64, 384, 112, 5, false>, ChainBlk<112, 672, 112, 5, true>, ChainBlk<112, 672, 112, 5, true>,
+                   ChainBlk<112, 336, 112, 5, true>, kChainNeckOut>;
+constexpr int kChainXSLds =
+    Chain16Lds<5, Ir2Geom<112, 672, 112, 5, true>::AP, Ir2Geom<112, 672, 112, 5, true>::BP>::FLOATS * 4;
+
+// neck weights as MFMA fragments [nt][kg][lane][4] (lane l: W[nt*16 + (l&15)][kg*16 + 4*(l>>4) + 0..3])
+int pack_neck_frags(fear_handle* h, int conv, float** out) {
+    const Conv& c = h->convs[conv];
+    const int n = c.cout, k = c.cin_g;
+    std::vector<float> buf;
+    for (int nt = 0; nt < n / 16; ++nt)
+        for (int kg = 0; kg < k / 16; ++kg)
+            for (int l = 0; l < 64; ++l)
+                for (int i = 0; i < 4; ++i) buf.push_back(c.w[(size_t)(nt * 16 + (l & 15)) * k + kg * 16 + (l >> 4) * 4 + i]);
+    return upload(h, buf, out);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Plan construction.  Activation buffers come from a small pool of equally sized slabs
 // (per-crop size = the largest intermediate tensor) handed out by liveness, so consecutive layers
@@ -614,6 +646,54 @@ int build_plan(fear_handle* h, int hw, bool with_head, Plan** out) {
     // ---- trunk + neck
     for (; bi < h->blocks.size(); ++bi) {
         const FearwBlock& b = h->blocks[bi];
+        // ---- the whole stride-16 stage + neck as one chain kernel (fp32 arithmetic, search branch)
+        if (h->fuse && h->chain && !h->math && with_head && b.kind == FEARW_IR && cur.H == 16 && cur.W == 16 &&
+            bi + 7 < h->blocks.size() && h->blocks[bi + 7].kind == FEARW_NECK) {
+            bool match = true;
+            for (int j = 0; j < 7 && match; ++j) {
+                const FearwBlock& bj = h->blocks[bi + j];
+                if (bj.kind != FEARW_IR || bj.conv[0] < 0) { match = false; break; }
+                const Conv& e = h->convs[bj.conv[0]];
+                const Conv& d = h->convs[bj.conv[1]];
+                const Conv& p = h->convs[bj.conv[2]];
+                const ChainShape& cs = kChainXS[j];
+                match = e.cin_g == cs.cin && d.cout == cs.cexp && p.cout == cs.cout && d.k == cs.ks && d.stride == 1 &&
+                        (int)bj.residual == cs.res && e.has_bias && p.has_bias && e.relu && d.relu && !p.relu;
+            }
+            const Conv& nk = h->convs[h->blocks[bi + 7].conv[0]];
+            match = match && nk.cin_g == kChainXS[6].cout && nk.cout == kChainNeckOut && nk.has_bias && !nk.relu;
+            if (match) {
+                Op op{};
+                op.type = OP_CHAIN16;
+                bool ok = true;
+                double fl = 0;
+                for (int j = 0; j < 7 && ok; ++j) {
+                    const FearwBlock& bj = h->blocks[bi + j];
+                    ok = pack_fused16(h, bj.conv[0], bj.conv[1], bj.conv[2], &op.chain_pk[j]) == FEAR_OK;
+                    op.chain_cp[j] = bj.conv[2];
+                    const ChainShape& cs = kChainXS[j];
+                    fl += 2.0 * 256 * ((double)cs.cin * cs.cexp + 25.0 * cs.cexp + (double)cs.cexp * cs.cout);
+                }
+                op.neck_conv = h->blocks[bi + 7].conv[0];
+                ok = ok && pack_neck_frags(h, op.neck_conv, &op.neck_pk) == FEAR_OK;
+                if (ok) {
+                    op.in_buf = cur.buf; op.in_ld = cur.ld; op.in_off = cur.off;
+                    op.H = 16; op.W = 16; op.Ho = 16; op.Wo = 16; op.C = kChainXS[0].cin; op.N = kChainNeckOut;
+                    T o;
+                    o.buf = pool.acquire(); o.ld = kChainNeckOut; o.off = 0; o.C = kChainNeckOut; o.H = 16; o.W = 16;
+                    op.out_buf = o.buf; op.out_ld = o.ld;
+                    snprintf(op.name, sizeof(op.name), "chain16_7blocks_neck_%dx%d", op.C, op.N);
+                    op.flops = fl + 2.0 * 256 * kChainXS[6].cout * kChainNeckOut;
+                    op.bytes = 4.0 * 256 * (op.C + op.N);
+                    ops.push_back(op);
+                    track(o);
+                    pool.release(cur.buf);
+                    cur = o;
+                    bi += 8;
+                    break;      // the neck is consumed: continue with the head
+                }
+            }
+        }
         if (b.kind == FEARW_IR) {
             T x = cur, e = cur, d, o;
             if (add_fused16(b.conv[0], b.conv[1], b.conv[2], x, o, b.residual ? &x : nullptr, 1, 0, 0, "ir16") ||
@@ -822,6 +902,8 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s) {
         for (const FusedTile& f : kFusedTileH)
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(f.kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, f.lds_bytes));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kChainXSKernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kChainXSLds));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kStemTile.kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kStemTile.lds_bytes));
         h->fused_attr_set = true;
@@ -925,6 +1007,15 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s) {
                 a.relu_dw = op.relu_dw; a.relu_out = op.relu;
                 ta.H = op.H; ta.W = op.W; ta.tiles_x = op.Wo / f.tw; ta.tiles_y = op.Ho / f.th;
                 hipLaunchKernelGGL(f.kernel, dim3((unsigned)n * ta.tiles_x * ta.tiles_y), dim3(64 * f.nw), f.lds_bytes, s, ta);
+                break;
+            }
+            case OP_CHAIN16: {
+                Chain16Args a{};
+                a.X = buf(op.in_buf) + op.in_off; a.ldx = op.in_ld;
+                a.Y = buf(op.out_buf); a.ldy = op.out_ld;
+                for (int j = 0; j < 7; ++j) { a.Wpk[j] = op.chain_pk[j]; a.bp[j] = h->convs[op.chain_cp[j]].d_b; }
+                a.neck_pk = op.neck_pk; a.neck_b = h->convs[op.neck_conv].d_b;
+                hipLaunchKernelGGL(kChainXSKernel, dim3(n), dim3(512), kChainXSLds, s, a);
                 break;
             }
             case OP_PW_SMALL: {
@@ -1036,6 +1127,10 @@ int fear_set_option(fear_handle* h, int option, int64_t value) {
             if (value != 0 && value != 1) return FEAR_ERR_SHAPE;
             if (h->math != (int)value) { h->math = (int)value; h->plans.clear(); }
             return FEAR_OK;
+        case FEAR_OPT_CHAIN:
+            if (value != 0 && value != 1) return FEAR_ERR_SHAPE;
+            if (h->chain != (int)value) { h->chain = (int)value; h->plans.clear(); }
+            return FEAR_OK;
         default: return FEAR_ERR_SHAPE;
     }
 }
@@ -1048,6 +1143,7 @@ int64_t fear_get_option(fear_handle* h, int option) {
         case FEAR_OPT_PROFILE_OP: return h->profile_op;
         case FEAR_OPT_FUSE: return h->fuse;
         case FEAR_OPT_MATH: return h->math;
+        case FEAR_OPT_CHAIN: return h->chain;
         default: return FEAR_ERR_SHAPE;
     }
 }

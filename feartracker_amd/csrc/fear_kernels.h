@@ -1521,4 +1521,264 @@ __global__ __launch_bounds__(64 * NW, MINW) void ir_tile_h_kernel(IrT2Args t) {
     }
 }
 
+// ================================================================================================
+// chain16: the whole stride-16 trunk stage (a run of inverted-residual blocks on the 16x16 map + the 1x1 neck) as
+// ONE kernel.  It rests on the fragment identity of the 16x16x4 MFMA used throughout: the accumulator fragment
+// of a block's projection (lane = pixel l&15, channels 4*(l>>4)..+3 of each 16-channel tile) IS the B-operand
+// fragment of the next block's expansion, so the activations of a crop stay in registers from block to block
+// (the residual add is a register add) and only the first block reads, and only the neck writes, global memory.
+// Each block runs the ir16v2 chunk pipeline (E tile double buffered in LDS, packed weights staged through LDS);
+// what disappears are 7 kernel prologues/epilogues, 7 activation round trips and the separate neck launch.
+template <int CIN_, int CEXP_, int COUT_, int KS_, bool RES_>
+struct ChainBlk {
+    static constexpr int CIN = CIN_, CEXP = CEXP_, COUT = COUT_, KS = KS_;
+    static constexpr bool RES = RES_;
+};
+
+struct Chain16Args {
+    const float* X;        // [B*256][ldx]  input of the first block
+    float* Y;              // [B*256][ldy]  neck output
+    int ldx, ldy;
+    const float* Wpk[8];   // per block: ir16v2 packed weights (Ir2Geom layout)
+    const float* bp[8];    // per block: projection bias [COUT]
+    const float* neck_pk;  // neck weights as fragments [NTN][KGN][256]
+    const float* neck_b;   // [COUT_NECK]
+};
+
+template <int KS, int AP_MAX, int BP_MAX>
+struct Chain16Lds {
+    static constexpr int P = KS / 2, PW = 16 + 2 * P, ES = 24;
+    static constexpr int EBUF = PW * PW * ES;
+    static constexpr int FLOATS = 2 * EBUF + 2 * AP_MAX + 2 * BP_MAX;
+};
+
+// one block of the chain: xin (registers) -> yout (registers)
+template <class B, int KS_LDS, int AP_MAX, int BP_MAX>
+__device__ __forceinline__ void chain16_block(const f32x4 (&xin)[2][B::CIN / 16], f32x4 (&yout)[2][B::COUT / 16],
+                                              const float* __restrict__ Wpk, const float* __restrict__ bp, float* lds) {
+    using G = Ir2Geom<B::CIN, B::CEXP, B::COUT, B::KS, true>;
+    using L = Chain16Lds<KS_LDS, AP_MAX, BP_MAX>;
+    static_assert(B::KS == KS_LDS, "all blocks of a chain share the depthwise kernel size (LDS tile geometry)");
+    constexpr int S = 16, P = G::P, PW = G::PW, ES = G::ES, NCHUNK = G::NCHUNK, NTP = G::NTP, KG = G::KG;
+    constexpr int AP = G::AP, BP = G::BP, EBUF = G::EBUF, CST = AP + BP;
+    constexpr int AP4 = AP / 4, BP4 = BP / 4, NRA = (AP4 + 511) / 512, NRB = (BP4 + 511) / 512;
+    static_assert(AP <= AP_MAX && BP <= BP_MAX && EBUF == L::EBUF, "LDS carve");
+    float* const Ebuf = lds;
+    float* const WA = lds + 2 * L::EBUF;
+    float* const WB = WA + 2 * AP_MAX;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int y0 = wave * 2;
+
+    f32x4 ra[NRA], rb[NRB];
+    auto load_a = [&](int c) {
+#pragma unroll
+        for (int r = 0; r < NRA; ++r) {
+            const int idx = tid + r * 512;
+            if (idx < AP4) ra[r] = *reinterpret_cast<const f32x4*>(Wpk + (long)c * CST + idx * 4);
+        }
+    };
+    auto store_a = [&](int c) {
+        float* dst = WA + (c & 1) * AP_MAX;
+#pragma unroll
+        for (int r = 0; r < NRA; ++r) {
+            const int idx = tid + r * 512;
+            if (idx < AP4) *reinterpret_cast<f32x4*>(dst + idx * 4) = ra[r];
+        }
+    };
+    auto load_b = [&](int c) {
+#pragma unroll
+        for (int r = 0; r < NRB; ++r) {
+            const int idx = tid + r * 512;
+            if (idx < BP4) rb[r] = *reinterpret_cast<const f32x4*>(Wpk + (long)c * CST + AP + idx * 4);
+        }
+    };
+    auto store_b = [&](int c) {
+        float* dst = WB + (c & 1) * BP_MAX;
+#pragma unroll
+        for (int r = 0; r < NRB; ++r) {
+            const int idx = tid + r * 512;
+            if (idx < BP4) *reinterpret_cast<f32x4*>(dst + idx * 4) = rb[r];
+        }
+    };
+    auto phase_a = [&](int c) {
+        const float* wa = WA + (c & 1) * AP_MAX;
+        float* E = Ebuf + (c & 1) * EBUF;
+        f32x4 acc[2];
+        acc[0] = acc[1] = *reinterpret_cast<const f32x4*>(wa + KG * 256 + lk * 4);
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) {
+            const f32x4 wf = *reinterpret_cast<const f32x4*>(wa + kg * 256 + lane * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i], xin[mt][kg][i], acc[mt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            f32x4 v = acc[mt];
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            *reinterpret_cast<f32x4*>(E + ((y0 + mt + P) * PW + li + P) * ES + lk * 4) = v;
+        }
+    };
+    f32x4 accp[2][NTP];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTP; ++nt) accp[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto phase_bc = [&](int c) {
+        const float* E = Ebuf + (c & 1) * EBUF;
+        const float* wb = WB + (c & 1) * BP_MAX;
+        const float* wd = wb + NTP * 256 + lk * 4;
+        f32x4 d0 = *reinterpret_cast<const f32x4*>(wd + B::KS * B::KS * 16);
+        f32x4 d1 = d0;
+        const float* e0 = E + (y0 * PW + li) * ES + lk * 4;
+#pragma unroll
+        for (int iy = 0; iy < B::KS + 1; ++iy) {
+#pragma unroll
+            for (int kx = 0; kx < B::KS; ++kx) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(e0 + (iy * PW + kx) * ES);
+                if (iy < B::KS) d0 += v * *reinterpret_cast<const f32x4*>(wd + (iy * B::KS + kx) * 16);
+                if (iy >= 1) d1 += v * *reinterpret_cast<const f32x4*>(wd + ((iy - 1) * B::KS + kx) * 16);
+            }
+        }
+        d0.x = fmaxf(d0.x, 0.f); d0.y = fmaxf(d0.y, 0.f); d0.z = fmaxf(d0.z, 0.f); d0.w = fmaxf(d0.w, 0.f);
+        d1.x = fmaxf(d1.x, 0.f); d1.y = fmaxf(d1.y, 0.f); d1.z = fmaxf(d1.z, 0.f); d1.w = fmaxf(d1.w, 0.f);
+#pragma unroll
+        for (int nt = 0; nt < NTP; ++nt) {
+            const f32x4 wp = *reinterpret_cast<const f32x4*>(wb + nt * 256 + lane * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                accp[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[i], d0[i], accp[0][nt], 0, 0, 0);
+                accp[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[i], d1[i], accp[1][nt], 0, 0, 0);
+            }
+        }
+    };
+
+    // prologue (the previous block / the kernel prologue ended with a barrier: stages and E are free)
+    load_a(0);
+    load_b(0);
+    store_a(0);
+    store_b(0);
+    if (NCHUNK > 1) { load_a(1); store_a(1); }
+    __syncthreads();
+    phase_a(0);
+    __syncthreads();
+    for (int c = 0; c < NCHUNK; ++c) {
+        if (c + 2 < NCHUNK) load_a(c + 2);
+        if (c + 1 < NCHUNK) load_b(c + 1);
+        if (c + 1 < NCHUNK) phase_a(c + 1);
+        phase_bc(c);
+        if (c + 2 < NCHUNK) store_a(c + 2);
+        if (c + 1 < NCHUNK) store_b(c + 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int nt = 0; nt < NTP; ++nt) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bp + nt * 16 + lk * 4);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            f32x4 v = accp[mt][nt] + b;
+            if (B::RES) v += xin[mt][nt];          // CIN == COUT: the block input fragment is the residual
+            yout[mt][nt] = v;
+        }
+    }
+}
+
+// FEAR-XS stride-16 stage: 7 blocks + neck.  (The engine matches the model's block table against this chain.)
+template <class B0, class B1, class B2, class B3, class B4, class B5, class B6, int CNECK>
+__global__ __launch_bounds__(512) void chain16_kernel(Chain16Args a) {
+    constexpr int KS = B0::KS;
+    constexpr int APM = Ir2Geom<B4::CIN, B4::CEXP, B4::COUT, KS, true>::AP;      // widest expand fragments (CIN = 112)
+    constexpr int BPM = Ir2Geom<B4::CIN, B4::CEXP, B4::COUT, KS, true>::BP;
+    using L = Chain16Lds<KS, APM, BPM>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const long crop = blockIdx.x;
+    const int y0 = wave * 2;
+    for (int i = tid * 4; i < 2 * L::EBUF; i += 512 * 4) *reinterpret_cast<f32x4*>(lds + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 x0[2][B0::CIN / 16];
+    const float* Xc = a.X + crop * 256 * a.ldx;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int kg = 0; kg < B0::CIN / 16; ++kg)
+            x0[mt][kg] = *reinterpret_cast<const f32x4*>(Xc + (long)((y0 + mt) * 16 + li) * a.ldx + kg * 16 + lk * 4);
+    __syncthreads();
+
+    f32x4 x1[2][B0::COUT / 16];
+    chain16_block<B0, KS, APM, BPM>(x0, x1, a.Wpk[0], a.bp[0], lds);
+    f32x4 x2[2][B1::COUT / 16];
+    chain16_block<B1, KS, APM, BPM>(x1, x2, a.Wpk[1], a.bp[1], lds);
+    f32x4 x3[2][B2::COUT / 16];
+    chain16_block<B2, KS, APM, BPM>(x2, x3, a.Wpk[2], a.bp[2], lds);
+    f32x4 x4[2][B3::COUT / 16];
+    chain16_block<B3, KS, APM, BPM>(x3, x4, a.Wpk[3], a.bp[3], lds);
+    f32x4 x5[2][B4::COUT / 16];
+    chain16_block<B4, KS, APM, BPM>(x4, x5, a.Wpk[4], a.bp[4], lds);
+    f32x4 x6[2][B5::COUT / 16];
+    chain16_block<B5, KS, APM, BPM>(x5, x6, a.Wpk[5], a.bp[5], lds);
+    f32x4 x7[2][B6::COUT / 16];
+    chain16_block<B6, KS, APM, BPM>(x6, x7, a.Wpk[6], a.bp[6], lds);
+
+    // ---- neck: Y = Wn . x7 + bn, 16 output tiles in groups of 4; fragments [nt][kg][256] staged through the (now
+    //      free) E area in two 4-tile slots
+    constexpr int KGN = B6::COUT / 16, NTN = CNECK / 16, GRP = 4, GFL = GRP * KGN * 256;   // floats per group
+    constexpr int G4 = GFL / 4, NRG = (G4 + 511) / 512;
+    static_assert(2 * GFL <= 2 * L::EBUF && NTN % GRP == 0, "neck staging");
+    f32x4 rg[NRG];
+    auto load_g = [&](int g) {
+#pragma unroll
+        for (int r = 0; r < NRG; ++r) {
+            const int idx = tid + r * 512;
+            if (idx < G4) rg[r] = *reinterpret_cast<const f32x4*>(a.neck_pk + (long)g * GFL + idx * 4);
+        }
+    };
+    auto store_g = [&](int g) {
+        float* dst = lds + (g & 1) * GFL;
+#pragma unroll
+        for (int r = 0; r < NRG; ++r) {
+            const int idx = tid + r * 512;
+            if (idx < G4) *reinterpret_cast<f32x4*>(dst + idx * 4) = rg[r];
+        }
+    };
+    load_g(0);
+    store_g(0);
+    __syncthreads();
+    for (int g = 0; g < NTN / GRP; ++g) {
+        if (g + 1 < NTN / GRP) load_g(g + 1);
+        const float* wg = lds + (g & 1) * GFL;
+        f32x4 acc[2][GRP];
+#pragma unroll
+        for (int q = 0; q < GRP; ++q) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(a.neck_b + (g * GRP + q) * 16 + lk * 4);
+            acc[0][q] = b;
+            acc[1][q] = b;
+        }
+#pragma unroll
+        for (int q = 0; q < GRP; ++q)
+#pragma unroll
+            for (int kg = 0; kg < KGN; ++kg) {
+                const f32x4 wf = *reinterpret_cast<const f32x4*>(wg + (q * KGN + kg) * 256 + lane * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i], x7[0][kg][i], acc[0][q], 0, 0, 0);
+                    acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i], x7[1][kg][i], acc[1][q], 0, 0, 0);
+                }
+            }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int q = 0; q < GRP; ++q) {
+                const long m = crop * 256 + (y0 + mt) * 16 + li;
+                *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + (g * GRP + q) * 16 + lk * 4) = acc[mt][q];
+            }
+        if (g + 1 < NTN / GRP) store_g(g + 1);
+        __syncthreads();
+    }
+}
+
 }  // namespace fear

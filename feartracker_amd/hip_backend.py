@@ -30,6 +30,7 @@ FEAR_OPT_PROFILE = 2
 FEAR_OPT_PROFILE_OP = 3
 FEAR_OPT_FUSE = 4
 FEAR_OPT_MATH = 5
+FEAR_OPT_CHAIN = 6
 
 _lib = None
 
@@ -157,6 +158,10 @@ class FEARNetHIP:
     def set_fuse(self, on: bool) -> None:
         """Fused block kernels (default) vs one kernel per conv layer (bring-up / A-B measurements)."""
         self._check(self._lib.fear_set_option(self._h, FEAR_OPT_FUSE, 1 if on else 0))
+
+    def set_chain(self, on: bool) -> None:
+        """Stride-16 trunk stage + neck as one chain kernel (default, fp32 mode) vs one fused kernel per block."""
+        self._check(self._lib.fear_set_option(self._h, FEAR_OPT_CHAIN, 1 if on else 0))
 
     def set_math(self, mode: int) -> None:
         """0: exact fp32 MFMA (default); 1: fp16 hi+lo split operands on the matrix pipe, fp32 accumulate."""

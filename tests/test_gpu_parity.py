@@ -275,3 +275,22 @@ def test_other_sizes_and_second_weight_set(oracle_net):
         assert rel_err(b, ref["TARGET_REGRESSION_LABEL_KEY"]) < REL and rel_err(c, ref["TARGET_CLASSIFICATION_KEY"]) < REL
     other = oracle_net.track(x, oracle_net.get_features(torch.zeros(2, 3, 128, 128)))
     assert rel_err(b, other["TARGET_REGRESSION_LABEL_KEY"]) > 1e-2     # different trained weights, different maps
+
+
+def test_chain_kernel_matches_per_block_kernels(hip_net):
+    """FEAR_OPT_CHAIN: the stride-16 trunk stage + neck as one register-resident chain kernel vs one fused kernel per
+    block (same arithmetic, activations kept in registers between blocks)."""
+    from feartracker_amd import FEARNetHIP
+    from conftest import WEIGHTS
+    per_block = FEARNetHIP(WEIGHTS, device=0, max_batch=8)
+    per_block.set_chain(False)
+    names_chain = [n for n, _, _ in hip_net.plan(256, True)]
+    names_blocks = [n for n, _, _ in per_block.plan(256, True)]
+    assert any(n.startswith("chain16") for n in names_chain) and not any(n.startswith("chain16") for n in names_blocks)
+    assert len(names_blocks) == len(names_chain) + 7
+    g = torch.Generator().manual_seed(55)
+    x = norm_u8(torch.randint(0, 256, (3, 3, 256, 256), dtype=torch.uint8, generator=g)).cuda()
+    z = hip_net.get_features(norm_u8(torch.randint(0, 256, (3, 3, 128, 128), dtype=torch.uint8, generator=g)).cuda())
+    b0, c0 = per_block.track_maps(x, z)
+    b1, c1 = hip_net.track_maps(x, z)
+    assert rel_err(b1, b0) < 1e-5 and rel_err(c1, c0) < 1e-5
