@@ -1622,11 +1622,17 @@ __device__ __forceinline__ void chain16_block(const f32x4 (&xin)[2][B::CIN / 16]
             *reinterpret_cast<f32x4*>(E + ((y0 + mt + P) * PW + li + P) * ES + lk * 4) = v;
         }
     };
-    f32x4 accp[2][NTP];
+    // the output fragments double as the projection accumulators, initialised with bias (+ residual)
+    f32x4 (&accp)[2][NTP] = yout;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int nt = 0; nt < NTP; ++nt) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bp + nt * 16 + lk * 4);
 #pragma unroll
-        for (int nt = 0; nt < NTP; ++nt) accp[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < 2; ++mt) {
+            accp[mt][nt] = b;
+            if (B::RES) accp[mt][nt] += xin[mt][nt];      // CIN == COUT: the block input fragment is the residual
+        }
+    }
     auto phase_bc = [&](int c) {
         const float* E = Ebuf + (c & 1) * EBUF;
         const float* wb = WB + (c & 1) * BP_MAX;
@@ -1657,6 +1663,7 @@ __device__ __forceinline__ void chain16_block(const f32x4 (&xin)[2][B::CIN / 16]
     };
 
     // prologue (the previous block / the kernel prologue ended with a barrier: stages and E are free)
+    __builtin_amdgcn_sched_barrier(0);      // keep the scheduler from moving code across block boundaries
     load_a(0);
     load_b(0);
     store_a(0);
@@ -1673,16 +1680,6 @@ __device__ __forceinline__ void chain16_block(const f32x4 (&xin)[2][B::CIN / 16]
         if (c + 2 < NCHUNK) store_a(c + 2);
         if (c + 1 < NCHUNK) store_b(c + 1);
         __syncthreads();
-    }
-#pragma unroll
-    for (int nt = 0; nt < NTP; ++nt) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(bp + nt * 16 + lk * 4);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            f32x4 v = accp[mt][nt] + b;
-            if (B::RES) v += xin[mt][nt];          // CIN == COUT: the block input fragment is the residual
-            yout[mt][nt] = v;
-        }
     }
 }
 
