@@ -14,6 +14,10 @@
 //   decode_kernel      sigmoid + arg-max + ltrb->xywh                   (FEARBoxCoder.decode, dataset/box_coder.py:75-107)
 //   normalize_kernel   uint8 HWC -> normalised fp32 NCHW                (Tracker._preprocess_image, base_tracker.py:97-103)
 #pragma once
+#include <type_traits>
+#ifndef FEAR_ABL
+#define FEAR_ABL 0      // timing ablations for tools/kbench only (bit mask); the product always builds with 0
+#endif
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -707,18 +711,108 @@ __global__ __launch_bounds__(512) void ir16v2_fused_kernel(Ir2Args a) {
     }
     __syncthreads();
 
+    // One barrier interval of the main loop.  The depthwise is a chain of KS*(KS+1) tap steps (kx outer, iy inner so the
+    // weight of (iy, kx) feeds row 0 now and row 1 in the next step); its LDS reads run D steps ahead of the FMAs that
+    // consume them, and the expansion MFMAs of the NEXT chunk are dealt out between the steps, so the wave never sits on an
+    // LDS round trip (the compiler's own order was read -> wait -> 4 FMAs, ~120 idle cycles per step, in lockstep on
+    // every wave).  sched_barrier(0) after each step keeps hipcc from re-serialising the pipeline.
+    constexpr int NS = KS * (KS + 1), D = 4;
+    constexpr int NU = EXPAND ? KG * 4 : 0;                    // expansion MFMA units (each = mt 0 and mt 1)
+    auto interval = [&](int c, auto has_a_tag) {
+        constexpr bool HAS_A = decltype(has_a_tag)::value;
+        const float* E = Ebuf + (c & 1) * EBUF;
+        const float* wb = WB + (c & 1) * BP;
+        const float* wd = wb + NTP * 256 + lk * 4;
+        const float* e0 = E + (y0 * PW + li) * ES + lk * 4;
+        const float* wa = WA + ((c + 1) & 1) * AP;
+        f32x4 acc[2];
+        f32x4 wfq[2];
+        if (HAS_A) {
+            acc[0] = acc[1] = *reinterpret_cast<const f32x4*>(wa + KG * 256 + lk * 4);   // bias
+            wfq[0] = *reinterpret_cast<const f32x4*>(wa + lane * 4);
+        }
+        f32x4 d0 = *reinterpret_cast<const f32x4*>(wd + KS * KS * 16);
+        f32x4 d1 = d0;
+        f32x4 ev[D], wv[D], wprev = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < D; ++t) {
+            const int kx = t / (KS + 1), iy = t % (KS + 1);
+            ev[t] = *reinterpret_cast<const f32x4*>(e0 + (iy * PW + kx) * ES);
+            if (iy < KS) wv[t] = *reinterpret_cast<const f32x4*>(wd + (iy * KS + kx) * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            const int iy = t % (KS + 1);
+            const f32x4 e = ev[t % D], w = wv[t % D];
+            if (t + D < NS && !(FEAR_ABL & 4)) {
+                const int kx2 = (t + D) / (KS + 1), iy2 = (t + D) % (KS + 1);
+                ev[t % D] = *reinterpret_cast<const f32x4*>(e0 + (iy2 * PW + kx2) * ES);
+                if (iy2 < KS) wv[t % D] = *reinterpret_cast<const f32x4*>(wd + (iy2 * KS + kx2) * 16);
+            }
+            if (HAS_A) {
+#pragma unroll
+                for (int u = t * NU / NS; u < (t + 1) * NU / NS; ++u) {
+                    const int kg = u / 4, i = u % 4;
+                    if (i == 0 && kg + 1 < KG) wfq[(kg + 1) & 1] = *reinterpret_cast<const f32x4*>(wa + (kg + 1) * 256 + lane * 4);
+                    if (FEAR_ABL & 8) continue;
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfq[kg & 1][i], xf[0][EXPAND ? kg : 0][i], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfq[kg & 1][i], xf[EXPAND ? 1 : 0][EXPAND ? kg : 0][i], acc[1], 0, 0, 0);
+                }
+            }
+            if (FEAR_ABL & 32) { d0.x += e.x + w.x; }
+            else {
+            if (iy < KS) d0 += e * w;
+            if (iy >= 1) d1 += e * wprev;
+            }
+            wprev = w;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        f32x4 wpq[2];
+        wpq[0] = *reinterpret_cast<const f32x4*>(wb + lane * 4);
+        if (HAS_A) {
+            float* En = Ebuf + ((c + 1) & 1) * EBUF;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                f32x4 v = acc[mt];
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                *reinterpret_cast<f32x4*>(En + ((y0 + mt + P) * PW + li + P) * ES + lk * 4) = v;
+            }
+        }
+        if (a.relu_dw) {
+            d0.x = fmaxf(d0.x, 0.f); d0.y = fmaxf(d0.y, 0.f); d0.z = fmaxf(d0.z, 0.f); d0.w = fmaxf(d0.w, 0.f);
+            d1.x = fmaxf(d1.x, 0.f); d1.y = fmaxf(d1.y, 0.f); d1.z = fmaxf(d1.z, 0.f); d1.w = fmaxf(d1.w, 0.f);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTP; ++nt) {
+            if (nt + 1 < NTP) wpq[(nt + 1) & 1] = *reinterpret_cast<const f32x4*>(wb + (nt + 1) * 256 + lane * 4);
+            if (FEAR_ABL & 16) { accp[0][nt] += d0 * wpq[nt & 1]; accp[1][nt] += d1 * wpq[nt & 1]; continue; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                accp[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wpq[nt & 1][i], d0[i], accp[0][nt], 0, 0, 0);
+                accp[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wpq[nt & 1][i], d1[i], accp[1][nt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
     for (int c = 0; c < NCHUNK; ++c) {
         // prefetch (registers only): EXPAND: A-part two chunks ahead; !EXPAND: next chunk's activations
         const int ca = EXPAND ? c + 2 : c + 1;
-        if (ca < NCHUNK) load_a(ca);
-        if (c + 1 < NCHUNK) load_b(c + 1);
+        if (!(FEAR_ABL & 2)) {
+            if (ca < NCHUNK) load_a(ca);
+            if (c + 1 < NCHUNK) load_b(c + 1);
+        }
         // (fp32 MFMA executes on the vector ALUs on gfx950 — tools/coexec.hip: an MFMA wave and a VALU wave on one
-        //  SIMD take the SUM of their times — so there is nothing to gain from staggering phases between waves)
-        if (EXPAND && c + 1 < NCHUNK) phase_a(c + 1);
-        phase_bc(c);
-        if (ca < NCHUNK) store_a(ca);
-        if (c + 1 < NCHUNK) store_b(c + 1);
-        __syncthreads();
+        //  SIMD take the SUM of their times — so staggering phases between waves buys nothing; what matters is that
+        //  neither wave of a SIMD waits on LDS latency)
+        if (EXPAND && c + 1 < NCHUNK) interval(c, std::true_type{});
+        else interval(c, std::false_type{});
+        if (!(FEAR_ABL & 2)) {
+            if (ca < NCHUNK) store_a(ca);
+            if (c + 1 < NCHUNK) store_b(c + 1);
+        }
+        if (!(FEAR_ABL & 1)) __syncthreads();
     }
 
     if (a.pred_cout > 0) {          // prediction head: lanes lk == 0 hold channels 0..3 of their pixel

@@ -72,6 +72,7 @@ static void bench(const char* tag, int crops, int iters) {
 int main(int argc, char** argv) {
     const int crops = argc > 1 ? atoi(argv[1]) : 256;
     const int iters = argc > 2 ? atoi(argv[2]) : 20;
+    printf("FEAR_ABL=%d\n", FEAR_ABL);
     bench<112, 672, 112, 5, true>("ir16_112x672x112_k5", crops, iters);
     bench<64, 384, 64, 5, true>("ir16_64x384x64_k5", crops, iters);
     bench<256, 256, 256, 3, false>("sep16_256x256x256_k3", crops, iters);
