@@ -561,6 +561,94 @@ struct Ir2Geom {
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
 };
 
+// One barrier interval of the fused 16x16 block kernels (ir16v2_fused_kernel, chain16_block): depthwise + projection of
+// chunk c from E / wb, and (HAS_A) the expansion of chunk c + 1 from wa into En.
+// The depthwise is a chain of KS*(KS+1) tap steps (kx outer, iy inner, so the weight of (iy, kx) feeds row 0 now and
+// row 1 in the next step); its LDS reads run D steps ahead of the FMAs that consume them and the expansion MFMAs are
+// dealt out between the steps, so the wave never sits on an LDS round trip (hipcc's own order was read -> wait -> 4 FMAs,
+// ~120 idle cycles per step, in lockstep on every wave).  sched_barrier(0) after each step keeps the scheduler from
+// re-serialising the pipeline.
+template <int KS, int PW, int ES, int KG, int NTP, bool HAS_A, int XM, int XK>
+__device__ __forceinline__ void ir16_interval(const float* __restrict__ E, float* __restrict__ En, const float* __restrict__ wa,
+                                              const float* __restrict__ wb, const f32x4 (&xf)[XM][XK], f32x4 (&accp)[2][NTP],
+                                              int y0, int li, int lk, int lane, bool relu_dw) {
+    constexpr int NS = KS * (KS + 1), D = 4, P = KS / 2;
+    constexpr int NU = HAS_A ? KG * 4 : 0;                     // expansion MFMA units (each = mt 0 and mt 1)
+    static_assert(!HAS_A || (XM == 2 && XK >= KG), "fragment array");
+    const float* wd = wb + NTP * 256 + lk * 4;
+    const float* e0 = E + (y0 * PW + li) * ES + lk * 4;
+    f32x4 acc[2];
+    f32x4 wfq[2];
+    if (HAS_A) {
+        acc[0] = acc[1] = *reinterpret_cast<const f32x4*>(wa + KG * 256 + lk * 4);   // bias
+        wfq[0] = *reinterpret_cast<const f32x4*>(wa + lane * 4);
+    }
+    f32x4 d0 = *reinterpret_cast<const f32x4*>(wd + KS * KS * 16);
+    f32x4 d1 = d0;
+    f32x4 ev[D], wv[D], wprev = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < D; ++t) {
+        const int kx = t / (KS + 1), iy = t % (KS + 1);
+        ev[t] = *reinterpret_cast<const f32x4*>(e0 + (iy * PW + kx) * ES);
+        if (iy < KS) wv[t] = *reinterpret_cast<const f32x4*>(wd + (iy * KS + kx) * 16);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+        const int iy = t % (KS + 1);
+        const f32x4 e = ev[t % D], w = wv[t % D];
+        if (t + D < NS && !(FEAR_ABL & 4)) {
+            const int kx2 = (t + D) / (KS + 1), iy2 = (t + D) % (KS + 1);
+            ev[t % D] = *reinterpret_cast<const f32x4*>(e0 + (iy2 * PW + kx2) * ES);
+            if (iy2 < KS) wv[t % D] = *reinterpret_cast<const f32x4*>(wd + (iy2 * KS + kx2) * 16);
+        }
+        if (HAS_A) {
+#pragma unroll
+            for (int u = t * NU / NS; u < (t + 1) * NU / NS; ++u) {
+                const int kg = u / 4, i = u % 4;
+                if (i == 0 && kg + 1 < KG) wfq[(kg + 1) & 1] = *reinterpret_cast<const f32x4*>(wa + (kg + 1) * 256 + lane * 4);
+                if (FEAR_ABL & 8) continue;
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfq[kg & 1][i], xf[0][HAS_A ? kg : 0][i], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfq[kg & 1][i], xf[HAS_A ? 1 : 0][HAS_A ? kg : 0][i], acc[1], 0, 0, 0);
+            }
+        }
+        if (FEAR_ABL & 32) {
+            d0.x += e.x + w.x;
+        } else {
+            if (iy < KS) d0 += e * w;
+            if (iy >= 1) d1 += e * wprev;
+        }
+        wprev = w;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    f32x4 wpq[2];
+    wpq[0] = *reinterpret_cast<const f32x4*>(wb + lane * 4);
+    if (HAS_A) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            f32x4 v = acc[mt];
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            *reinterpret_cast<f32x4*>(En + ((y0 + mt + P) * PW + li + P) * ES + lk * 4) = v;
+        }
+    }
+    if (relu_dw) {
+        d0.x = fmaxf(d0.x, 0.f); d0.y = fmaxf(d0.y, 0.f); d0.z = fmaxf(d0.z, 0.f); d0.w = fmaxf(d0.w, 0.f);
+        d1.x = fmaxf(d1.x, 0.f); d1.y = fmaxf(d1.y, 0.f); d1.z = fmaxf(d1.z, 0.f); d1.w = fmaxf(d1.w, 0.f);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NTP; ++nt) {
+        if (nt + 1 < NTP) wpq[(nt + 1) & 1] = *reinterpret_cast<const f32x4*>(wb + (nt + 1) * 256 + lane * 4);
+        if (FEAR_ABL & 16) { accp[0][nt] += d0 * wpq[nt & 1]; accp[1][nt] += d1 * wpq[nt & 1]; continue; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            accp[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wpq[nt & 1][i], d0[i], accp[0][nt], 0, 0, 0);
+            accp[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wpq[nt & 1][i], d1[i], accp[1][nt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+
 template <int CIN, int CEXP, int COUT, int KS, bool EXPAND>
 __global__ __launch_bounds__(512) void ir16v2_fused_kernel(Ir2Args a) {
     using G = Ir2Geom<CIN, CEXP, COUT, KS, EXPAND>;
@@ -666,38 +754,6 @@ __global__ __launch_bounds__(512) void ir16v2_fused_kernel(Ir2Args a) {
 #pragma unroll
         for (int nt = 0; nt < NTP; ++nt) accp[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // phases B + C of chunk c: depthwise on the VALU from E[c&1], projection MFMAs, weights from WB[c&1]
-    auto phase_bc = [&](int c) {
-        const float* E = Ebuf + (c & 1) * EBUF;
-        const float* wb = WB + (c & 1) * BP;
-        const float* wd = wb + NTP * 256 + lk * 4;
-        f32x4 d0 = *reinterpret_cast<const f32x4*>(wd + KS * KS * 16);
-        f32x4 d1 = d0;
-        const float* e0 = E + (y0 * PW + li) * ES + lk * 4;
-#pragma unroll
-        for (int iy = 0; iy < KS + 1; ++iy) {
-#pragma unroll
-            for (int kx = 0; kx < KS; ++kx) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(e0 + (iy * PW + kx) * ES);
-                if (iy < KS) d0 += v * *reinterpret_cast<const f32x4*>(wd + (iy * KS + kx) * 16);
-                if (iy >= 1) d1 += v * *reinterpret_cast<const f32x4*>(wd + ((iy - 1) * KS + kx) * 16);
-            }
-        }
-        if (a.relu_dw) {
-            d0.x = fmaxf(d0.x, 0.f); d0.y = fmaxf(d0.y, 0.f); d0.z = fmaxf(d0.z, 0.f); d0.w = fmaxf(d0.w, 0.f);
-            d1.x = fmaxf(d1.x, 0.f); d1.y = fmaxf(d1.y, 0.f); d1.z = fmaxf(d1.z, 0.f); d1.w = fmaxf(d1.w, 0.f);
-        }
-#pragma unroll
-        for (int nt = 0; nt < NTP; ++nt) {
-            const f32x4 wp = *reinterpret_cast<const f32x4*>(wb + nt * 256 + lane * 4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                accp[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[i], d0[i], accp[0][nt], 0, 0, 0);
-                accp[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[i], d1[i], accp[1][nt], 0, 0, 0);
-            }
-        }
-    };
-
     // ---- prologue: stage A(0), A(1), BC(0); produce E[0]
     load_a(0);
     load_b(0);
@@ -711,91 +767,6 @@ __global__ __launch_bounds__(512) void ir16v2_fused_kernel(Ir2Args a) {
     }
     __syncthreads();
 
-    // One barrier interval of the main loop.  The depthwise is a chain of KS*(KS+1) tap steps (kx outer, iy inner so the
-    // weight of (iy, kx) feeds row 0 now and row 1 in the next step); its LDS reads run D steps ahead of the FMAs that
-    // consume them, and the expansion MFMAs of the NEXT chunk are dealt out between the steps, so the wave never sits on an
-    // LDS round trip (the compiler's own order was read -> wait -> 4 FMAs, ~120 idle cycles per step, in lockstep on
-    // every wave).  sched_barrier(0) after each step keeps hipcc from re-serialising the pipeline.
-    constexpr int NS = KS * (KS + 1), D = 4;
-    constexpr int NU = EXPAND ? KG * 4 : 0;                    // expansion MFMA units (each = mt 0 and mt 1)
-    auto interval = [&](int c, auto has_a_tag) {
-        constexpr bool HAS_A = decltype(has_a_tag)::value;
-        const float* E = Ebuf + (c & 1) * EBUF;
-        const float* wb = WB + (c & 1) * BP;
-        const float* wd = wb + NTP * 256 + lk * 4;
-        const float* e0 = E + (y0 * PW + li) * ES + lk * 4;
-        const float* wa = WA + ((c + 1) & 1) * AP;
-        f32x4 acc[2];
-        f32x4 wfq[2];
-        if (HAS_A) {
-            acc[0] = acc[1] = *reinterpret_cast<const f32x4*>(wa + KG * 256 + lk * 4);   // bias
-            wfq[0] = *reinterpret_cast<const f32x4*>(wa + lane * 4);
-        }
-        f32x4 d0 = *reinterpret_cast<const f32x4*>(wd + KS * KS * 16);
-        f32x4 d1 = d0;
-        f32x4 ev[D], wv[D], wprev = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < D; ++t) {
-            const int kx = t / (KS + 1), iy = t % (KS + 1);
-            ev[t] = *reinterpret_cast<const f32x4*>(e0 + (iy * PW + kx) * ES);
-            if (iy < KS) wv[t] = *reinterpret_cast<const f32x4*>(wd + (iy * KS + kx) * 16);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < NS; ++t) {
-            const int iy = t % (KS + 1);
-            const f32x4 e = ev[t % D], w = wv[t % D];
-            if (t + D < NS && !(FEAR_ABL & 4)) {
-                const int kx2 = (t + D) / (KS + 1), iy2 = (t + D) % (KS + 1);
-                ev[t % D] = *reinterpret_cast<const f32x4*>(e0 + (iy2 * PW + kx2) * ES);
-                if (iy2 < KS) wv[t % D] = *reinterpret_cast<const f32x4*>(wd + (iy2 * KS + kx2) * 16);
-            }
-            if (HAS_A) {
-#pragma unroll
-                for (int u = t * NU / NS; u < (t + 1) * NU / NS; ++u) {
-                    const int kg = u / 4, i = u % 4;
-                    if (i == 0 && kg + 1 < KG) wfq[(kg + 1) & 1] = *reinterpret_cast<const f32x4*>(wa + (kg + 1) * 256 + lane * 4);
-                    if (FEAR_ABL & 8) continue;
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfq[kg & 1][i], xf[0][EXPAND ? kg : 0][i], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfq[kg & 1][i], xf[EXPAND ? 1 : 0][EXPAND ? kg : 0][i], acc[1], 0, 0, 0);
-                }
-            }
-            if (FEAR_ABL & 32) { d0.x += e.x + w.x; }
-            else {
-            if (iy < KS) d0 += e * w;
-            if (iy >= 1) d1 += e * wprev;
-            }
-            wprev = w;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        f32x4 wpq[2];
-        wpq[0] = *reinterpret_cast<const f32x4*>(wb + lane * 4);
-        if (HAS_A) {
-            float* En = Ebuf + ((c + 1) & 1) * EBUF;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                f32x4 v = acc[mt];
-                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                *reinterpret_cast<f32x4*>(En + ((y0 + mt + P) * PW + li + P) * ES + lk * 4) = v;
-            }
-        }
-        if (a.relu_dw) {
-            d0.x = fmaxf(d0.x, 0.f); d0.y = fmaxf(d0.y, 0.f); d0.z = fmaxf(d0.z, 0.f); d0.w = fmaxf(d0.w, 0.f);
-            d1.x = fmaxf(d1.x, 0.f); d1.y = fmaxf(d1.y, 0.f); d1.z = fmaxf(d1.z, 0.f); d1.w = fmaxf(d1.w, 0.f);
-        }
-#pragma unroll
-        for (int nt = 0; nt < NTP; ++nt) {
-            if (nt + 1 < NTP) wpq[(nt + 1) & 1] = *reinterpret_cast<const f32x4*>(wb + (nt + 1) * 256 + lane * 4);
-            if (FEAR_ABL & 16) { accp[0][nt] += d0 * wpq[nt & 1]; accp[1][nt] += d1 * wpq[nt & 1]; continue; }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                accp[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wpq[nt & 1][i], d0[i], accp[0][nt], 0, 0, 0);
-                accp[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wpq[nt & 1][i], d1[i], accp[1][nt], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-
     for (int c = 0; c < NCHUNK; ++c) {
         // prefetch (registers only): EXPAND: A-part two chunks ahead; !EXPAND: next chunk's activations
         const int ca = EXPAND ? c + 2 : c + 1;
@@ -806,8 +777,12 @@ __global__ __launch_bounds__(512) void ir16v2_fused_kernel(Ir2Args a) {
         // (fp32 MFMA executes on the vector ALUs on gfx950 — tools/coexec.hip: an MFMA wave and a VALU wave on one
         //  SIMD take the SUM of their times — so staggering phases between waves buys nothing; what matters is that
         //  neither wave of a SIMD waits on LDS latency)
-        if (EXPAND && c + 1 < NCHUNK) interval(c, std::true_type{});
-        else interval(c, std::false_type{});
+        const float* Ec = Ebuf + (c & 1) * EBUF;
+        float* En = Ebuf + ((c + 1) & 1) * EBUF;
+        const float* wa = WA + ((c + 1) & 1) * AP;
+        const float* wb = WB + (c & 1) * BP;
+        if (EXPAND && c + 1 < NCHUNK) ir16_interval<KS, PW, ES, KG, NTP, EXPAND>(Ec, En, wa, wb, xf, accp, y0, li, lk, lane, a.relu_dw);
+        else ir16_interval<KS, PW, ES, KG, NTP, false>(Ec, En, wa, wb, xf, accp, y0, li, lk, lane, a.relu_dw);
         if (!(FEAR_ABL & 2)) {
             if (ca < NCHUNK) store_a(ca);
             if (c + 1 < NCHUNK) store_b(c + 1);
@@ -1727,35 +1702,6 @@ __device__ __forceinline__ void chain16_block(const f32x4 (&xin)[2][B::CIN / 16]
             if (B::RES) accp[mt][nt] += xin[mt][nt];      // CIN == COUT: the block input fragment is the residual
         }
     }
-    auto phase_bc = [&](int c) {
-        const float* E = Ebuf + (c & 1) * EBUF;
-        const float* wb = WB + (c & 1) * BP_MAX;
-        const float* wd = wb + NTP * 256 + lk * 4;
-        f32x4 d0 = *reinterpret_cast<const f32x4*>(wd + B::KS * B::KS * 16);
-        f32x4 d1 = d0;
-        const float* e0 = E + (y0 * PW + li) * ES + lk * 4;
-#pragma unroll
-        for (int iy = 0; iy < B::KS + 1; ++iy) {
-#pragma unroll
-            for (int kx = 0; kx < B::KS; ++kx) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(e0 + (iy * PW + kx) * ES);
-                if (iy < B::KS) d0 += v * *reinterpret_cast<const f32x4*>(wd + (iy * B::KS + kx) * 16);
-                if (iy >= 1) d1 += v * *reinterpret_cast<const f32x4*>(wd + ((iy - 1) * B::KS + kx) * 16);
-            }
-        }
-        d0.x = fmaxf(d0.x, 0.f); d0.y = fmaxf(d0.y, 0.f); d0.z = fmaxf(d0.z, 0.f); d0.w = fmaxf(d0.w, 0.f);
-        d1.x = fmaxf(d1.x, 0.f); d1.y = fmaxf(d1.y, 0.f); d1.z = fmaxf(d1.z, 0.f); d1.w = fmaxf(d1.w, 0.f);
-#pragma unroll
-        for (int nt = 0; nt < NTP; ++nt) {
-            const f32x4 wp = *reinterpret_cast<const f32x4*>(wb + nt * 256 + lane * 4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                accp[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[i], d0[i], accp[0][nt], 0, 0, 0);
-                accp[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[i], d1[i], accp[1][nt], 0, 0, 0);
-            }
-        }
-    };
-
     // prologue (the previous block / the kernel prologue ended with a barrier: stages and E are free)
     __builtin_amdgcn_sched_barrier(0);      // keep the scheduler from moving code across block boundaries
     load_a(0);
@@ -1769,8 +1715,12 @@ __device__ __forceinline__ void chain16_block(const f32x4 (&xin)[2][B::CIN / 16]
     for (int c = 0; c < NCHUNK; ++c) {
         if (c + 2 < NCHUNK) load_a(c + 2);
         if (c + 1 < NCHUNK) load_b(c + 1);
-        if (c + 1 < NCHUNK) phase_a(c + 1);
-        phase_bc(c);
+        const float* Ec = Ebuf + (c & 1) * EBUF;
+        float* En = Ebuf + ((c + 1) & 1) * EBUF;
+        const float* wa = WA + ((c + 1) & 1) * AP_MAX;
+        const float* wb = WB + (c & 1) * BP_MAX;
+        if (c + 1 < NCHUNK) ir16_interval<B::KS, PW, ES, KG, NTP, true>(Ec, En, wa, wb, xin, accp, y0, li, lk, lane, true);
+        else ir16_interval<B::KS, PW, ES, KG, NTP, false>(Ec, En, wa, wb, xin, accp, y0, li, lk, lane, true);
         if (c + 2 < NCHUNK) store_a(c + 2);
         if (c + 1 < NCHUNK) store_b(c + 1);
         __syncthreads();
