@@ -829,6 +829,208 @@ __global__ __launch_bounds__(512) void ir16v2_fused_kernel(Ir2Args a) {
 // fragments (zero padded where CIN / COUT / CEXP are not multiples of 16), prefetched global -> registers
 // during chunk c and committed to the alternate LDS stage before the chunk's last barrier.  CE = 16,
 // single E tile (so several workgroups fit a CU and overlap each other's phases and HBM traffic).
+// ================================================================================================
+// sep16: depthwise-separable conv (dw KSxKS + 1x1, the BoxTower's SepConv) on a 16x16 map, one crop per block — the
+// no-expansion sibling of ir16v2 with the depthwise of chunk c + 1 software-pipelined UNDER the projection MFMAs of chunk c:
+// the wave's instruction stream per tap step is [LDS reads 4 steps ahead][~NTP*8/NS projection MFMAs][4 packed FMAs], so
+// neither the LDS round trips nor the FMAs leave the vector ALUs idle between MFMAs.
+//   interval c reads  E[(c+1)&1], WD[(c+1)&1]  (depthwise of chunk c+1)  and  WP[c&1] (projection of chunk c)
+//   interval c writes E[c&1] <- X chunk c+2, WD[c&1] <- wd(c+2), WP[(c+1)&1] <- wp(c+1)   (all last read before barrier c-1)
+// Packed weights: the BC-part layout of Ir2Args (AP = 0): per chunk NTP fragments x 256 | Wd[KS*KS][16] | bd[16].
+template <int CIN, int COUT, int KS>
+struct Sep16Geom {
+    static constexpr int S = 16, P = KS / 2, PW = S + 2 * P, ES = 24, NCHUNK = CIN / 16, NTP = COUT / 16;
+    static constexpr int WPF = NTP * 256, WDF = KS * KS * 16 + 16, CST = WPF + WDF;
+    static constexpr int EBUF = PW * PW * ES;
+    static constexpr int LDS_BYTES = (2 * EBUF + 2 * WPF + 2 * WDF) * 4;
+};
+
+template <int CIN, int COUT, int KS>
+__global__ __launch_bounds__(512) void sep16_kernel(Ir2Args a) {
+    using G = Sep16Geom<CIN, COUT, KS>;
+    constexpr int S = G::S, P = G::P, PW = G::PW, ES = G::ES, NCHUNK = G::NCHUNK, NTP = G::NTP;
+    constexpr int WPF = G::WPF, WDF = G::WDF, CST = G::CST, EBUF = G::EBUF;
+    constexpr int WP4 = WPF / 4, WD4 = WDF / 4, NRP = (WP4 + 511) / 512;
+    constexpr int NS = KS * (KS + 1), D = 4, NU = NTP * 4;
+    static_assert(CIN % 16 == 0 && COUT % 16 == 0 && NCHUNK >= 2 && WD4 <= 512 && NS >= D, "shape");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const Ebuf = lds;                    // [2][EBUF]
+    float* const WP = lds + 2 * EBUF;           // [2][WPF]
+    float* const WD = WP + 2 * WPF;             // [2][WDF]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const long crop = blockIdx.x;
+    const float* Xc = a.X + crop * 256 * a.ldx;
+    const int y0 = wave * 2;
+
+    for (int i = tid * 4; i < 2 * EBUF; i += 512 * 4) *reinterpret_cast<f32x4*>(lds + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 rx[2], rp[NRP], rd;
+    auto load_x = [&](int c) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+            rx[mt] = *reinterpret_cast<const f32x4*>(Xc + (long)((y0 + mt) * S + li) * a.ldx + c * 16 + lk * 4);
+    };
+    auto store_x = [&](int c) {
+        float* E = Ebuf + (c & 1) * EBUF;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) *reinterpret_cast<f32x4*>(E + ((y0 + mt + P) * PW + li + P) * ES + lk * 4) = rx[mt];
+    };
+    auto load_p = [&](int c) {
+#pragma unroll
+        for (int r = 0; r < NRP; ++r) {
+            const int idx = tid + r * 512;
+            if (idx < WP4) rp[r] = *reinterpret_cast<const f32x4*>(a.Wpk + (long)c * CST + idx * 4);
+        }
+    };
+    auto store_p = [&](int c) {
+        float* dst = WP + (c & 1) * WPF;
+#pragma unroll
+        for (int r = 0; r < NRP; ++r) {
+            const int idx = tid + r * 512;
+            if (idx < WP4) *reinterpret_cast<f32x4*>(dst + idx * 4) = rp[r];
+        }
+    };
+    auto load_d = [&](int c) {
+        if (tid < WD4) rd = *reinterpret_cast<const f32x4*>(a.Wpk + (long)c * CST + WPF + tid * 4);
+    };
+    auto store_d = [&](int c) {
+        if (tid < WD4) *reinterpret_cast<f32x4*>(WD + (c & 1) * WDF + tid * 4) = rd;
+    };
+
+    f32x4 accp[2][NTP];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTP; ++nt) accp[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // depthwise of chunk cd (reads run D tap steps ahead) with the projection MFMAs of the previous chunk dealt between
+    // the steps; PROJ = false for the prologue (nothing to project yet), DW = false for the last interval
+    f32x4 d0, d1;                       // depthwise result of the chunk being projected
+    auto interval = [&](int c, auto proj_tag, auto dw_tag) {
+        constexpr bool PROJ = decltype(proj_tag)::value && !(FEAR_ABL & 16), DW = decltype(dw_tag)::value && !(FEAR_ABL & 64);
+        if (FEAR_ABL & 64) { d0 = d1 = rx[0]; }
+        const int cd = PROJ ? c + 1 : c;
+        const float* wd = WD + (cd & 1) * WDF + lk * 4;
+        const float* e0 = Ebuf + (cd & 1) * EBUF + (y0 * PW + li) * ES + lk * 4;
+        const float* wp = WP + (c & 1) * WPF;
+        f32x4 n0, n1, ev[D], wv[D], wprev = (f32x4){0.f, 0.f, 0.f, 0.f}, wpq[2];
+        if (PROJ) wpq[0] = *reinterpret_cast<const f32x4*>(wp + lane * 4);
+        if (DW) {
+            n0 = n1 = *reinterpret_cast<const f32x4*>(wd + KS * KS * 16);
+#pragma unroll
+            for (int t = 0; t < D; ++t) {
+                const int kx = t / (KS + 1), iy = t % (KS + 1);
+                ev[t] = *reinterpret_cast<const f32x4*>(e0 + (iy * PW + kx) * ES);
+                if (iy < KS) wv[t] = *reinterpret_cast<const f32x4*>(wd + (iy * KS + kx) * 16);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            const int iy = t % (KS + 1);
+            f32x4 e, w;
+            if (DW) {
+                e = ev[t % D]; w = wv[t % D];
+                if (t + D < NS) {
+                    const int kx2 = (t + D) / (KS + 1), iy2 = (t + D) % (KS + 1);
+                    ev[t % D] = *reinterpret_cast<const f32x4*>(e0 + (iy2 * PW + kx2) * ES);
+                    if (iy2 < KS) wv[t % D] = *reinterpret_cast<const f32x4*>(wd + (iy2 * KS + kx2) * 16);
+                }
+            }
+            if (PROJ) {
+#pragma unroll
+                for (int u = t * NU / NS; u < (t + 1) * NU / NS; ++u) {
+                    const int nt = u / 4, i = u % 4;
+                    if (i == 0 && nt + 1 < NTP) wpq[(nt + 1) & 1] = *reinterpret_cast<const f32x4*>(wp + (nt + 1) * 256 + lane * 4);
+                    accp[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wpq[nt & 1][i], d0[i], accp[0][nt], 0, 0, 0);
+                    accp[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wpq[nt & 1][i], d1[i], accp[1][nt], 0, 0, 0);
+                }
+            }
+            if (DW) {
+                if (iy < KS) n0 += e * w;
+                if (iy >= 1) n1 += e * wprev;
+                wprev = w;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (DW) {
+            if (a.relu_dw) {
+                n0.x = fmaxf(n0.x, 0.f); n0.y = fmaxf(n0.y, 0.f); n0.z = fmaxf(n0.z, 0.f); n0.w = fmaxf(n0.w, 0.f);
+                n1.x = fmaxf(n1.x, 0.f); n1.y = fmaxf(n1.y, 0.f); n1.z = fmaxf(n1.z, 0.f); n1.w = fmaxf(n1.w, 0.f);
+            }
+            d0 = n0;
+            d1 = n1;
+        }
+    };
+
+    // ---- prologue: E[0], E[1], WD[0], WD[1], WP[0]; depthwise of chunk 0
+    load_x(0);
+    load_d(0);
+    load_p(0);
+    __syncthreads();                       // zero fill done
+    store_x(0);
+    store_d(0);
+    store_p(0);
+    load_x(1);
+    load_d(1);
+    store_x(1);
+    store_d(1);
+    __syncthreads();
+    interval(0, std::false_type{}, std::true_type{});
+    __syncthreads();                       // E[0] / WD[0] are overwritten at the end of interval 0
+
+    for (int c = 0; c < ((FEAR_ABL & 256) ? 0 : NCHUNK); ++c) {
+        if (!(FEAR_ABL & 2)) {
+        if (c + 2 < NCHUNK) { load_x(c + 2); load_d(c + 2); }
+        if (c + 1 < NCHUNK) load_p(c + 1);
+        }
+        auto commit = [&] {
+            if (FEAR_ABL & 2) return;
+            if (c + 2 < NCHUNK) { store_x(c + 2); store_d(c + 2); }
+            if (c + 1 < NCHUNK) store_p(c + 1);
+        };
+        if (c + 1 < NCHUNK) interval(c, std::true_type{}, std::true_type{});
+        else interval(c, std::true_type{}, std::false_type{});
+        commit();      // (committing mid-interval stalls on the global loads: they need most of an interval to land)
+        if (!(FEAR_ABL & 1)) __syncthreads();
+    }
+
+    if (a.pred_cout > 0) {          // prediction head: lanes lk == 0 hold channels 0..3 of their pixel
+        if (lk == 0) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int px = (y0 + mt) * S + li;
+                const f32x4 v = accp[mt][0];
+                const float vals[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    if (n < a.pred_cout) {
+                        float o = vals[n] + a.bp[n];
+                        if (a.pred_act == 2) o = expf(o);
+                        a.Y[(crop * a.pred_cout + n) * 256 + px] = o;
+                    }
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NTP; ++nt) {
+        const int n = nt * 16 + lk * 4;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(a.bp + n);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const long m = crop * 256 + (y0 + mt) * S + li;
+            f32x4 v = accp[mt][nt] + b;
+            if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
+            if (a.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = v;
+        }
+    }
+}
+
 template <int CIN, int CEXPP, int COUT, int KS, int ST, int TW, int TH, bool EXPAND>
 struct IrT2Geom {
     static constexpr int CE = 16, P = KS / 2, IWR = (TW - 1) * ST + KS, IHR = (TH - 1) * ST + KS, ES = CE + 4;

@@ -52,6 +52,15 @@ static Ir2Args make_args(int crops, size_t packed_floats) {
     return a;
 }
 
+template <int CIN, int COUT, int KS>
+static void bench_sep(const char* tag, int crops, int iters) {
+    const double flops = 2.0 * 256 * ((double)CIN * KS * KS + (double)CIN * COUT) * crops;
+    using G = Sep16Geom<CIN, COUT, KS>;
+    Ir2Args a = make_args<CIN, COUT>(crops, (size_t)G::NCHUNK * G::CST);
+    const double us = time_kernel(sep16_kernel<CIN, COUT, KS>, G::LDS_BYTES, crops, iters, a);
+    printf("%-24s fp32-mfma  %8.1f us  %6.1f TF/s\n", tag, us, flops / us * 1e-6);
+}
+
 template <int CIN, int CEXP, int COUT, int KS, bool EXPAND>
 static void bench(const char* tag, int crops, int iters) {
     const double flops = 2.0 * 256 * ((EXPAND ? (double)CIN * CEXP : 0.0) + (double)CEXP * KS * KS + (double)CEXP * COUT) * crops;
@@ -75,6 +84,7 @@ int main(int argc, char** argv) {
     printf("FEAR_ABL=%d\n", FEAR_ABL);
     bench<112, 672, 112, 5, true>("ir16_112x672x112_k5", crops, iters);
     bench<64, 384, 64, 5, true>("ir16_64x384x64_k5", crops, iters);
-    bench<256, 256, 256, 3, false>("sep16_256x256x256_k3", crops, iters);
+    bench_sep<256, 256, 3>("sep16_256x256_k3", crops, iters);
+    bench_sep<320, 256, 3>("sep16_320x256_k3", crops, iters);
     return 0;
 }
