@@ -35,7 +35,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/fear_engine.hip for gfx950 (cross-compiles without a GPU)."""
     if not force and not is_stale():
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-fno-honor-nans",
            "-Rpass-analysis=kernel-resource-usage", "-o", LIB + ".tmp", SRC]
     if verbose:
         print(" ".join(cmd))

@@ -259,11 +259,12 @@ struct Fused16 {
 };
 #define FUSED16(CIN, CEXP, COUT, KS, EXP) \
     {CIN, CEXP, COUT, KS, EXP, ir16v2_fused_kernel<CIN, CEXP, COUT, KS, (EXP) != 0>, Ir2Geom<CIN, CEXP, COUT, KS, (EXP) != 0>::LDS_BYTES}
+#define SEP16(CIN, COUT, KS) {CIN, CIN, COUT, KS, 0, sep16_kernel<CIN, COUT, KS>, Sep16Geom<CIN, COUT, KS>::LDS_BYTES}
 const Fused16 kFused16[] = {
     FUSED16(64, 192, 64, 5, 1),   FUSED16(64, 384, 64, 5, 1),  FUSED16(64, 384, 112, 5, 1),
     FUSED16(112, 672, 112, 5, 1), FUSED16(112, 336, 112, 5, 1),
-    FUSED16(256, 256, 256, 3, 0), FUSED16(320, 320, 256, 3, 0),
-    FUSED16(256, 256, 16, 3, 0),    // bbox_pred / cls_pred: 4 / 1 output channels padded to one 16-channel tile
+    SEP16(256, 256, 3), SEP16(320, 256, 3),
+    SEP16(256, 16, 3),              // bbox_pred / cls_pred: 4 / 1 output channels padded to one 16-channel tile
 };
 
 // Spatially tiled fused block kernels (ir_tile_fused_kernel) for the high-resolution trunk stages.

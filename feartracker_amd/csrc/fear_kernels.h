@@ -561,6 +561,19 @@ struct Ir2Geom {
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
 };
 
+// d += a * b as two v_pk_fma_f32.  Written as inline asm because hipcc's post-RA peephole "unpacks" packed fp32 FMAs that
+// follow an MFMA into two v_fma_f32 (it assumes they hide in the MFMA's shadow; fp32 MFMAs occupy the same vector ALU on
+// gfx950 — tools/coexec.hip — so the unpacked pair simply costs twice the issue cycles: 4.3 vs 2.5 cycles per FMA pair).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void pk_fma4(f32x4& d, const f32x4& a, const f32x4& b) {
+    f32x2 dl = __builtin_shufflevector(d, d, 0, 1), dh = __builtin_shufflevector(d, d, 2, 3);
+    const f32x2 al = __builtin_shufflevector(a, a, 0, 1), ah = __builtin_shufflevector(a, a, 2, 3);
+    const f32x2 bl = __builtin_shufflevector(b, b, 0, 1), bh = __builtin_shufflevector(b, b, 2, 3);
+    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(dl) : "v"(al), "v"(bl));
+    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(dh) : "v"(ah), "v"(bh));
+    d = __builtin_shufflevector(dl, dh, 0, 1, 2, 3);
+}
+
 // One barrier interval of the fused 16x16 block kernels (ir16v2_fused_kernel, chain16_block): depthwise + projection of
 // chunk c from E / wb, and (HAS_A) the expansion of chunk c + 1 from wa into En.
 // The depthwise is a chain of KS*(KS+1) tap steps (kx outer, iy inner, so the weight of (iy, kx) feeds row 0 now and
@@ -615,8 +628,8 @@ __device__ __forceinline__ void ir16_interval(const float* __restrict__ E, float
         if (FEAR_ABL & 32) {
             d0.x += e.x + w.x;
         } else {
-            if (iy < KS) d0 += e * w;
-            if (iy >= 1) d1 += e * wprev;
+            if (iy < KS) pk_fma4(d0, e, w);
+            if (iy >= 1) pk_fma4(d1, e, wprev);
         }
         wprev = w;
         __builtin_amdgcn_sched_barrier(0);
@@ -1165,10 +1178,10 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
 #pragma unroll
         for (int nt = 0; nt < NTP; ++nt) accp[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int c = 0; c < NCHUNK; ++c) {
+    for (int c = 0; c < ((FEAR_ABL & 256) ? 0 : NCHUNK); ++c) {
         const float* wa = WS + (c & 1) * CST;
         const float* wb = wa + AP;
-        if (EXPAND) __syncthreads();          // stage c&1 committed (first chunk: by store_w(0) above)
+        if (EXPAND && !(FEAR_ABL & 1)) __syncthreads();          // stage c&1 committed (first chunk: by store_w(0) above)
         // ---- phase A: E <- relu(expand) (or the raw activations)
         if (EXPAND) {
             f32x4 wf[KG > 0 ? KG : 1];
@@ -1182,8 +1195,10 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
 #pragma unroll
                 for (int kg = 0; kg < KG; ++kg)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
+                    for (int q = 0; q < 4; ++q) {
+                        if (FEAR_ABL & 8) { acc += wf[kg] * xf[i][kg][q]; continue; }
                         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kg][q], xf[i][kg][q], acc, 0, 0, 0);
+                    }
                 acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
                 if (eoff[i] >= 0) *reinterpret_cast<f32x4*>(E + eoff[i] + lk * 4) = acc;
             }
@@ -1195,8 +1210,8 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
             }
         }
         // prefetch the next chunk's weights (and activations) while this chunk computes
-        if (c + 1 < NCHUNK) { load_w(c + 1); load_x(c + 1); }
-        __syncthreads();
+        if (c + 1 < NCHUNK && !(FEAR_ABL & 2)) { load_w(c + 1); load_x(c + 1); }
+        if (!(FEAR_ABL & 1)) __syncthreads();
         // ---- phase B: depthwise from E, weights from the LDS stage
         f32x4 d[MTC];
         {
@@ -1209,10 +1224,12 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
             for (int iy = 0; iy < (MTC - 1) * ST + KS; ++iy) {
 #pragma unroll
                 for (int kx = 0; kx < KS; ++kx) {
+                    if ((FEAR_ABL & 4) && (iy | kx)) continue;
                     const f32x4 v = *reinterpret_cast<const f32x4*>(Ebase + (iy * IWR + kx) * ES);
 #pragma unroll
                     for (int r = 0; r < MTC; ++r) {
                         const int ky = iy - r * ST;
+                        if (FEAR_ABL & 32) { d[r].x += v.x; continue; }
                         if (ky >= 0 && ky < KS) d[r] += v * *reinterpret_cast<const f32x4*>(wd + (ky * KS + kx) * 16);
                     }
                 }
@@ -1231,11 +1248,13 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int r = 0; r < MTC; ++r)
+                for (int r = 0; r < MTC; ++r) {
+                    if (FEAR_ABL & 16) { accp[r][nt] += wp * d[r][q]; continue; }
                     accp[r][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[q], d[r][q], accp[r][nt], 0, 0, 0);
+                }
         }
-        if (c + 1 < NCHUNK) store_w(c + 1);
-        if (!EXPAND || c + 1 == NCHUNK) __syncthreads();   // E is rewritten next chunk (EXPAND syncs at loop top)
+        if (c + 1 < NCHUNK && !(FEAR_ABL & 2)) store_w(c + 1);
+        if ((!EXPAND || c + 1 == NCHUNK) && !(FEAR_ABL & 1)) __syncthreads();   // E is rewritten next chunk (EXPAND syncs at loop top)
     }
 
 #pragma unroll

@@ -74,7 +74,33 @@ __global__ __launch_bounds__(512) void probe(float* out, long long* clk, int ite
     f32x4 d0 = {}, d1 = {};
     const long long c0 = clock64(), w0 = wall_clock64();      // shader clock vs the constant 100 MHz counter
     const float a = 0.5f + lane, b = 0.25f;
-    if (mode >= 7) {
+    if (mode == 10 || mode == 11) {      // issue rate of v_pk_fma_f32 (10) vs v_fma_f32 (11): 8 independent chains, 2 waves per SIMD
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 p[8];
+        float q[16];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p[i] = (f32x2){a + i, b + i};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) q[i] = a + i;
+        const f32x2 m2 = (f32x2){1.0001f, 0.9999f}, c2 = (f32x2){0.5f, 0.25f};
+        for (int it = 0; it < iters; ++it) {
+            if (mode == 10) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(m2), "v"(c2));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(q[i]) : "v"(m2.x), "v"(c2.x));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d0.x += p[i].x + p[i].y;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) d0.y += q[i];
+    } else if (mode >= 7) {
         for (int it = 0; it < iters; ++it) {
             if (mode == 7) step_burst<7>(acc, d0, d1, lds, lane, a, b);
             else if (mode == 8) step_burst<8>(acc, d0, d1, lds, lane, a, b);
@@ -117,7 +143,7 @@ int main() {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int iters = 2000;
-    for (int mode : {1, 2, 3, 4, 5, 6, 7, 8, 9}) {
+    for (int mode : {1, 6, 7, 9, 10, 11}) {
         hipLaunchKernelGGL(probe, dim3(256), dim3(512), 0, 0, out, clk, iters, mode);
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0));
