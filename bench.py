@@ -112,6 +112,8 @@ def main() -> None:
                     help="0: fp32 MFMA (exact fp32, default); 1: fp16 hi+lo split operands on the matrix pipe, fp32 accumulate")
     ap.add_argument("--no-chain", action="store_true", help="A/B: one fused kernel per stride-16 block instead of the chain kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-math", action="store_true",
+                    help="skip the supplementary run in the other arithmetic mode (profiling runs: keeps the trace to one plan)")
     ap.add_argument("--dump-ops", action="store_true", help="print the per-kernel time table to stderr")
     args = ap.parse_args()
 
@@ -209,16 +211,18 @@ def main() -> None:
 
     # the same K steps in the other arithmetic mode (supplementary number, same protocol)
     other = 1 - args.math
-    net.set_math(other)
-    for _ in range(max(3, args.warmup // 2)):
-        step()
-    barrier()
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed_other = time.perf_counter() - t1
-    if world > 1:
+    elapsed_other = None
+    if not args.no_other_math:
+        net.set_math(other)
+        for _ in range(max(3, args.warmup // 2)):
+            step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        elapsed_other = time.perf_counter() - t1
+    if world > 1 and elapsed_other is not None:
         t = torch.tensor([elapsed_other], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed_other = float(t.item())
@@ -268,13 +272,14 @@ def main() -> None:
                                 "pointwise convs of the fused 16x16 blocks: fp32 activations split into fp16 hi+lo, exact-fp16 "
                                 "weights, v_mfma_f32_16x16x32_f16, fp32 accumulate; everything else fp32")},
             "roofline": roof,
-            "other_math_mode": {
+        }
+        if elapsed_other is not None:
+            out["other_math_mode"] = {
                 "math": ("fp16 hi+lo split activations x exact-fp16 weights on the f16 matrix pipe, fp32 accumulate "
                          "(deviation from the fp32-MFMA path ~1e-6 rel, tests/test_gpu_parity.py)" if other == 1 else
                          "fp32 MFMA (exact fp32)"),
                 "value": world * B * args.steps / elapsed_other, "unit": "crops/s",
-                "ms_per_step": 1e3 * elapsed_other / args.steps},
-        }
+                "ms_per_step": 1e3 * elapsed_other / args.steps}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(search_u8, tmpl_u8, DEFAULT_WEIGHTS)
         print(json.dumps(out))

@@ -962,8 +962,8 @@ __global__ __launch_bounds__(512) void sep16_kernel(Ir2Args a) {
                 }
             }
             if (DW) {
-                if (iy < KS) n0 += e * w;
-                if (iy >= 1) n1 += e * wprev;
+                if (iy < KS) pk_fma4(n0, e, w);
+                if (iy >= 1) pk_fma4(n1, e, wprev);
                 wprev = w;
             }
             __builtin_amdgcn_sched_barrier(0);

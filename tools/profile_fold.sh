@@ -1,0 +1,18 @@
+#!/bin/bash
+# Folds gpurun_out/round/* (written by tools/profile_round.sh on the GPU box) into the committed profiles/rNN_* files.
+# usage: bash tools/profile_fold.sh 01
+set -eu
+N=${1:?round number, e.g. 01}
+O=gpurun_out/round
+P=profiles
+mkdir -p $P
+tail -1 $O/bench.json > $P/r${N}_bench.json
+for m in 0 1; do
+  cp $O/trace_math$m/p_kernel_stats.csv $P/r${N}_kernel_stats_math$m.csv
+  grep -E "^\s+[0-9]+ \S+\s+[0-9.]+ ms/step|sum of kernels" $O/trace_math$m.err > $P/r${N}_bench_dump_ops_math$m.txt
+  python tools/trace_to_ops.py $O/trace_math$m/p_kernel_trace.csv $O/trace_math$m.err 20 > $P/r${N}_per_op_math$m.csv
+done
+cp $P/r${N}_per_op_math0.csv $P/r${N}_per_op.csv
+python tools/pmc_to_traffic.py $O/pmc_FETCH_SIZE/p_counter_collection.csv $O/pmc_WRITE_SIZE/p_counter_collection.csv > $P/r${N}_traffic.json
+tail -1 $O/latency.json > $P/r${N}_latency_batch1.json
+ls -la $P

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Collects everything profiles/rNN_* is built from, on the GPU box (run through gpurun from the repo root):
+#   gpurun --timeout 1500 -- 'bash tools/profile_round.sh'
+# then fold the results locally with tools/profile_fold.sh <round>.
+#   1. python bench.py                       -> gpurun_out/round/bench.json (+ cpu_baseline)
+#   2. rocprofv3 --kernel-trace --stats       (math 0 and math 1, --dump-ops: per-op table on stderr)
+#   3. rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes (no other trace domains)
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/round
+rm -rf "$O"; mkdir -p "$O"
+cd /tmp && export TMPDIR=/tmp
+python "$R/bench.py" > "$O/bench.json" 2> "$O/bench.err"
+for m in 0 1; do
+  rocprofv3 --kernel-trace --stats -d "$O/trace_math$m" -o p --output-format csv -- \
+    python "$R/bench.py" --steps 20 --warmup 5 --math $m --no-cpu-baseline --no-other-math --dump-ops > "$O/trace_math$m.json" 2> "$O/trace_math$m.err"
+done
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c -d "$O/pmc_$c" -o p --output-format csv -- \
+    python "$R/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-other-math > "$O/pmc_$c.json" 2> "$O/pmc_$c.err"
+done
+python "$R/bench_latency.py" > "$O/latency.json" 2> "$O/latency.err"
+tail -c 600 "$O/bench.json"
