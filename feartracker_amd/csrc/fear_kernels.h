@@ -1053,7 +1053,8 @@ struct IrT2Geom {
     static constexpr int AP = EXPAND ? KG * 256 + 16 : 0;
     static constexpr int BP = NTP * 256 + KS * KS * 16 + 16;
     static constexpr int EBUF = IHR * IWR * ES;
-    static constexpr int LDS_BYTES = (EBUF + 2 * (AP + BP)) * 4;
+    static constexpr int DUMMY = 256;      // 64 lanes x 16 B: where lanes outside the clipped region park their phase-A store
+    static constexpr int LDS_BYTES = (EBUF + 2 * (AP + BP) + DUMMY) * 4;
 };
 
 struct IrT2Args {
@@ -1135,7 +1136,8 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
         const int qq = valid ? q : 0;
         const int cy = (int)(((float)qq + 0.5f) * inv_cw), cx = qq - cy * CW;   // exact for qq < 2^16, CW <= 64
         const int gy = cy_lo + cy, gx = cx_lo + cx;
-        eoff[i] = valid ? ((gy - iy0) * IWR + (gx - ix0)) * ES : -1;
+        // invalid lanes (beyond the clipped region) store to a dummy slot: phase A stays branch free
+        eoff[i] = valid ? ((gy - iy0) * IWR + (gx - ix0)) * ES + lk * 4 : EBUF + 2 * CST + lane * 4;
         xoff[i] = ((long)gy * t.W + gx) * a.ldx;
         if (STEM) {
             const float* pimg = Xc + (long)(2 * gy - 1) * 2 * t.W + 2 * gx - 1;
@@ -1190,7 +1192,7 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
             const f32x4 bias = *reinterpret_cast<const f32x4*>(wa + KG * 256 + lk * 4);
 #pragma unroll
             for (int i = 0; i < MTA; ++i) {
-                if ((wave + 8 * i) * 16 >= NPIX) break;
+                if ((wave + 8 * i) * 16 >= NPIX) break;            // wave-uniform: whole m-tile beyond the clipped region
                 f32x4 acc = bias;
 #pragma unroll
                 for (int kg = 0; kg < KG; ++kg)
@@ -1200,13 +1202,13 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
                         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kg][q], xf[i][kg][q], acc, 0, 0, 0);
                     }
                 acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
-                if (eoff[i] >= 0) *reinterpret_cast<f32x4*>(E + eoff[i] + lk * 4) = acc;
+                *reinterpret_cast<f32x4*>(E + eoff[i]) = acc;
             }
         } else {
 #pragma unroll
             for (int i = 0; i < MTA; ++i) {
                 if ((wave + 8 * i) * 16 >= NPIX) break;
-                if (eoff[i] >= 0) *reinterpret_cast<f32x4*>(E + eoff[i] + lk * 4) = rx[i];
+                *reinterpret_cast<f32x4*>(E + eoff[i]) = rx[i];
             }
         }
         // prefetch the next chunk's weights (and activations) while this chunk computes
