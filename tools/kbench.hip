@@ -84,6 +84,37 @@ static void bench_tile(const char* tag, int crops, int iters, int hw) {
     printf("%-24s fp32-tile  %8.1f us  %6.1f TF/s  (LDS %d B)\n", tag, us, flops / us * 1e-6, G::LDS_BYTES);
 }
 
+static void bench_stem(int crops, int iters) {
+    using G = IrT2Geom<27, 16, 16, 3, 1, 32, 16, true>;
+    const int hw = 128;
+    const double flops = 2.0 * (27.0 * 16 + 16.0 * 9 + 16.0 * 16) * hw * hw * crops;
+    IrT2Args t{};
+    Ir2Args& a = t.b;
+    a.ldx = 0; a.ldr = 16; a.ldy = 16;
+    a.X = dev_rand((size_t)crops * 3 * 256 * 256, 2.f);
+    a.Wpk = dev_rand((size_t)G::NCHUNK * (G::AP + G::BP), 0.01f);
+    a.bp = dev_rand(64, 0.2f);
+    float* y;
+    CK(hipMalloc(&y, (size_t)crops * hw * hw * 16 * sizeof(float)));
+    a.Y = y; a.relu_dw = 1; a.relu_out = 0;
+    t.H = hw; t.W = hw; t.tiles_x = hw / 32; t.tiles_y = hw / 16;
+    auto k = ir_tile_v2_kernel<27, 16, 16, 3, 1, 32, 16, true, 4, true>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const dim3 grid((unsigned)crops * t.tiles_x * t.tiles_y);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, grid, dim3(512), G::LDS_BYTES, 0, t);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k, grid, dim3(512), G::LDS_BYTES, 0, t);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = 1e3 * ms / iters;
+    printf("%-24s fp32-stem  %8.1f us  %6.1f TF/s  (LDS %d B)\n", "stem_irt_3x16x16_hw256", us, flops / us * 1e-6, G::LDS_BYTES);
+}
+
 template <int CIN, int COUT, int KS>
 static void bench_sep(const char* tag, int crops, int iters) {
     const double flops = 2.0 * 256 * ((double)CIN * KS * KS + (double)CIN * COUT) * crops;
@@ -116,6 +147,7 @@ int main(int argc, char** argv) {
     printf("FEAR_ABL=%d\n", FEAR_ABL);
     bench<112, 672, 112, 5, true>("ir16_112x672x112_k5", crops, iters);
     bench<64, 384, 64, 5, true>("ir16_64x384x64_k5", crops, iters);
+    bench_stem(crops, iters);
     bench_tile<16, 96, 24, 3, 2, 16, 8, true, 4>("irt_16x96x24_k3s2_hw128", crops, iters, 128);
     bench_tile<24, 144, 32, 5, 2, 16, 8, true, 4>("irt_24x144x32_k5s2_hw64", crops, iters, 64);
     bench_tile<32, 192, 32, 5, 1, 16, 16, true, 2>("irt_32x192x32_k5s1_hw32", crops, iters, 32);
