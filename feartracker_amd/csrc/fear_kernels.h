@@ -561,6 +561,26 @@ struct Ir2Geom {
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
 };
 
+// Asynchronous global -> LDS copy of NF contiguous floats (a packed weight block) by the 8 waves of a workgroup, 1 KiB per
+// wave instruction (global_load_lds_dwordx4: lane l's 16 bytes land at dst + 16*l; no VGPRs, no ds_write).  The copy is
+// complete for the issuing wave after s_waitcnt vmcnt(0) — __syncthreads() includes it — and visible to the others after
+// the barrier.  dst must not be read by anyone during the interval the copy is in flight.
+template <int NF>
+__device__ __forceinline__ void lds_copy_async(const float* __restrict__ src, float* dst, int wave, int lane) {
+    static_assert(NF % 4 == 0, "16-byte granules");
+    constexpr int NK = NF / 256, REM = NF % 256;
+#pragma unroll
+    for (int k = 0; k < (NK + 7) / 8; ++k) {
+        const int piece = wave + 8 * k;
+        if (piece < NK)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 256 + lane * 4),
+                                             (__attribute__((address_space(3))) void*)(dst + piece * 256), 16, 0, 0);
+    }
+    if (REM > 0 && wave == NK % 8 && lane * 4 < REM)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + NK * 256 + lane * 4),
+                                         (__attribute__((address_space(3))) void*)(dst + NK * 256), 16, 0, 0);
+}
+
 // d += a * b as two v_pk_fma_f32.  Written as inline asm because hipcc's post-RA peephole "unpacks" packed fp32 FMAs that
 // follow an MFMA into two v_fma_f32 (it assumes they hide in the MFMA's shadow; fp32 MFMAs occupy the same vector ALU on
 // gfx950 — tools/coexec.hip — so the unpacked pair simply costs twice the issue cycles: 4.3 vs 2.5 cycles per FMA pair).
@@ -879,7 +899,7 @@ __global__ __launch_bounds__(512) void sep16_kernel(Ir2Args a) {
 
     for (int i = tid * 4; i < 2 * EBUF; i += 512 * 4) *reinterpret_cast<f32x4*>(lds + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    f32x4 rx[2], rp[NRP], rd;
+    f32x4 rx[2];
     auto load_x = [&](int c) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -890,27 +910,10 @@ __global__ __launch_bounds__(512) void sep16_kernel(Ir2Args a) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) *reinterpret_cast<f32x4*>(E + ((y0 + mt + P) * PW + li + P) * ES + lk * 4) = rx[mt];
     };
-    auto load_p = [&](int c) {
-#pragma unroll
-        for (int r = 0; r < NRP; ++r) {
-            const int idx = tid + r * 512;
-            if (idx < WP4) rp[r] = *reinterpret_cast<const f32x4*>(a.Wpk + (long)c * CST + idx * 4);
-        }
-    };
-    auto store_p = [&](int c) {
-        float* dst = WP + (c & 1) * WPF;
-#pragma unroll
-        for (int r = 0; r < NRP; ++r) {
-            const int idx = tid + r * 512;
-            if (idx < WP4) *reinterpret_cast<f32x4*>(dst + idx * 4) = rp[r];
-        }
-    };
-    auto load_d = [&](int c) {
-        if (tid < WD4) rd = *reinterpret_cast<const f32x4*>(a.Wpk + (long)c * CST + WPF + tid * 4);
-    };
-    auto store_d = [&](int c) {
-        if (tid < WD4) *reinterpret_cast<f32x4*>(WD + (c & 1) * WDF + tid * 4) = rd;
-    };
+    // weights go global -> LDS directly (asynchronous, no registers): the projection fragments of chunk c into WP[c & 1],
+    // the depthwise taps + bias into WD[c & 1]
+    auto stage_p = [&](int c) { lds_copy_async<WPF>(a.Wpk + (long)c * CST, WP + (c & 1) * WPF, wave, lane); };
+    auto stage_d = [&](int c) { lds_copy_async<WDF>(a.Wpk + (long)c * CST + WPF, WD + (c & 1) * WDF, wave, lane); };
 
     f32x4 accp[2][NTP];
 #pragma unroll
@@ -980,29 +983,27 @@ __global__ __launch_bounds__(512) void sep16_kernel(Ir2Args a) {
 
     // ---- prologue: E[0], E[1], WD[0], WD[1], WP[0]; depthwise of chunk 0
     load_x(0);
-    load_d(0);
-    load_p(0);
     __syncthreads();                       // zero fill done
+    stage_d(0);
+    stage_p(0);
+    stage_d(1);
     store_x(0);
-    store_d(0);
-    store_p(0);
     load_x(1);
-    load_d(1);
     store_x(1);
-    store_d(1);
     __syncthreads();
     interval(0, std::false_type{}, std::true_type{});
     __syncthreads();                       // E[0] / WD[0] are overwritten at the end of interval 0
 
     for (int c = 0; c < ((FEAR_ABL & 256) ? 0 : NCHUNK); ++c) {
         if (!(FEAR_ABL & 2)) {
-        if (c + 2 < NCHUNK) { load_x(c + 2); load_d(c + 2); }
-        if (c + 1 < NCHUNK) load_p(c + 1);
+            // in flight during this interval: WD[c&1] (last read by the depthwise of chunk c, before the previous barrier),
+            // WP[(c+1)&1] (last read by the projection of chunk c-1)
+            if (c + 2 < NCHUNK) { load_x(c + 2); stage_d(c + 2); }
+            if (c + 1 < NCHUNK) stage_p(c + 1);
         }
         auto commit = [&] {
             if (FEAR_ABL & 2) return;
-            if (c + 2 < NCHUNK) { store_x(c + 2); store_d(c + 2); }
-            if (c + 1 < NCHUNK) store_p(c + 1);
+            if (c + 2 < NCHUNK) store_x(c + 2);
         };
         if (c + 1 < NCHUNK) interval(c, std::true_type{}, std::true_type{});
         else interval(c, std::true_type{}, std::false_type{});
