@@ -98,7 +98,8 @@ struct Op {
     int C = 0, N = 0;         // input / output channels
     int relu = 0, act = 0;
     int out_external = 0;     // 1: features NCHW, 2: bbox, 3: cls
-    int tmpl_cls = 0;         // OP_CORR: use the classification template
+    int tmpl_cls = 0;         // OP_CORR / corr_fused: use the classification template
+    int corr_fused = 0;       // OP_IR16 (sep16): the pixel-wise correlation runs in this kernel's epilogue
     int conv_e = -1, conv_d = -1, conv_p = -1;  // OP_IR16: expand (or -1) / depthwise / project convs
     int relu_dw = 0;
     int fused_id = -1;        // OP_IR16: index into the fused-kernel table
@@ -330,6 +331,11 @@ const Fused16 kFused16H[] = {
     FUSED16H(256, 256, 16, 3, 0),
 };
 static_assert(sizeof(kFused16H) == sizeof(kFused16), "the two tables must list the same shapes in the same order");
+
+// encode SepConv + pixel-wise correlation in one kernel (fp32 mode)
+constexpr int kCorrC = 256, kCorrTz = 64;
+auto* const kSep16CorrKernel = sep16_kernel<kCorrC, kCorrC, 3, true>;
+constexpr int kSep16CorrLds = Sep16Geom<kCorrC, kCorrC, 3, true>::LDS_BYTES;
 
 int find_fused16(int cin, int cexp, int cout, int ks, int expand) {
     if (cout <= 4) cout = 16;     // prediction heads run on the one-tile instantiation
@@ -764,12 +770,23 @@ int build_plan(fear_handle* h, int hw, bool with_head, Plan** out) {
             if (corr_dw.cout != enc_pw.cout + tz) return FEAR_ERR_FORMAT;
             T d, cat;
             // encode pointwise writes channels [0, C) of the concat buffer; correlation fills [C, C+64)
+            bool corr_done = false;
             if (!add_fused16(-1, enc->conv[0], enc->conv[1], feat, cat, nullptr, 0, 1, corr_dw.cout, "sep16")) {
                 add_dw(enc->conv[0], feat, d, 0);
                 add_pw(enc->conv[1], d, cat, nullptr, 1, corr_dw.cout, 0, -1);
                 pool.release(d.buf);
+            } else if (!h->math && enc_pw.cout == kCorrC && h->convs[enc->conv[0]].cout == kCorrC &&
+                       h->convs[enc->conv[0]].k == 3 && tz == kCorrTz) {
+                // the correlation rides in the encode kernel's epilogue: its output fragments are the B operand as they stand
+                Op& eop = ops.back();
+                eop.corr_fused = 1;
+                eop.tmpl_cls = is_cls ? 1 : 0;
+                set_name(eop, is_cls ? "sep16_corr_cls_%dx%d_k%d" : "sep16_corr_reg_%dx%d_k%d", enc_pw.cout, tz, 3);
+                eop.flops += 2.0 * S * S * enc_pw.cout * tz;
+                eop.bytes += 4.0 * (S * S * tz + (double)enc_pw.cout * tz);
+                corr_done = true;
             }
-            {
+            if (!corr_done) {
                 Op op{};
                 op.type = OP_CORR;
                 op.in_buf = cat.buf; op.in_ld = cat.ld; op.in_off = 0;
@@ -903,6 +920,8 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s) {
         for (const FusedTile& f : kFusedTileH)
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(f.kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, f.lds_bytes));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kSep16CorrKernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kSep16CorrLds));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kChainXSKernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kChainXSLds));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kStemTile.kernel),
@@ -993,7 +1012,13 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s) {
                     a.pred_cout = op.pred_cout; a.pred_act = op.act;
                     a.Y = op.out_external == 3 ? ext.cls_out : ext.bbox_out;
                 }
-                hipLaunchKernelGGL(f.kernel, dim3(n), dim3(512), f.lds_bytes, s, a);
+                if (op.corr_fused) {
+                    a.Z = (op.tmpl_cls && ext.tmpl_cls) ? ext.tmpl_cls : ext.tmpl;
+                    a.z_stride = (long)kCorrC * kCorrTz;
+                    hipLaunchKernelGGL(kSep16CorrKernel, dim3(n), dim3(512), kSep16CorrLds, s, a);
+                } else {
+                    hipLaunchKernelGGL(f.kernel, dim3(n), dim3(512), f.lds_bytes, s, a);
+                }
                 break;
             }
             case OP_IRTILE: {

@@ -546,6 +546,10 @@ struct Ir2Args {
     // prediction heads (bbox_pred / cls_pred): COUT is padded to 16 in the kernel, only the first pred_cout channels
     // are real; they are written NCHW ([crop][pred_cout][256]) with optional exp (pred_act == 2)
     int pred_cout, pred_act;
+    // sep16_kernel<..., CORR = true>: per-crop template features z [crop][COUT][64] (the caller's NCHW (C, 8, 8) tensor);
+    // the pixel-wise correlation of the block's output with z is written to channels [COUT, COUT + 64) of Y
+    const float* Z;
+    long z_stride;
 };
 
 template <int CIN, int CEXP, int COUT, int KS, bool EXPAND>
@@ -870,17 +874,22 @@ __global__ __launch_bounds__(512) void ir16v2_fused_kernel(Ir2Args a) {
 //   interval c reads  E[(c+1)&1], WD[(c+1)&1]  (depthwise of chunk c+1)  and  WP[c&1] (projection of chunk c)
 //   interval c writes E[c&1] <- X chunk c+2, WD[c&1] <- wd(c+2), WP[(c+1)&1] <- wp(c+1)   (all last read before barrier c-1)
 // Packed weights: the BC-part layout of Ir2Args (AP = 0): per chunk NTP fragments x 256 | Wd[KS*KS][16] | bd[16].
-template <int CIN, int COUT, int KS>
+template <int CIN, int COUT, int KS, bool CORR = false>
 struct Sep16Geom {
     static constexpr int S = 16, P = KS / 2, PW = S + 2 * P, ES = 24, NCHUNK = CIN / 16, NTP = COUT / 16;
     static constexpr int WPF = NTP * 256, WDF = KS * KS * 16 + 16, CST = WPF + WDF;
     static constexpr int EBUF = PW * PW * ES;
-    static constexpr int LDS_BYTES = (2 * EBUF + 2 * WPF + 2 * WDF) * 4;
+    static constexpr int ZF = CORR ? COUT * 64 : 0;            // the crop's template features, resident for the epilogue
+    static constexpr int LDS_BYTES = (2 * EBUF + 2 * WPF + 2 * WDF + ZF) * 4;
 };
 
-template <int CIN, int COUT, int KS>
+// CORR = true appends the pixel-wise correlation with the crop's template features (MobileCorrelation, blocks.py:121-123):
+// corr[px][t] = sum_c y[px][c] * z[c][t] — the block's output fragments are the B operand as they stand, z (64 KiB,
+// fetched into LDS by an asynchronous copy at kernel start) supplies the A fragments; the 64 correlation channels go to
+// Y[.., COUT .. COUT+64), i.e. next to the features in the concat buffer the following SepConv reads.
+template <int CIN, int COUT, int KS, bool CORR = false>
 __global__ __launch_bounds__(512) void sep16_kernel(Ir2Args a) {
-    using G = Sep16Geom<CIN, COUT, KS>;
+    using G = Sep16Geom<CIN, COUT, KS, CORR>;
     constexpr int S = G::S, P = G::P, PW = G::PW, ES = G::ES, NCHUNK = G::NCHUNK, NTP = G::NTP;
     constexpr int WPF = G::WPF, WDF = G::WDF, CST = G::CST, EBUF = G::EBUF;
     constexpr int WP4 = WPF / 4, WD4 = WDF / 4, NRP = (WP4 + 511) / 512;
@@ -890,6 +899,7 @@ __global__ __launch_bounds__(512) void sep16_kernel(Ir2Args a) {
     float* const Ebuf = lds;                    // [2][EBUF]
     float* const WP = lds + 2 * EBUF;           // [2][WPF]
     float* const WD = WP + 2 * WPF;             // [2][WDF]
+    float* const ZL = WD + 2 * WDF;             // [COUT][64] (CORR)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
@@ -898,6 +908,7 @@ __global__ __launch_bounds__(512) void sep16_kernel(Ir2Args a) {
     const int y0 = wave * 2;
 
     for (int i = tid * 4; i < 2 * EBUF; i += 512 * 4) *reinterpret_cast<f32x4*>(lds + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (CORR) lds_copy_async<G::ZF>(a.Z + crop * a.z_stride, ZL, wave, lane);
 
     f32x4 rx[2];
     auto load_x = [&](int c) {
@@ -1041,6 +1052,38 @@ __global__ __launch_bounds__(512) void sep16_kernel(Ir2Args a) {
             if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
             if (a.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = v;
+            if (CORR) accp[mt][nt] = v;          // the finished feature fragment = B operand of the correlation
+        }
+    }
+    if (CORR) {
+        constexpr int TZ = 64, NTZ = TZ / 16;
+        f32x4 cacc[2][NTZ];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int q = 0; q < NTZ; ++q) cacc[mt][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kg = 0; kg < NTP; ++kg) {
+            // A fragment of (kg, q): lane l holds z[kg*16 + 4*(l>>4) + i][q*16 + (l&15)], i = 0..3
+            const float* zr = ZL + (kg * 16 + lk * 4) * TZ + li;
+            f32x4 zf[NTZ];
+#pragma unroll
+            for (int q = 0; q < NTZ; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) zf[q][i] = zr[i * TZ + q * 16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < NTZ; ++q) {
+                    cacc[0][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(zf[q][i], accp[0][kg][i], cacc[0][q], 0, 0, 0);
+                    cacc[1][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(zf[q][i], accp[1][kg][i], cacc[1][q], 0, 0, 0);
+                }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const long m = crop * 256 + (y0 + mt) * S + li;
+#pragma unroll
+            for (int q = 0; q < NTZ; ++q) *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + COUT + q * 16 + lk * 4) = cacc[mt][q];
         }
     }
 }
