@@ -283,11 +283,11 @@ const FusedTile kFusedTile[] = {
     FTILE(16, 16, 16, 16, 3, 1, 32, 16, 0, 4, 128),    // fbnet_c stage 1  (e1, 128x128)
     FTILE(16, 96, 96, 24, 3, 2, 16, 8, 1, 4, 128),     // stage 2          (e6 s2, 128 -> 64)
     FTILE(24, 24, 32, 24, 3, 1, 16, 16, 0, 4, 64),     // stages 4, 5      (e1, 64x64; 24 channels padded to 32)
-    FTILE(24, 144, 144, 32, 5, 2, 16, 8, 1, 4, 64),    // stage 6          (e6 s2, 64 -> 32)
+    FTILE(24, 144, 144, 32, 5, 2, 16, 16, 1, 2, 64),   // stage 6          (e6 s2, 64 -> 32)
     FTILE(32, 96, 96, 32, 5, 1, 16, 16, 1, 2, 32),     // stage 7  (4 corner tiles: 18x18 clipped region)
-    FTILE(32, 192, 192, 32, 5, 1, 16, 16, 1, 2, 32),   // stage 8
+    FTILE(32, 192, 192, 32, 5, 1, 16, 32, 1, 2, 32),   // stage 8  (two 16x32 tiles per map: 4 rows per wave share the depthwise reads)
     FTILE(32, 192, 192, 32, 3, 1, 32, 16, 1, 2, 32),   // stage 9
-    FTILE(32, 192, 192, 64, 5, 2, 16, 8, 1, 2, 32),    // stage 10         (e6 s2, 32 -> 16)
+    FTILE(32, 192, 192, 64, 5, 2, 16, 16, 1, 2, 32),   // stage 10         (e6 s2, 32 -> 16: the whole 16x16 output map)
 };
 #define FTILEH(CIN, CEXP, CEXPP, COUT, KS, ST, TW, TH, EXP, NW, MINW, HW)                                             \
     {CIN, CEXP, COUT, KS, ST, EXP, HW, TW, TH,                                                                        \

@@ -15,6 +15,12 @@
 //   normalize_kernel   uint8 HWC -> normalised fp32 NCHW                (Tracker._preprocess_image, base_tracker.py:97-103)
 #pragma once
 #include <type_traits>
+#ifndef IR16_GS
+#define IR16_GS 2      // tap steps per scheduling group of ir16_interval
+#endif
+#ifndef IR16_D
+#define IR16_D 4       // LDS read-ahead of ir16_interval, in tap steps
+#endif
 #ifndef FEAR_ABL
 #define FEAR_ABL 0      // timing ablations for tools/kbench only (bit mask); the product always builds with 0
 #endif
@@ -609,9 +615,13 @@ template <int KS, int PW, int ES, int KG, int NTP, bool HAS_A, int XM, int XK>
 __device__ __forceinline__ void ir16_interval(const float* __restrict__ E, float* __restrict__ En, const float* __restrict__ wa,
                                               const float* __restrict__ wb, const f32x4 (&xf)[XM][XK], f32x4 (&accp)[2][NTP],
                                               int y0, int li, int lk, int lane, bool relu_dw) {
-    constexpr int NS = KS * (KS + 1), D = 4, P = KS / 2;
+    // GS tap steps form one scheduling group: [LDS reads for the group D steps ahead][the group's MFMAs][the group's packed
+    // FMAs] — switching the vector ALU between MFMA and VALU instructions costs ~8 cycles (tools/coexec.hip modes 7/9), so
+    // the groups are made as coarse as the read-ahead window allows
+    constexpr int NS = KS * (KS + 1), GS = IR16_GS, D = IR16_D, P = KS / 2;
     constexpr int NU = HAS_A ? KG * 4 : 0;                     // expansion MFMA units (each = mt 0 and mt 1)
     static_assert(!HAS_A || (XM == 2 && XK >= KG), "fragment array");
+    static_assert(NS % GS == 0 && D >= GS && D % GS == 0, "step grouping");
     const float* wd = wb + NTP * 256 + lk * 4;
     const float* e0 = E + (y0 * PW + li) * ES + lk * 4;
     f32x4 acc[2];
@@ -631,17 +641,22 @@ __device__ __forceinline__ void ir16_interval(const float* __restrict__ E, float
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int t = 0; t < NS; ++t) {
-        const int iy = t % (KS + 1);
-        const f32x4 e = ev[t % D], w = wv[t % D];
-        if (t + D < NS && !(FEAR_ABL & 4)) {
-            const int kx2 = (t + D) / (KS + 1), iy2 = (t + D) % (KS + 1);
-            ev[t % D] = *reinterpret_cast<const f32x4*>(e0 + (iy2 * PW + kx2) * ES);
-            if (iy2 < KS) wv[t % D] = *reinterpret_cast<const f32x4*>(wd + (iy2 * KS + kx2) * 16);
+    for (int g = 0; g < NS; g += GS) {
+        f32x4 e[GS], w[GS];
+#pragma unroll
+        for (int s0 = 0; s0 < GS; ++s0) {
+            const int t = g + s0;
+            e[s0] = ev[t % D];
+            w[s0] = wv[t % D];
+            if (t + D < NS && !(FEAR_ABL & 4)) {
+                const int kx2 = (t + D) / (KS + 1), iy2 = (t + D) % (KS + 1);
+                ev[t % D] = *reinterpret_cast<const f32x4*>(e0 + (iy2 * PW + kx2) * ES);
+                if (iy2 < KS) wv[t % D] = *reinterpret_cast<const f32x4*>(wd + (iy2 * KS + kx2) * 16);
+            }
         }
         if (HAS_A) {
 #pragma unroll
-            for (int u = t * NU / NS; u < (t + 1) * NU / NS; ++u) {
+            for (int u = g * NU / NS; u < (g + GS) * NU / NS; ++u) {
                 const int kg = u / 4, i = u % 4;
                 if (i == 0 && kg + 1 < KG) wfq[(kg + 1) & 1] = *reinterpret_cast<const f32x4*>(wa + (kg + 1) * 256 + lane * 4);
                 if (FEAR_ABL & 8) continue;
@@ -649,13 +664,17 @@ __device__ __forceinline__ void ir16_interval(const float* __restrict__ E, float
                 acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfq[kg & 1][i], xf[HAS_A ? 1 : 0][HAS_A ? kg : 0][i], acc[1], 0, 0, 0);
             }
         }
-        if (FEAR_ABL & 32) {
-            d0.x += e.x + w.x;
-        } else {
-            if (iy < KS) pk_fma4(d0, e, w);
-            if (iy >= 1) pk_fma4(d1, e, wprev);
+#pragma unroll
+        for (int s0 = 0; s0 < GS; ++s0) {
+            const int iy = (g + s0) % (KS + 1);
+            if (FEAR_ABL & 32) {
+                d0.x += e[s0].x + w[s0].x;
+            } else {
+                if (iy < KS) pk_fma4(d0, e[s0], w[s0]);
+                if (iy >= 1) pk_fma4(d1, e[s0], wprev);
+            }
+            wprev = w[s0];
         }
-        wprev = w;
         __builtin_amdgcn_sched_barrier(0);
     }
     f32x4 wpq[2];

@@ -55,6 +55,7 @@ static Ir2Args make_args(int crops, size_t packed_floats) {
 template <int CIN, int CEXP, int COUT, int KS, int ST, int TW, int TH, bool EXPAND, int MINW>
 static void bench_tile(const char* tag, int crops, int iters, int hw) {
     using G = IrT2Geom<CIN, CEXP, COUT, KS, ST, TW, TH, EXPAND>;
+    if (G::LDS_BYTES > 160 * 1024) { printf("%-24s skipped: LDS %d B\n", tag, G::LDS_BYTES); return; }
     const int ho = hw / ST;
     const double flops = 2.0 * ((EXPAND ? (double)CIN * CEXP * hw * hw : 0.0) + ((double)CEXP * KS * KS + (double)CEXP * COUT) * ho * ho) * crops;
     IrT2Args t{};
@@ -151,6 +152,22 @@ int main(int argc, char** argv) {
     bench_tile<16, 96, 24, 3, 2, 16, 8, true, 4>("irt_16x96x24_k3s2_hw128", crops, iters, 128);
     bench_tile<24, 144, 32, 5, 2, 16, 8, true, 4>("irt_24x144x32_k5s2_hw64", crops, iters, 64);
     bench_tile<32, 192, 32, 5, 1, 16, 16, true, 2>("irt_32x192x32_k5s1_hw32", crops, iters, 32);
+    bench_tile<32, 192, 32, 5, 1, 16, 32, true, 2>("irt_32x192x32_k5 16x32", crops, iters, 32);
+    bench_tile<32, 192, 32, 5, 1, 32, 16, true, 2>("irt_32x192x32_k5 32x16", crops, iters, 32);
+    bench_tile<32, 192, 32, 3, 1, 32, 16, true, 2>("irt_32x192x32_k3 32x16", crops, iters, 32);
+    bench_tile<32, 192, 32, 3, 1, 16, 32, true, 2>("irt_32x192x32_k3 16x32", crops, iters, 32);
+    bench_tile<32, 192, 32, 3, 1, 16, 16, true, 2>("irt_32x192x32_k3 16x16", crops, iters, 32);
+    bench_tile<32, 192, 64, 5, 2, 16, 8, true, 2>("irt_32x192x64_k5s2 16x8", crops, iters, 32);
+    bench_tile<32, 192, 64, 5, 2, 16, 16, true, 2>("irt_32x192x64_k5s2 16x16", crops, iters, 32);
+    bench_tile<24, 144, 32, 5, 2, 16, 16, true, 2>("irt_24x144x32_k5s2 16x16", crops, iters, 64);
+    bench_tile<24, 144, 32, 5, 2, 32, 8, true, 2>("irt_24x144x32_k5s2 32x8", crops, iters, 64);
+    bench_tile<24, 144, 32, 5, 2, 32, 16, true, 2>("irt_24x144x32_k5s2 32x16", crops, iters, 64);
+    bench_tile<16, 96, 24, 3, 2, 16, 16, true, 2>("irt_16x96x24_k3s2 16x16", crops, iters, 128);
+    bench_tile<16, 96, 24, 3, 2, 32, 8, true, 2>("irt_16x96x24_k3s2 32x8", crops, iters, 128);
+    bench_tile<16, 96, 24, 3, 2, 32, 16, true, 2>("irt_16x96x24_k3s2 32x16", crops, iters, 128);
+    bench_tile<32, 96, 32, 5, 1, 16, 16, true, 2>("irt_32x96x32_k5 16x16", crops, iters, 32);
+    bench_tile<32, 96, 32, 5, 1, 16, 32, true, 2>("irt_32x96x32_k5 16x32", crops, iters, 32);
+    bench_tile<32, 192, 64, 5, 2, 16, 16, true, 2>("irt_32x192x64_k5s2 16x16", crops, iters, 32);
     bench_sep<256, 256, 3>("sep16_256x256_k3", crops, iters);
     bench_sep<320, 256, 3>("sep16_320x256_k3", crops, iters);
     return 0;
