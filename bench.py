@@ -23,6 +23,7 @@ Prints ONE JSON line (rank 0).  Extra objects:
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -100,6 +101,23 @@ def pmc_traffic(op_name: str):
         return None
 
 
+@contextlib.contextmanager
+def _c_stdout_to_stderr():
+    import ctypes
+    libc = ctypes.CDLL(None)
+    sys.stdout.flush()
+    libc.fflush(None)
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        libc.fflush(None)
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,9 +144,19 @@ def main() -> None:
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback on the product path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
-    if world > 1:
+    # FEAR_BENCH_FORCE_DIST=1 takes the distributed code path (RCCL process group, barriers, all-gather) with a single rank
+    # too: the only way to exercise it on a one-GPU box
+    use_dist = world > 1 or os.environ.get("FEAR_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        # RCCL prints a version banner through C stdio on STDOUT when the first communicator comes up; stdout must carry
+        # exactly one JSON line, so fd 1 points at stderr while the communicator is created (and libc's buffer is flushed
+        # there before fd 1 is restored)
+        with _c_stdout_to_stderr():
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.barrier()
+            torch.cuda.synchronize()
 
     from feartracker_amd import FEARNetHIP, DEFAULT_WEIGHTS
     from feartracker_amd.sharding import gather_maps
@@ -145,15 +173,15 @@ def main() -> None:
     bbox_v, cls_v = packed[:, :4], packed[:, 4:]   # views are not contiguous per tensor -> use own outputs
     bbox = torch.empty((B, 4, 16, 16), dtype=torch.float32, device=dev)
     cls = torch.empty((B, 1, 16, 16), dtype=torch.float32, device=dev)
-    gathered = torch.empty((world * B, 5, 16, 16), dtype=torch.float32, device=dev) if world > 1 else None
+    gathered = torch.empty((world * B, 5, 16, 16), dtype=torch.float32, device=dev) if use_dist else None
 
     def step():
         net.track_maps(search, tmpl_feats, out=(bbox, cls))
-        if world > 1:
+        if use_dist:
             gather_maps(bbox, cls, packed, gathered)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -204,7 +232,7 @@ def main() -> None:
     dom_ms = sum(reads[i][0] for i in dom_ops)
     dom_cnt = sum(reads[i][1] for i in dom_ops)
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -222,7 +250,7 @@ def main() -> None:
             step()
         barrier()
         elapsed_other = time.perf_counter() - t1
-    if world > 1 and elapsed_other is not None:
+    if use_dist and elapsed_other is not None:
         t = torch.tensor([elapsed_other], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed_other = float(t.item())
@@ -283,7 +311,7 @@ def main() -> None:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(search_u8, tmpl_u8, DEFAULT_WEIGHTS)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -82,3 +82,31 @@ def test_shard_range_covers_everything():
                 assert a[1] == b[0]
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.gpu
+def test_rccl_gather_of_hip_maps_single_rank():
+    """The real collective on the real device path: RCCL ("nccl" backend) all-gather of the maps the HIP engine wrote,
+    world_size 1 (the GPU box has one GPU; world_size 2 runs on gloo above).  Exercises process-group init with a device
+    id, the packed (B,5,16,16) layout and stream ordering between the engine's launches and the collective."""
+    from conftest import WEIGHTS
+    from feartracker_amd import FEARNetHIP
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        net = FEARNetHIP(WEIGHTS, device=0, max_batch=8)
+        g = torch.Generator().manual_seed(3)
+        search = torch.randn(5, 3, 256, 256, generator=g).to(dev)
+        z = net.get_features(torch.randn(5, 3, 128, 128, generator=g).to(dev))
+        bbox, cls = net.track_maps(search, z)
+        full = gather_maps(bbox, cls)
+        dist.barrier()
+        torch.cuda.synchronize()
+        assert full.shape == (5, 5, 16, 16)
+        assert torch.equal(full[:, :4], bbox) and torch.equal(full[:, 4:], cls)
+        b2, c2 = track_sharded(net, search, z)
+        assert torch.equal(b2, bbox) and torch.equal(c2, cls)
+    finally:
+        dist.destroy_process_group()
