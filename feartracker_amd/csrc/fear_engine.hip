@@ -99,6 +99,9 @@ struct Op {
     int relu = 0, act = 0;
     int out_external = 0;     // 1: features NCHW, 2: bbox, 3: cls
     int tmpl_cls = 0;         // OP_CORR / corr_fused: use the classification template
+    int pred_fused = 0;       // OP_IR16 (sep16): the prediction SepConv that consumes this layer runs in its epilogue
+    float* pred_packed = nullptr;
+    int pred_conv_p = -1;
     int corr_fused = 0;       // OP_IR16 (sep16): the pixel-wise correlation runs in this kernel's epilogue
     int conv_e = -1, conv_d = -1, conv_p = -1;  // OP_IR16: expand (or -1) / depthwise / project convs
     int relu_dw = 0;
@@ -331,6 +334,10 @@ const Fused16 kFused16H[] = {
     FUSED16H(256, 256, 16, 3, 0),
 };
 static_assert(sizeof(kFused16H) == sizeof(kFused16), "the two tables must list the same shapes in the same order");
+
+// last tower SepConv + the prediction SepConv in one kernel (fp32 mode)
+auto* const kSep16PredKernel = sep16_kernel<256, 256, 3, false, true>;
+constexpr int kSep16PredLds = Sep16Geom<256, 256, 3>::LDS_BYTES;
 
 // encode SepConv + pixel-wise correlation in one kernel (fp32 mode)
 constexpr int kCorrC = 256, kCorrTz = 64;
@@ -822,6 +829,24 @@ int build_plan(fear_handle* h, int hw, bool with_head, Plan** out) {
                 x = y;
             }
             if (h->convs[pred->conv[1]].cout != (is_cls ? 1 : 4)) return FEAR_ERR_FORMAT;
+            // the prediction head rides in the epilogue of the last tower SepConv (its output never reaches HBM)
+            if (h->fuse && !h->math && !ops.empty() && ops.back().type == OP_IR16 && ops.back().out_buf == x.buf &&
+                ops.back().C == 256 && ops.back().N == 256 && !ops.back().corr_fused && ops.back().res_buf < 0 &&
+                h->convs[ops.back().conv_d].k == 3 && h->convs[pred->conv[0]].k == 3 && h->convs[pred->conv[0]].cout == 256 &&
+                h->convs[pred->conv[0]].stride == 1 && h->convs[pred->conv[1]].has_bias && !h->convs[pred->conv[0]].relu) {
+                Op& top = ops.back();
+                if (pack_fused16(h, -1, pred->conv[0], pred->conv[1], &top.pred_packed) == FEAR_OK) {
+                    const Conv& pc = h->convs[pred->conv[1]];
+                    top.pred_fused = 1;
+                    top.pred_conv_p = pred->conv[1];
+                    top.pred_cout = pc.cout; top.act = pred->act; top.out_external = is_cls ? 3 : 2;
+                    set_name(top, is_cls ? "sep16_cls_pred_%dx%dx%d" : "sep16_bbox_pred_%dx%dx%d", 256, 256, pc.cout);
+                    top.flops += 2.0 * 256 * (256.0 * 9 + 256.0 * pc.cout);
+                    top.bytes = 4.0 * 256 * (256 + pc.cout);
+                    pool.release(x.buf);
+                    return FEAR_OK;
+                }
+            }
             if (add_fused_pred(pred->conv[0], pred->conv[1], x, pred->act, is_cls ? 3 : 2)) {
                 pool.release(x.buf);
                 return FEAR_OK;
@@ -920,6 +945,8 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s) {
         for (const FusedTile& f : kFusedTileH)
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(f.kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, f.lds_bytes));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kSep16PredKernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kSep16PredLds));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kSep16CorrKernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kSep16CorrLds));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kChainXSKernel),
@@ -1008,7 +1035,11 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s) {
                 a.R = op.res_buf >= 0 ? buf(op.res_buf) : nullptr; a.ldr = op.res_ld;
                 a.Y = op.out_buf >= 0 ? buf(op.out_buf) : nullptr; a.ldy = op.out_ld;
                 a.relu_dw = op.relu_dw; a.relu_out = op.relu;
-                if (op.pred_cout > 0) {
+                if (op.pred_fused) {
+                    a.pred_cout = op.pred_cout; a.pred_act = op.act;
+                    a.P_Wpk = op.pred_packed; a.P_bp = h->convs[op.pred_conv_p].d_b;
+                    a.P_Y = op.out_external == 3 ? ext.cls_out : ext.bbox_out;
+                } else if (op.pred_cout > 0) {
                     a.pred_cout = op.pred_cout; a.pred_act = op.act;
                     a.Y = op.out_external == 3 ? ext.cls_out : ext.bbox_out;
                 }
@@ -1016,6 +1047,8 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s) {
                     a.Z = (op.tmpl_cls && ext.tmpl_cls) ? ext.tmpl_cls : ext.tmpl;
                     a.z_stride = (long)kCorrC * kCorrTz;
                     hipLaunchKernelGGL(kSep16CorrKernel, dim3(n), dim3(512), kSep16CorrLds, s, a);
+                } else if (op.pred_fused) {
+                    hipLaunchKernelGGL(kSep16PredKernel, dim3(n), dim3(512), kSep16PredLds, s, a);
                 } else {
                     hipLaunchKernelGGL(f.kernel, dim3(n), dim3(512), f.lds_bytes, s, a);
                 }

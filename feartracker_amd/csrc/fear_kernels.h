@@ -556,6 +556,12 @@ struct Ir2Args {
     // the pixel-wise correlation of the block's output with z is written to channels [COUT, COUT + 64) of Y
     const float* Z;
     long z_stride;
+    // sep16_kernel<..., PRED = true>: the prediction SepConv (dw KSxKS + 1x1 to pred_cout <= 4 channels [+ exp]) that consumes
+    // this layer's output runs in the epilogue; P_Wpk = its packed weights (COUT/16 chunks x [1 fragment | Wd | bd]),
+    // P_bp its bias, P_Y the caller's NCHW map.  The layer's own output is then not written at all.
+    const float* P_Wpk;
+    const float* P_bp;
+    float* P_Y;
 };
 
 template <int CIN, int CEXP, int COUT, int KS, bool EXPAND>
@@ -906,9 +912,13 @@ struct Sep16Geom {
 // corr[px][t] = sum_c y[px][c] * z[c][t] — the block's output fragments are the B operand as they stand, z (64 KiB,
 // fetched into LDS by an asynchronous copy at kernel start) supplies the A fragments; the 64 correlation channels go to
 // Y[.., COUT .. COUT+64), i.e. next to the features in the concat buffer the following SepConv reads.
-template <int CIN, int COUT, int KS, bool CORR = false>
+// PRED = true: the prediction head that follows a tower (SepConv to <= 4 channels) is computed in the epilogue, chunk by
+// chunk: the finished output fragments of 16 channels go to an LDS tile (never to HBM), the head's depthwise runs from it
+// and its one-tile projection accumulates over the COUT/16 chunks.
+template <int CIN, int COUT, int KS, bool CORR = false, bool PRED = false>
 __global__ __launch_bounds__(512) void sep16_kernel(Ir2Args a) {
     using G = Sep16Geom<CIN, COUT, KS, CORR>;
+    static_assert(!(CORR && PRED), "one epilogue at a time");
     constexpr int S = G::S, P = G::P, PW = G::PW, ES = G::ES, NCHUNK = G::NCHUNK, NTP = G::NTP;
     constexpr int WPF = G::WPF, WDF = G::WDF, CST = G::CST, EBUF = G::EBUF;
     constexpr int WP4 = WPF / 4, WD4 = WDF / 4, NRP = (WP4 + 511) / 512;
@@ -1041,6 +1051,73 @@ __global__ __launch_bounds__(512) void sep16_kernel(Ir2Args a) {
         if (!(FEAR_ABL & 1)) __syncthreads();
     }
 
+    if (PRED) {
+        constexpr int PCH = 256 + KS * KS * 16 + 16;          // packed floats per chunk of the head: 1 fragment | Wd | bd
+        static_assert(NTP * PCH <= 2 * WPF, "the head's weights are staged in the projection-weight area");
+        lds_copy_async<NTP * PCH>(a.P_Wpk, WP, wave, lane);   // WP / WD are free: the main loop ended with a barrier
+        f32x4 pacc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int c = 0; c < NTP; ++c) {         // fully unrolled: accp[..][c] must be a compile-time register reference
+            // this layer's output channels [16c, 16c+16) -> E[c & 1] (last read two iterations ago, one barrier in between)
+            float* E = Ebuf + (c & 1) * EBUF;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bp + c * 16 + lk * 4);
+            f32x4 v0 = accp[0][c] + bv, v1 = accp[1][c] + bv;
+            if (a.relu_out) {
+                v0.x = fmaxf(v0.x, 0.f); v0.y = fmaxf(v0.y, 0.f); v0.z = fmaxf(v0.z, 0.f); v0.w = fmaxf(v0.w, 0.f);
+                v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); v1.z = fmaxf(v1.z, 0.f); v1.w = fmaxf(v1.w, 0.f);
+            }
+            *reinterpret_cast<f32x4*>(E + ((y0 + P) * PW + li + P) * ES + lk * 4) = v0;
+            *reinterpret_cast<f32x4*>(E + ((y0 + 1 + P) * PW + li + P) * ES + lk * 4) = v1;
+            __syncthreads();                                   // (first pass: also completes the weight copy)
+            const float* wpk = WP + c * PCH;
+            const float* wd = wpk + 256 + lk * 4;
+            const float* e0 = E + (y0 * PW + li) * ES + lk * 4;
+            f32x4 n0 = *reinterpret_cast<const f32x4*>(wd + KS * KS * 16), n1 = n0, wprev = (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 ev[D], wv[D];
+#pragma unroll
+            for (int t = 0; t < D; ++t) {
+                const int kx = t / (KS + 1), iy = t % (KS + 1);
+                ev[t] = *reinterpret_cast<const f32x4*>(e0 + (iy * PW + kx) * ES);
+                if (iy < KS) wv[t] = *reinterpret_cast<const f32x4*>(wd + (iy * KS + kx) * 16);
+            }
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+                const int iy = t % (KS + 1);
+                const f32x4 e = ev[t % D], w = wv[t % D];
+                if (t + D < NS) {
+                    const int kx2 = (t + D) / (KS + 1), iy2 = (t + D) % (KS + 1);
+                    ev[t % D] = *reinterpret_cast<const f32x4*>(e0 + (iy2 * PW + kx2) * ES);
+                    if (iy2 < KS) wv[t % D] = *reinterpret_cast<const f32x4*>(wd + (iy2 * KS + kx2) * 16);
+                }
+                if (iy < KS) pk_fma4(n0, e, w);
+                if (iy >= 1) pk_fma4(n1, e, wprev);
+                wprev = w;
+            }
+            // (no activation between the head's depthwise and its 1x1: SepConv = dw -> pw, as in the towers)
+            const f32x4 wf = *reinterpret_cast<const f32x4*>(wpk + lane * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                pacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i], n0[i], pacc[0], 0, 0, 0);
+                pacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i], n1[i], pacc[1], 0, 0, 0);
+            }
+        }
+        if (lk == 0) {              // lanes lk == 0 hold channels 0..3 of their pixel
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int px = (y0 + mt) * S + li;
+                const float vals[4] = {pacc[mt].x, pacc[mt].y, pacc[mt].z, pacc[mt].w};
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    if (n < a.pred_cout) {
+                        float o = vals[n] + a.P_bp[n];
+                        if (a.pred_act == 2) o = expf(o);
+                        a.P_Y[(crop * a.pred_cout + n) * 256 + px] = o;
+                    }
+                }
+            }
+        }
+        return;
+    }
     if (a.pred_cout > 0) {          // prediction head: lanes lk == 0 hold channels 0..3 of their pixel
         if (lk == 0) {
 #pragma unroll
