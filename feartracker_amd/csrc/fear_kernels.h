@@ -1219,6 +1219,7 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
     float* const E = lds;               // [EBUF]
     float* const WS = lds + EBUF;       // [2][AP + BP]
 
+    const long long tk_start = (FEAR_ABL & 4096) ? wall_clock64() : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int tiles = t.tiles_x * t.tiles_y;
@@ -1338,10 +1339,14 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
 #pragma unroll
         for (int nt = 0; nt < NTP; ++nt) accp[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    const long long tk_begin = (FEAR_ABL & 4096) ? wall_clock64() : 0;   // kbench -DFEAR_ABL=4096: 10 ns ticks per region
+    long long tm[6] = {0, 0, 0, 0, 0, 0};
     for (int c = 0; c < ((FEAR_ABL & 256) ? 0 : NCHUNK); ++c) {
         const float* wa = WS + (c & 1) * CST;
         const float* wb = wa + AP;
+        const long long tk0 = (FEAR_ABL & 4096) ? wall_clock64() : 0;
         if (EXPAND && !(FEAR_ABL & 1)) __syncthreads();          // stage c&1 committed (first chunk: by store_w(0) above)
+        const long long tk1 = (FEAR_ABL & 4096) ? wall_clock64() : 0;
         // ---- phase A: E <- relu(expand) (or the raw activations)
         if (EXPAND) {
             f32x4 wf[KG > 0 ? KG : 1];
@@ -1382,7 +1387,9 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
         }
         // prefetch the next chunk's weights (and activations) while this chunk computes
         if (c + 1 < NCHUNK && !(FEAR_ABL & 2)) { load_w(c + 1); load_x(c + 1); }
+        const long long tk2 = (FEAR_ABL & 4096) ? wall_clock64() : 0;
         if (!(FEAR_ABL & 1)) __syncthreads();
+        const long long tk3 = (FEAR_ABL & 4096) ? wall_clock64() : 0;
         // ---- phase B: depthwise from E, weights from the LDS stage
         f32x4 d[MTC];
         {
@@ -1412,6 +1419,7 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
                 }
             }
         }
+        const long long tk4 = (FEAR_ABL & 4096) ? wall_clock64() : 0;
         // ---- phase C: projection
 #pragma unroll
         for (int nt = 0; nt < NTP; ++nt) {
@@ -1424,9 +1432,15 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
                     accp[r][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[q], d[r][q], accp[r][nt], 0, 0, 0);
                 }
         }
+        const long long tk5 = (FEAR_ABL & 4096) ? wall_clock64() : 0;
         if (c + 1 < NCHUNK && !(FEAR_ABL & 2)) store_w(c + 1);
         if ((!EXPAND || c + 1 == NCHUNK) && !(FEAR_ABL & 1)) __syncthreads();   // E is rewritten next chunk (EXPAND syncs at loop top)
+        if (FEAR_ABL & 4096) {
+            const long long tk6 = wall_clock64();
+            tm[0] += tk1 - tk0; tm[1] += tk2 - tk1; tm[2] += tk3 - tk2; tm[3] += tk4 - tk3; tm[4] += tk5 - tk4; tm[5] += tk6 - tk5;
+        }
     }
+    const long long tk_loop_end = (FEAR_ABL & 4096) ? wall_clock64() : 0;
 
 #pragma unroll
     for (int nt = 0; nt < NTP; ++nt) {
@@ -1443,6 +1457,12 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
             if (a.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             if (!(FEAR_ABL & 2048) || v.x == 1234.5f) *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = v;
         }
+    }
+    if ((FEAR_ABL & 4096) && a.P_Y && blockIdx.x == 1000 && lane == 0) {
+        float* dbg = a.P_Y + wave * 10;
+        for (int q = 0; q < 6; ++q) dbg[q] = (float)tm[q];
+        dbg[6] = (float)(tk_begin - tk_start);
+        dbg[7] = (float)(wall_clock64() - tk_loop_end);
     }
 }
 

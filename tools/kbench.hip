@@ -67,6 +67,10 @@ static void bench_tile(const char* tag, int crops, int iters, int hw) {
     float* y;
     CK(hipMalloc(&y, (size_t)crops * ho * ho * COUT * sizeof(float)));
     a.Y = y; a.relu_dw = 1; a.relu_out = 0;
+    float* dbg;
+    CK(hipMalloc(&dbg, 80 * sizeof(float)));
+    CK(hipMemset(dbg, 0, 80 * sizeof(float)));
+    a.P_Y = dbg;
     t.H = hw; t.W = hw; t.tiles_x = ho / TW; t.tiles_y = ho / TH;
     auto k = ir_tile_v2_kernel<CIN, CEXP, COUT, KS, ST, TW, TH, EXPAND, MINW>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
@@ -83,6 +87,14 @@ static void bench_tile(const char* tag, int crops, int iters, int hw) {
     CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = 1e3 * ms / iters;
     printf("%-24s fp32-tile  %8.1f us  %6.1f TF/s  (LDS %d B)\n", tag, us, flops / us * 1e-6, G::LDS_BYTES);
+    if (FEAR_ABL & 4096) {
+        float h[80];
+        CK(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+        for (int w = 0; w < 8; w += 4)
+            printf("   wave %d (block 1000): prologue %.2f | top barrier %.2f | phase A %.2f | mid barrier %.2f | phase B %.2f | phase C %.2f | end %.2f | epilogue %.2f us\n",
+                   w, h[w * 10 + 6] * 0.01, h[w * 10] * 0.01, h[w * 10 + 1] * 0.01, h[w * 10 + 2] * 0.01, h[w * 10 + 3] * 0.01,
+                   h[w * 10 + 4] * 0.01, h[w * 10 + 5] * 0.01, h[w * 10 + 7] * 0.01);
+    }
 }
 
 static void bench_stem(int crops, int iters) {
