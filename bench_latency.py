@@ -73,20 +73,26 @@ def main():
     hip = FEARTracker(net, cuda_id=0, **DEFAULT_TRACKING_CONFIG)
     hip_ms, hip_boxes = run(hip, frames, init_box, args.repeats, torch.cuda.synchronize)
 
-    # device crop path (fear_crop_normalize): whole update() timed, frame uploaded per call
-    dev = FEARTracker(net, cuda_id=0, device_crop=True, **DEFAULT_TRACKING_CONFIG)
-    dev_boxes, dev_t, dev_n = [], 0.0, 0
-    for rep in range(args.repeats):
-        dev.initialize(frames[0], np.array(init_box))
-        for f in frames[1:]:
-            t0 = time.perf_counter()
-            b = dev.update(f)["bbox"]
-            torch.cuda.synchronize()
-            if rep > 0 or args.repeats == 1:
-                dev_t += time.perf_counter() - t0
-                dev_n += 1
-            if rep == 0:
-                dev_boxes.append(np.array(b))
+    # device crop path (fear_crop_normalize) and device crop + device post-processing (fear_decode): whole update() timed,
+    # frame uploaded per call
+    def run_device(**opts):
+        trk = FEARTracker(net, cuda_id=0, **dict(DEFAULT_TRACKING_CONFIG, **opts))
+        boxes, t_sum, n_sum = [], 0.0, 0
+        for rep in range(args.repeats):
+            trk.initialize(frames[0], np.array(init_box))
+            for f in frames[1:]:
+                t0 = time.perf_counter()
+                b = trk.update(f)["bbox"]
+                torch.cuda.synchronize()
+                if rep > 0 or args.repeats == 1:
+                    t_sum += time.perf_counter() - t0
+                    n_sum += 1
+                if rep == 0:
+                    boxes.append(np.array(b))
+        return boxes, t_sum, n_sum
+
+    dev_boxes, dev_t, dev_n = run_device(device_crop=True)
+    dpp_boxes, dpp_t, dpp_n = run_device(device_crop=True, device_postprocess=True)
 
     from oracle.fear_oracle import OracleNet  # CPU baseline leg only
     torch.set_num_threads(min(16, os.cpu_count() or 1))
@@ -100,6 +106,8 @@ def main():
         "split_ms": hip_ms, "cpu_oracle_split_ms": cpu_ms, "cpu_oracle_ms_per_frame": sum(cpu_ms.values()),
         "device_crop_ms_per_frame": 1e3 * dev_t / max(dev_n, 1),
         "device_crop_boxes_identical": bool(np.array_equal(np.stack(dev_boxes), hip_boxes)),
+        "device_crop_and_postprocess_ms_per_frame": 1e3 * dpp_t / max(dpp_n, 1),
+        "device_crop_and_postprocess_boxes_identical": bool(np.array_equal(np.stack(dpp_boxes), hip_boxes)),
         "cpu_threads": torch.get_num_threads(), "boxes_identical_to_cpu_oracle": bool(np.array_equal(hip_boxes, cpu_boxes)),
         "data": os.path.basename(args.video), "math": args.math}))
 

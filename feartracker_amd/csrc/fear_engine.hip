@@ -1258,6 +1258,21 @@ int fear_track(fear_handle* h, const float* search, const float* tmpl, const flo
     return FEAR_OK;
 }
 
+int fear_decode_smooth(fear_handle* h, const float* cls, const float* bbox, int n, int score_size, int total_stride,
+                       int instance_size, const double* prev_size, const double* window, double penalty_k,
+                       double window_influence, double lr, int32_t* rc, double* xywh, float* score, void* stream) {
+    if (!h) return FEAR_ERR_NULL;
+    if (n < 0 || score_size < 1 || score_size > 64) return FEAR_ERR_SHAPE;
+    if (n == 0) return FEAR_OK;
+    if (!cls || !bbox || !prev_size || !window || !rc || !xywh || !score) return FEAR_ERR_NULL;
+    HIP_TRY(h, hipSetDevice(h->device));
+    DecodeSmoothArgs a{cls, bbox, prev_size, window, rc, xywh, score, n, score_size, total_stride, instance_size,
+                       penalty_k, window_influence, lr};
+    hipLaunchKernelGGL(decode_smooth_kernel, dim3(n), dim3(64), 0, static_cast<hipStream_t>(stream), a);
+    HIP_TRY(h, hipGetLastError());
+    return FEAR_OK;
+}
+
 int fear_decode(fear_handle* h, const float* cls, const float* bbox, int n, int score_size, int total_stride,
                 int instance_size, int32_t* rc, double* xywh, float* score, void* stream) {
     if (!h) return FEAR_ERR_NULL;

@@ -12,6 +12,7 @@
 //   dw_conv_kernel     depthwise kxk (k=3/5, s=1/2) + bias/ReLU         (IR depthwise, SepConv.depthwise blocks.py:57-66)
 //   pw_small_kernel    1x1 conv with Cout<=4 (+exp), NCHW out           (bbox_pred / cls_pred, blocks.py:167-168,186-192)
 //   decode_kernel      sigmoid + arg-max + ltrb->xywh                   (FEARBoxCoder.decode, dataset/box_coder.py:75-107)
+//   decode_smooth_kernel  the smooth=True post-processing              (Tracker._postprocess, base_tracker.py:149-205)
 //   normalize_kernel   uint8 HWC -> normalised fp32 NCHW                (Tracker._preprocess_image, base_tracker.py:97-103)
 #pragma once
 #include <type_traits>
@@ -422,6 +423,83 @@ __global__ __launch_bounds__(64) void decode_kernel(DecodeArgs a) {
         a.xywh[crop * 4 + 2] = x1 - x0;
         a.xywh[crop * 4 + 3] = y1 - y0;
         a.score[crop] = best;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tracker._postprocess with tracking_config["smooth"] (base_tracker.py:149-205): scale / aspect-ratio change penalty
+// against the previous size, cosine-window blend, first-maximum arg-max of the blended score, box decode at that cell and
+// the penalty*score-weighted size smoothing.  float64 where the reference is float64 (grids, sizes, penalty, blended score
+// — the box coder's grids are float64 tensors, so everything they touch is promoted), fp32 where it is fp32 (sigmoid of the
+// logits; the three-factor learning rate is rounded to fp32 after each product like the reference's 0-dim fp32 tensor).
+// One wave per crop.
+struct DecodeSmoothArgs {
+    const float* cls;        // [n][S*S] logits
+    const float* bbox;       // [n][4][S*S] l, t, r, b
+    const double* prev_size; // [n][2] previous (w, h) in search-crop pixels
+    const double* window;    // [S*S] cosine window
+    int32_t* rc;             // [n][2]
+    double* xywh;            // [n][4]  x, y, smoothed w, smoothed h
+    float* score;            // [n]     sigmoid(cls) at the arg-max cell
+    int n, S, stride, instance;
+    double penalty_k, window_influence, lr;
+};
+
+__device__ __forceinline__ double smooth_penalty(double w, double h, double pw, double ph, double penalty_k) {
+    auto sq = [](double a, double b) { const double pad = (a + b) * 0.5; return sqrt((a + pad) * (b + pad)); };
+    auto lim = [](double r) { return fmax(r, 1.0 / r); };
+    const double s_c = lim(sq(w, h) / sq(pw, ph));
+    const double r_c = lim((pw / ph) / (w / h));
+    return exp(-(r_c * s_c - 1.0) * penalty_k);
+}
+
+__global__ __launch_bounds__(64) void decode_smooth_kernel(DecodeSmoothArgs a) {
+    const int crop = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int cells = a.S * a.S;
+    const float* c = a.cls + (long)crop * cells;
+    const float* bb = a.bbox + (long)crop * 4 * cells;
+    const double pw = a.prev_size[crop * 2], ph = a.prev_size[crop * 2 + 1];
+    double best = -1.0;
+    int best_i = 0x7fffffff;
+    for (int i = lane; i < cells; i += 64) {
+        const int r = i / a.S, col = i % a.S;
+        const double gx = (double)(col - a.S / 2) * a.stride + a.instance / 2;
+        const double gy = (double)(r - a.S / 2) * a.stride + a.instance / 2;
+        const double x0 = gx - (double)bb[i], y0 = gy - (double)bb[cells + i];
+        const double x1 = gx + (double)bb[2 * cells + i], y1 = gy + (double)bb[3 * cells + i];
+        const double pen = smooth_penalty(x1 - x0, y1 - y0, pw, ph, a.penalty_k);
+        const float sg = 1.f / (1.f + expf(-c[i]));
+        const double ps = pen * (double)sg * (1.0 - a.window_influence) + a.window[i] * a.window_influence;
+        if (ps > best) { best = ps; best_i = i; }       // strictly greater keeps the first index per lane
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double ob = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(best_i, off, 64);
+        if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
+    }
+    if (lane == 0) {
+        const int r = best_i / a.S, col = best_i % a.S;
+        const double gx = (double)(col - a.S / 2) * a.stride + a.instance / 2;
+        const double gy = (double)(r - a.S / 2) * a.stride + a.instance / 2;
+        const double x0 = gx - (double)bb[best_i], y0 = gy - (double)bb[cells + best_i];
+        const double x1 = gx + (double)bb[2 * cells + best_i], y1 = gy + (double)bb[3 * cells + best_i];
+        const double w = x1 - x0, h = y1 - y0;
+        const double pen = smooth_penalty(w, h, pw, ph, a.penalty_k);
+        const float sg = 1.f / (1.f + expf(-c[best_i]));
+        // lr = fp32(fp32(penalty) * fp32(score)) * fp32(lr), each product rounded to fp32 (base_tracker.py:159)
+        const float lr32 = ((float)pen * sg) * (float)a.lr;
+        const double lr = (double)lr32;
+        // _smooth_size (base_tracker.py:126-139), evaluated as written there
+        const double sw = w * lr, sh = h * lr, qw = pw * (1.0 - lr), qh = ph * (1.0 - lr);
+        a.rc[crop * 2] = r;
+        a.rc[crop * 2 + 1] = col;
+        a.xywh[crop * 4 + 0] = x0;
+        a.xywh[crop * 4 + 1] = y0;
+        a.xywh[crop * 4 + 2] = qw + lr * (sw + qw);
+        a.xywh[crop * 4 + 3] = qh + lr * (sh + qh);
+        a.score[crop] = sg;
     }
 }
 

@@ -57,6 +57,9 @@ def load_library() -> ctypes.CDLL:
     lib.fear_track.restype = i32
     lib.fear_decode.argtypes = [vp, f32p, f32p, i32, i32, i32, i32, vp, vp, f32p, vp]
     lib.fear_decode.restype = i32
+    f64 = ctypes.c_double
+    lib.fear_decode_smooth.argtypes = [vp, f32p, f32p, i32, i32, i32, i32, vp, vp, f64, f64, f64, vp, vp, f32p, vp]
+    lib.fear_decode_smooth.restype = i32
     lib.fear_normalize_u8.argtypes = [vp, vp, i32, i32, f32p, vp]
     lib.fear_normalize_u8.restype = i32
     lib.fear_crop_normalize.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, f32p, vp]
@@ -86,7 +89,7 @@ def load_library() -> ctypes.CDLL:
 
 
 EXPORTED_SYMBOLS = (
-    "fear_create", "fear_destroy", "fear_features", "fear_track", "fear_decode", "fear_normalize_u8",
+    "fear_create", "fear_destroy", "fear_features", "fear_track", "fear_decode", "fear_decode_smooth", "fear_normalize_u8",
     "fear_crop_normalize",
     "fear_set_option", "fear_get_option", "fear_plan_size", "fear_plan_op", "fear_profile_read",
     "fear_profile_reset", "fear_workspace_bytes", "fear_strerror", "fear_last_hip_error", "fear_version",
@@ -245,6 +248,29 @@ class FEARNetHIP:
             self._check(self._lib.fear_decode(self._h, cls.data_ptr(), bbox.data_ptr(), n, score_size, total_stride,
                                               instance_size, rc.data_ptr(), xywh.data_ptr(), score.data_ptr(),
                                               self._stream()))
+        return rc, xywh, score
+
+    @torch.no_grad()
+    def decode_smooth(self, cls: torch.Tensor, bbox: torch.Tensor, prev_size, window, penalty_k: float,
+                      window_influence: float, lr: float, score_size: int = 16, total_stride: int = 16,
+                      instance_size: int = 256):
+        """Device `smooth=True` post-processing (base_tracker.py:149-205), batched: penalty against `prev_size`
+        (N,2), window blend, arg-max, decode, size smoothing.  Returns (rc int32 (N,2), xywh float64 (N,4), score (N,))."""
+        cls = self._prep(cls, "cls")
+        bbox = self._prep(bbox, "bbox")
+        n = cls.shape[0]
+        prev = torch.as_tensor(prev_size, dtype=torch.float64).reshape(-1, 2).to(self.device).contiguous()
+        win = torch.as_tensor(window, dtype=torch.float64).reshape(-1).to(self.device).contiguous()
+        if prev.shape[0] != n or win.numel() != score_size * score_size:
+            raise ValueError("prev_size must be (N,2) and window (score_size, score_size)")
+        rc = torch.empty((n, 2), dtype=torch.int32, device=self.device)
+        xywh = torch.empty((n, 4), dtype=torch.float64, device=self.device)
+        score = torch.empty((n,), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self._lib.fear_decode_smooth(self._h, cls.data_ptr(), bbox.data_ptr(), n, score_size, total_stride,
+                                                     instance_size, prev.data_ptr(), win.data_ptr(), float(penalty_k),
+                                                     float(window_influence), float(lr), rc.data_ptr(), xywh.data_ptr(),
+                                                     score.data_ptr(), self._stream()))
         return rc, xywh, score
 
     @torch.no_grad()

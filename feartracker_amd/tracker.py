@@ -244,6 +244,19 @@ class FEARTracker(Tracker):
         return self._postprocess(track_result=self.net.track(search, self._template_features))
 
     def _postprocess(self, track_result: Dict[str, torch.Tensor]):
+        cfg = self.tracking_config
+        if cfg.get("device_postprocess", False) and hasattr(self.net, "decode_smooth"):
+            # whole post-processing in one device kernel (fear_decode / fear_decode_smooth), one 40-byte D2H; identical
+            # boxes to the host path below (tests/test_gpu_parity.py); not a key of the reference config
+            cls_map, reg_map = track_result[TARGET_CLASSIFICATION_KEY], track_result[TARGET_REGRESSION_LABEL_KEY]
+            if cfg.get("smooth", False):
+                _, xywh, score = self.net.decode_smooth(
+                    cls_map, reg_map, np.asarray(self.tracking_state.prev_size, dtype=np.float64)[None], self.window,
+                    cfg["penalty_k"], cfg["window_influence"], cfg["lr"], cfg["score_size"], cfg["total_stride"],
+                    cfg["instance_size"])
+            else:
+                _, xywh, score = self.net.decode(cls_map, reg_map, cfg["score_size"], cfg["total_stride"], cfg["instance_size"])
+            return xywh[0].cpu().numpy(), np.float32(score[0].item())
         reg = track_result[TARGET_REGRESSION_LABEL_KEY].detach()
         cls_score = track_result[TARGET_CLASSIFICATION_KEY].detach().float().sigmoid()
         score_map, penalty = self._confidence_postprocess(cls_score=cls_score, regression_map=reg.float())

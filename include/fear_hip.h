@@ -70,6 +70,16 @@ int fear_track(fear_handle* h, const float* search, const float* tmpl, const flo
 int fear_decode(fear_handle* h, const float* cls, const float* bbox, int n, int score_size, int total_stride,
                 int instance_size, int32_t* rc, double* xywh, float* score, void* stream);
 
+/* Tracker._postprocess with tracking_config["smooth"] = True (base_tracker.py:149-205: _confidence_postprocess,
+ * box_coder.decode on the blended score, _postprocess_bbox, _smooth_size) on device, batched.
+ *   prev_size : (n, 2) float64  previous box size in search-crop pixels (TrackingState.prev_size)
+ *   window    : (score_size^2) float64  the tracker's window (np.hanning outer product for "cosine")
+ *   penalty_k, window_influence, lr : the tracking_config values (siam_tracker.yaml)
+ *   rc / xywh / score as fear_decode; xywh[2:4] is the smoothed size                             */
+int fear_decode_smooth(fear_handle* h, const float* cls, const float* bbox, int n, int score_size, int total_stride,
+                       int instance_size, const double* prev_size, const double* window, double penalty_k,
+                       double window_influence, double lr, int32_t* rc, double* xywh, float* score, void* stream);
+
 /* Tracker._preprocess_image (base_tracker.py:97-103) on device: uint8 HWC RGB crops ->
  * normalised fp32 NCHW, (px - 255*mean) * (1/(255*std)).
  *   u8  : (n, hw, hw, 3) uint8     out : (n, 3, hw, hw) fp32                                    */

@@ -294,3 +294,51 @@ def test_chain_kernel_matches_per_block_kernels(hip_net):
     b0, c0 = per_block.track_maps(x, z)
     b1, c1 = hip_net.track_maps(x, z)
     assert rel_err(b1, b0) < 1e-5 and rel_err(c1, c0) < 1e-5
+
+
+def test_device_smooth_postprocess_matches_reference_fixture_and_host(hip_net, golden_dir):
+    """fear_decode_smooth vs (a) the reference's own smooth=True result (tests/golden/postprocess.npz, generated by
+    importing the reference tracker) and (b) the host restatement on a seeded batch with per-crop previous sizes."""
+    from feartracker_amd import DEFAULT_TRACKING_CONFIG, FEARTracker
+    from feartracker_amd.constants import TARGET_CLASSIFICATION_KEY, TARGET_REGRESSION_LABEL_KEY
+    cfg = dict(DEFAULT_TRACKING_CONFIG)
+    d = np.load(f"{golden_dir}/postprocess.npz")
+    window = np.outer(np.hanning(16), np.hanning(16))
+    rc, xywh, score = hip_net.decode_smooth(torch.from_numpy(d["cls"]).cuda(), torch.from_numpy(d["reg"]).cuda(),
+                                            np.array([[51.2, 51.2]]), window, cfg["penalty_k"], cfg["window_influence"], cfg["lr"])
+    np.testing.assert_allclose(xywh.cpu().numpy()[0], d["bbox_smooth1"], rtol=1e-9, atol=1e-9)
+    assert abs(float(score[0]) - float(d["score_smooth1"])) < 1e-6
+    assert tuple(rc.cpu().numpy()[0]) == tuple(int(v) for v in np.unravel_index(np.argmax(d["pscore"]), (16, 16)))
+
+    class _NoNet:
+        pass
+
+    g = torch.Generator().manual_seed(77)
+    n = 9
+    cls = torch.randn(n, 1, 16, 16, generator=g) * 2.0
+    reg = torch.rand(n, 4, 16, 16, generator=g) * 70.0 + 5.0
+    prev = (torch.rand(n, 2, generator=g) * 80.0 + 20.0).double().numpy()
+    rc, xywh, score = hip_net.decode_smooth(cls.cuda(), reg.cuda(), prev, window, cfg["penalty_k"], cfg["window_influence"], cfg["lr"])
+    trk = FEARTracker(_NoNet(), cuda_id="cpu", **dict(cfg, smooth=True))
+    for i in range(n):
+        trk.tracking_state.prev_size = prev[i].copy()
+        bbox_h, score_h = trk._postprocess({TARGET_CLASSIFICATION_KEY: cls[i:i + 1].clone(),
+                                            TARGET_REGRESSION_LABEL_KEY: reg[i:i + 1].clone()})
+        np.testing.assert_allclose(xywh.cpu().numpy()[i], bbox_h, rtol=1e-9, atol=1e-9)
+        assert abs(float(score[i]) - float(score_h)) < 1e-6
+
+
+@pytest.mark.parametrize("smooth", [False, True])
+def test_tracker_device_postprocess_clip(hip_net, golden_dir, smooth):
+    """`device_postprocess=True` (fear_decode / fear_decode_smooth) gives the same boxes as the host post-processing on
+    every frame of the synthetic clip, with and without the smooth=True branch."""
+    from feartracker_amd import DEFAULT_TRACKING_CONFIG, FEARTracker
+    d = np.load(f"{golden_dir}/clip_synth.npz")
+    frames, init = d["frames"], d["init_bbox"]
+    boxes = {}
+    for dev_pp in (False, True):
+        trk = FEARTracker(hip_net, cuda_id=0, **dict(DEFAULT_TRACKING_CONFIG, smooth=smooth, device_postprocess=dev_pp))
+        trk.initialize(frames[0], init.copy())
+        boxes[dev_pp] = [trk.update(f)["bbox"] for f in frames[1:]]
+    for a, b in zip(boxes[False], boxes[True]):
+        assert list(a) == list(b)
