@@ -143,10 +143,10 @@ def test_tracker_clip_through_drop_in_api(hip_net, golden_dir):
     assert abs(float(score) - float(d["scores"][0])) < 1e-4
 
 
-def test_full_size_batch_properties(hip_net):
-    """BASELINE.json configs[1] size (B=256): size-independent properties instead of an oracle run —
+def test_full_size_batch_properties(hip_net, oracle_net):
+    """BASELINE.json configs[1] size (B=256): size-independent properties instead of a full oracle run —
     batch invariance (crop i alone == crop i inside the batch, bit for bit), permutation equivariance,
-    finite and strictly positive ltrb distances."""
+    finite and strictly positive ltrb distances — plus the oracle itself on a sample of the batch."""
     from feartracker_amd import FEARNetHIP
     from conftest import WEIGHTS
     net = FEARNetHIP(WEIGHTS, device=0, max_batch=256)
@@ -159,6 +159,10 @@ def test_full_size_batch_properties(hip_net):
     for i in (0, 17, 255):
         bi, ci = net.track_maps(x[i:i + 1], z[i:i + 1])
         assert torch.equal(bi[0], bbox[i]) and torch.equal(ci[0], cls[i])
+    sample = [3, 64, 129, 200, 254]
+    ref = oracle_net.track(x[sample].cpu(), z[sample].cpu())
+    assert rel_err(bbox[sample], ref["TARGET_REGRESSION_LABEL_KEY"]) < REL
+    assert rel_err(cls[sample], ref["TARGET_CLASSIFICATION_KEY"]) < REL
     perm = torch.randperm(256, generator=g).cuda()
     bp, cp = net.track_maps(x[perm].contiguous(), z[perm].contiguous())
     assert torch.equal(bp, bbox[perm]) and torch.equal(cp, cls[perm])

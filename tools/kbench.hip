@@ -163,6 +163,11 @@ int main(int argc, char** argv) {
     bench_stem(crops, iters);
     bench_tile<16, 96, 24, 3, 2, 16, 8, true, 4>("irt_16x96x24_k3s2_hw128", crops, iters, 128);
     bench_tile<24, 144, 32, 5, 2, 16, 8, true, 4>("irt_24x144x32_k5s2_hw64", crops, iters, 64);
+    bench_tile<24, 32, 24, 3, 1, 16, 16, false, 4>("irt_24x24x24_k3 e1 16x16", crops, iters, 64);
+    bench_tile<24, 32, 24, 3, 1, 32, 16, false, 4>("irt_24x24x24_k3 e1 32x16", crops, iters, 64);
+    bench_tile<24, 32, 24, 3, 1, 16, 32, false, 4>("irt_24x24x24_k3 e1 16x32", crops, iters, 64);
+    bench_tile<24, 32, 24, 3, 1, 32, 32, false, 4>("irt_24x24x24_k3 e1 32x32", crops, iters, 64);
+    bench_tile<24, 32, 24, 3, 1, 16, 8, false, 4>("irt_24x24x24_k3 e1 16x8", crops, iters, 64);
     bench_tile<32, 192, 32, 5, 1, 16, 16, true, 2>("irt_32x192x32_k5s1_hw32", crops, iters, 32);
     bench_tile<32, 192, 32, 5, 1, 16, 32, true, 2>("irt_32x192x32_k5 16x32", crops, iters, 32);
     bench_tile<32, 192, 32, 5, 1, 32, 16, true, 2>("irt_32x192x32_k5 32x16", crops, iters, 32);
