@@ -346,3 +346,21 @@ def test_tracker_device_postprocess_clip(hip_net, golden_dir, smooth):
         boxes[dev_pp] = [trk.update(f)["bbox"] for f in frames[1:]]
     for a, b in zip(boxes[False], boxes[True]):
         assert list(a) == list(b)
+
+
+def test_repeated_launches_are_bit_identical():
+    """Race detector: the same B=256 batch through the whole plan 40 times (both arithmetic modes) must give bit-identical
+    maps every time — the fused kernels hand data between waves through LDS tiles, barriers and asynchronous copies."""
+    from feartracker_amd import FEARNetHIP
+    from conftest import WEIGHTS
+    net = FEARNetHIP(WEIGHTS, device=0, max_batch=256)
+    g = torch.Generator().manual_seed(2024)
+    x = norm_u8(torch.randint(0, 256, (256, 3, 256, 256), dtype=torch.uint8, generator=g)).cuda()
+    z = net.get_features(norm_u8(torch.randint(0, 256, (256, 3, 128, 128), dtype=torch.uint8, generator=g)).cuda())
+    for mode in (0, 1):
+        net.set_math(mode)
+        b0, c0 = net.track_maps(x, z)
+        b0, c0 = b0.clone(), c0.clone()
+        for _ in range(40):
+            b, c = net.track_maps(x, z)
+            assert torch.equal(b, b0) and torch.equal(c, c0)
