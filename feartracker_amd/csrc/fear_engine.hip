@@ -102,6 +102,7 @@ struct Op {
     int pred_fused = 0;       // OP_IR16 (sep16): the prediction SepConv that consumes this layer runs in its epilogue
     float* pred_packed = nullptr;
     int pred_conv_p = -1;
+    int lane = 0;             // 1: bbox branch of the head, may run on the handle's second stream (small batches)
     int corr_fused = 0;       // OP_IR16 (sep16): the pixel-wise correlation runs in this kernel's epilogue
     int conv_e = -1, conv_d = -1, conv_p = -1;  // OP_IR16: expand (or -1) / depthwise / project convs
     int relu_dw = 0;
@@ -127,6 +128,7 @@ struct Plan {
     int hw = 0;
     bool with_head = false;
     std::vector<Op> ops;
+    int head_first = -1;             // index of the first head op when the two branches were planned on disjoint buffers
     int n_bufs = 0;
     size_t buf_floats_per_crop = 0;  // every pool buffer has this many floats per crop
 };
@@ -152,6 +154,8 @@ struct fear_handle {
     size_t workspace_floats = 0;
     std::vector<float*> weight_allocs;
     std::vector<hipEvent_t> event_pool;   // recycled profiling events (creation is slow enough to perturb timing)
+    hipStream_t branch_stream = nullptr;  // second stream for the bbox branch of the head at small batch sizes
+    hipEvent_t branch_fork = nullptr, branch_join = nullptr;
 };
 
 namespace {
@@ -339,6 +343,8 @@ static_assert(sizeof(kFused16H) == sizeof(kFused16), "the two tables must list t
 auto* const kSep16PredKernel = sep16_kernel<256, 256, 3, false, true>;
 constexpr int kSep16PredLds = Sep16Geom<256, 256, 3>::LDS_BYTES;
 
+constexpr int kDualBranchMaxBatch = 32;   // handles sized for at most this many crops per pass run the head's branches concurrently
+
 // encode SepConv + pixel-wise correlation in one kernel (fp32 mode)
 constexpr int kCorrC = 256, kCorrTz = 64;
 auto* const kSep16CorrKernel = sep16_kernel<kCorrC, kCorrC, 3, true>;
@@ -460,13 +466,22 @@ int pack_neck_frags(fear_handle* h, int conv, float** out) {
 // (per-crop size = the largest intermediate tensor) handed out by liveness, so consecutive layers
 // keep re-using the same few address ranges (friendly to the 256 MiB Infinity Cache).
 struct Pool {
-    std::vector<int> free_ids;
+    std::vector<int> free_ids, held;
     int count = 0;
+    bool hold = false;       // while set, released buffers are not handed out again (ops that may run concurrently)
     int acquire() {
         if (!free_ids.empty()) { int id = free_ids.back(); free_ids.pop_back(); return id; }
         return count++;
     }
-    void release(int id) { if (id >= 0) free_ids.push_back(id); }
+    void release(int id) {
+        if (id < 0) return;
+        (hold ? held : free_ids).push_back(id);
+    }
+    void flush() {
+        hold = false;
+        free_ids.insert(free_ids.end(), held.begin(), held.end());
+        held.clear();
+    }
 };
 
 struct T {  // tensor view inside the plan
@@ -870,10 +885,21 @@ int build_plan(fear_handle* h, int hw, bool with_head, Plan** out) {
             pool.release(d.buf);
             return FEAR_OK;
         };
+        // Small batches (one workgroup per crop leaves most CUs idle): the two branches are independent, so the bbox branch is
+        // planned on buffers of its own and run_plan puts it on a second stream next to the cls branch.
+        const bool dual = h->max_batch <= kDualBranchMaxBatch;
+        const size_t head_first = ops.size();
+        pool.hold = dual;
         int st = branch(role[FEARW_CLS_ENCODE], role[FEARW_CLS_CORR], cls_tower, role[FEARW_CLS_PRED], true);
         if (st != FEAR_OK) return st;
+        const size_t reg_first = ops.size();
         st = branch(role[FEARW_REG_ENCODE], role[FEARW_REG_CORR], bbox_tower, role[FEARW_BBOX_PRED], false);
         if (st != FEAR_OK) return st;
+        pool.flush();
+        if (dual) {
+            for (size_t i = reg_first; i < ops.size(); ++i) ops[i].lane = 1;
+            plan->head_first = (int)head_first;
+        }
         pool.release(feat.buf);
     }
     plan->n_bufs = pool.count;
@@ -931,7 +957,7 @@ struct Ext {
     float* cls_out;
 };
 
-int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s) {
+int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main) {
     if (!h->fused_attr_set) {
         for (const Fused16& f : kFused16)
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(f.kernel),
@@ -957,9 +983,23 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s) {
     }
     const size_t slab = p.buf_floats_per_crop * h->max_batch;
     auto buf = [&](int id) -> float* { return h->workspace + (size_t)id * slab; };
+    // head branches on two streams (plans built for small passes only; per-op profiling keeps everything on one stream)
+    const bool dual = p.head_first >= 0 && !h->profile;
+    if (dual && !h->branch_stream) {
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->branch_stream, hipStreamNonBlocking));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->branch_fork, hipEventDisableTiming));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->branch_join, hipEventDisableTiming));
+    }
+    bool forked = false;
     int op_index = -1;
     for (Op& op : p.ops) {
         ++op_index;
+        if (dual && op_index == p.head_first) {
+            HIP_TRY(h, hipEventRecord(h->branch_fork, s_main));            // the trunk's output is ready after this point
+            HIP_TRY(h, hipStreamWaitEvent(h->branch_stream, h->branch_fork, 0));
+            forked = true;
+        }
+        const hipStream_t s = (dual && op.lane == 1) ? h->branch_stream : s_main;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         // a selected op also selects every op with the same name (= same kernel symbol and shape)
         const bool prof = h->profile && (h->profile_op < 0 || h->profile_op == op_index ||
@@ -1093,6 +1133,10 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s) {
             op.events.emplace_back(e0, e1);
         }
     }
+    if (forked) {                                    // the caller's stream continues once the bbox branch is done too
+        HIP_TRY(h, hipEventRecord(h->branch_join, h->branch_stream));
+        HIP_TRY(h, hipStreamWaitEvent(s_main, h->branch_join, 0));
+    }
     HIP_TRY(h, hipGetLastError());
     return FEAR_OK;
 }
@@ -1158,6 +1202,9 @@ int fear_destroy(fear_handle* h) {
     hipDeviceSynchronize();
     drain_events(h);
     for (hipEvent_t e : h->event_pool) hipEventDestroy(e);
+    if (h->branch_stream) hipStreamDestroy(h->branch_stream);
+    if (h->branch_fork) hipEventDestroy(h->branch_fork);
+    if (h->branch_join) hipEventDestroy(h->branch_join);
     for (float* p : h->weight_allocs) hipFree(p);
     if (h->workspace) hipFree(h->workspace);
     delete h;
@@ -1169,6 +1216,8 @@ int fear_set_option(fear_handle* h, int option, int64_t value) {
     switch (option) {
         case FEAR_OPT_MAX_BATCH:
             if (value < 1 || value > 65536) return FEAR_ERR_SHAPE;
+            // plans for small passes keep the head's branches on disjoint buffers (two streams): rebuild when that changes
+            if ((h->max_batch <= kDualBranchMaxBatch) != ((int)value <= kDualBranchMaxBatch)) h->plans.clear();
             h->max_batch = (int)value;
             return FEAR_OK;
         case FEAR_OPT_PROFILE:
