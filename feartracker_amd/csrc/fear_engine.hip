@@ -102,6 +102,8 @@ struct Op {
     int pred_fused = 0;       // OP_IR16 (sep16): the prediction SepConv that consumes this layer runs in its epilogue
     float* pred_packed = nullptr;
     int pred_conv_p = -1;
+    int splitk = 0;           // OP_IR16: > 0 = workgroups per crop (split over expansion chunks) + a reduce launch
+    int part_buf = -1;        //          scratch buffer of the partial projections
     int lane = 0;             // 1: bbox branch of the head, may run on the handle's second stream (small batches)
     int corr_fused = 0;       // OP_IR16 (sep16): the pixel-wise correlation runs in this kernel's epilogue
     int conv_e = -1, conv_d = -1, conv_p = -1;  // OP_IR16: expand (or -1) / depthwise / project convs
@@ -264,10 +266,12 @@ struct Fused16 {
     int cin, cexp, cout, ks, expand;
     void (*kernel)(Ir2Args);
     int lds_bytes;
+    void (*kernel_splitk)(Ir2Args);     // small-batch variant: several workgroups per crop, one chunk range each (or nullptr)
 };
 #define FUSED16(CIN, CEXP, COUT, KS, EXP) \
-    {CIN, CEXP, COUT, KS, EXP, ir16v2_fused_kernel<CIN, CEXP, COUT, KS, (EXP) != 0>, Ir2Geom<CIN, CEXP, COUT, KS, (EXP) != 0>::LDS_BYTES}
-#define SEP16(CIN, COUT, KS) {CIN, CIN, COUT, KS, 0, sep16_kernel<CIN, COUT, KS>, Sep16Geom<CIN, COUT, KS>::LDS_BYTES}
+    {CIN, CEXP, COUT, KS, EXP, ir16v2_fused_kernel<CIN, CEXP, COUT, KS, (EXP) != 0>, Ir2Geom<CIN, CEXP, COUT, KS, (EXP) != 0>::LDS_BYTES, \
+     ir16v2_fused_kernel<CIN, CEXP, COUT, KS, (EXP) != 0, true>}
+#define SEP16(CIN, COUT, KS) {CIN, CIN, COUT, KS, 0, sep16_kernel<CIN, COUT, KS>, Sep16Geom<CIN, COUT, KS>::LDS_BYTES, nullptr}
 const Fused16 kFused16[] = {
     FUSED16(64, 192, 64, 5, 1),   FUSED16(64, 384, 64, 5, 1),  FUSED16(64, 384, 112, 5, 1),
     FUSED16(112, 672, 112, 5, 1), FUSED16(112, 336, 112, 5, 1),
@@ -563,7 +567,21 @@ int build_plan(fear_handle* h, int hw, bool with_head, Plan** out) {
         outT.buf = pool.acquire(); outT.ld = out_ld > 0 ? out_ld : p.cout; outT.off = 0; outT.C = p.cout; outT.H = 16; outT.W = 16;
         op.out_buf = outT.buf; op.out_ld = outT.ld;
         if (res) { op.res_buf = res->buf; op.res_ld = res->ld; }
-        snprintf(op.name, sizeof(op.name), "%s_%dx%dx%d_k%d", tag, cin, d.cout, p.cout, d.k);
+        // small passes: one workgroup per crop leaves the GPU idle — split the expansion chunks of a crop over several
+        // workgroups (each projects its own chunks), then add the partial projections up
+        if (!h->math && ce >= 0 && h->max_batch <= kDualBranchMaxBatch && kFused16[id].kernel_splitk) {
+            const int nchunk = d.cout / 16;
+            int w = 0;
+            for (int cand = 8; cand >= 2 && !w; --cand)
+                if (nchunk % cand == 0 && nchunk / cand >= 2) w = cand;
+            if (w) {
+                op.splitk = w;
+                if ((size_t)w * 256 * p.cout > max_elems) max_elems = (size_t)w * 256 * p.cout;
+                op.part_buf = pool.acquire();
+                pool.release(op.part_buf);          // only alive inside this op (the next acquire may reuse it)
+            }
+        }
+        snprintf(op.name, sizeof(op.name), op.splitk ? "%s_splitk_%dx%dx%d_k%d" : "%s_%dx%dx%d_k%d", tag, cin, d.cout, p.cout, d.k);
         op.flops = 2.0 * 256 * ((ce >= 0 ? (double)cin * d.cout : 0.0) + (double)d.cout * d.k * d.k + (double)d.cout * p.cout);
         op.bytes = 4.0 * 256 * (cin + p.cout + (res ? p.cout : 0));
         ops.push_back(op);
@@ -676,7 +694,7 @@ int build_plan(fear_handle* h, int hw, bool with_head, Plan** out) {
     for (; bi < h->blocks.size(); ++bi) {
         const FearwBlock& b = h->blocks[bi];
         // ---- the whole stride-16 stage + neck as one chain kernel (fp32 arithmetic, search branch)
-        if (h->fuse && h->chain && !h->math && with_head && b.kind == FEARW_IR && cur.H == 16 && cur.W == 16 &&
+        if (h->fuse && h->chain && !h->math && h->max_batch > kDualBranchMaxBatch && with_head && b.kind == FEARW_IR && cur.H == 16 && cur.W == 16 &&
             bi + 7 < h->blocks.size() && h->blocks[bi + 7].kind == FEARW_NECK) {
             bool match = true;
             for (int j = 0; j < 7 && match; ++j) {
@@ -959,9 +977,13 @@ struct Ext {
 
 int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main) {
     if (!h->fused_attr_set) {
-        for (const Fused16& f : kFused16)
+        for (const Fused16& f : kFused16) {
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(f.kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, f.lds_bytes));
+            if (f.kernel_splitk)
+                HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(f.kernel_splitk),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, f.lds_bytes));
+        }
         for (const Fused16& f : kFused16H)
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(f.kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, f.lds_bytes));
@@ -1083,7 +1105,21 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
                     a.pred_cout = op.pred_cout; a.pred_act = op.act;
                     a.Y = op.out_external == 3 ? ext.cls_out : ext.bbox_out;
                 }
-                if (op.corr_fused) {
+                if (op.splitk) {
+                    // several workgroups per crop, each over its own chunk range -> partial projections -> reduce
+                    Ir2Args pa = a;
+                    const Conv& dconv = h->convs[op.conv_d];
+                    pa.kc_count = dconv.cout / 16 / op.splitk;
+                    pa.Y = buf(op.part_buf); pa.ldy = op.N;
+                    pa.kc_part_stride = (long)n * 256 * op.N;
+                    pa.R = nullptr;
+                    hipLaunchKernelGGL(f.kernel_splitk, dim3(n, op.splitk), dim3(512), f.lds_bytes, s, pa);
+                    SplitKReduceArgs ra{};
+                    ra.P = pa.Y; ra.bias = a.bp; ra.R = a.R; ra.Y = a.Y; ra.part_stride = pa.kc_part_stride;
+                    ra.W = op.splitk; ra.M = n * 256; ra.N = op.N; ra.ldp = op.N; ra.ldr = a.ldr; ra.ldy = a.ldy; ra.relu = a.relu_out;
+                    const long total = (long)ra.M * (ra.N / 4);
+                    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ra);
+                } else if (op.corr_fused) {
                     a.Z = (op.tmpl_cls && ext.tmpl_cls) ? ext.tmpl_cls : ext.tmpl;
                     a.z_stride = (long)kCorrC * kCorrTz;
                     hipLaunchKernelGGL(kSep16CorrKernel, dim3(n), dim3(512), kSep16CorrLds, s, a);

@@ -427,6 +427,30 @@ __global__ __launch_bounds__(64) void decode_kernel(DecodeArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Sum of the split-K partial projections + bias (+ residual) (+ ReLU):  Y[m][n] = sum_w P[w][m][n] + b[n] + R[m][n]
+struct SplitKReduceArgs {
+    const float* P;      // [W][M][ldp]
+    const float* bias;   // [N]
+    const float* R;      // [M][ldr] or nullptr
+    float* Y;            // [M][ldy]
+    long part_stride;    // floats between consecutive partials
+    int W, M, N, ldp, ldr, ldy, relu;
+};
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(SplitKReduceArgs a) {
+    const int q = a.N / 4;                                   // float4 per row
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)a.M * q) return;
+    const long m = idx / q;
+    const int n = (int)(idx - m * q) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(a.bias + n);
+    for (int w = 0; w < a.W; ++w) v += *reinterpret_cast<const f32x4*>(a.P + w * a.part_stride + m * a.ldp + n);
+    if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
+    if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = v;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Tracker._postprocess with tracking_config["smooth"] (base_tracker.py:149-205): scale / aspect-ratio change penalty
 // against the previous size, cosine-window blend, first-maximum arg-max of the blended score, box decode at that cell and
 // the penalty*score-weighted size smoothing.  float64 where the reference is float64 (grids, sizes, penalty, blended score
@@ -640,6 +664,11 @@ struct Ir2Args {
     const float* P_Wpk;
     const float* P_bp;
     float* P_Y;
+    // split-K variants (small batches): every crop is handled by gridDim.y workgroups, workgroup y taking the kc_count
+    // 16-channel chunks from chunk y * kc_count on and writing its RAW partial projection (no bias / residual / activation)
+    // to Y + y * kc_part_stride; splitk_reduce_kernel adds the partials up
+    int kc_count;
+    long kc_part_stride;
 };
 
 template <int CIN, int CEXP, int COUT, int KS, bool EXPAND>
@@ -789,10 +818,13 @@ __device__ __forceinline__ void ir16_interval(const float* __restrict__ E, float
 }
 
 
-template <int CIN, int CEXP, int COUT, int KS, bool EXPAND>
+template <int CIN, int CEXP, int COUT, int KS, bool EXPAND, bool SPLITK = false>
 __global__ __launch_bounds__(512) void ir16v2_fused_kernel(Ir2Args a) {
     using G = Ir2Geom<CIN, CEXP, COUT, KS, EXPAND>;
-    constexpr int S = G::S, P = G::P, PW = G::PW, ES = G::ES, NCHUNK = G::NCHUNK, NTP = G::NTP, KG = G::KG;
+    constexpr int S = G::S, P = G::P, PW = G::PW, ES = G::ES, NTP = G::NTP, KG = G::KG;
+    // split-K: this workgroup's chunk range (run-time); otherwise the whole expansion
+    const int NCHUNK = SPLITK ? a.kc_count : G::NCHUNK;
+    const float* const Wpk = SPLITK ? a.Wpk + (long)blockIdx.y * a.kc_count * (G::AP + G::BP) : a.Wpk;
     constexpr int AP = G::AP, BP = G::BP, EBUF = G::EBUF, CST = AP + BP;
     constexpr int AP4 = AP / 4, BP4 = BP / 4;                 // float4 counts
     constexpr int NRA = (AP4 + 511) / 512, NRB = (BP4 + 511) / 512;
@@ -826,7 +858,7 @@ __global__ __launch_bounds__(512) void ir16v2_fused_kernel(Ir2Args a) {
 #pragma unroll
             for (int r = 0; r < NRA; ++r) {
                 const int idx = tid + r * 512;
-                if (idx < AP4) ra[r] = *reinterpret_cast<const f32x4*>(a.Wpk + (long)c * CST + idx * 4);
+                if (idx < AP4) ra[r] = *reinterpret_cast<const f32x4*>(Wpk + (long)c * CST + idx * 4);
             }
         } else {
 #pragma unroll
@@ -853,7 +885,7 @@ __global__ __launch_bounds__(512) void ir16v2_fused_kernel(Ir2Args a) {
 #pragma unroll
         for (int r = 0; r < NRB; ++r) {
             const int idx = tid + r * 512;
-            if (idx < BP4) rb[r] = *reinterpret_cast<const f32x4*>(a.Wpk + (long)c * CST + AP + idx * 4);
+            if (idx < BP4) rb[r] = *reinterpret_cast<const f32x4*>(Wpk + (long)c * CST + AP + idx * 4);
         }
     };
     auto store_b = [&](int c) {
@@ -930,6 +962,17 @@ __global__ __launch_bounds__(512) void ir16v2_fused_kernel(Ir2Args a) {
         if (!(FEAR_ABL & 1)) __syncthreads();
     }
 
+    if (SPLITK) {                   // raw partial sums; bias, residual and activation belong to splitk_reduce_kernel
+        float* Yp = a.Y + (long)blockIdx.y * a.kc_part_stride;
+#pragma unroll
+        for (int nt = 0; nt < NTP; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const long m = crop * 256 + (y0 + mt) * S + li;
+                *reinterpret_cast<f32x4*>(Yp + m * a.ldy + nt * 16 + lk * 4) = accp[mt][nt];
+            }
+        return;
+    }
     if (a.pred_cout > 0) {          // prediction head: lanes lk == 0 hold channels 0..3 of their pixel
         if (lk == 0) {
 #pragma unroll

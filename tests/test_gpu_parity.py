@@ -88,9 +88,14 @@ def test_empty_ragged_and_chunked_batches(hip_net, oracle_net):
     x = norm_u8(torch.randint(0, 256, (7, 3, 256, 256), dtype=torch.uint8, generator=g)).cuda()
     z = hip_net.get_features(norm_u8(torch.randint(0, 256, (7, 3, 128, 128), dtype=torch.uint8, generator=g)).cuda())
     small = FEARNetHIP(WEIGHTS, device=0, max_batch=3)
-    b1, c1 = hip_net.track_maps(x, z)
+    one_pass = FEARNetHIP(WEIGHTS, device=0, max_batch=8)
+    b1, c1 = one_pass.track_maps(x, z)
     b2, c2 = small.track_maps(x, z)
     assert torch.equal(b1, b2) and torch.equal(c1, c2)       # per-crop results do not depend on batching
+    # (handles sized for > 32 crops per pass run the throughput plan — chain kernel instead of split-K blocks: a different
+    #  fp32 summation order, not bit-identical but the same maps)
+    b0, c0 = hip_net.track_maps(x, z)
+    assert rel_err(b2, b0) < 1e-5 and rel_err(c2, c0) < 1e-5
     assert torch.equal(small.get_features(x[:, :, :128, :128].contiguous()),
                        hip_net.get_features(x[:, :, :128, :128].contiguous()))
     # a single template broadcast over the batch (the tracker keeps one template per track)
@@ -286,9 +291,11 @@ def test_chain_kernel_matches_per_block_kernels(hip_net):
     block (same arithmetic, activations kept in registers between blocks)."""
     from feartracker_amd import FEARNetHIP
     from conftest import WEIGHTS
-    per_block = FEARNetHIP(WEIGHTS, device=0, max_batch=8)
+    # (handles sized for <= 32 crops per pass use the small-batch plan instead: split-K blocks, two-stream head)
+    chained = FEARNetHIP(WEIGHTS, device=0, max_batch=64)
+    per_block = FEARNetHIP(WEIGHTS, device=0, max_batch=64)
     per_block.set_chain(False)
-    names_chain = [n for n, _, _ in hip_net.plan(256, True)]
+    names_chain = [n for n, _, _ in chained.plan(256, True)]
     names_blocks = [n for n, _, _ in per_block.plan(256, True)]
     assert any(n.startswith("chain16") for n in names_chain) and not any(n.startswith("chain16") for n in names_blocks)
     assert len(names_blocks) == len(names_chain) + 7
@@ -296,8 +303,14 @@ def test_chain_kernel_matches_per_block_kernels(hip_net):
     x = norm_u8(torch.randint(0, 256, (3, 3, 256, 256), dtype=torch.uint8, generator=g)).cuda()
     z = hip_net.get_features(norm_u8(torch.randint(0, 256, (3, 3, 128, 128), dtype=torch.uint8, generator=g)).cuda())
     b0, c0 = per_block.track_maps(x, z)
-    b1, c1 = hip_net.track_maps(x, z)
+    b1, c1 = chained.track_maps(x, z)
     assert rel_err(b1, b0) < 1e-5 and rel_err(c1, c0) < 1e-5
+    # the small-batch plan (max_batch <= 32): split-K blocks instead of the chain, same maps
+    small = FEARNetHIP(WEIGHTS, device=0, max_batch=8)
+    names_small = [n for n, _, _ in small.plan(256, True)]
+    assert any("splitk" in n for n in names_small) and not any(n.startswith("chain16") for n in names_small)
+    b2, c2 = small.track_maps(x, z)
+    assert rel_err(b2, b0) < 1e-5 and rel_err(c2, c0) < 1e-5
 
 
 def test_device_smooth_postprocess_matches_reference_fixture_and_host(hip_net, golden_dir):
@@ -364,3 +377,26 @@ def test_repeated_launches_are_bit_identical():
         for _ in range(40):
             b, c = net.track_maps(x, z)
             assert torch.equal(b, b0) and torch.equal(c, c0)
+
+
+def test_small_batch_plan_vs_oracle_and_clip(oracle_net, golden_dir):
+    """Handles sized for <= 32 crops per pass run the latency plan (split-K 16x16 blocks + reduce, the head's branches on
+    two streams): parity with the oracle on a seeded batch, and the tracker loop at max_batch 1 reproduces the clip."""
+    from feartracker_amd import DEFAULT_TRACKING_CONFIG, FEARNetHIP, FEARTracker
+    from conftest import WEIGHTS
+    net = FEARNetHIP(WEIGHTS, device=0, max_batch=8)
+    assert any("splitk" in n for n, _, _ in net.plan(256, True))
+    g = torch.Generator().manual_seed(404)
+    x = norm_u8(torch.randint(0, 256, (5, 3, 256, 256), dtype=torch.uint8, generator=g))
+    t = norm_u8(torch.randint(0, 256, (5, 3, 128, 128), dtype=torch.uint8, generator=g))
+    ref = oracle_net.track(x, oracle_net.get_features(t))
+    b, c = net.track_maps(x.cuda(), net.get_features(t.cuda()))
+    assert rel_err(b, ref["TARGET_REGRESSION_LABEL_KEY"]) < REL and rel_err(c, ref["TARGET_CLASSIFICATION_KEY"]) < REL
+    for _ in range(20):                      # the two streams and the partial-sum scratch must not race
+        b2, c2 = net.track_maps(x.cuda(), net.get_features(t.cuda()))
+        assert torch.equal(b, b2) and torch.equal(c, c2)
+    d = np.load(f"{golden_dir}/clip_synth.npz")
+    trk = FEARTracker(FEARNetHIP(WEIGHTS, device=0, max_batch=1), cuda_id=0, **DEFAULT_TRACKING_CONFIG)
+    trk.initialize(d["frames"][0], d["init_bbox"])
+    boxes = [np.array(d["init_bbox"])] + [np.array(trk.update(f)["bbox"]) for f in d["frames"][1:]]
+    np.testing.assert_array_equal(np.stack(boxes), d["tracked"])
