@@ -267,16 +267,18 @@ struct Fused16 {
     void (*kernel)(Ir2Args);
     int lds_bytes;
     void (*kernel_splitk)(Ir2Args);     // small-batch variant: several workgroups per crop, one chunk range each (or nullptr)
+    int splitk_kc;                      // chunks per workgroup compiled into that variant (0: run-time, Ir2Args::kc_count)
 };
 #define FUSED16(CIN, CEXP, COUT, KS, EXP) \
     {CIN, CEXP, COUT, KS, EXP, ir16v2_fused_kernel<CIN, CEXP, COUT, KS, (EXP) != 0>, Ir2Geom<CIN, CEXP, COUT, KS, (EXP) != 0>::LDS_BYTES, \
-     ir16v2_fused_kernel<CIN, CEXP, COUT, KS, (EXP) != 0, true>}
-#define SEP16(CIN, COUT, KS) {CIN, CIN, COUT, KS, 0, sep16_kernel<CIN, COUT, KS>, Sep16Geom<CIN, COUT, KS>::LDS_BYTES, nullptr}
+     ir16v2_fused_kernel<CIN, CEXP, COUT, KS, (EXP) != 0, true>, 0}
+#define SEP16(CIN, COUT, KS, KC) \
+    {CIN, CIN, COUT, KS, 0, sep16_kernel<CIN, COUT, KS>, Sep16Geom<CIN, COUT, KS>::LDS_BYTES, sep16_kernel<CIN, COUT, KS, false, false, KC>, KC}
 const Fused16 kFused16[] = {
     FUSED16(64, 192, 64, 5, 1),   FUSED16(64, 384, 64, 5, 1),  FUSED16(64, 384, 112, 5, 1),
     FUSED16(112, 672, 112, 5, 1), FUSED16(112, 336, 112, 5, 1),
-    SEP16(256, 256, 3), SEP16(320, 256, 3),
-    SEP16(256, 16, 3),              // bbox_pred / cls_pred: 4 / 1 output channels padded to one 16-channel tile
+    SEP16(256, 256, 3, 4), SEP16(320, 256, 3, 4),
+    SEP16(256, 16, 3, 2),              // bbox_pred / cls_pred: 4 / 1 output channels padded to one 16-channel tile
 };
 
 // Spatially tiled fused block kernels (ir_tile_fused_kernel) for the high-resolution trunk stages.
@@ -569,11 +571,15 @@ int build_plan(fear_handle* h, int hw, bool with_head, Plan** out) {
         if (res) { op.res_buf = res->buf; op.res_ld = res->ld; }
         // small passes: one workgroup per crop leaves the GPU idle — split the expansion chunks of a crop over several
         // workgroups (each projects its own chunks), then add the partial projections up
-        if (!h->math && ce >= 0 && h->max_batch <= kDualBranchMaxBatch && kFused16[id].kernel_splitk) {
+        if (!h->math && h->max_batch <= kDualBranchMaxBatch && kFused16[id].kernel_splitk) {
             const int nchunk = d.cout / 16;
             int w = 0;
-            for (int cand = 8; cand >= 2 && !w; --cand)
-                if (nchunk % cand == 0 && nchunk / cand >= 2) w = cand;
+            if (kFused16[id].splitk_kc > 0) {
+                w = nchunk / kFused16[id].splitk_kc;              // the variant's chunk count per workgroup is compiled in
+            } else {
+                for (int cand = 8; cand >= 2 && !w; --cand)
+                    if (nchunk % cand == 0 && nchunk / cand >= 2) w = cand;
+            }
             if (w) {
                 op.splitk = w;
                 if ((size_t)w * 256 * p.cout > max_elems) max_elems = (size_t)w * 256 * p.cout;
@@ -815,7 +821,7 @@ int build_plan(fear_handle* h, int hw, bool with_head, Plan** out) {
                 add_dw(enc->conv[0], feat, d, 0);
                 add_pw(enc->conv[1], d, cat, nullptr, 1, corr_dw.cout, 0, -1);
                 pool.release(d.buf);
-            } else if (!h->math && enc_pw.cout == kCorrC && h->convs[enc->conv[0]].cout == kCorrC &&
+            } else if (!h->math && h->max_batch > kDualBranchMaxBatch && enc_pw.cout == kCorrC && h->convs[enc->conv[0]].cout == kCorrC &&
                        h->convs[enc->conv[0]].k == 3 && tz == kCorrTz) {
                 // the correlation rides in the encode kernel's epilogue: its output fragments are the B operand as they stand
                 Op& eop = ops.back();
@@ -863,7 +869,7 @@ int build_plan(fear_handle* h, int hw, bool with_head, Plan** out) {
             }
             if (h->convs[pred->conv[1]].cout != (is_cls ? 1 : 4)) return FEAR_ERR_FORMAT;
             // the prediction head rides in the epilogue of the last tower SepConv (its output never reaches HBM)
-            if (h->fuse && !h->math && !ops.empty() && ops.back().type == OP_IR16 && ops.back().out_buf == x.buf &&
+            if (h->fuse && !h->math && h->max_batch > kDualBranchMaxBatch && !ops.empty() && ops.back().type == OP_IR16 && ops.back().out_buf == x.buf &&
                 ops.back().C == 256 && ops.back().N == 256 && !ops.back().corr_fused && ops.back().res_buf < 0 &&
                 h->convs[ops.back().conv_d].k == 3 && h->convs[pred->conv[0]].k == 3 && h->convs[pred->conv[0]].cout == 256 &&
                 h->convs[pred->conv[0]].stride == 1 && h->convs[pred->conv[1]].has_bias && !h->convs[pred->conv[0]].relu) {

@@ -1036,15 +1036,20 @@ struct Sep16Geom {
 // PRED = true: the prediction head that follows a tower (SepConv to <= 4 channels) is computed in the epilogue, chunk by
 // chunk: the finished output fragments of 16 channels go to an LDS tile (never to HBM), the head's depthwise runs from it
 // and its one-tile projection accumulates over the COUT/16 chunks.
-template <int CIN, int COUT, int KS, bool CORR = false, bool PRED = false>
+// SPLITK = k > 0 (small batches): gridDim.y workgroups per crop, workgroup y handling the k input chunks from chunk y*k on
+// and writing its raw partial projection (see Ir2Args::kc_count); bias, ReLU and the fused epilogues are not available.
+template <int CIN, int COUT, int KS, bool CORR = false, bool PRED = false, int SPLITK = 0>
 __global__ __launch_bounds__(512) void sep16_kernel(Ir2Args a) {
     using G = Sep16Geom<CIN, COUT, KS, CORR>;
-    static_assert(!(CORR && PRED), "one epilogue at a time");
-    constexpr int S = G::S, P = G::P, PW = G::PW, ES = G::ES, NCHUNK = G::NCHUNK, NTP = G::NTP;
+    static_assert(!(CORR && PRED) && !(SPLITK && (CORR || PRED)), "one epilogue at a time");
+    static_assert(SPLITK == 0 || (SPLITK >= 2 && G::NCHUNK % SPLITK == 0), "SPLITK = chunks per workgroup (compile time)");
+    constexpr int S = G::S, P = G::P, PW = G::PW, ES = G::ES, NTP = G::NTP;
+    constexpr int NCHUNK = SPLITK ? SPLITK : G::NCHUNK;         // split-K: this workgroup's share of the input chunks
+    const int c_base = SPLITK ? (int)blockIdx.y * SPLITK : 0;
     constexpr int WPF = G::WPF, WDF = G::WDF, CST = G::CST, EBUF = G::EBUF;
     constexpr int WP4 = WPF / 4, WD4 = WDF / 4, NRP = (WP4 + 511) / 512;
     constexpr int NS = KS * (KS + 1), D = 4, NU = NTP * 4;
-    static_assert(CIN % 16 == 0 && COUT % 16 == 0 && NCHUNK >= 2 && WD4 <= 512 && NS >= D, "shape");
+    static_assert(CIN % 16 == 0 && COUT % 16 == 0 && G::NCHUNK >= 2 && WD4 <= 512 && NS >= D, "shape");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* const Ebuf = lds;                    // [2][EBUF]
     float* const WP = lds + 2 * EBUF;           // [2][WPF]
@@ -1064,7 +1069,7 @@ __global__ __launch_bounds__(512) void sep16_kernel(Ir2Args a) {
     auto load_x = [&](int c) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
-            rx[mt] = *reinterpret_cast<const f32x4*>(Xc + (long)((y0 + mt) * S + li) * a.ldx + c * 16 + lk * 4);
+            rx[mt] = *reinterpret_cast<const f32x4*>(Xc + (long)((y0 + mt) * S + li) * a.ldx + (c_base + c) * 16 + lk * 4);
     };
     auto store_x = [&](int c) {
         float* E = Ebuf + (c & 1) * EBUF;
@@ -1073,8 +1078,8 @@ __global__ __launch_bounds__(512) void sep16_kernel(Ir2Args a) {
     };
     // weights go global -> LDS directly (asynchronous, no registers): the projection fragments of chunk c into WP[c & 1],
     // the depthwise taps + bias into WD[c & 1]
-    auto stage_p = [&](int c) { lds_copy_async<WPF>(a.Wpk + (long)c * CST, WP + (c & 1) * WPF, wave, lane); };
-    auto stage_d = [&](int c) { lds_copy_async<WDF>(a.Wpk + (long)c * CST + WPF, WD + (c & 1) * WDF, wave, lane); };
+    auto stage_p = [&](int c) { lds_copy_async<WPF>(a.Wpk + (long)(c_base + c) * CST, WP + (c & 1) * WPF, wave, lane); };
+    auto stage_d = [&](int c) { lds_copy_async<WDF>(a.Wpk + (long)(c_base + c) * CST + WPF, WD + (c & 1) * WDF, wave, lane); };
 
     f32x4 accp[2][NTP];
 #pragma unroll
@@ -1172,6 +1177,17 @@ __global__ __launch_bounds__(512) void sep16_kernel(Ir2Args a) {
         if (!(FEAR_ABL & 1)) __syncthreads();
     }
 
+    if (SPLITK) {                   // raw partial sums; bias and ReLU belong to splitk_reduce_kernel
+        float* Yp = a.Y + (long)blockIdx.y * a.kc_part_stride;
+#pragma unroll
+        for (int nt = 0; nt < NTP; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const long m = crop * 256 + (y0 + mt) * S + li;
+                *reinterpret_cast<f32x4*>(Yp + m * a.ldy + nt * 16 + lk * 4) = accp[mt][nt];
+            }
+        return;
+    }
     if (PRED) {
         constexpr int PCH = 256 + KS * KS * 16 + 16;          // packed floats per chunk of the head: 1 fragment | Wd | bd
         static_assert(NTP * PCH <= 2 * WPF, "the head's weights are staged in the projection-weight area");
