@@ -148,6 +148,8 @@ struct fear_handle {
     int profile_op = -1;   // -1: every op, else only this op index of each plan
     int fuse = 1;          // 1: use the fused block kernels where an instantiation exists
     int chain = 1;         // 1: run the stride-16 trunk stage as one register-resident chain kernel (fp32 mode)
+    int small_pass = 96;   // passes of at most this many crops run the small-batch plan (FEAR_OPT_SMALL_PASS; 0: never);
+                           // measured crossover with the throughput plan: ~110 crops (1.70 vs 1.93 ms at 96, 2.14 vs 2.01 at 128)
     int math = 0;          // 0: fp32 MFMA everywhere; 1: fp16-split operands on the matrix pipe in the fused 16x16 blocks
     bool fused_attr_set = false;
     int last_hip_error = 0;
@@ -349,7 +351,6 @@ static_assert(sizeof(kFused16H) == sizeof(kFused16), "the two tables must list t
 auto* const kSep16PredKernel = sep16_kernel<256, 256, 3, false, true>;
 constexpr int kSep16PredLds = Sep16Geom<256, 256, 3>::LDS_BYTES;
 
-constexpr int kDualBranchMaxBatch = 32;   // handles sized for at most this many crops per pass run the head's branches concurrently
 
 // encode SepConv + pixel-wise correlation in one kernel (fp32 mode)
 constexpr int kCorrC = 256, kCorrTz = 64;
@@ -496,8 +497,9 @@ struct T {  // tensor view inside the plan
 
 void set_name(Op& op, const char* fmt, int a, int b, int c) { snprintf(op.name, sizeof(op.name), fmt, a, b, c); }
 
-int build_plan(fear_handle* h, int hw, bool with_head, Plan** out) {
-    auto key = std::make_pair(hw, with_head ? 1 : 0);
+// small = the small-batch plan (few crops per pass): split-K 16x16 kernels, the head's branches on two streams
+int build_plan(fear_handle* h, int hw, bool with_head, bool small, Plan** out) {
+    auto key = std::make_pair(hw, (with_head ? 1 : 0) + (small ? 2 : 0));
     auto it = h->plans.find(key);
     if (it != h->plans.end()) { *out = it->second.get(); return FEAR_OK; }
     if (hw < 32 || hw % 32 != 0 || hw > 1024) return FEAR_ERR_SHAPE;
@@ -571,7 +573,7 @@ int build_plan(fear_handle* h, int hw, bool with_head, Plan** out) {
         if (res) { op.res_buf = res->buf; op.res_ld = res->ld; }
         // small passes: one workgroup per crop leaves the GPU idle — split the expansion chunks of a crop over several
         // workgroups (each projects its own chunks), then add the partial projections up
-        if (!h->math && h->max_batch <= kDualBranchMaxBatch && kFused16[id].kernel_splitk) {
+        if (!h->math && small && kFused16[id].kernel_splitk) {
             const int nchunk = d.cout / 16;
             int w = 0;
             if (kFused16[id].splitk_kc > 0) {
@@ -700,7 +702,7 @@ int build_plan(fear_handle* h, int hw, bool with_head, Plan** out) {
     for (; bi < h->blocks.size(); ++bi) {
         const FearwBlock& b = h->blocks[bi];
         // ---- the whole stride-16 stage + neck as one chain kernel (fp32 arithmetic, search branch)
-        if (h->fuse && h->chain && !h->math && h->max_batch > kDualBranchMaxBatch && with_head && b.kind == FEARW_IR && cur.H == 16 && cur.W == 16 &&
+        if (h->fuse && h->chain && !h->math && !small && with_head && b.kind == FEARW_IR && cur.H == 16 && cur.W == 16 &&
             bi + 7 < h->blocks.size() && h->blocks[bi + 7].kind == FEARW_NECK) {
             bool match = true;
             for (int j = 0; j < 7 && match; ++j) {
@@ -821,7 +823,7 @@ int build_plan(fear_handle* h, int hw, bool with_head, Plan** out) {
                 add_dw(enc->conv[0], feat, d, 0);
                 add_pw(enc->conv[1], d, cat, nullptr, 1, corr_dw.cout, 0, -1);
                 pool.release(d.buf);
-            } else if (!h->math && h->max_batch > kDualBranchMaxBatch && enc_pw.cout == kCorrC && h->convs[enc->conv[0]].cout == kCorrC &&
+            } else if (!h->math && !small && enc_pw.cout == kCorrC && h->convs[enc->conv[0]].cout == kCorrC &&
                        h->convs[enc->conv[0]].k == 3 && tz == kCorrTz) {
                 // the correlation rides in the encode kernel's epilogue: its output fragments are the B operand as they stand
                 Op& eop = ops.back();
@@ -869,7 +871,7 @@ int build_plan(fear_handle* h, int hw, bool with_head, Plan** out) {
             }
             if (h->convs[pred->conv[1]].cout != (is_cls ? 1 : 4)) return FEAR_ERR_FORMAT;
             // the prediction head rides in the epilogue of the last tower SepConv (its output never reaches HBM)
-            if (h->fuse && !h->math && h->max_batch > kDualBranchMaxBatch && !ops.empty() && ops.back().type == OP_IR16 && ops.back().out_buf == x.buf &&
+            if (h->fuse && !h->math && !small && !ops.empty() && ops.back().type == OP_IR16 && ops.back().out_buf == x.buf &&
                 ops.back().C == 256 && ops.back().N == 256 && !ops.back().corr_fused && ops.back().res_buf < 0 &&
                 h->convs[ops.back().conv_d].k == 3 && h->convs[pred->conv[0]].k == 3 && h->convs[pred->conv[0]].cout == 256 &&
                 h->convs[pred->conv[0]].stride == 1 && h->convs[pred->conv[1]].has_bias && !h->convs[pred->conv[0]].relu) {
@@ -911,7 +913,7 @@ int build_plan(fear_handle* h, int hw, bool with_head, Plan** out) {
         };
         // Small batches (one workgroup per crop leaves most CUs idle): the two branches are independent, so the bbox branch is
         // planned on buffers of its own and run_plan puts it on a second stream next to the cls branch.
-        const bool dual = h->max_batch <= kDualBranchMaxBatch;
+        const bool dual = small;
         const size_t head_first = ops.size();
         pool.hold = dual;
         int st = branch(role[FEARW_CLS_ENCODE], role[FEARW_CLS_CORR], cls_tower, role[FEARW_CLS_PRED], true);
@@ -1258,8 +1260,6 @@ int fear_set_option(fear_handle* h, int option, int64_t value) {
     switch (option) {
         case FEAR_OPT_MAX_BATCH:
             if (value < 1 || value > 65536) return FEAR_ERR_SHAPE;
-            // plans for small passes keep the head's branches on disjoint buffers (two streams): rebuild when that changes
-            if ((h->max_batch <= kDualBranchMaxBatch) != ((int)value <= kDualBranchMaxBatch)) h->plans.clear();
             h->max_batch = (int)value;
             return FEAR_OK;
         case FEAR_OPT_PROFILE:
@@ -1281,6 +1281,10 @@ int fear_set_option(fear_handle* h, int option, int64_t value) {
             if (value != 0 && value != 1) return FEAR_ERR_SHAPE;
             if (h->chain != (int)value) { h->chain = (int)value; h->plans.clear(); }
             return FEAR_OK;
+        case FEAR_OPT_SMALL_PASS:
+            if (value < 0 || value > 65536) return FEAR_ERR_SHAPE;
+            h->small_pass = (int)value;
+            return FEAR_OK;
         default: return FEAR_ERR_SHAPE;
     }
 }
@@ -1294,9 +1298,13 @@ int64_t fear_get_option(fear_handle* h, int option) {
         case FEAR_OPT_FUSE: return h->fuse;
         case FEAR_OPT_MATH: return h->math;
         case FEAR_OPT_CHAIN: return h->chain;
+        case FEAR_OPT_SMALL_PASS: return h->small_pass;
         default: return FEAR_ERR_SHAPE;
     }
 }
+
+// the plan a pass of nb crops runs on
+static bool small_pass(const fear_handle* h, int nb) { return h->fuse && nb <= h->small_pass; }
 
 int fear_features(fear_handle* h, const float* img, int n, int hw, float* out, void* stream) {
     if (!h) return FEAR_ERR_NULL;
@@ -1304,14 +1312,14 @@ int fear_features(fear_handle* h, const float* img, int n, int hw, float* out, v
     if (n == 0) return FEAR_OK;   // empty batch: nothing to read or write, null tensors are fine
     if (!img || !out) return FEAR_ERR_NULL;
     HIP_TRY(h, hipSetDevice(h->device));
-    Plan* p = nullptr;
-    int st = build_plan(h, hw, false, &p);
-    if (st != FEAR_OK) return st;
-    st = ensure_workspace(h, *p);
-    if (st != FEAR_OK) return st;
     const int fhw = (hw / 16) * (hw / 16);
     for (int b0 = 0; b0 < n; b0 += h->max_batch) {
         const int nb = n - b0 < h->max_batch ? n - b0 : h->max_batch;
+        Plan* p = nullptr;
+        int st = build_plan(h, hw, false, small_pass(h, nb), &p);
+        if (st != FEAR_OK) return st;
+        st = ensure_workspace(h, *p);
+        if (st != FEAR_OK) return st;
         Ext ext{};
         ext.img = img + (size_t)b0 * 3 * hw * hw;
         ext.feat_out = out + (size_t)b0 * h->feat_channels * fhw;
@@ -1329,14 +1337,14 @@ int fear_track(fear_handle* h, const float* search, const float* tmpl, const flo
     if (!search || !tmpl || !bbox || !cls) return FEAR_ERR_NULL;
     HIP_TRY(h, hipSetDevice(h->device));
     const int hw = 256;
-    Plan* p = nullptr;
-    int st = build_plan(h, hw, true, &p);
-    if (st != FEAR_OK) return st;
-    st = ensure_workspace(h, *p);
-    if (st != FEAR_OK) return st;
     const size_t tz = (size_t)h->feat_channels * 64;
     for (int b0 = 0; b0 < n; b0 += h->max_batch) {
         const int nb = n - b0 < h->max_batch ? n - b0 : h->max_batch;
+        Plan* p = nullptr;
+        int st = build_plan(h, hw, true, small_pass(h, nb), &p);
+        if (st != FEAR_OK) return st;
+        st = ensure_workspace(h, *p);
+        if (st != FEAR_OK) return st;
         Ext ext{};
         ext.img = search + (size_t)b0 * 3 * hw * hw;
         ext.tmpl = tmpl + (size_t)b0 * tz;
@@ -1420,7 +1428,7 @@ int fear_crop_normalize(fear_handle* h, const uint8_t* frame_u8, int frame_h, in
 int fear_plan_size(fear_handle* h, int hw, int with_head) {
     if (!h) return FEAR_ERR_NULL;
     Plan* p = nullptr;
-    int st = build_plan(h, hw, with_head != 0, &p);
+    int st = build_plan(h, hw, with_head != 0, small_pass(h, h->max_batch), &p);   // the plan a full pass (max_batch crops) runs on
     if (st != FEAR_OK) return st;
     return (int)p->ops.size();
 }
@@ -1429,7 +1437,7 @@ int fear_plan_op(fear_handle* h, int hw, int with_head, int i, char* name64, dou
                  double* bytes_per_crop) {
     if (!h) return FEAR_ERR_NULL;
     Plan* p = nullptr;
-    int st = build_plan(h, hw, with_head != 0, &p);
+    int st = build_plan(h, hw, with_head != 0, small_pass(h, h->max_batch), &p);   // the plan a full pass (max_batch crops) runs on
     if (st != FEAR_OK) return st;
     if (i < 0 || i >= (int)p->ops.size()) return FEAR_ERR_SHAPE;
     const Op& op = p->ops[i];
@@ -1442,7 +1450,7 @@ int fear_plan_op(fear_handle* h, int hw, int with_head, int i, char* name64, dou
 int fear_profile_read(fear_handle* h, int hw, int with_head, int i, double* total_ms, int64_t* launches) {
     if (!h) return FEAR_ERR_NULL;
     Plan* p = nullptr;
-    int st = build_plan(h, hw, with_head != 0, &p);
+    int st = build_plan(h, hw, with_head != 0, small_pass(h, h->max_batch), &p);   // the plan a full pass (max_batch crops) runs on
     if (st != FEAR_OK) return st;
     if (i < 0 || i >= (int)p->ops.size()) return FEAR_ERR_SHAPE;
     st = drain_events(h);

@@ -31,6 +31,7 @@ FEAR_OPT_PROFILE_OP = 3
 FEAR_OPT_FUSE = 4
 FEAR_OPT_MATH = 5
 FEAR_OPT_CHAIN = 6
+FEAR_OPT_SMALL_PASS = 7
 
 _lib = None
 
@@ -165,6 +166,10 @@ class FEARNetHIP:
     def set_chain(self, on: bool) -> None:
         """Stride-16 trunk stage + neck as one chain kernel (default, fp32 mode) vs one fused kernel per block."""
         self._check(self._lib.fear_set_option(self._h, FEAR_OPT_CHAIN, 1 if on else 0))
+
+    def set_small_pass(self, crops: int) -> None:
+        """Passes of at most `crops` crops run the small-batch plan (split-K 16x16 kernels, two-stream head); 0 = never."""
+        self._check(self._lib.fear_set_option(self._h, FEAR_OPT_SMALL_PASS, int(crops)))
 
     def set_math(self, mode: int) -> None:
         """0: exact fp32 MFMA (default); 1: fp16 hi+lo split operands on the matrix pipe, fp32 accumulate."""

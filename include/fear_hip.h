@@ -104,6 +104,9 @@ int fear_crop_normalize(fear_handle* h, const uint8_t* frame_u8, int frame_h, in
                                /*     v_mfma_f32_16x16x32_f16 on the matrix pipe, fp32 accumulate  */
 #define FEAR_OPT_CHAIN 6       /* 1 (default): stride-16 trunk stage + neck as one register-resident chain kernel */
                                /*   (fp32 mode); 0: one fused kernel per block                                 */
+#define FEAR_OPT_SMALL_PASS 7  /* passes of at most this many crops (default 96; 0 = never) run the small-batch plan:      */
+                               /*   several workgroups per crop in the 16x16 kernels (split over channel chunks, partial   */
+                               /*   sums reduced afterwards), the head's two branches on two streams                       */
 int fear_set_option(fear_handle* h, int option, int64_t value);
 int64_t fear_get_option(fear_handle* h, int option);
 

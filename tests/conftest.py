@@ -27,10 +27,16 @@ def oracle_net():
     return OracleNet(WEIGHTS)
 
 
-@pytest.fixture(scope="session")
-def hip_net():
+@pytest.fixture(scope="session", params=["throughput_plan", "small_batch_plan"])
+def hip_net(request):
+    """The engine on both of its launch plans: passes of <= FEAR_OPT_SMALL_PASS crops normally take the small-batch plan
+    (split-K 16x16 kernels, two-stream head); with the option at 0 every pass takes the throughput plan (chain kernel, fused
+    correlation / prediction epilogues) whatever its size."""
     import torch
     if not torch.cuda.is_available():
         pytest.fail("GPU test selected but no GPU is visible (the HIP path has no CPU fallback)")
     from feartracker_amd import FEARNetHIP
-    return FEARNetHIP(WEIGHTS, device=0, max_batch=64)
+    net = FEARNetHIP(WEIGHTS, device=0, max_batch=64)
+    if request.param == "throughput_plan":
+        net.set_small_pass(0)
+    return net

@@ -92,8 +92,7 @@ def test_empty_ragged_and_chunked_batches(hip_net, oracle_net):
     b1, c1 = one_pass.track_maps(x, z)
     b2, c2 = small.track_maps(x, z)
     assert torch.equal(b1, b2) and torch.equal(c1, c2)       # per-crop results do not depend on batching
-    # (handles sized for > 32 crops per pass run the throughput plan — chain kernel instead of split-K blocks: a different
-    #  fp32 summation order, not bit-identical but the same maps)
+    # (the two launch plans differ in fp32 summation order — chain kernel vs split-K blocks: not bit-identical, same maps)
     b0, c0 = hip_net.track_maps(x, z)
     assert rel_err(b2, b0) < 1e-5 and rel_err(c2, c0) < 1e-5
     assert torch.equal(small.get_features(x[:, :, :128, :128].contiguous()),
@@ -155,6 +154,7 @@ def test_full_size_batch_properties(hip_net, oracle_net):
     from feartracker_amd import FEARNetHIP
     from conftest import WEIGHTS
     net = FEARNetHIP(WEIGHTS, device=0, max_batch=256)
+    net.set_small_pass(0)        # one launch plan at every size: crop i alone must then equal crop i in the batch bit for bit
     g = torch.Generator().manual_seed(99)
     x = norm_u8(torch.randint(0, 256, (256, 3, 256, 256), dtype=torch.uint8, generator=g)).cuda()
     t = norm_u8(torch.randint(0, 256, (256, 3, 128, 128), dtype=torch.uint8, generator=g)).cuda()
@@ -164,6 +164,9 @@ def test_full_size_batch_properties(hip_net, oracle_net):
     for i in (0, 17, 255):
         bi, ci = net.track_maps(x[i:i + 1], z[i:i + 1])
         assert torch.equal(bi[0], bbox[i]) and torch.equal(ci[0], cls[i])
+    net.set_small_pass(96)       # default again: a single crop now takes the small-batch plan (another summation order)
+    b1, c1 = net.track_maps(x[17:18], z[17:18])
+    assert rel_err(b1[0], bbox[17]) < 1e-5 and rel_err(c1[0], cls[17]) < 1e-5
     sample = [3, 64, 129, 200, 254]
     ref = oracle_net.track(x[sample].cpu(), z[sample].cpu())
     assert rel_err(bbox[sample], ref["TARGET_REGRESSION_LABEL_KEY"]) < REL
@@ -291,9 +294,11 @@ def test_chain_kernel_matches_per_block_kernels(hip_net):
     block (same arithmetic, activations kept in registers between blocks)."""
     from feartracker_amd import FEARNetHIP
     from conftest import WEIGHTS
-    # (handles sized for <= 32 crops per pass use the small-batch plan instead: split-K blocks, two-stream head)
+    # (throughput plan forced: passes of <= FEAR_OPT_SMALL_PASS crops would take the small-batch plan instead)
     chained = FEARNetHIP(WEIGHTS, device=0, max_batch=64)
+    chained.set_small_pass(0)
     per_block = FEARNetHIP(WEIGHTS, device=0, max_batch=64)
+    per_block.set_small_pass(0)
     per_block.set_chain(False)
     names_chain = [n for n, _, _ in chained.plan(256, True)]
     names_blocks = [n for n, _, _ in per_block.plan(256, True)]
@@ -305,7 +310,7 @@ def test_chain_kernel_matches_per_block_kernels(hip_net):
     b0, c0 = per_block.track_maps(x, z)
     b1, c1 = chained.track_maps(x, z)
     assert rel_err(b1, b0) < 1e-5 and rel_err(c1, c0) < 1e-5
-    # the small-batch plan (max_batch <= 32): split-K blocks instead of the chain, same maps
+    # the small-batch plan (what a pass of 3 crops normally runs on): split-K blocks instead of the chain, same maps
     small = FEARNetHIP(WEIGHTS, device=0, max_batch=8)
     names_small = [n for n, _, _ in small.plan(256, True)]
     assert any("splitk" in n for n in names_small) and not any(n.startswith("chain16") for n in names_small)
@@ -380,8 +385,8 @@ def test_repeated_launches_are_bit_identical():
 
 
 def test_small_batch_plan_vs_oracle_and_clip(oracle_net, golden_dir):
-    """Handles sized for <= 32 crops per pass run the latency plan (split-K 16x16 blocks + reduce, the head's branches on
-    two streams): parity with the oracle on a seeded batch, and the tracker loop at max_batch 1 reproduces the clip."""
+    """Passes of <= FEAR_OPT_SMALL_PASS (96) crops run the small-batch plan (split-K 16x16 blocks + reduce, the head's
+    branches on two streams): parity with the oracle on a seeded batch, and the tracker loop at max_batch 1 reproduces the clip."""
     from feartracker_amd import DEFAULT_TRACKING_CONFIG, FEARNetHIP, FEARTracker
     from conftest import WEIGHTS
     net = FEARNetHIP(WEIGHTS, device=0, max_batch=8)
