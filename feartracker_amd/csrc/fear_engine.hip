@@ -102,6 +102,7 @@ struct Op {
     int pred_fused = 0;       // OP_IR16 (sep16): the prediction SepConv that consumes this layer runs in its epilogue
     float* pred_packed = nullptr;
     int pred_conv_p = -1;
+    int small_tiles = 0;      // OP_IRTILE: use kFusedTileSmall (small-batch plan)
     int splitk = 0;           // OP_IR16: > 0 = workgroups per crop (split over expansion chunks) + a reduce launch
     int part_buf = -1;        //          scratch buffer of the partial projections
     int lane = 0;             // 1: bbox branch of the head, may run on the handle's second stream (small batches)
@@ -325,6 +326,19 @@ static_assert(sizeof(kFusedTileH) == sizeof(kFusedTile), "the two tile tables mu
 const FusedTile kStemTile = {16, 16, 16, 3, 1, 0, 128, 32, 16,
                              ir_tile_v2_kernel<27, 16, 16, 3, 1, 32, 16, true, 4, true>,
                              IrT2Geom<27, 16, 16, 3, 1, 32, 16, true>::LDS_BYTES, 8};
+
+// the same blocks with smaller tiles = more workgroups per crop, for the small-batch plan (same order as kFusedTile)
+const FusedTile kFusedTileSmall[] = {
+    FTILE(16, 16, 16, 16, 3, 1, 32, 16, 0, 4, 128),
+    FTILE(16, 96, 96, 24, 3, 2, 16, 8, 1, 4, 128),
+    FTILE(24, 24, 32, 24, 3, 1, 16, 16, 0, 4, 64),
+    FTILE(24, 144, 144, 32, 5, 2, 16, 8, 1, 4, 64),    // 8 tiles per crop instead of 4
+    FTILE(32, 96, 96, 32, 5, 1, 16, 16, 1, 2, 32),
+    FTILE(32, 192, 192, 32, 5, 1, 16, 16, 1, 2, 32),   // 4 instead of 2
+    FTILE(32, 192, 192, 32, 3, 1, 16, 16, 1, 2, 32),   // 4 instead of 2
+    FTILE(32, 192, 192, 64, 5, 2, 16, 8, 1, 2, 32),    // 2 instead of 1
+};
+static_assert(sizeof(kFusedTileSmall) == sizeof(kFusedTile), "same blocks, same order");
 
 int find_fused_tile(int cin, int cexp, int cout, int ks, int st, int expand, int hw) {
     for (size_t i = 0; i < sizeof(kFusedTile) / sizeof(kFusedTile[0]); ++i) {
@@ -628,13 +642,15 @@ int build_plan(fear_handle* h, int hw, bool with_head, bool small, Plan** out) {
         const int id = find_fused_tile(cin, d.cout, p.cout, d.k, d.stride, ce >= 0 ? 1 : 0, in.H);
         if (id < 0) return false;
         const int use_h = h->math && ce >= 0;   // e1 blocks (no expand GEMM) stay on the fp32 kernel
-        const FusedTile& f = use_h ? kFusedTileH[id] : kFusedTile[id];
+        const bool small_tiles = small && !use_h;
+        const FusedTile& f = use_h ? kFusedTileH[id] : (small_tiles ? kFusedTileSmall[id] : kFusedTile[id]);
         const int ho = in.H / d.stride;
         if (ho % f.th != 0 || ho % f.tw != 0) return false;
         if (!p.has_bias) return false;
         Op op{};
         op.type = OP_IRTILE; op.fused_id = id; op.conv_e = ce; op.conv_d = cd; op.conv_p = cp;
         op.math = use_h;
+        op.small_tiles = small_tiles ? 1 : 0;
         if ((use_h ? pack_fused_h(h, ce, cd, cp, &op.d_packed) : pack_fused16(h, ce, cd, cp, &op.d_packed)) != FEAR_OK)
             return false;
         op.in_buf = in.buf; op.in_ld = in.ld; op.in_off = in.off;
@@ -998,6 +1014,9 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
         for (const FusedTile& f : kFusedTile)
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(f.kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, f.lds_bytes));
+        for (const FusedTile& f : kFusedTileSmall)
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(f.kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, f.lds_bytes));
         for (const FusedTile& f : kFusedTileH)
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(f.kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, f.lds_bytes));
@@ -1139,7 +1158,8 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
                 break;
             }
             case OP_IRTILE: {
-                const FusedTile& f = op.stem ? kStemTile : (op.math ? kFusedTileH[op.fused_id] : kFusedTile[op.fused_id]);
+                const FusedTile& f = op.stem ? kStemTile : (op.math ? kFusedTileH[op.fused_id] :
+                                                            (op.small_tiles ? kFusedTileSmall[op.fused_id] : kFusedTile[op.fused_id]));
                 IrT2Args ta{};
                 Ir2Args& a = ta.b;
                 if (op.stem) { a.X = ext.img; a.ldx = 0; }
