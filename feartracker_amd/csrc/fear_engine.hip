@@ -103,6 +103,7 @@ struct Op {
     float* pred_packed = nullptr;
     int pred_conv_p = -1;
     int small_tiles = 0;      // OP_IRTILE: use kFusedTileSmall (small-batch plan)
+    int pw_split = 0;         // OP_PW / OP_CORR: spread the output-channel passes over gridDim.y workgroups (small-batch plan)
     int splitk = 0;           // OP_IR16: > 0 = workgroups per crop (split over expansion chunks) + a reduce launch
     int part_buf = -1;        //          scratch buffer of the partial projections
     int lane = 0;             // 1: bbox branch of the head, may run on the handle's second stream (small batches)
@@ -944,6 +945,9 @@ int build_plan(fear_handle* h, int hw, bool with_head, bool small, Plan** out) {
         }
         pool.release(feat.buf);
     }
+    if (small)
+        for (Op& op : ops)
+            if (op.type == OP_PW || op.type == OP_CORR) op.pw_split = 1;
     plan->n_bufs = pool.count;
     plan->buf_floats_per_crop = (max_elems + 63) & ~(size_t)63;
     *out = plan.get();
@@ -1082,9 +1086,11 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
                 a.M = n * op.H * op.W; a.K = op.C; a.N = op.N; a.relu = op.relu;
                 if (op.out_external == 1) { a.Y = ext.feat_out; a.ldy = op.N; a.nchw_hw = op.H * op.W; }
                 else { a.Y = buf(op.out_buf) + op.out_off; a.ldy = op.out_ld; a.nchw_hw = 0; }
-                const int nt = pick_nt((op.N + 15) / 16);
+                const int n_tiles = (op.N + 15) / 16;
+                int nt = pick_nt(n_tiles);
                 const int rows_per_block = 4 * 2 * 16;
                 dim3 grid((a.M + rows_per_block - 1) / rows_per_block);
+                if (op.pw_split && n_tiles % 2 == 0) { nt = 2; grid.y = n_tiles / 2; }
                 launch_pw_nt<2, false>(nt, grid, s, a);
                 break;
             }
@@ -1098,7 +1104,9 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
                 a.rows_per_crop = op.H * op.W; a.w_crop_stride = (long)op.C * op.N;
                 const int rows_per_block = 4 * 2 * 16;
                 dim3 grid((a.M + rows_per_block - 1) / rows_per_block);
-                launch_pw_nt<2, true>(pick_nt(op.N / 16), grid, s, a);
+                int nt = pick_nt(op.N / 16);
+                if (op.pw_split) { nt = 1; grid.y = op.N / 16; }
+                launch_pw_nt<2, true>(nt, grid, s, a);
                 break;
             }
             case OP_DW: {

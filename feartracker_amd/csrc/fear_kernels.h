@@ -84,7 +84,8 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(PwArgs a) {
     }
 
     const int n_tiles = (a.N + 15) >> 4;
-    for (int nc = 0; nc < n_tiles; nc += NT) {
+    // gridDim.y > 1 (small-batch plan): the passes over the output channel tiles are dealt to different workgroups
+    for (int nc = blockIdx.y * NT; nc < n_tiles; nc += NT * gridDim.y) {
         f32x4 acc[MT][NT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
