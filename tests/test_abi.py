@@ -75,3 +75,36 @@ def test_product_package_never_imports_the_oracle():
             if fn.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, fn)).read()
                 assert "oracle" not in text.replace("no oracle", ""), f"{fn} mentions the oracle"
+
+
+@pytest.mark.gpu
+def test_error_codes_and_options_on_device():
+    """Status codes of the entry points on a live handle: empty batches are fine with null tensors, negative sizes and
+    null tensors are reported (never a crash), options round-trip and reject out-of-range values."""
+    import ctypes
+    import torch
+    from feartracker_amd import FEARNetHIP
+    from feartracker_amd import hip_backend as hb
+    from conftest import WEIGHTS
+    net = FEARNetHIP(WEIGHTS, device=0, max_batch=4)
+    lib, h = net._lib, net._h
+    OK, NULL, SHAPE = 0, -1, -2
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.fear_track(h, None, None, None, 0, None, None, st) == OK
+    assert lib.fear_track(h, None, None, None, -1, None, None, st) == SHAPE
+    assert lib.fear_track(h, None, None, None, 2, None, None, st) == NULL
+    assert lib.fear_features(h, None, 0, 128, None, st) == OK
+    assert lib.fear_features(h, None, 1, 128, None, st) == NULL
+    x = torch.zeros(1, 3, 100, 100, device="cuda")
+    out = torch.zeros(1, 256, 8, 8, device="cuda")
+    assert lib.fear_features(h, x.data_ptr(), 1, 100, out.data_ptr(), st) == SHAPE       # not a multiple of 32
+    assert lib.fear_decode(h, None, None, 0, 16, 16, 256, None, None, None, st) == OK
+    assert lib.fear_decode(h, None, None, 3, 16, 16, 256, None, None, None, st) == NULL
+    assert lib.fear_decode(h, None, None, 3, 0, 16, 256, None, None, None, st) == SHAPE
+    assert lib.fear_decode_smooth(h, None, None, 0, 16, 16, 256, None, None, 0.1, 0.3, 0.3, None, None, None, st) == OK
+    assert lib.fear_decode_smooth(h, None, None, 2, 16, 16, 256, None, None, 0.1, 0.3, 0.3, None, None, None, st) == NULL
+    for opt, good, bad in ((hb.FEAR_OPT_MAX_BATCH, 17, 0), (hb.FEAR_OPT_MATH, 1, 2), (hb.FEAR_OPT_CHAIN, 0, 5),
+                           (hb.FEAR_OPT_SMALL_PASS, 12, -1), (hb.FEAR_OPT_FUSE, 0, 3)):
+        assert lib.fear_set_option(h, opt, good) == OK and lib.fear_get_option(h, opt) == good
+        assert lib.fear_set_option(h, opt, bad) == SHAPE and lib.fear_get_option(h, opt) == good
+    assert lib.fear_set_option(h, 999, 1) == SHAPE
