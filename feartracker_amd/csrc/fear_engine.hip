@@ -303,7 +303,7 @@ const FusedTile kFusedTile[] = {
     FTILE(24, 144, 144, 32, 5, 2, 16, 16, 1, 2, 64),   // stage 6          (e6 s2, 64 -> 32)
     FTILE(32, 96, 96, 32, 5, 1, 16, 16, 1, 2, 32),     // stage 7  (4 corner tiles: 18x18 clipped region)
     FTILE(32, 192, 192, 32, 5, 1, 16, 32, 1, 2, 32),   // stage 8  (two 16x32 tiles per map: 4 rows per wave share the depthwise reads)
-    FTILE(32, 192, 192, 32, 3, 1, 32, 16, 1, 2, 32),   // stage 9
+    FTILE(32, 192, 192, 32, 3, 1, 32, 32, 1, 2, 32),   // stage 9  (the whole 32x32 map per workgroup: no halo to re-expand)
     FTILE(32, 192, 192, 64, 5, 2, 16, 16, 1, 2, 32),   // stage 10         (e6 s2, 32 -> 16: the whole 16x16 output map)
 };
 #define FTILEH(CIN, CEXP, CEXPP, COUT, KS, ST, TW, TH, EXP, NW, MINW, HW)                                             \
@@ -396,12 +396,17 @@ int pack_fused16(fear_handle* h, int ce, int cd, int cp, float** out) {
     std::vector<float> buf;
     for (int c0 = 0; c0 < cexpp; c0 += 16) {
         if (e) {
-            for (int kg = 0; kg < kg_n; ++kg)
+            for (int kg = 0; kg < kg_n; ++kg) {
+                // a last k-group of 8 channels is packed two per lane group (k = 2*(l>>4) + i, i < 2): the tile kernel then
+                // spends two MFMA steps on it instead of four (IrT2Geom::KHALF)
+                const bool khalf = cin % 16 == 8 && kg == kg_n - 1;
                 for (int l = 0; l < 64; ++l)
                     for (int i = 0; i < 4; ++i) {
-                        const int n = c0 + (l & 15), k = kg * 16 + (l >> 4) * 4 + i;
+                        const int n = c0 + (l & 15);
+                        const int k = khalf ? (i < 2 ? kg * 16 + (l >> 4) * 2 + i : cin) : kg * 16 + (l >> 4) * 4 + i;
                         buf.push_back(n < cexp && k < cin ? e->w[(size_t)n * cin + k] : 0.f);
                     }
+            }
             for (int ch = 0; ch < 16; ++ch) buf.push_back(e->has_bias && c0 + ch < cexp ? e->b[c0 + ch] : 0.f);
         }
         for (int nt = 0; nt < ntp; ++nt)

@@ -157,34 +157,38 @@ static void bench(const char* tag, int crops, int iters) {
 int main(int argc, char** argv) {
     const int crops = argc > 1 ? atoi(argv[1]) : 256;
     const int iters = argc > 2 ? atoi(argv[2]) : 20;
+    const bool all = argc > 3;      // any third argument: also the tile-shape sweep and the 16x16 kernels
     printf("FEAR_ABL=%d\n", FEAR_ABL);
+    // the product's tile table (fear_engine.hip kFusedTile), in plan order
+    bench_stem(crops, iters);
+    bench_tile<16, 96, 24, 3, 2, 16, 8, true, 4>("s2  irt_16x96x24_k3s2_hw128", crops, iters, 128);
+    bench_tile<24, 32, 24, 3, 1, 16, 16, false, 4>("s45 irt_24x24x24_k3 e1 16x16", crops, iters, 64);
+    bench_tile<24, 144, 32, 5, 2, 16, 16, true, 2>("s6  irt_24x144x32_k5s2 16x16", crops, iters, 64);
+    bench_tile<32, 96, 32, 5, 1, 16, 16, true, 2>("s7  irt_32x96x32_k5 16x16", crops, iters, 32);
+    bench_tile<32, 192, 32, 5, 1, 16, 32, true, 2>("s8  irt_32x192x32_k5 16x32", crops, iters, 32);
+    bench_tile<32, 192, 32, 3, 1, 32, 32, true, 2>("s9  irt_32x192x32_k3 32x32", crops, iters, 32);
+    bench_tile<32, 192, 64, 5, 2, 16, 16, true, 2>("s10 irt_32x192x64_k5s2 16x16", crops, iters, 32);
+    if (!all) return 0;
     bench<112, 672, 112, 5, true>("ir16_112x672x112_k5", crops, iters);
     bench<64, 384, 64, 5, true>("ir16_64x384x64_k5", crops, iters);
-    bench_stem(crops, iters);
-    bench_tile<16, 96, 24, 3, 2, 16, 8, true, 4>("irt_16x96x24_k3s2_hw128", crops, iters, 128);
-    bench_tile<24, 144, 32, 5, 2, 16, 8, true, 4>("irt_24x144x32_k5s2_hw64", crops, iters, 64);
-    bench_tile<24, 32, 24, 3, 1, 16, 16, false, 4>("irt_24x24x24_k3 e1 16x16", crops, iters, 64);
+    bench_tile<24, 144, 32, 5, 2, 16, 8, true, 4>("irt_24x144x32_k5s2 16x8", crops, iters, 64);
     bench_tile<24, 32, 24, 3, 1, 32, 16, false, 4>("irt_24x24x24_k3 e1 32x16", crops, iters, 64);
     bench_tile<24, 32, 24, 3, 1, 16, 32, false, 4>("irt_24x24x24_k3 e1 16x32", crops, iters, 64);
     bench_tile<24, 32, 24, 3, 1, 32, 32, false, 4>("irt_24x24x24_k3 e1 32x32", crops, iters, 64);
     bench_tile<24, 32, 24, 3, 1, 16, 8, false, 4>("irt_24x24x24_k3 e1 16x8", crops, iters, 64);
-    bench_tile<32, 192, 32, 5, 1, 16, 16, true, 2>("irt_32x192x32_k5s1_hw32", crops, iters, 32);
-    bench_tile<32, 192, 32, 5, 1, 16, 32, true, 2>("irt_32x192x32_k5 16x32", crops, iters, 32);
+    bench_tile<32, 192, 32, 5, 1, 16, 16, true, 2>("irt_32x192x32_k5 16x16", crops, iters, 32);
     bench_tile<32, 192, 32, 5, 1, 32, 16, true, 2>("irt_32x192x32_k5 32x16", crops, iters, 32);
-    bench_tile<32, 192, 32, 3, 1, 32, 16, true, 2>("irt_32x192x32_k3 32x16", crops, iters, 32);
+    bench_tile<32, 192, 32, 5, 1, 32, 32, true, 2>("irt_32x192x32_k5 32x32", crops, iters, 32);
     bench_tile<32, 192, 32, 3, 1, 16, 32, true, 2>("irt_32x192x32_k3 16x32", crops, iters, 32);
     bench_tile<32, 192, 32, 3, 1, 16, 16, true, 2>("irt_32x192x32_k3 16x16", crops, iters, 32);
+    bench_tile<32, 192, 32, 3, 1, 32, 16, true, 2>("irt_32x192x32_k3 32x16", crops, iters, 32);
     bench_tile<32, 192, 64, 5, 2, 16, 8, true, 2>("irt_32x192x64_k5s2 16x8", crops, iters, 32);
-    bench_tile<32, 192, 64, 5, 2, 16, 16, true, 2>("irt_32x192x64_k5s2 16x16", crops, iters, 32);
-    bench_tile<24, 144, 32, 5, 2, 16, 16, true, 2>("irt_24x144x32_k5s2 16x16", crops, iters, 64);
     bench_tile<24, 144, 32, 5, 2, 32, 8, true, 2>("irt_24x144x32_k5s2 32x8", crops, iters, 64);
-    bench_tile<24, 144, 32, 5, 2, 32, 16, true, 2>("irt_24x144x32_k5s2 32x16", crops, iters, 64);
     bench_tile<16, 96, 24, 3, 2, 16, 16, true, 2>("irt_16x96x24_k3s2 16x16", crops, iters, 128);
     bench_tile<16, 96, 24, 3, 2, 32, 8, true, 2>("irt_16x96x24_k3s2 32x8", crops, iters, 128);
-    bench_tile<16, 96, 24, 3, 2, 32, 16, true, 2>("irt_16x96x24_k3s2 32x16", crops, iters, 128);
-    bench_tile<32, 96, 32, 5, 1, 16, 16, true, 2>("irt_32x96x32_k5 16x16", crops, iters, 32);
+    bench_tile<16, 96, 24, 3, 2, 32, 8, true, 4>("irt_16x96x24_k3s2 32x8 w4", crops, iters, 128);
     bench_tile<32, 96, 32, 5, 1, 16, 32, true, 2>("irt_32x96x32_k5 16x32", crops, iters, 32);
-    bench_tile<32, 192, 64, 5, 2, 16, 16, true, 2>("irt_32x192x64_k5s2 16x16", crops, iters, 32);
+    bench_tile<32, 96, 32, 5, 1, 32, 32, true, 2>("irt_32x96x32_k5 32x32", crops, iters, 32);
     bench_sep<256, 256, 3>("sep16_256x256_k3", crops, iters);
     bench_sep<320, 256, 3>("sep16_320x256_k3", crops, iters);
     return 0;
