@@ -18,7 +18,14 @@ Prints ONE JSON line (rank 0).  Extra objects:
   roofline     dominant kernel (largest share of device time): algorithmic FLOPs or bytes per launch /
                its average launch duration, measured with HIP events recorded around that kernel on the
                launch stream inside the timed region.
-  cpu_baseline the CPU oracle (torch fp32, all host cores) timed on a bounded sample of the same workload.
+  cpu_baseline the CPU oracle (torch fp32, best thread count on the host) timed on a bounded sample of the same workload,
+               with the B=1 and B=32 legs of BASELINE.md §3.2 and the host's lscpu model string.
+  latency_batch1  BASELINE configs[0] stand-in: the drop-in tracker's update() at batch 1 on the 480x256 demo-geometry clip
+               (no H.264 decoder exists on the box, profiles/r02_box_probe.txt), ms/frame for the reference-style host crop
+               path and for device crop + device post-processing, the CPU-oracle tracker beside it, boxes compared.
+
+`python bench.py --gpus N` with N > 1 and no torch.distributed environment re-executes itself under
+torch.distributed.run (one rank per GPU, 127.0.0.1 rendezvous); the driver's explicit torchrun launch works as before.
 """
 from __future__ import annotations
 
@@ -48,36 +55,128 @@ def norm_u8(u8_nchw: torch.Tensor) -> torch.Tensor:
 
 
 def synth_batch(batch: int, rank: int):
-    """Seeded synthetic crops; every rank draws its own slice of one global stream (seed 0)."""
-    g = torch.Generator().manual_seed(1000 + rank)
-    search = torch.randint(0, 256, (batch, 3, 256, 256), dtype=torch.uint8, generator=g)
-    tmpl = torch.randint(0, 256, (batch, 3, 128, 128), dtype=torch.uint8, generator=g)
+    """Seeded synthetic crops: ONE generator stream, seed 0, sliced by rank — rank r owns the r-th block of
+    (search crops, template crops) of that stream, so the N-GPU global batch is the concatenation of the blocks."""
+    g = torch.Generator().manual_seed(0)
+    for _ in range(rank + 1):
+        search = torch.randint(0, 256, (batch, 3, 256, 256), dtype=torch.uint8, generator=g)
+        tmpl = torch.randint(0, 256, (batch, 3, 128, 128), dtype=torch.uint8, generator=g)
     return search, tmpl
 
 
-def cpu_baseline(search_u8, tmpl_u8, weights, budget_s: float = 15.0):
-    """Oracle (kind='port') on the host cores, bounded sample: batches of 8 crops until ~budget_s."""
+def _lscpu_model() -> str:
+    try:
+        import subprocess
+        for line in subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout.splitlines():
+            if line.startswith("Model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(search_u8, tmpl_u8, weights, budget_s: float = 10.0):
+    """Oracle (kind='port') on the host cores, bounded sample: batches of 8 crops for ~budget_s (the headline CPU number),
+    plus the two legs BASELINE.md §3.2 names — B=1 (20 warm-up + up to 100 timed calls) and B=32 — each bounded to a few
+    seconds so that the default bench run stays within minutes."""
     from oracle.fear_oracle import OracleNet  # checker/baseline only, never on the product path
     # torch/oneDNN fp32 conv throughput on this graph peaks at ~16 threads on the 2x64-core EPYC host
     # (tools/cpu_sweep.py: 16 thr 93 crops/s, 32 thr 85, 64 thr 42, 128 thr 15); use the best setting.
     cores = min(16, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     net = OracleNet(weights)
-    bs = 8
-    x = norm_u8(search_u8[:bs])
-    z = net.get_features(norm_u8(tmpl_u8[:bs]))
-    net.track(x, z)  # warm-up
-    t0 = time.perf_counter()
-    crops = 0
-    while True:
-        net.track(x, z)
-        crops += bs
-        dt = time.perf_counter() - t0
-        if dt > budget_s or crops >= 4096:
-            break
-    return {"value": crops / dt, "unit": "crops/s", "cores": torch.get_num_threads(), "kind": "port",
-            "host_cpus": os.cpu_count(),
-            "sample": f"{crops} crops (batches of {bs}) of the same synthetic 256x256 workload, torch fp32 oracle, {dt:.1f}s"}
+
+    def leg(bs, warm, max_iters, budget):
+        x = norm_u8(search_u8[:bs])
+        z = net.get_features(norm_u8(tmpl_u8[:bs]))
+        for _ in range(warm):
+            net.track(x, z)
+        t0 = time.perf_counter()
+        it = 0
+        while True:
+            net.track(x, z)
+            it += 1
+            dt = time.perf_counter() - t0
+            if dt > budget or it >= max_iters:
+                return it * bs / dt, it, dt
+
+    v8, it8, dt8 = leg(8, 1, 512, budget_s)
+    v1, it1, dt1 = leg(1, 20, 100, 5.0)
+    v32, it32, dt32 = leg(32, 1, 20, 6.0)
+    return {"value": v8, "unit": "crops/s", "cores": torch.get_num_threads(), "kind": "port",
+            "host_cpus": os.cpu_count(), "cpu_model": _lscpu_model(),
+            "sample": f"{it8 * 8} crops (batches of 8) of the same synthetic 256x256 workload, torch fp32 oracle, {dt8:.1f}s",
+            "batch1": {"value": v1, "unit": "crops/s", "ms_per_crop": 1e3 / v1, "iters": it1,
+                       "protocol": "20 warm-up + <=100 timed calls (README.md:43, Benchmark.swift:55-77)"},
+            "batch32": {"value": v32, "unit": "crops/s", "iters": it32, "seconds": dt32}}
+
+
+def latency_batch1(weights, frames_cap: int = 120):
+    """BASELINE configs[0] / SURVEY §8d config 1 at batch 1: `initialize` + `update` per frame through the drop-in tracker on
+    the 480x256 demo-geometry clip (tests/clipgen.py: the init box of demo_video.py:45-46; assets/test.mp4 itself cannot be
+    decoded on this box).  Host-crop path (what the reference config runs), device crop + device post-processing
+    (fear_crop_normalize + fear_track + fear_decode), and the CPU-oracle tracker on the same frames."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from clipgen import DEMO_INIT_BBOX, demo_clip
+    from feartracker_amd import DEFAULT_TRACKING_CONFIG, FEARNetHIP, FEARTracker
+    from feartracker_amd import geometry as geo
+    frames, _ = demo_clip(frames_cap)
+    init = np.array(DEMO_INIT_BBOX)
+    net = FEARNetHIP(weights, device=torch.cuda.current_device(), max_batch=1)
+
+    def loop(trk, sync, split):
+        t = dict(crop=0.0, pre_h2d=0.0, net=0.0, post=0.0, total=0.0)
+        boxes = []
+        for rep in range(2):                          # first pass = warm-up
+            trk.initialize(frames[0], init.copy())
+            cfg, st = trk.tracking_config, trk.tracking_state
+            for f in frames[1:]:
+                t0 = time.perf_counter()
+                if split:
+                    crop, box_in_crop, ctx = geo.get_extended_crop(f, st.bbox, cfg["instance_size"], cfg["search_context"],
+                                                                   padding_value=st.mean_color)
+                    st.mapping, st.prev_size = ctx, box_in_crop[2:]
+                    t1 = time.perf_counter()
+                    x = trk._preprocess_image(crop, trk._search_transform)
+                    sync()
+                    t2 = time.perf_counter()
+                    out = trk.net.track(x, trk._template_features)
+                    sync()
+                    t3 = time.perf_counter()
+                    pred, _ = trk._postprocess(out)
+                    pred = geo.clamp_bbox(trk._rescale_bbox(pred, st.mapping), f.shape)
+                    st.bbox = pred
+                    st.paths.append(pred)
+                    t4 = time.perf_counter()
+                    if rep:
+                        t["crop"] += t1 - t0; t["pre_h2d"] += t2 - t1; t["net"] += t3 - t2; t["post"] += t4 - t3
+                else:
+                    pred = trk.update(f)["bbox"]
+                    sync()
+                    t4 = time.perf_counter()
+                if rep:
+                    t["total"] += t4 - t0
+                    boxes.append(np.array(pred))
+        n = len(frames) - 1
+        return {k: 1e3 * v / n for k, v in t.items() if v > 0}, np.stack(boxes)
+
+    sync = torch.cuda.synchronize
+    host_ms, host_boxes = loop(FEARTracker(net, cuda_id=torch.cuda.current_device(), **DEFAULT_TRACKING_CONFIG), sync, True)
+    dev_ms, dev_boxes = loop(FEARTracker(net, cuda_id=torch.cuda.current_device(),
+                                         **dict(DEFAULT_TRACKING_CONFIG, device_crop=True, device_postprocess=True)), sync, False)
+    from oracle.fear_oracle import OracleNet  # CPU baseline leg only
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    ncpu = min(len(frames), 41)
+    frames_all, frames = frames, frames[:ncpu]
+    cpu_ms, cpu_boxes = loop(FEARTracker(OracleNet(weights), cuda_id="cpu", **DEFAULT_TRACKING_CONFIG), lambda: None, True)
+    frames = frames_all
+    return {"unit": "ms/frame", "frames": len(frames) - 1, "frame_shape": list(frames[0].shape), "clip": "tests/clipgen.demo_clip "
+            "(480x256, init box [163,53,45,174]; assets/test.mp4 not decodable here: no H.264 decoder)",
+            "host_crop_path": host_ms, "device_crop_and_postprocess": dev_ms,
+            "device_boxes_identical_to_host_path": bool(np.array_equal(dev_boxes, host_boxes)),
+            "cpu_oracle_tracker": dict(cpu_ms, frames=ncpu - 1, threads=torch.get_num_threads()),
+            "boxes_identical_to_cpu_oracle": bool(np.array_equal(host_boxes[:ncpu - 1], cpu_boxes))}
 
 
 def pmc_traffic(op_name: str):
@@ -96,9 +195,9 @@ def pmc_traffic(op_name: str):
                     sym = r["kernel"]
                     break
         t = json.load(open(traffic))
-        return t[sym]["traffic_bytes_per_launch"] if sym in t else None
+        return (t[sym]["traffic_bytes_per_launch"], os.path.relpath(traffic, ROOT)) if sym in t else (None, None)
     except Exception:
-        return None
+        return None, None
 
 
 @contextlib.contextmanager
@@ -133,14 +232,28 @@ def main() -> None:
     ap.add_argument("--no-other-math", action="store_true",
                     help="skip the supplementary run in the other arithmetic mode (profiling runs: keeps the trace to one plan)")
     ap.add_argument("--dump-ops", action="store_true", help="print the per-kernel time table to stderr")
+    ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 tracker latency object")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become N ranks (one per GPU) under torch.distributed.run on this node
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus} needs {args.gpus} GPUs on this node, {have} visible")
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback on the product path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
@@ -159,7 +272,7 @@ def main() -> None:
             torch.cuda.synchronize()
 
     from feartracker_amd import FEARNetHIP, DEFAULT_WEIGHTS
-    from feartracker_amd.sharding import gather_maps
+    from feartracker_amd.sharding import gather_packed
 
     B = args.batch
     net = FEARNetHIP(DEFAULT_WEIGHTS, device=local_rank, max_batch=args.max_batch)
@@ -170,15 +283,17 @@ def main() -> None:
     search = norm_u8(search_u8.to(dev)).contiguous()
     tmpl_feats = net.get_features(norm_u8(tmpl_u8.to(dev)).contiguous())
     packed = torch.empty((B, 5, 16, 16), dtype=torch.float32, device=dev)
-    bbox_v, cls_v = packed[:, :4], packed[:, 4:]   # views are not contiguous per tensor -> use own outputs
     bbox = torch.empty((B, 4, 16, 16), dtype=torch.float32, device=dev)
     cls = torch.empty((B, 1, 16, 16), dtype=torch.float32, device=dev)
     gathered = torch.empty((world * B, 5, 16, 16), dtype=torch.float32, device=dev) if use_dist else None
 
     def step():
-        net.track_maps(search, tmpl_feats, out=(bbox, cls))
         if use_dist:
-            gather_maps(bbox, cls, packed, gathered)
+            # the engine writes (bbox | cls) straight into the packed send buffer: the step is its kernels + ONE collective
+            net.track_packed(search, tmpl_feats, out=packed)
+            gather_packed(packed, gathered)
+        else:
+            net.track_maps(search, tmpl_feats, out=(bbox, cls))
 
     def barrier():
         if use_dist:
@@ -232,10 +347,18 @@ def main() -> None:
     dom_ms = sum(reads[i][0] for i in dom_ops)
     dom_cnt = sum(reads[i][1] for i in dom_ops)
 
+    gather_ms = None
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # the collective alone (outside the timed region): K all-gathers of the packed maps, barrier-bracketed
+        barrier()
+        tg = time.perf_counter()
+        for _ in range(args.steps):
+            gather_packed(packed, gathered)
+        barrier()
+        gather_ms = 1e3 * (time.perf_counter() - tg) / args.steps
 
     # the same K steps in the other arithmetic mode (supplementary number, same protocol)
     other = 1 - args.math
@@ -274,7 +397,11 @@ def main() -> None:
             achieved = by * crops_per_launch / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": achieved / PEAK_HBM_GBS}
-        roof.update({"traffic": pmc_traffic(name), "kernel": name, "avg_launch_ms": avg_ms, "launches": dom_cnt,
+        traffic, traffic_file = pmc_traffic(name)
+        roof.update({"traffic": traffic, "traffic_source": (f"offline PMC: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                                            f"command, committed as {traffic_file} (not measured in this run)")
+                                                           if traffic is not None else None,
+                     "kernel": name, "avg_launch_ms": avg_ms, "launches": dom_cnt,
                      "launches_per_step": len(dom_ops) * max(1, -(-B // args.max_batch)),
                      "share_of_step": group_time[dom_name] / max(sum(op_time), 1e-12),
                      "whole_path_tflops": value * FLOPS_PER_CROP / 1e12 / world,
@@ -308,8 +435,15 @@ def main() -> None:
                          "fp32 MFMA (exact fp32)"),
                 "value": world * B * args.steps / elapsed_other, "unit": "crops/s",
                 "ms_per_step": 1e3 * elapsed_other / args.steps}
+        if use_dist:
+            out["collective"] = {"backend": "nccl (RCCL)", "ranks": world, "op": "all_gather_into_tensor",
+                                 "bytes_per_rank": B * 5 * 16 * 16 * 4, "ms_alone": gather_ms}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(search_u8, tmpl_u8, DEFAULT_WEIGHTS)
+        if not args.no_latency and world == 1 and not use_dist:
+            del net, search, tmpl_feats
+            torch.cuda.empty_cache()
+            out["latency_batch1"] = latency_batch1(DEFAULT_WEIGHTS)
         print(json.dumps(out))
     if use_dist:
         dist.barrier()

@@ -131,6 +131,7 @@ struct Op {
 struct Plan {
     int hw = 0;
     bool with_head = false;
+    bool small = false;
     std::vector<Op> ops;
     int head_first = -1;             // index of the first head op when the two branches were planned on disjoint buffers
     int n_bufs = 0;
@@ -158,7 +159,13 @@ struct fear_handle {
     std::map<std::pair<int, int>, std::unique_ptr<Plan>> plans;
     float* workspace = nullptr;
     size_t workspace_floats = 0;
-    std::vector<float*> weight_allocs;
+    std::vector<float*> weight_allocs;    // per-conv weights: live as long as the handle
+    std::vector<float*> plan_allocs;      // weights packed for the fused kernels of the cached plans: freed with the plans
+    bool building_plan = false;           // upload() books into plan_allocs while a plan is being built
+    int plan_crops = 0;                   // FEAR_OPT_PLAN_CROPS: crop count whose plan the introspection calls describe (0: max_batch)
+    hipStream_t last_stream = nullptr;    // the caller stream of the previous call: a call on another stream first waits for it
+    bool last_stream_valid = false;       // (the workspace and the branch stream are shared by all calls on a handle)
+    hipEvent_t stream_switch = nullptr;
     std::vector<hipEvent_t> event_pool;   // recycled profiling events (creation is slow enough to perturb timing)
     hipStream_t branch_stream = nullptr;  // second stream for the bbox branch of the head at small batch sizes
     hipEvent_t branch_fork = nullptr, branch_join = nullptr;
@@ -180,7 +187,7 @@ int upload(fear_handle* h, const std::vector<float>& host, float** dev) {
     if (host.empty()) return FEAR_OK;
     float* p = nullptr;
     if (hipMalloc(&p, host.size() * sizeof(float)) != hipSuccess) return FEAR_ERR_ALLOC;
-    h->weight_allocs.push_back(p);
+    (h->building_plan ? h->plan_allocs : h->weight_allocs).push_back(p);
     HIP_TRY(h, hipMemcpy(p, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
     *dev = p;
     return FEAR_OK;
@@ -194,7 +201,7 @@ int parse_model(fear_handle* h, const uint8_t* blob, size_t nbytes) {
         return FEAR_ERR_FORMAT;
     const size_t tables = sizeof(FearwHeader) + (size_t)hd.n_convs * sizeof(FearwConv) +
                           (size_t)hd.n_blocks * sizeof(FearwBlock);
-    if (nbytes < tables + hd.payload_bytes) return FEAR_ERR_FORMAT;
+    if (tables > nbytes || hd.payload_bytes > nbytes - tables) return FEAR_ERR_FORMAT;
     const uint8_t* payload = blob + tables;
     const FearwConv* ct = reinterpret_cast<const FearwConv*>(blob + sizeof(FearwHeader));
     const FearwBlock* bt = reinterpret_cast<const FearwBlock*>(blob + sizeof(FearwHeader) +
@@ -206,14 +213,18 @@ int parse_model(fear_handle* h, const uint8_t* blob, size_t nbytes) {
         Conv& c = h->convs[i];
         c.cout = fc.cout; c.cin_g = fc.cin_per_group; c.groups = fc.groups; c.k = fc.k;
         c.stride = fc.stride; c.pad = fc.pad; c.relu = fc.relu; c.has_bias = fc.has_bias;
+        // bounded dimensions first, so that the products below cannot wrap and a malformed blob cannot ask for a huge allocation
+        if (c.cout < 1 || c.cout > 8192 || c.cin_g < 1 || c.cin_g > 8192 || c.groups < 1 || c.groups > 8192 ||
+            (c.k != 1 && c.k != 3 && c.k != 5))
+            return FEAR_ERR_FORMAT;
         const size_t nw = (size_t)c.cout * c.cin_g * c.k * c.k;
-        if (fc.w_off + nw * 2 > hd.payload_bytes) return FEAR_ERR_FORMAT;
+        if (fc.w_off > hd.payload_bytes || nw * 2 > hd.payload_bytes - fc.w_off) return FEAR_ERR_FORMAT;
         if (c.pad != c.k / 2 || (c.stride != 1 && c.stride != 2)) return FEAR_ERR_FORMAT;
         c.w.resize(nw);
         const uint16_t* src = reinterpret_cast<const uint16_t*>(payload + fc.w_off);
         for (size_t j = 0; j < nw; ++j) c.w[j] = half_to_float(src[j]);
         if (c.has_bias) {
-            if (fc.b_off + (size_t)c.cout * 2 > hd.payload_bytes) return FEAR_ERR_FORMAT;
+            if (fc.b_off > hd.payload_bytes || (size_t)c.cout * 2 > hd.payload_bytes - fc.b_off) return FEAR_ERR_FORMAT;
             c.b.resize(c.cout);
             const uint16_t* bs = reinterpret_cast<const uint16_t*>(payload + fc.b_off);
             for (int j = 0; j < c.cout; ++j) c.b[j] = half_to_float(bs[j]);
@@ -222,10 +233,17 @@ int parse_model(fear_handle* h, const uint8_t* blob, size_t nbytes) {
     h->blocks.resize(hd.n_blocks);
     for (uint32_t i = 0; i < hd.n_blocks; ++i) {
         memcpy(&h->blocks[i], bt + i, sizeof(FearwBlock));
+        const FearwBlock& b = h->blocks[i];
         for (int j = 0; j < 3; ++j)
-            if (h->blocks[i].conv[j] >= (int)hd.n_convs) return FEAR_ERR_FORMAT;
-        if (h->blocks[i].kind == FEARW_SEP) h->has_head = true;
-        if (h->blocks[i].kind == FEARW_NECK) h->feat_channels = h->convs[h->blocks[i].conv[0]].cout;
+            if (b.conv[j] < -1 || b.conv[j] >= (int)hd.n_convs) return FEAR_ERR_FORMAT;
+        // mandatory conv slots per block kind: stem / neck conv[0]; IR depthwise + project (expand optional); SepConv dw + pw
+        const bool ok = b.kind == FEARW_STEM || b.kind == FEARW_NECK ? b.conv[0] >= 0
+                      : b.kind == FEARW_IR                           ? b.conv[1] >= 0 && b.conv[2] >= 0
+                      : b.kind == FEARW_SEP                          ? b.conv[0] >= 0 && b.conv[1] >= 0
+                                                                     : false;
+        if (!ok) return FEAR_ERR_FORMAT;
+        if (b.kind == FEARW_SEP) h->has_head = true;
+        if (b.kind == FEARW_NECK) h->feat_channels = h->convs[b.conv[0]].cout;
     }
     if (h->blocks.empty() || h->blocks[0].kind != FEARW_STEM || h->feat_channels == 0) return FEAR_ERR_FORMAT;
     return FEAR_OK;
@@ -518,15 +536,30 @@ struct T {  // tensor view inside the plan
 void set_name(Op& op, const char* fmt, int a, int b, int c) { snprintf(op.name, sizeof(op.name), fmt, a, b, c); }
 
 // small = the small-batch plan (few crops per pass): split-K 16x16 kernels, the head's branches on two streams
-int build_plan(fear_handle* h, int hw, bool with_head, bool small, Plan** out) {
-    auto key = std::make_pair(hw, (with_head ? 1 : 0) + (small ? 2 : 0));
-    auto it = h->plans.find(key);
+int build_plan_uncached(fear_handle* h, int hw, bool with_head, int mode, Plan** out);
+
+// mode: 0 = throughput plan, 1 = small-batch plan, 2 = the small-batch plan with the deepest split (a handful of crops)
+int build_plan(fear_handle* h, int hw, bool with_head, int mode, Plan** out) {
+    auto it = h->plans.find(std::make_pair(hw, (with_head ? 1 : 0) + 2 * mode));
     if (it != h->plans.end()) { *out = it->second.get(); return FEAR_OK; }
+    h->building_plan = true;          // packed weights uploaded from here on belong to the plan cache
+    const int st = build_plan_uncached(h, hw, with_head, mode, out);
+    h->building_plan = false;
+    return st;
+}
+
+int build_plan_uncached(fear_handle* h, int hw, bool with_head, int mode, Plan** out) {
+    const bool small = mode != 0;
+    // chunks of a 16x16 block are dealt to at most this many workgroups per crop: every workgroup writes a full partial
+    // output map, so a deep split only pays while the crops are few (batch 1: 0.545 -> 0.512 ms per track call)
+    const int splitk_max = mode == 2 ? 24 : 8;
+    auto key = std::make_pair(hw, (with_head ? 1 : 0) + 2 * mode);
     if (hw < 32 || hw % 32 != 0 || hw > 1024) return FEAR_ERR_SHAPE;
     if (with_head && !h->has_head) return FEAR_ERR_NOHEAD;
     std::unique_ptr<Plan> plan(new Plan);
     plan->hw = hw;
     plan->with_head = with_head;
+    plan->small = small;
     Pool pool;
     size_t max_elems = 0;
     auto track = [&](const T& t) {
@@ -599,7 +632,7 @@ int build_plan(fear_handle* h, int hw, bool with_head, bool small, Plan** out) {
             if (kFused16[id].splitk_kc > 0) {
                 w = nchunk / kFused16[id].splitk_kc;              // the variant's chunk count per workgroup is compiled in
             } else {
-                for (int cand = 8; cand >= 2 && !w; --cand)
+                for (int cand = splitk_max; cand >= 2 && !w; --cand)
                     if (nchunk % cand == 0 && nchunk / cand >= 2) w = cand;
             }
             if (w) {
@@ -960,8 +993,13 @@ int build_plan(fear_handle* h, int hw, bool with_head, bool small, Plan** out) {
     return FEAR_OK;
 }
 
+// crops a pass of this plan can hold: the small-batch plan never sees more than FEAR_OPT_SMALL_PASS crops
+size_t pass_cap(const fear_handle* h, const Plan& p) {
+    return p.small && h->small_pass > 0 && h->small_pass < h->max_batch ? (size_t)h->small_pass : (size_t)h->max_batch;
+}
+
 int ensure_workspace(fear_handle* h, const Plan& p) {
-    const size_t need = (size_t)p.n_bufs * p.buf_floats_per_crop * h->max_batch;
+    const size_t need = (size_t)p.n_bufs * p.buf_floats_per_crop * pass_cap(h, p);
     if (need <= h->workspace_floats) return FEAR_OK;
     if (h->workspace) {
         HIP_TRY(h, hipDeviceSynchronize());
@@ -1006,6 +1044,7 @@ struct Ext {
     float* feat_out;
     float* bbox_out;
     float* cls_out;
+    long bbox_stride = 4 * 256, cls_stride = 256;   // floats between consecutive crops' maps (fear_track_packed: 5 * 256 both)
 };
 
 int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main) {
@@ -1039,7 +1078,15 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kStemTile.lds_bytes));
         h->fused_attr_set = true;
     }
-    const size_t slab = p.buf_floats_per_crop * h->max_batch;
+    // one workspace per handle: a call on another stream than the previous one must not overtake it
+    if (h->last_stream_valid && h->last_stream != s_main) {
+        if (!h->stream_switch) HIP_TRY(h, hipEventCreateWithFlags(&h->stream_switch, hipEventDisableTiming));
+        HIP_TRY(h, hipEventRecord(h->stream_switch, h->last_stream));
+        HIP_TRY(h, hipStreamWaitEvent(s_main, h->stream_switch, 0));
+    }
+    h->last_stream = s_main;
+    h->last_stream_valid = true;
+    const size_t slab = p.buf_floats_per_crop * pass_cap(h, p);
     auto buf = [&](int id) -> float* { return h->workspace + (size_t)id * slab; };
     // head branches on two streams (plans built for small passes only; per-op profiling keeps everything on one stream)
     const bool dual = p.head_first >= 0 && !h->profile;
@@ -1141,9 +1188,11 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
                     a.pred_cout = op.pred_cout; a.pred_act = op.act;
                     a.P_Wpk = op.pred_packed; a.P_bp = h->convs[op.pred_conv_p].d_b;
                     a.P_Y = op.out_external == 3 ? ext.cls_out : ext.bbox_out;
+                    a.pred_stride = op.out_external == 3 ? ext.cls_stride : ext.bbox_stride;
                 } else if (op.pred_cout > 0) {
                     a.pred_cout = op.pred_cout; a.pred_act = op.act;
                     a.Y = op.out_external == 3 ? ext.cls_out : ext.bbox_out;
+                    a.pred_stride = op.out_external == 3 ? ext.cls_stride : ext.bbox_stride;
                 }
                 if (op.splitk) {
                     // several workgroups per crop, each over its own chunk range -> partial projections -> reduce
@@ -1199,6 +1248,7 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
                 a.X = buf(op.in_buf); a.ldx = op.in_ld; a.W = c->d_w; a.bias = c->d_b;
                 a.Y = op.out_external == 3 ? ext.cls_out : ext.bbox_out;
                 a.M = n * op.H * op.W; a.K = op.C; a.N = op.N; a.hw = op.H * op.W; a.act = op.act;
+                a.crop_stride = op.out_external == 3 ? ext.cls_stride : ext.bbox_stride;
                 dim3 grid(((long)a.M * 16 + 255) / 256);
                 if (op.N == 1) hipLaunchKernelGGL((pw_small_kernel<1>), grid, dim3(256), 0, s, a);
                 else hipLaunchKernelGGL((pw_small_kernel<4>), grid, dim3(256), 0, s, a);
@@ -1232,6 +1282,20 @@ int drain_events(fear_handle* h) {
             }
             op.events.clear();
         }
+    return FEAR_OK;
+}
+
+// Forget every cached plan (an option that shapes the plans changed): finish outstanding work, fold and recycle the
+// profiling events the ops still own, free the weights that were packed for those plans.
+int drop_plans(fear_handle* h) {
+    if (h->plans.empty() && h->plan_allocs.empty()) return FEAR_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    const int st = drain_events(h);
+    if (st != FEAR_OK) return st;
+    h->plans.clear();
+    for (float* p : h->plan_allocs) hipFree(p);
+    h->plan_allocs.clear();
     return FEAR_OK;
 }
 
@@ -1282,7 +1346,9 @@ int fear_destroy(fear_handle* h) {
     if (h->branch_stream) hipStreamDestroy(h->branch_stream);
     if (h->branch_fork) hipEventDestroy(h->branch_fork);
     if (h->branch_join) hipEventDestroy(h->branch_join);
+    if (h->stream_switch) hipEventDestroy(h->stream_switch);
     for (float* p : h->weight_allocs) hipFree(p);
+    for (float* p : h->plan_allocs) hipFree(p);
     if (h->workspace) hipFree(h->workspace);
     delete h;
     return FEAR_OK;
@@ -1304,19 +1370,23 @@ int fear_set_option(fear_handle* h, int option, int64_t value) {
             return FEAR_OK;
         case FEAR_OPT_FUSE:
             if (value != 0 && value != 1) return FEAR_ERR_SHAPE;
-            if (h->fuse != (int)value) { h->fuse = (int)value; h->plans.clear(); }
+            if (h->fuse != (int)value) { h->fuse = (int)value; return drop_plans(h); }
             return FEAR_OK;
         case FEAR_OPT_MATH:
             if (value != 0 && value != 1) return FEAR_ERR_SHAPE;
-            if (h->math != (int)value) { h->math = (int)value; h->plans.clear(); }
+            if (h->math != (int)value) { h->math = (int)value; return drop_plans(h); }
             return FEAR_OK;
         case FEAR_OPT_CHAIN:
             if (value != 0 && value != 1) return FEAR_ERR_SHAPE;
-            if (h->chain != (int)value) { h->chain = (int)value; h->plans.clear(); }
+            if (h->chain != (int)value) { h->chain = (int)value; return drop_plans(h); }
             return FEAR_OK;
         case FEAR_OPT_SMALL_PASS:
             if (value < 0 || value > 65536) return FEAR_ERR_SHAPE;
             h->small_pass = (int)value;
+            return FEAR_OK;
+        case FEAR_OPT_PLAN_CROPS:
+            if (value < 0 || value > 65536) return FEAR_ERR_SHAPE;
+            h->plan_crops = (int)value;
             return FEAR_OK;
         default: return FEAR_ERR_SHAPE;
     }
@@ -1332,12 +1402,17 @@ int64_t fear_get_option(fear_handle* h, int option) {
         case FEAR_OPT_MATH: return h->math;
         case FEAR_OPT_CHAIN: return h->chain;
         case FEAR_OPT_SMALL_PASS: return h->small_pass;
+        case FEAR_OPT_PLAN_CROPS: return h->plan_crops;
         default: return FEAR_ERR_SHAPE;
     }
 }
 
-// the plan a pass of nb crops runs on
-static bool small_pass(const fear_handle* h, int nb) { return h->fuse && nb <= h->small_pass; }
+// the plan a pass of nb crops runs on (build_plan's mode)
+constexpr int kTinyPass = 8;
+static int small_pass(const fear_handle* h, int nb) { return h->fuse && nb <= h->small_pass ? (nb <= kTinyPass ? 2 : 1) : 0; }
+
+// the plan fear_plan_* / fear_profile_read describe: that of a pass of FEAR_OPT_PLAN_CROPS crops (default: a full pass)
+static int introspected_small(const fear_handle* h) { return small_pass(h, h->plan_crops > 0 ? h->plan_crops : h->max_batch); }
 
 int fear_features(fear_handle* h, const float* img, int n, int hw, float* out, void* stream) {
     if (!h) return FEAR_ERR_NULL;
@@ -1362,8 +1437,8 @@ int fear_features(fear_handle* h, const float* img, int n, int hw, float* out, v
     return FEAR_OK;
 }
 
-int fear_track(fear_handle* h, const float* search, const float* tmpl, const float* tmpl_cls, int n, float* bbox,
-               float* cls, void* stream) {
+static int track_impl(fear_handle* h, const float* search, const float* tmpl, const float* tmpl_cls, int n, float* bbox,
+                      long bbox_stride, float* cls, long cls_stride, void* stream) {
     if (!h) return FEAR_ERR_NULL;
     if (n < 0) return FEAR_ERR_SHAPE;
     if (n == 0) return FEAR_OK;
@@ -1382,12 +1457,25 @@ int fear_track(fear_handle* h, const float* search, const float* tmpl, const flo
         ext.img = search + (size_t)b0 * 3 * hw * hw;
         ext.tmpl = tmpl + (size_t)b0 * tz;
         ext.tmpl_cls = tmpl_cls ? tmpl_cls + (size_t)b0 * tz : nullptr;
-        ext.bbox_out = bbox + (size_t)b0 * 4 * 256;
-        ext.cls_out = cls + (size_t)b0 * 256;
+        ext.bbox_out = bbox + (size_t)b0 * bbox_stride;
+        ext.cls_out = cls + (size_t)b0 * cls_stride;
+        ext.bbox_stride = bbox_stride;
+        ext.cls_stride = cls_stride;
         st = run_plan(h, *p, nb, ext, static_cast<hipStream_t>(stream));
         if (st != FEAR_OK) return st;
     }
     return FEAR_OK;
+}
+
+int fear_track(fear_handle* h, const float* search, const float* tmpl, const float* tmpl_cls, int n, float* bbox,
+               float* cls, void* stream) {
+    return track_impl(h, search, tmpl, tmpl_cls, n, bbox, 4 * 256, cls, 256, stream);
+}
+
+int fear_track_packed(fear_handle* h, const float* search, const float* tmpl, const float* tmpl_cls, int n, float* maps,
+                      void* stream) {
+    // bbox -> channels 0..3, cls -> channel 4 of one (n,5,16,16) tensor: the payload of the multi-GPU all-gather
+    return track_impl(h, search, tmpl, tmpl_cls, n, maps, 5 * 256, maps ? maps + 4 * 256 : nullptr, 5 * 256, stream);
 }
 
 int fear_decode_smooth(fear_handle* h, const float* cls, const float* bbox, int n, int score_size, int total_stride,
@@ -1461,7 +1549,7 @@ int fear_crop_normalize(fear_handle* h, const uint8_t* frame_u8, int frame_h, in
 int fear_plan_size(fear_handle* h, int hw, int with_head) {
     if (!h) return FEAR_ERR_NULL;
     Plan* p = nullptr;
-    int st = build_plan(h, hw, with_head != 0, small_pass(h, h->max_batch), &p);   // the plan a full pass (max_batch crops) runs on
+    int st = build_plan(h, hw, with_head != 0, introspected_small(h), &p);
     if (st != FEAR_OK) return st;
     return (int)p->ops.size();
 }
@@ -1470,7 +1558,7 @@ int fear_plan_op(fear_handle* h, int hw, int with_head, int i, char* name64, dou
                  double* bytes_per_crop) {
     if (!h) return FEAR_ERR_NULL;
     Plan* p = nullptr;
-    int st = build_plan(h, hw, with_head != 0, small_pass(h, h->max_batch), &p);   // the plan a full pass (max_batch crops) runs on
+    int st = build_plan(h, hw, with_head != 0, introspected_small(h), &p);
     if (st != FEAR_OK) return st;
     if (i < 0 || i >= (int)p->ops.size()) return FEAR_ERR_SHAPE;
     const Op& op = p->ops[i];
@@ -1483,7 +1571,7 @@ int fear_plan_op(fear_handle* h, int hw, int with_head, int i, char* name64, dou
 int fear_profile_read(fear_handle* h, int hw, int with_head, int i, double* total_ms, int64_t* launches) {
     if (!h) return FEAR_ERR_NULL;
     Plan* p = nullptr;
-    int st = build_plan(h, hw, with_head != 0, small_pass(h, h->max_batch), &p);   // the plan a full pass (max_batch crops) runs on
+    int st = build_plan(h, hw, with_head != 0, introspected_small(h), &p);
     if (st != FEAR_OK) return st;
     if (i < 0 || i >= (int)p->ops.size()) return FEAR_ERR_SHAPE;
     st = drain_events(h);

@@ -345,6 +345,7 @@ struct PwSmallArgs {
     float* Y;         // [M/hw][N][hw]
     int ldx, M, K, N, hw;
     int act;          // 0 none, 2 exp
+    long crop_stride; // floats between consecutive crops' maps in Y (N * hw for a dense tensor)
 };
 
 template <int N>
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(256) void pw_small_kernel(PwSmallArgs a) {
         for (int n = 0; n < N; ++n) {
             float v = acc[n] + a.bias[n];
             if (a.act == 2) v = expf(v);
-            a.Y[(crop * N + n) * a.hw + px] = v;
+            a.Y[crop * a.crop_stride + (long)n * a.hw + px] = v;
         }
     }
 }
@@ -411,6 +412,8 @@ __global__ __launch_bounds__(64) void decode_kernel(DecodeArgs a) {
         if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
     }
     if (lane == 0) {
+        // a map of NaNs never satisfies `s > best`: stay inside the map (cell 0 = torch.argmax's answer for an all-NaN map)
+        if ((unsigned)best_i >= (unsigned)cells) best_i = 0;
         const int r = best_i / a.S, col = best_i % a.S;
         const double gx = (double)(col - a.S / 2) * a.stride + a.instance / 2;
         const double gy = (double)(r - a.S / 2) * a.stride + a.instance / 2;
@@ -505,6 +508,8 @@ __global__ __launch_bounds__(64) void decode_smooth_kernel(DecodeSmoothArgs a) {
         if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
     }
     if (lane == 0) {
+        // a map of NaNs never satisfies `s > best`: stay inside the map (cell 0 = torch.argmax's answer for an all-NaN map)
+        if ((unsigned)best_i >= (unsigned)cells) best_i = 0;
         const int r = best_i / a.S, col = best_i % a.S;
         const double gx = (double)(col - a.S / 2) * a.stride + a.instance / 2;
         const double gy = (double)(r - a.S / 2) * a.stride + a.instance / 2;
@@ -655,6 +660,8 @@ struct Ir2Args {
     // prediction heads (bbox_pred / cls_pred): COUT is padded to 16 in the kernel, only the first pred_cout channels
     // are real; they are written NCHW ([crop][pred_cout][256]) with optional exp (pred_act == 2)
     int pred_cout, pred_act;
+    long pred_stride;     // floats between consecutive crops' maps (pred_cout * 256 for a dense NCHW tensor; 5 * 256 when the
+                          // caller's bbox and cls maps are the two slices of one packed (n,5,16,16) tensor)
     // sep16_kernel<..., CORR = true>: per-crop template features z [crop][COUT][64] (the caller's NCHW (C, 8, 8) tensor);
     // the pixel-wise correlation of the block's output with z is written to channels [COUT, COUT + 64) of Y
     const float* Z;
@@ -986,7 +993,7 @@ __global__ __launch_bounds__(512) void ir16v2_fused_kernel(Ir2Args a) {
                     if (n < a.pred_cout) {
                         float o = vals[n] + a.bp[n];
                         if (a.pred_act == 2) o = expf(o);
-                        a.Y[(crop * a.pred_cout + n) * 256 + px] = o;
+                        a.Y[crop * a.pred_stride + n * 256 + px] = o;
                     }
                 }
             }
@@ -1249,7 +1256,7 @@ __global__ __launch_bounds__(512) void sep16_kernel(Ir2Args a) {
                     if (n < a.pred_cout) {
                         float o = vals[n] + a.P_bp[n];
                         if (a.pred_act == 2) o = expf(o);
-                        a.P_Y[(crop * a.pred_cout + n) * 256 + px] = o;
+                        a.P_Y[crop * a.pred_stride + n * 256 + px] = o;
                     }
                 }
             }
@@ -1268,7 +1275,7 @@ __global__ __launch_bounds__(512) void sep16_kernel(Ir2Args a) {
                     if (n < a.pred_cout) {
                         float o = vals[n] + a.bp[n];
                         if (a.pred_act == 2) o = expf(o);
-                        a.Y[(crop * a.pred_cout + n) * 256 + px] = o;
+                        a.Y[crop * a.pred_stride + n * 256 + px] = o;
                     }
                 }
             }
@@ -1892,7 +1899,7 @@ __global__ __launch_bounds__(512) void ir16h_fused_kernel(Ir2Args a) {
                     if (n < a.pred_cout) {
                         float o = vals[n] + a.bp[n];
                         if (a.pred_act == 2) o = expf(o);
-                        a.Y[(crop * a.pred_cout + n) * 256 + px] = o;
+                        a.Y[crop * a.pred_stride + n * 256 + px] = o;
                     }
                 }
             }

@@ -22,7 +22,7 @@ import torch  # must be imported before the library so that both share one libam
 from .constants import TARGET_CLASSIFICATION_KEY, TARGET_REGRESSION_LABEL_KEY
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libfear_hip.so")
+LIB_PATH = os.environ.get("FEAR_LIB", os.path.join(_PKG, "libfear_hip.so"))   # FEAR_LIB: development builds (tools/)
 DEFAULT_WEIGHTS = os.path.join(_PKG, "weights", "fear_xs_noembs.fearw")
 
 FEAR_OPT_MAX_BATCH = 1
@@ -32,6 +32,7 @@ FEAR_OPT_FUSE = 4
 FEAR_OPT_MATH = 5
 FEAR_OPT_CHAIN = 6
 FEAR_OPT_SMALL_PASS = 7
+FEAR_OPT_PLAN_CROPS = 8
 
 _lib = None
 
@@ -56,6 +57,8 @@ def load_library() -> ctypes.CDLL:
     lib.fear_features.restype = i32
     lib.fear_track.argtypes = [vp, f32p, f32p, f32p, i32, f32p, f32p, vp]
     lib.fear_track.restype = i32
+    lib.fear_track_packed.argtypes = [vp, f32p, f32p, f32p, i32, f32p, vp]
+    lib.fear_track_packed.restype = i32
     lib.fear_decode.argtypes = [vp, f32p, f32p, i32, i32, i32, i32, vp, vp, f32p, vp]
     lib.fear_decode.restype = i32
     f64 = ctypes.c_double
@@ -90,7 +93,7 @@ def load_library() -> ctypes.CDLL:
 
 
 EXPORTED_SYMBOLS = (
-    "fear_create", "fear_destroy", "fear_features", "fear_track", "fear_decode", "fear_decode_smooth", "fear_normalize_u8",
+    "fear_create", "fear_destroy", "fear_features", "fear_track", "fear_track_packed", "fear_decode", "fear_decode_smooth", "fear_normalize_u8",
     "fear_crop_normalize",
     "fear_set_option", "fear_get_option", "fear_plan_size", "fear_plan_op", "fear_profile_read",
     "fear_profile_reset", "fear_workspace_bytes", "fear_strerror", "fear_last_hip_error", "fear_version",
@@ -171,6 +174,10 @@ class FEARNetHIP:
         """Passes of at most `crops` crops run the small-batch plan (split-K 16x16 kernels, two-stream head); 0 = never."""
         self._check(self._lib.fear_set_option(self._h, FEAR_OPT_SMALL_PASS, int(crops)))
 
+    def set_plan_crops(self, crops: int) -> None:
+        """Crop count whose launch plan `plan()` / `profile_read()` describe (0 = a full pass of max_batch crops)."""
+        self._check(self._lib.fear_set_option(self._h, FEAR_OPT_PLAN_CROPS, int(crops)))
+
     def set_math(self, mode: int) -> None:
         """0: exact fp32 MFMA (default); 1: fp16 hi+lo split operands on the matrix pipe, fp32 accumulate."""
         self._check(self._lib.fear_set_option(self._h, FEAR_OPT_MATH, int(mode)))
@@ -228,6 +235,36 @@ class FEARNetHIP:
             self._check(self._lib.fear_track(self._h, search.data_ptr(), z.data_ptr(), zu_ptr, n,
                                              bbox.data_ptr(), cls.data_ptr(), self._stream()))
         return bbox, cls
+
+    @torch.no_grad()
+    def track_packed(self, search, template_features, update=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`track` with both maps written into one (N,5,16,16) tensor — bbox in channels 0..3, cls in channel 4 —
+        the payload of the multi-GPU all-gather (sharding.py); no pack/cat kernel."""
+        search = self._prep(search, "search")
+        z = self._prep(template_features, "template_features")
+        n = search.shape[0]
+        if tuple(search.shape[1:]) != (3, 256, 256):
+            raise ValueError(f"search must be (N,3,256,256), got {tuple(search.shape)}")
+        if z.shape[0] == 1 and n > 1:
+            z = z.expand(n, -1, -1, -1).contiguous()
+        if tuple(z.shape) != (n, self.feat_channels, 8, 8):
+            raise ValueError(f"template_features must be ({n},256,8,8), got {tuple(z.shape)}")
+        zu_ptr = None
+        if update is not None:
+            zu = self._prep(update, "update")
+            if zu.shape[0] == 1 and n > 1:
+                zu = zu.expand(n, -1, -1, -1).contiguous()
+            if tuple(zu.shape) != tuple(z.shape):
+                raise ValueError("update template must have the shape of template_features")
+            zu_ptr = zu.data_ptr()
+        if out is None:
+            out = torch.empty((n, 5, 16, 16), dtype=torch.float32, device=self.device)
+        elif tuple(out.shape) != (n, 5, 16, 16) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != self.device:
+            raise ValueError("out must be a contiguous fp32 (N,5,16,16) tensor on the engine's device")
+        with torch.cuda.device(self.device):
+            self._check(self._lib.fear_track_packed(self._h, search.data_ptr(), z.data_ptr(), zu_ptr, n, out.data_ptr(),
+                                                    self._stream()))
+        return out
 
     @torch.no_grad()
     def forward(self, x: Tuple[torch.Tensor, torch.Tensor]) -> Dict[str, torch.Tensor]:

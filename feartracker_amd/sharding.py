@@ -45,6 +45,17 @@ def gather_maps(bbox: torch.Tensor, cls: torch.Tensor, packed: Optional[torch.Te
     return gathered
 
 
+def gather_packed(packed: torch.Tensor, gathered: Optional[torch.Tensor] = None, group=None) -> torch.Tensor:
+    """All-gather equally sized shards of already packed (B,5,S,S) maps (`FEARNetHIP.track_packed` writes them in that
+    layout, so the collective is the only operation of the step besides the engine's own kernels)."""
+    world = dist.get_world_size(group)
+    if gathered is None:
+        gathered = torch.empty((world * packed.shape[0],) + tuple(packed.shape[1:]), dtype=packed.dtype,
+                               device=packed.device)
+    dist.all_gather_into_tensor(gathered, packed, group=group)
+    return gathered
+
+
 def track_sharded(net, search: torch.Tensor, template_features: torch.Tensor, group=None):
     """Run `net.track` on this rank's contiguous shard of a replicated global batch and all-gather.
 
@@ -56,15 +67,22 @@ def track_sharded(net, search: torch.Tensor, template_features: torch.Tensor, gr
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n = search.shape[0]
     lo, hi = shard_range(n, world, rank)
-    out = net.track(search[lo:hi], template_features[lo:hi])
     from .constants import TARGET_CLASSIFICATION_KEY, TARGET_REGRESSION_LABEL_KEY
-    bbox, cls = out[TARGET_REGRESSION_LABEL_KEY], out[TARGET_CLASSIFICATION_KEY]
-    if world == 1:
-        return bbox, cls
     cap = (n + world - 1) // world
-    packed = torch.zeros((cap, 5) + tuple(bbox.shape[2:]), dtype=bbox.dtype, device=bbox.device)
-    if hi > lo:
-        pack_maps(bbox, cls, packed[: hi - lo])
+    if world > 1 and hasattr(net, "track_packed"):
+        # the engine writes this rank's maps straight into the head of the (padded) send buffer
+        s_hw = 16
+        packed = torch.zeros((cap, 5, s_hw, s_hw), dtype=torch.float32, device=net.device)
+        if hi > lo:
+            net.track_packed(search[lo:hi], template_features[lo:hi], out=packed[: hi - lo])
+    else:
+        out = net.track(search[lo:hi], template_features[lo:hi])
+        bbox, cls = out[TARGET_REGRESSION_LABEL_KEY], out[TARGET_CLASSIFICATION_KEY]
+        if world == 1:
+            return bbox, cls
+        packed = torch.zeros((cap, 5) + tuple(bbox.shape[2:]), dtype=bbox.dtype, device=bbox.device)
+        if hi > lo:
+            pack_maps(bbox, cls, packed[: hi - lo])
     gathered = torch.empty((world * cap,) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
     dist.all_gather_into_tensor(gathered, packed, group=group)
     parts = []

@@ -17,8 +17,10 @@
  *     reference's layouts: fp32 NCHW in and out.  Internal NHWC buffers are private.
  *   - no exceptions cross the ABI: 0 on success, negative FEAR_ERR_* otherwise;
  *     `fear_strerror` maps a status to text.
- *   - a handle is bound to one device, owns the packed weights and a workspace, and is not
- *     thread-safe; use one handle per device (one process per GPU for multi-GPU).
+ *   - a handle is bound to one device, owns the packed weights and ONE workspace, and is not
+ *     thread-safe; use one handle per device (one process per GPU for multi-GPU).  Calls on a
+ *     handle are ordered: a call given another stream than the previous call first waits (on the
+ *     device) for that call's work, because both use the same workspace.
  */
 #ifndef FEAR_HIP_H
 #define FEAR_HIP_H
@@ -61,6 +63,12 @@ int fear_features(fear_handle* h, const float* img, int n, int hw, float* out, v
  *   cls      : (n, 1, 16, 16) classification logits (0.1 factor already applied)              */
 int fear_track(fear_handle* h, const float* search, const float* tmpl, const float* tmpl_cls, int n,
                float* bbox, float* cls, void* stream);
+
+/* fear_track writing both maps into ONE packed tensor, the payload of the multi-GPU all-gather:
+ *   maps : (n, 5, 16, 16) fp32 — channels 0..3 = bbox (ltrb), channel 4 = cls.  Same arithmetic, same kernels; only the
+ *   per-crop output stride differs (replaces a torch.cat of FEARNet.track's two outputs, fear_net.py:90-96).        */
+int fear_track_packed(fear_handle* h, const float* search, const float* tmpl, const float* tmpl_cls, int n,
+                      float* maps, void* stream);
 
 /* FEARBoxCoder.decode (box_coder.py:75-107) with use_sigmoid=True on device, one wavefront per crop:
  *   rc    : (n, 2) int32   arg-max cell (row, col), first maximum
@@ -107,6 +115,9 @@ int fear_crop_normalize(fear_handle* h, const uint8_t* frame_u8, int frame_h, in
 #define FEAR_OPT_SMALL_PASS 7  /* passes of at most this many crops (default 96; 0 = never) run the small-batch plan:      */
                                /*   several workgroups per crop in the 16x16 kernels (split over channel chunks, partial   */
                                /*   sums reduced afterwards), the head's two branches on two streams                       */
+#define FEAR_OPT_PLAN_CROPS 8  /* crop count whose launch plan fear_plan_size / fear_plan_op / fear_profile_read describe (a    */
+                               /*   pass of <= FEAR_OPT_SMALL_PASS crops runs another plan than a full one); 0 (default) =     */
+                               /*   FEAR_OPT_MAX_BATCH, i.e. the plan of a full pass                                           */
 int fear_set_option(fear_handle* h, int option, int64_t value);
 int64_t fear_get_option(fear_handle* h, int option);
 

@@ -45,7 +45,7 @@ def test_option_ids_match_header():
     text = open(os.path.join(ROOT, "include", "fear_hip.h")).read()
     ids = dict(re.findall(r"#define (FEAR_OPT_[A-Z_]+) (\d+)", text))
     assert ids == {"FEAR_OPT_MAX_BATCH": "1", "FEAR_OPT_PROFILE": "2", "FEAR_OPT_PROFILE_OP": "3", "FEAR_OPT_FUSE": "4",
-                   "FEAR_OPT_MATH": "5", "FEAR_OPT_CHAIN": "6", "FEAR_OPT_SMALL_PASS": "7"}
+                   "FEAR_OPT_MATH": "5", "FEAR_OPT_CHAIN": "6", "FEAR_OPT_SMALL_PASS": "7", "FEAR_OPT_PLAN_CROPS": "8"}
     for name, val in ids.items():
         assert getattr(hip_backend, name) == int(val)
 
@@ -58,6 +58,42 @@ def test_truncated_model_is_rejected():
     bad = bytearray(blob)
     bad[8] = 9          # version field
     assert lib.fear_create(bytes(bad), len(bad), 0, ctypes.byref(h)) == -3
+
+
+def test_malformed_tables_are_rejected_not_followed():
+    """conv indices below -1 / missing mandatory convs, offsets that wrap, unbounded dimensions must give
+    FEAR_ERR_FORMAT (parse happens before any device call, so this runs without a GPU)."""
+    import struct
+    lib = hip_backend.load_library()
+    blob = open(hip_backend.DEFAULT_WEIGHTS, "rb").read()
+    magic, version, n_convs, n_blocks, dtype, payload = struct.unpack_from("<8s4IQ", blob, 0)
+    conv0, blk0 = 64, 64 + 72 * n_convs
+    h = ctypes.c_void_p()
+
+    def create(b):
+        return lib.fear_create(bytes(b), len(b), 0, ctypes.byref(h))
+
+    bad = bytearray(blob)
+    struct.pack_into("<i", bad, blk0 + 32 * 1 + 8 + 4, -7)            # block 1 (an IR block): depthwise index -7
+    assert create(bad) == -3
+    bad = bytearray(blob)
+    struct.pack_into("<i", bad, blk0 + 32 * 1 + 8 + 8, -1)            # ... mandatory project conv missing
+    assert create(bad) == -3
+    bad = bytearray(blob)
+    struct.pack_into("<i", bad, blk0 + 8, -1)                         # stem conv missing
+    assert create(bad) == -3
+    bad = bytearray(blob)
+    struct.pack_into("<Q", bad, conv0 + 32, 2 ** 64 - 16)             # w_off that wraps when the size is added
+    assert create(bad) == -3
+    bad = bytearray(blob)
+    struct.pack_into("<I", bad, conv0, 2 ** 31)                       # cout far beyond any model
+    assert create(bad) == -3
+    bad = bytearray(blob)
+    struct.pack_into("<Q", bad, 24, 2 ** 64 - 8)                      # payload_bytes that wraps the size check
+    assert create(bad) == -3
+    bad = bytearray(blob)
+    struct.pack_into("<I", bad, conv0 + 12, 7)                        # kernel size 7
+    assert create(bad) == -3
 
 
 def test_product_fails_loudly_without_gpu():
@@ -93,6 +129,8 @@ def test_error_codes_and_options_on_device():
     assert lib.fear_track(h, None, None, None, 0, None, None, st) == OK
     assert lib.fear_track(h, None, None, None, -1, None, None, st) == SHAPE
     assert lib.fear_track(h, None, None, None, 2, None, None, st) == NULL
+    assert lib.fear_track_packed(h, None, None, None, 0, None, st) == OK
+    assert lib.fear_track_packed(h, None, None, None, 2, None, st) == NULL
     assert lib.fear_features(h, None, 0, 128, None, st) == OK
     assert lib.fear_features(h, None, 1, 128, None, st) == NULL
     x = torch.zeros(1, 3, 100, 100, device="cuda")
@@ -104,7 +142,7 @@ def test_error_codes_and_options_on_device():
     assert lib.fear_decode_smooth(h, None, None, 0, 16, 16, 256, None, None, 0.1, 0.3, 0.3, None, None, None, st) == OK
     assert lib.fear_decode_smooth(h, None, None, 2, 16, 16, 256, None, None, 0.1, 0.3, 0.3, None, None, None, st) == NULL
     for opt, good, bad in ((hb.FEAR_OPT_MAX_BATCH, 17, 0), (hb.FEAR_OPT_MATH, 1, 2), (hb.FEAR_OPT_CHAIN, 0, 5),
-                           (hb.FEAR_OPT_SMALL_PASS, 12, -1), (hb.FEAR_OPT_FUSE, 0, 3)):
+                           (hb.FEAR_OPT_SMALL_PASS, 12, -1), (hb.FEAR_OPT_FUSE, 0, 3), (hb.FEAR_OPT_PLAN_CROPS, 3, -2)):
         assert lib.fear_set_option(h, opt, good) == OK and lib.fear_get_option(h, opt) == good
         assert lib.fear_set_option(h, opt, bad) == SHAPE and lib.fear_get_option(h, opt) == good
     assert lib.fear_set_option(h, 999, 1) == SHAPE

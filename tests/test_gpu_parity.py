@@ -1,6 +1,11 @@
-"""GPU parity: hand-written HIP path (through the C ABI) vs the CPU oracle and the golden
-fixtures.  Tolerance: 1e-3 relative (north_star), asserted as max|a-b| <= 1e-3 * max|b| per map,
-plus arg-max identity whenever the oracle's top-2 logit margin exceeds the observed error."""
+"""GPU parity: hand-written HIP path (through the C ABI) vs the CPU oracle and the golden fixtures.
+
+Tolerance (north_star: "within 1e-3 rel fp32"), asserted ELEMENT-WISE:  |a - b| <= 1e-3 * |b| + atol  with
+  bbox maps  atol = 1e-3   (ltrb distances in search-crop pixels, all > 0: a thousandth of a pixel)
+  cls maps   atol = 1e-4   (logits; a 1e-4 logit moves sigmoid(cls) by at most 2.5e-5)
+  features   atol = 1e-4 * max|b|   (signed activations that cross zero)
+plus the map-level max-norm error (measured ~1e-6) and arg-max identity wherever the oracle's top-2 logit margin
+exceeds 4x the observed logit error."""
 import numpy as np
 import pytest
 import torch
@@ -8,11 +13,54 @@ import torch
 pytestmark = pytest.mark.gpu
 
 REL = 1e-3
+ATOL_BBOX, ATOL_CLS = 1e-3, 1e-4
 
 
-def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
-    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+def rel_err(a, b) -> float:
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def assert_close_elementwise(a, b, atol: float, what: str = "") -> None:
+    """|a - b| <= REL * |b| + atol for every element."""
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    excess = (a - b).abs() - (REL * b.abs() + atol)
+    worst = int(excess.argmax())
+    assert float(excess.max()) <= 0.0, (f"{what}: element {worst}: got {a.reshape(-1)[worst].item()!r} expected "
+                                        f"{b.reshape(-1)[worst].item()!r} (rtol {REL}, atol {atol})")
+
+
+def assert_maps_close(bbox, cls, ref_bbox, ref_cls) -> None:
+    assert_close_elementwise(bbox, ref_bbox, ATOL_BBOX, "bbox")
+    assert_close_elementwise(cls, ref_cls, ATOL_CLS, "cls")
+    assert rel_err(bbox, ref_bbox) < REL and rel_err(cls, ref_cls) < REL
+
+
+def assert_features_close(got, ref) -> None:
+    ref_t = torch.as_tensor(ref)
+    assert_close_elementwise(got, ref_t, 1e-4 * float(ref_t.abs().max()), "features")
+    assert rel_err(got, ref_t) < REL
+
+
+def assert_argmax_identity(hip_net, bbox, cls, ref_cls) -> int:
+    """Device decode picks the oracle's arg-max cell wherever the oracle's top-2 logit margin exceeds 4x the observed
+    logit error (a smaller margin is a numerical tie no fp32 implementation is obliged to break the same way).
+    Returns the number of crops the identity was required on."""
+    ref_cls = torch.as_tensor(ref_cls).detach().float().cpu()
+    n = ref_cls.shape[0]
+    err = float((cls.detach().float().cpu() - ref_cls).abs().max())
+    flat = ref_cls.reshape(n, -1)
+    top2 = torch.topk(flat, 2, dim=1).values
+    margin = top2[:, 0] - top2[:, 1]
+    rc, _, _ = hip_net.decode(cls, bbox)
+    rc = rc.cpu().long()
+    want = flat.argmax(dim=1)
+    need = margin > 4 * err
+    got = rc[:, 0] * ref_cls.shape[-1] + rc[:, 1]
+    assert torch.equal(got[need], want[need]), (got[need], want[need], margin[need])
+    return int(need.sum())
 
 
 def norm_u8(u8_nchw: torch.Tensor) -> torch.Tensor:
@@ -28,7 +76,7 @@ def test_features_vs_oracle_template_and_search(hip_net, oracle_net):
         ref = oracle_net.get_features(x)
         got = hip_net.get_features(x.cuda())
         assert got.shape == ref.shape
-        assert rel_err(got, ref) < REL
+        assert_features_close(got, ref)
 
 
 def test_track_vs_golden_maps(hip_net, golden_dir):
@@ -36,11 +84,10 @@ def test_track_vs_golden_maps(hip_net, golden_dir):
     x = norm_u8(torch.from_numpy(d["search_u8"]))
     z = torch.from_numpy(d["template_features"])
     bbox, cls = hip_net.track_maps(x.cuda(), z.cuda())
-    assert rel_err(bbox, torch.from_numpy(d["bbox"])) < REL
-    assert rel_err(cls, torch.from_numpy(d["cls"])) < REL
+    assert_maps_close(bbox, cls, d["bbox"], d["cls"])
     # template branch as well
     zt = hip_net.get_features(norm_u8(torch.from_numpy(d["template_u8"])).cuda())
-    assert rel_err(zt, z) < REL
+    assert_features_close(zt, z)
     # arg-max identity where the margin allows it
     err = float((cls.cpu() - torch.from_numpy(d["cls"])).abs().max())
     rc, xywh, score = hip_net.decode(cls, bbox)
@@ -58,8 +105,8 @@ def test_track_vs_oracle_seeded_batches(hip_net, oracle_net):
         z = oracle_net.get_features(t)
         ref = oracle_net.track(x, z)
         bbox, cls = hip_net.track_maps(x.cuda(), z.cuda())
-        assert rel_err(bbox, ref["TARGET_REGRESSION_LABEL_KEY"]) < REL
-        assert rel_err(cls, ref["TARGET_CLASSIFICATION_KEY"]) < REL
+        assert_maps_close(bbox, cls, ref["TARGET_REGRESSION_LABEL_KEY"], ref["TARGET_CLASSIFICATION_KEY"])
+        assert_argmax_identity(hip_net, bbox, cls, ref["TARGET_CLASSIFICATION_KEY"])
 
 
 def test_head_modules_fixture_via_update_template(hip_net, oracle_net, golden_dir):
@@ -70,8 +117,8 @@ def test_head_modules_fixture_via_update_template(hip_net, oracle_net, golden_di
     zu = oracle_net.get_features(norm_u8(torch.randint(0, 256, (2, 3, 128, 128), dtype=torch.uint8, generator=g)))
     ref = oracle_net.track(x, z, update=zu)
     out = hip_net.track(x.cuda(), z.cuda(), update=zu.cuda())
-    assert rel_err(out["TARGET_REGRESSION_LABEL_KEY"], ref["TARGET_REGRESSION_LABEL_KEY"]) < REL
-    assert rel_err(out["TARGET_CLASSIFICATION_KEY"], ref["TARGET_CLASSIFICATION_KEY"]) < REL
+    assert_maps_close(out["TARGET_REGRESSION_LABEL_KEY"], out["TARGET_CLASSIFICATION_KEY"],
+                      ref["TARGET_REGRESSION_LABEL_KEY"], ref["TARGET_CLASSIFICATION_KEY"])
     plain = hip_net.track(x.cuda(), z.cuda())
     assert torch.equal(plain["TARGET_REGRESSION_LABEL_KEY"], out["TARGET_REGRESSION_LABEL_KEY"])
     assert not torch.equal(plain["TARGET_CLASSIFICATION_KEY"], out["TARGET_CLASSIFICATION_KEY"])
@@ -167,17 +214,25 @@ def test_full_size_batch_properties(hip_net, oracle_net):
     net.set_small_pass(96)       # default again: a single crop now takes the small-batch plan (another summation order)
     b1, c1 = net.track_maps(x[17:18], z[17:18])
     assert rel_err(b1[0], bbox[17]) < 1e-5 and rel_err(c1[0], cls[17]) < 1e-5
-    sample = [3, 64, 129, 200, 254]
+    sample = list(range(3, 256, 8))                    # 32 of the 256 crops through the oracle
     ref = oracle_net.track(x[sample].cpu(), z[sample].cpu())
-    assert rel_err(bbox[sample], ref["TARGET_REGRESSION_LABEL_KEY"]) < REL
-    assert rel_err(cls[sample], ref["TARGET_CLASSIFICATION_KEY"]) < REL
+    assert_maps_close(bbox[sample], cls[sample], ref["TARGET_REGRESSION_LABEL_KEY"], ref["TARGET_CLASSIFICATION_KEY"])
+    assert assert_argmax_identity(net, bbox[sample], cls[sample], ref["TARGET_CLASSIFICATION_KEY"]) >= 16
     perm = torch.randperm(256, generator=g).cuda()
     bp, cp = net.track_maps(x[perm].contiguous(), z[perm].contiguous())
     assert torch.equal(bp, bbox[perm]) and torch.equal(cp, cls[perm])
+    # device decode on the whole batch: the arg-max cell of the engine's own logits (ties in the top-2 excepted), its score,
+    # and the packed-output entry point (fear_track_packed) giving the very same maps
     rc, xywh, score = net.decode(cls, bbox)
-    flat = cls.reshape(256, -1).sigmoid()
-    assert torch.equal(rc[:, 0].long() * 16 + rc[:, 1].long(), flat.argmax(dim=1)) or \
-        torch.allclose(score, flat.max(dim=1).values)
+    flat = cls.reshape(256, -1)
+    top2 = torch.topk(flat, 2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-5
+    assert int(clear.sum()) >= 250
+    assert torch.equal((rc[:, 0].long() * 16 + rc[:, 1].long())[clear], flat.argmax(dim=1)[clear])
+    assert torch.allclose(score, flat.max(dim=1).values.sigmoid(), rtol=1e-6, atol=1e-7)
+    packed = net.track_packed(x, z)
+    assert packed.shape == (256, 5, 16, 16)
+    assert torch.equal(packed[:, :4], bbox) and torch.equal(packed[:, 4:], cls)
 
 
 def test_fused_and_layerwise_plans_agree(hip_net, oracle_net):
@@ -194,8 +249,7 @@ def test_fused_and_layerwise_plans_agree(hip_net, oracle_net):
     b1, c1 = hip_net.track_maps(x, z)
     assert rel_err(b1, b0) < 1e-4 and rel_err(c1, c0) < 1e-4
     ref = oracle_net.track(x.cpu(), z.cpu())
-    assert rel_err(b0, ref["TARGET_REGRESSION_LABEL_KEY"]) < REL
-    assert rel_err(c0, ref["TARGET_CLASSIFICATION_KEY"]) < REL
+    assert_maps_close(b0, c0, ref["TARGET_REGRESSION_LABEL_KEY"], ref["TARGET_CLASSIFICATION_KEY"])
 
 
 def test_matrix_pipe_split_mode_matches_fp32(hip_net, oracle_net, golden_dir):
@@ -211,7 +265,7 @@ def test_matrix_pipe_split_mode_matches_fp32(hip_net, oracle_net, golden_dir):
     z = torch.from_numpy(d["template_features"]).cuda()
     b1, c1 = fast.track_maps(x, z)
     b0, c0 = hip_net.track_maps(x, z)
-    assert rel_err(b1, torch.from_numpy(d["bbox"])) < REL and rel_err(c1, torch.from_numpy(d["cls"])) < REL
+    assert_maps_close(b1, c1, d["bbox"], d["cls"])
     dev_b, dev_c = rel_err(b1, b0), rel_err(c1, c0)
     print(f"split-vs-fp32 deviation: bbox {dev_b:.2e} cls {dev_c:.2e}")
     assert dev_b < 1e-4 and dev_c < 1e-4
@@ -223,7 +277,7 @@ def test_matrix_pipe_split_mode_matches_fp32(hip_net, oracle_net, golden_dir):
     zs = oracle_net.get_features(norm_u8(torch.randint(0, 256, (5, 3, 128, 128), dtype=torch.uint8, generator=g)))
     ref = oracle_net.track(xs, zs)
     bb, cc = fast.track_maps(xs.cuda(), zs.cuda())
-    assert rel_err(bb, ref["TARGET_REGRESSION_LABEL_KEY"]) < REL and rel_err(cc, ref["TARGET_CLASSIFICATION_KEY"]) < REL
+    assert_maps_close(bb, cc, ref["TARGET_REGRESSION_LABEL_KEY"], ref["TARGET_CLASSIFICATION_KEY"])
 
 
 def test_device_crop_is_bit_identical_to_host_crop(hip_net, golden_dir):
@@ -274,7 +328,7 @@ def test_other_sizes_and_second_weight_set(oracle_net):
     g = torch.Generator().manual_seed(123)
     for hw in (32, 96, 192, 320):
         x = torch.randn(2, 3, hw, hw, generator=g)
-        assert rel_err(net.get_features(x.cuda()), oracle_net.get_features(x)) < REL
+        assert_features_close(net.get_features(x.cuda()), oracle_net.get_features(x))
     with pytest.raises(Exception):
         net.get_features(torch.randn(1, 3, 100, 100).cuda())          # not a multiple of 32
     demo, demo_ref = FEARNetHIP(WEIGHTS_DEMO, device=0, max_batch=4), OracleNet(WEIGHTS_DEMO)
@@ -284,7 +338,7 @@ def test_other_sizes_and_second_weight_set(oracle_net):
     for mode in (0, 1):
         demo.set_math(mode)
         b, c = demo.track_maps(x.cuda(), z.cuda())
-        assert rel_err(b, ref["TARGET_REGRESSION_LABEL_KEY"]) < REL and rel_err(c, ref["TARGET_CLASSIFICATION_KEY"]) < REL
+        assert_maps_close(b, c, ref["TARGET_REGRESSION_LABEL_KEY"], ref["TARGET_CLASSIFICATION_KEY"])
     other = oracle_net.track(x, oracle_net.get_features(torch.zeros(2, 3, 128, 128)))
     assert rel_err(b, other["TARGET_REGRESSION_LABEL_KEY"]) > 1e-2     # different trained weights, different maps
 
@@ -396,7 +450,8 @@ def test_small_batch_plan_vs_oracle_and_clip(oracle_net, golden_dir):
     t = norm_u8(torch.randint(0, 256, (5, 3, 128, 128), dtype=torch.uint8, generator=g))
     ref = oracle_net.track(x, oracle_net.get_features(t))
     b, c = net.track_maps(x.cuda(), net.get_features(t.cuda()))
-    assert rel_err(b, ref["TARGET_REGRESSION_LABEL_KEY"]) < REL and rel_err(c, ref["TARGET_CLASSIFICATION_KEY"]) < REL
+    assert_maps_close(b, c, ref["TARGET_REGRESSION_LABEL_KEY"], ref["TARGET_CLASSIFICATION_KEY"])
+    assert_argmax_identity(net, b, c, ref["TARGET_CLASSIFICATION_KEY"])
     for _ in range(20):                      # the two streams and the partial-sum scratch must not race
         b2, c2 = net.track_maps(x.cuda(), net.get_features(t.cuda()))
         assert torch.equal(b, b2) and torch.equal(c, c2)
@@ -532,3 +587,83 @@ def test_real_clip_bbox_parity(hip_net, oracle_net, golden_dir):
         trk.initialize(frames[0], init.copy())
         boxes[name] = [np.array(trk.update(f)["bbox"]) for f in frames[1:]]
     np.testing.assert_array_equal(np.stack(boxes["hip"]), np.stack(boxes["oracle"]))
+
+
+def test_plan_introspection_follows_the_pass_size():
+    """fear_plan_* / fear_profile_read describe the plan a pass of FEAR_OPT_PLAN_CROPS crops runs on — a
+    single crop of a max_batch=256 handle takes the small-batch plan, and its profile counters must land there."""
+    from feartracker_amd import FEARNetHIP
+    from conftest import WEIGHTS
+    net = FEARNetHIP(WEIGHTS, device=0, max_batch=256)
+    full = [n for n, _, _ in net.plan(256, True)]
+    assert any(n.startswith("chain16") for n in full)
+    net.set_plan_crops(1)
+    one = [n for n, _, _ in net.plan(256, True)]
+    assert any("splitk" in n for n in one) and not any(n.startswith("chain16") for n in one)
+    g = torch.Generator().manual_seed(8)
+    x = norm_u8(torch.randint(0, 256, (1, 3, 256, 256), dtype=torch.uint8, generator=g)).cuda()
+    z = net.get_features(norm_u8(torch.randint(0, 256, (1, 3, 128, 128), dtype=torch.uint8, generator=g)).cuda())
+    net.set_profile(True)
+    net.profile_reset()
+    net.track_maps(x, z)
+    counts_one = [c for _, c in net.profile_read(256, True)]
+    net.set_plan_crops(0)
+    counts_full = [c for _, c in net.profile_read(256, True)]
+    net.set_profile(False)
+    assert all(c == 1 for c in counts_one) and all(c == 0 for c in counts_full)
+    # a pass of 20 crops takes the small-batch plan with the shallower split: same op list, fewer workgroups per crop
+    net.set_plan_crops(20)
+    assert [n for n, _, _ in net.plan(256, True)] == one
+
+
+def test_option_toggles_do_not_leak_device_memory():
+    """every FEAR_OPT_MATH / FUSE / CHAIN change used to re-upload the packed weights of the rebuilt plans and
+    never free the old ones."""
+    from feartracker_amd import FEARNetHIP
+    from conftest import WEIGHTS
+    net = FEARNetHIP(WEIGHTS, device=0, max_batch=4)
+    g = torch.Generator().manual_seed(9)
+    x = norm_u8(torch.randint(0, 256, (2, 3, 256, 256), dtype=torch.uint8, generator=g)).cuda()
+    z = net.get_features(norm_u8(torch.randint(0, 256, (2, 3, 128, 128), dtype=torch.uint8, generator=g)).cuda())
+
+    def cycle():
+        for mode in (1, 0):
+            net.set_math(mode)
+            net.track_maps(x, z)
+        torch.cuda.synchronize()
+
+    cycle()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(12):
+        cycle()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 << 20, f"{(free0 - free1) >> 20} MiB lost over 24 option toggles"
+
+
+def test_all_nan_maps_decode_inside_the_map(hip_net):
+    """a map of NaNs must not send the decode kernels out of bounds (cell 0, like torch.argmax)."""
+    cls = torch.full((2, 1, 16, 16), float("nan"), device="cuda")
+    cls[1] = 0.5
+    bbox = torch.ones(2, 4, 16, 16, device="cuda")
+    rc, xywh, _ = hip_net.decode(cls, bbox)
+    assert tuple(rc[0].tolist()) == (0, 0) and tuple(rc[1].tolist()) == (0, 0)
+    rc2, _, _ = hip_net.decode_smooth(cls, bbox, np.array([[40.0, 40.0]] * 2), np.outer(np.hanning(16), np.hanning(16)),
+                                      0.062, 0.38, 0.765)
+    assert 0 <= int(rc2[0, 0]) < 16 and 0 <= int(rc2[0, 1]) < 16
+
+
+def test_calls_on_two_streams_are_ordered(hip_net):
+    """One handle, one workspace: a call on another torch stream must wait for the previous call instead of racing it."""
+    g = torch.Generator().manual_seed(10)
+    x = norm_u8(torch.randint(0, 256, (4, 3, 256, 256), dtype=torch.uint8, generator=g)).cuda()
+    z = hip_net.get_features(norm_u8(torch.randint(0, 256, (4, 3, 128, 128), dtype=torch.uint8, generator=g)).cuda())
+    b0, c0 = hip_net.track_maps(x, z)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for i in range(10):
+        with torch.cuda.stream(s1 if i % 2 == 0 else s2):
+            outs.append(hip_net.track_maps(x, z))
+    torch.cuda.synchronize()
+    for b, c in outs:
+        assert torch.equal(b, b0) and torch.equal(c, c0)
