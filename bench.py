@@ -20,6 +20,7 @@ Prints ONE JSON line (rank 0).  Extra objects:
                launch stream inside the timed region.
   cpu_baseline the CPU oracle (torch fp32, best thread count on the host) timed on a bounded sample of the same workload,
                with the B=1 and B=32 legs of BASELINE.md §3.2 and the host's lscpu model string.
+  config4_fear_m_bf16  BASELINE configs[3]: synthetic deeper trunk (no reference definition), bf16 MFMA pointwise path, B=512.
   latency_batch1  BASELINE configs[0] stand-in: the drop-in tracker's update() at batch 1 on the 480x256 demo-geometry clip
                (no H.264 decoder exists on the box, profiles/r02_box_probe.txt), ms/frame for the reference-style host crop
                path and for device crop + device post-processing, the CPU-oracle tracker beside it, boxes compared.
@@ -109,6 +110,49 @@ def cpu_baseline(search_u8, tmpl_u8, weights, budget_s: float = 10.0):
             "batch1": {"value": v1, "unit": "crops/s", "ms_per_crop": 1e3 / v1, "iters": it1,
                        "protocol": "20 warm-up + <=100 timed calls (README.md:43, Benchmark.swift:55-77)"},
             "batch32": {"value": v32, "unit": "crops/s", "iters": it32, "seconds": dt32}}
+
+
+def config4_fear_m(dev, steps: int = 20, warmup: int = 5, batch: int = 512):
+    """BASELINE.json configs[3]: "FEAR-M (deeper FBNet) bf16, batch=512 on 1xMI355X — MFMA pointwise-conv path".  The
+    reference defines no FEAR-M (blocks.py:22-25), so this is the synthetic deeper trunk of tools/make_fear_m.py (every
+    residual block of FEAR-XS twice, seeded random weights) — a perf/numerics configuration with no reference parity
+    target; its parity target is this engine's own fp32 path on the same file (deviation reported here)."""
+    from feartracker_amd import FEARNetHIP
+    from feartracker_amd.hip_backend import WEIGHTS_FEAR_M
+    net = FEARNetHIP(WEIGHTS_FEAR_M, device=dev.index, max_batch=batch)
+    g = torch.Generator().manual_seed(4)
+    search = norm_u8(torch.randint(0, 256, (batch, 3, 256, 256), dtype=torch.uint8, generator=g).to(dev)).contiguous()
+    z = net.get_features(norm_u8(torch.randint(0, 256, (batch, 3, 128, 128), dtype=torch.uint8, generator=g).to(dev)).contiguous())
+    bbox = torch.empty((batch, 4, 16, 16), dtype=torch.float32, device=dev)
+    cls = torch.empty((batch, 1, 16, 16), dtype=torch.float32, device=dev)
+    res = {}
+    ref = None
+    for mode, tag in ((0, "fp32"), (2, "bf16")):
+        net.set_math(mode)
+        for _ in range(warmup):
+            net.track_maps(search, z, out=(bbox, cls))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            net.track_maps(search, z, out=(bbox, cls))
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        res[tag] = {"value": batch / dt, "unit": "crops/s", "ms_per_step": 1e3 * dt}
+        if ref is None:
+            ref = (bbox[:32].clone(), cls[:32].clone())
+            flops = sum(f for _, f, _ in net.plan(256, True))
+        else:
+            res[tag]["max_rel_dev_bbox_vs_fp32"] = float(((bbox[:32] - ref[0]).abs() / ref[0].abs()).max())
+            res[tag]["max_abs_dev_cls_logit_vs_fp32"] = float((cls[:32] - ref[1]).abs().max())
+            rc0, _, _ = net.decode(ref[1], ref[0])
+            rc1, _, _ = net.decode(cls[:32], bbox[:32])
+            res[tag]["argmax_cell_agreement_vs_fp32"] = float((rc0 == rc1).all(dim=1).float().mean())
+    return {"workload": f"synthetic FEAR-M (tools/make_fear_m.py: FEAR-XS with every residual block twice, 28 IR blocks, "
+                        f"{flops / 2e6:.0f} M MAC/crop, seeded random weights; NO reference definition), batch={batch}, 256x256 search",
+            "metric": "search-region crops/sec", "dtype": "bf16 operands on v_mfma_f32_16x16x32_bf16, fp32 accumulate (FEAR_OPT_MATH=2); "
+                                                         "depthwise / bias / residuals fp32",
+            "value": res["bf16"]["value"], "unit": "crops/s", "steps": steps, "warmup": warmup,
+            "tflops_bf16_path": res["bf16"]["value"] * flops / 1e12, "bf16": res["bf16"], "fp32_same_model": res["fp32"]}
 
 
 def latency_batch1(weights, frames_cap: int = 120):
@@ -233,6 +277,7 @@ def main() -> None:
                     help="skip the supplementary run in the other arithmetic mode (profiling runs: keeps the trace to one plan)")
     ap.add_argument("--dump-ops", action="store_true", help="print the per-kernel time table to stderr")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 tracker latency object")
+    ap.add_argument("--no-fear-m", action="store_true", help="skip the BASELINE configs[3] object (synthetic FEAR-M, bf16, B=512)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -440,6 +485,11 @@ def main() -> None:
                                  "bytes_per_rank": B * 5 * 16 * 16 * 4, "ms_alone": gather_ms}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(search_u8, tmpl_u8, DEFAULT_WEIGHTS)
+        if not args.no_fear_m and world == 1 and not use_dist:
+            del net, search, tmpl_feats
+            torch.cuda.empty_cache()
+            out["config4_fear_m_bf16"] = config4_fear_m(dev)
+            net = search = tmpl_feats = None
         if not args.no_latency and world == 1 and not use_dist:
             del net, search, tmpl_feats
             torch.cuda.empty_cache()

@@ -72,6 +72,14 @@ uint16_t float_to_half(float f) {
     return (uint16_t)(sign | h);
 }
 
+uint16_t float_to_bf16(float f) {     // round to nearest even, like v_cvt_pk_bf16_f32
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    if ((x & 0x7f800000u) == 0x7f800000u) return (uint16_t)((x >> 16) | ((x & 0xffffu) ? 0x40u : 0));
+    x += 0x7fffu + ((x >> 16) & 1u);
+    return (uint16_t)(x >> 16);
+}
+
 struct Conv {
     int cout, cin_g, groups, k, stride, pad, relu, has_bias;
     std::vector<float> w;  // OIHW fp32
@@ -340,6 +348,22 @@ const FusedTile kFusedTileH[] = {
     FTILEH(32, 192, 192, 64, 5, 2, 16, 4, 1, 4, 2, 32),    // stage 10
 };
 static_assert(sizeof(kFusedTileH) == sizeof(kFusedTile), "the two tile tables must list the same blocks in the same order");
+#define FTILEB(CIN, CEXP, CEXPP, COUT, KS, ST, TW, TH, EXP, NW, MINW, HW)                                             \
+    {CIN, CEXP, COUT, KS, ST, EXP, HW, TW, TH,                                                                        \
+     ir_tile_h_kernel<CIN, CEXPP, COUT, KS, ST, TW, TH, (EXP) != 0, NW, MINW, 2>,                                      \
+     IrTHGeom<CIN, CEXPP, COUT, KS, ST, TW, TH, (EXP) != 0, NW>::LDS_BYTES, NW}
+// same blocks, bf16 operands (FEAR_OPT_MATH = 2): one matrix-pipe MFMA per product instead of two
+const FusedTile kFusedTileB[] = {
+    FTILEB(16, 16, 32, 16, 3, 1, 32, 8, 0, 8, 2, 128),
+    FTILEB(16, 96, 96, 24, 3, 2, 16, 4, 1, 4, 2, 128),
+    FTILEB(24, 24, 32, 24, 3, 1, 16, 16, 0, 8, 2, 64),
+    FTILEB(24, 144, 160, 32, 5, 2, 16, 4, 1, 4, 2, 64),
+    FTILEB(32, 96, 96, 32, 5, 1, 16, 16, 1, 8, 2, 32),
+    FTILEB(32, 192, 192, 32, 5, 1, 16, 16, 1, 8, 2, 32),
+    FTILEB(32, 192, 192, 32, 3, 1, 16, 16, 1, 8, 2, 32),
+    FTILEB(32, 192, 192, 64, 5, 2, 16, 4, 1, 4, 2, 32),
+};
+static_assert(sizeof(kFusedTileB) == sizeof(kFusedTile), "same blocks, same order");
 
 // stem (3x3 s2, 3 -> 16) fused in front of the first e1 block: one entry, keyed by the block's shape and map size
 const FusedTile kStemTile = {16, 16, 16, 3, 1, 0, 128, 32, 16,
@@ -379,6 +403,16 @@ const Fused16 kFused16H[] = {
     FUSED16H(256, 256, 16, 3, 0),
 };
 static_assert(sizeof(kFused16H) == sizeof(kFused16), "the two tables must list the same shapes in the same order");
+#define FUSED16B(CIN, CEXP, COUT, KS, EXP) \
+    {CIN, CEXP, COUT, KS, EXP, ir16h_fused_kernel<CIN, CEXP, COUT, KS, (EXP) != 0, 2>, IrHGeom<CIN, CEXP, COUT, KS, (EXP) != 0>::LDS_BYTES}
+// bf16 operands (FEAR_OPT_MATH = 2)
+const Fused16 kFused16B[] = {
+    FUSED16B(64, 192, 64, 5, 1),   FUSED16B(64, 384, 64, 5, 1),  FUSED16B(64, 384, 112, 5, 1),
+    FUSED16B(112, 672, 112, 5, 1), FUSED16B(112, 336, 112, 5, 1),
+    FUSED16B(256, 256, 256, 3, 0), FUSED16B(320, 320, 256, 3, 0),
+    FUSED16B(256, 256, 16, 3, 0),
+};
+static_assert(sizeof(kFused16B) == sizeof(kFused16), "same shapes, same order");
 
 // last tower SepConv + the prediction SepConv in one kernel (fp32 mode)
 auto* const kSep16PredKernel = sep16_kernel<256, 256, 3, false, true>;
@@ -444,8 +478,9 @@ int pack_fused16(fear_handle* h, int ce, int cd, int cp, float** out) {
 // Packed weights for the matrix-pipe (fp16-split) fused kernels, per 32-channel chunk (IrHGeom layout):
 //   [A-part: 2 n-tiles x KG32 fragments of 64 lanes x 8 halfs | be[32] fp32]
 //   [BC-part: NTP fragments | Wd[k*k][32] fp32 | bd[32] fp32]
-// The model's weights are fp16 values, so the fp32 -> fp16 conversion here is exact.
-int pack_fused_h(fear_handle* h, int ce, int cd, int cp, float** out) {
+// The model's weights are fp16 values, so the fp32 -> fp16 conversion here is exact.  bf16 = true (FEAR_OPT_MATH = 2)
+// rounds them to bf16 instead.
+int pack_fused_h(fear_handle* h, int ce, int cd, int cp, float** out, bool bf16 = false) {
     const Conv& d = h->convs[cd];
     const Conv& p = h->convs[cp];
     const Conv* e = ce >= 0 ? &h->convs[ce] : nullptr;
@@ -459,7 +494,8 @@ int pack_fused_h(fear_handle* h, int ce, int cd, int cp, float** out) {
             uint16_t hv[8];
             for (int j = 0; j < 8; ++j) {
                 const int r = row0 + (l & 15), c = col0 + (l >> 4) * 8 + j;
-                hv[j] = float_to_half(r < rows && c < cols ? w[(size_t)r * cols + c] : 0.f);
+                const float wv = r < rows && c < cols ? w[(size_t)r * cols + c] : 0.f;
+                hv[j] = bf16 ? float_to_bf16(wv) : float_to_half(wv);   // fp16 -> fp16 is exact; -> bf16 rounds to 8 bits
             }
             float f4[4];
             memcpy(f4, hv, 16);
@@ -616,7 +652,7 @@ int build_plan_uncached(fear_handle* h, int hw, bool with_head, int mode, Plan**
         Op op{};
         op.type = OP_IR16; op.fused_id = id; op.conv_e = ce; op.conv_d = cd; op.conv_p = cp;
         op.math = h->math;
-        if ((h->math ? pack_fused_h(h, ce, cd, cp, &op.d_packed) : pack_fused16(h, ce, cd, cp, &op.d_packed)) != FEAR_OK)
+        if ((h->math ? pack_fused_h(h, ce, cd, cp, &op.d_packed, h->math == 2) : pack_fused16(h, ce, cd, cp, &op.d_packed)) != FEAR_OK)
             return false;
         op.in_buf = in.buf; op.in_ld = in.ld; op.in_off = in.off;
         op.H = 16; op.W = 16; op.Ho = 16; op.Wo = 16; op.C = cin; op.N = p.cout;
@@ -661,7 +697,7 @@ int build_plan_uncached(fear_handle* h, int hw, bool with_head, int mode, Plan**
         Op op{};
         op.type = OP_IR16; op.fused_id = id; op.conv_e = -1; op.conv_d = cd; op.conv_p = cp;
         op.math = h->math;
-        if ((h->math ? pack_fused_h(h, -1, cd, cp, &op.d_packed) : pack_fused16(h, -1, cd, cp, &op.d_packed)) != FEAR_OK)
+        if ((h->math ? pack_fused_h(h, -1, cd, cp, &op.d_packed, h->math == 2) : pack_fused16(h, -1, cd, cp, &op.d_packed)) != FEAR_OK)
             return false;
         op.in_buf = in.buf; op.in_ld = in.ld; op.in_off = in.off;
         op.H = 16; op.W = 16; op.Ho = 16; op.Wo = 16; op.C = d.cout; op.N = p.cout;
@@ -680,9 +716,9 @@ int build_plan_uncached(fear_handle* h, int hw, bool with_head, int mode, Plan**
         const int cin = ce >= 0 ? h->convs[ce].cin_g : d.cout;
         const int id = find_fused_tile(cin, d.cout, p.cout, d.k, d.stride, ce >= 0 ? 1 : 0, in.H);
         if (id < 0) return false;
-        const int use_h = h->math && ce >= 0;   // e1 blocks (no expand GEMM) stay on the fp32 kernel
+        const int use_h = ce >= 0 ? h->math : 0;   // e1 blocks (no expand GEMM) stay on the fp32 kernel
         const bool small_tiles = small && !use_h;
-        const FusedTile& f = use_h ? kFusedTileH[id] : (small_tiles ? kFusedTileSmall[id] : kFusedTile[id]);
+        const FusedTile& f = use_h == 2 ? kFusedTileB[id] : use_h ? kFusedTileH[id] : (small_tiles ? kFusedTileSmall[id] : kFusedTile[id]);
         const int ho = in.H / d.stride;
         if (ho % f.th != 0 || ho % f.tw != 0) return false;
         if (!p.has_bias) return false;
@@ -690,7 +726,7 @@ int build_plan_uncached(fear_handle* h, int hw, bool with_head, int mode, Plan**
         op.type = OP_IRTILE; op.fused_id = id; op.conv_e = ce; op.conv_d = cd; op.conv_p = cp;
         op.math = use_h;
         op.small_tiles = small_tiles ? 1 : 0;
-        if ((use_h ? pack_fused_h(h, ce, cd, cp, &op.d_packed) : pack_fused16(h, ce, cd, cp, &op.d_packed)) != FEAR_OK)
+        if ((use_h ? pack_fused_h(h, ce, cd, cp, &op.d_packed, use_h == 2) : pack_fused16(h, ce, cd, cp, &op.d_packed)) != FEAR_OK)
             return false;
         op.in_buf = in.buf; op.in_ld = in.ld; op.in_off = in.off;
         op.H = in.H; op.W = in.W; op.Ho = ho; op.Wo = ho; op.C = cin; op.N = p.cout;
@@ -1068,6 +1104,12 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
         for (const FusedTile& f : kFusedTileH)
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(f.kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, f.lds_bytes));
+        for (const FusedTile& f : kFusedTileB)
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(f.kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, f.lds_bytes));
+        for (const Fused16& f : kFused16B)
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(f.kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, f.lds_bytes));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kSep16PredKernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kSep16PredLds));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kSep16CorrKernel),
@@ -1177,7 +1219,7 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
                 break;
             }
             case OP_IR16: {
-                const Fused16& f = op.math ? kFused16H[op.fused_id] : kFused16[op.fused_id];
+                const Fused16& f = op.math == 2 ? kFused16B[op.fused_id] : op.math ? kFused16H[op.fused_id] : kFused16[op.fused_id];
                 Ir2Args a{};
                 a.X = buf(op.in_buf) + op.in_off; a.ldx = op.in_ld;
                 a.Wpk = op.d_packed; a.bp = h->convs[op.conv_p].d_b;
@@ -1220,7 +1262,7 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
                 break;
             }
             case OP_IRTILE: {
-                const FusedTile& f = op.stem ? kStemTile : (op.math ? kFusedTileH[op.fused_id] :
+                const FusedTile& f = op.stem ? kStemTile : (op.math == 2 ? kFusedTileB[op.fused_id] : op.math ? kFusedTileH[op.fused_id] :
                                                             (op.small_tiles ? kFusedTileSmall[op.fused_id] : kFusedTile[op.fused_id]));
                 IrT2Args ta{};
                 Ir2Args& a = ta.b;
@@ -1373,7 +1415,7 @@ int fear_set_option(fear_handle* h, int option, int64_t value) {
             if (h->fuse != (int)value) { h->fuse = (int)value; return drop_plans(h); }
             return FEAR_OK;
         case FEAR_OPT_MATH:
-            if (value != 0 && value != 1) return FEAR_ERR_SHAPE;
+            if (value < 0 || value > 2) return FEAR_ERR_SHAPE;
             if (h->math != (int)value) { h->math = (int)value; return drop_plans(h); }
             return FEAR_OK;
         case FEAR_OPT_CHAIN:

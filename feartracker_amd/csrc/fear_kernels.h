@@ -1676,8 +1676,36 @@ __device__ __forceinline__ void split_half8(const f32x4& a, const f32x4& b, h8& 
     lo = __builtin_convertvector(x - __builtin_convertvector(hi, f32x8), h8);
 }
 
-template <int CIN, int CEXP, int COUT, int KS, bool EXPAND>
+// The two matrix-pipe arithmetic modes of the *_h kernels (FEAR_OPT_MATH):
+//   MM = 1  fp32 activation = fp16 hi + fp16 lo, exact-fp16 weights, two v_mfma_f32_16x16x32_f16 per product: fp32-grade
+//   MM = 2  activation and weights rounded to bf16 (RNE, v_cvt_pk_bf16_f32), ONE v_mfma_f32_16x16x32_bf16, fp32
+//           accumulate: genuinely reduced precision (8 mantissa bits per operand) — the "bf16 MFMA pointwise-conv path" of
+//           BASELINE.json configs[3]; bias, ReLU, depthwise, residuals stay fp32 as in mode 1
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+template <int MM> struct MatOps;
+template <> struct MatOps<1> {
+    using V = h8;
+    static __device__ __forceinline__ void split(const f32x4& a, const f32x4& b, V& hi, V& lo) { split_half8(a, b, hi, lo); }
+    static __device__ __forceinline__ f32x4 mma(const V& w, const V& hi, const V& lo, f32x4 acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, hi, acc, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(w, lo, acc, 0, 0, 0);
+    }
+};
+template <> struct MatOps<2> {
+    using V = bf8;
+    static __device__ __forceinline__ void split(const f32x4& a, const f32x4& b, V& hi, V& lo) {
+        hi = __builtin_convertvector(__builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7), bf8);
+        lo = hi;      // unused
+    }
+    static __device__ __forceinline__ f32x4 mma(const V& w, const V& hi, const V&, f32x4 acc) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, hi, acc, 0, 0, 0);
+    }
+};
+
+template <int CIN, int CEXP, int COUT, int KS, bool EXPAND, int MM = 1>
 __global__ __launch_bounds__(512) void ir16h_fused_kernel(Ir2Args a) {
+    using MX = MatOps<MM>;
+    using V8 = typename MX::V;
     using G = IrHGeom<CIN, CEXP, COUT, KS, EXPAND>;
     constexpr int S = G::S, P = G::P, PW = G::RW, ES = G::ES, NCHUNK = G::NCHUNK, NTP = G::NTP, KG = G::KG;
     constexpr int AP = G::AP, BP = G::BP, EBUF = G::EBUF, CST = AP + BP;
@@ -1698,7 +1726,7 @@ __global__ __launch_bounds__(512) void ir16h_fused_kernel(Ir2Args a) {
     for (int i = tid * 4; i < 2 * EBUF; i += 512 * 4) *reinterpret_cast<f32x4*>(lds + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // activation fragments (hi / lo halves) of this wave's two pixel rows, resident for every chunk
-    h8 xhi[EXPAND ? 2 : 1][EXPAND ? KG : 1], xlo[EXPAND ? 2 : 1][EXPAND ? KG : 1];
+    V8 xhi[EXPAND ? 2 : 1][EXPAND ? KG : 1], xlo[EXPAND ? 2 : 1][EXPAND ? KG : 1];
     if (EXPAND) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -1709,7 +1737,7 @@ __global__ __launch_bounds__(512) void ir16h_fused_kernel(Ir2Args a) {
                 f32x4 v0 = (f32x4){0.f, 0.f, 0.f, 0.f}, v1 = v0;
                 if (k < CIN) v0 = *reinterpret_cast<const f32x4*>(px);
                 if (k + 4 < CIN) v1 = *reinterpret_cast<const f32x4*>(px + 4);
-                split_half8(v0, v1, xhi[mt][kg], xlo[mt][kg]);
+                MX::split(v0, v1, xhi[mt][kg], xlo[mt][kg]);
             }
     }
 
@@ -1781,11 +1809,10 @@ __global__ __launch_bounds__(512) void ir16h_fused_kernel(Ir2Args a) {
         for (int kg = 0; kg < KG; ++kg)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                const h8 wf = *reinterpret_cast<const h8*>(wa + (nt * KG + kg) * 256 + lane * 4);
+                const V8 wf = *reinterpret_cast<const V8*>(wa + (nt * KG + kg) * 256 + lane * 4);
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xhi[mt][kg], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xlo[mt][kg], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = MX::mma(wf, xhi[mt][kg], xlo[mt][kg], acc[mt][nt]);
                 }
             }
 #pragma unroll
@@ -1841,7 +1868,7 @@ __global__ __launch_bounds__(512) void ir16h_fused_kernel(Ir2Args a) {
                 }
             }
         }
-        h8 dhi[2], dlo[2];
+        V8 dhi[2], dlo[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             f32x4 q0 = r == 0 ? __builtin_shufflevector(d8[0], d8[0], 0, 1, 2, 3) : __builtin_shufflevector(d8[0], d8[0], 4, 5, 6, 7);
@@ -1850,15 +1877,14 @@ __global__ __launch_bounds__(512) void ir16h_fused_kernel(Ir2Args a) {
                 q0.x = fmaxf(q0.x, 0.f); q0.y = fmaxf(q0.y, 0.f); q0.z = fmaxf(q0.z, 0.f); q0.w = fmaxf(q0.w, 0.f);
                 q1.x = fmaxf(q1.x, 0.f); q1.y = fmaxf(q1.y, 0.f); q1.z = fmaxf(q1.z, 0.f); q1.w = fmaxf(q1.w, 0.f);
             }
-            split_half8(q0, q1, dhi[r], dlo[r]);
+            MX::split(q0, q1, dhi[r], dlo[r]);
         }
 #pragma unroll
         for (int nt = 0; nt < NTP; ++nt) {
-            const h8 wp = *reinterpret_cast<const h8*>(wb + nt * 256 + lane * 4);
+            const V8 wp = *reinterpret_cast<const V8*>(wb + nt * 256 + lane * 4);
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                accp[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wp, dhi[r], accp[r][nt], 0, 0, 0);
-                accp[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wp, dlo[r], accp[r][nt], 0, 0, 0);
+                accp[r][nt] = MX::mma(wp, dhi[r], dlo[r], accp[r][nt]);
             }
         }
     };
@@ -1939,8 +1965,10 @@ struct IrTHGeom {
     static constexpr int LDS_BYTES = (EBUF + 2 * (AP + BP)) * 4;
 };
 
-template <int CIN, int CEXPP, int COUT, int KS, int ST, int TW, int TH, bool EXPAND, int NW, int MINW>
+template <int CIN, int CEXPP, int COUT, int KS, int ST, int TW, int TH, bool EXPAND, int NW, int MINW, int MM = 1>
 __global__ __launch_bounds__(64 * NW, MINW) void ir_tile_h_kernel(IrT2Args t) {
+    using MX = MatOps<MM>;
+    using V8 = typename MX::V;
     using G = IrTHGeom<CIN, CEXPP, COUT, KS, ST, TW, TH, EXPAND, NW>;
     const Ir2Args& a = t.b;
     constexpr int P = G::P, IWR = G::IWR, IHR = G::IHR, ES = G::ES, SEG = G::SEG, MTC = G::MTC, MTA = G::MTA;
@@ -1988,7 +2016,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ir_tile_h_kernel(IrT2Args t) {
 
     int eoff[MTA];
     long xoff[MTA];
-    h8 xhi[EXPAND ? MTA : 1][EXPAND ? KG : 1], xlo[EXPAND ? MTA : 1][EXPAND ? KG : 1];
+    V8 xhi[EXPAND ? MTA : 1][EXPAND ? KG : 1], xlo[EXPAND ? MTA : 1][EXPAND ? KG : 1];
 #pragma unroll
     for (int i = 0; i < MTA; ++i) {
         const int q = (wave + NW * i) * 16 + li;
@@ -2005,7 +2033,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ir_tile_h_kernel(IrT2Args t) {
                 f32x4 v0 = (f32x4){0.f, 0.f, 0.f, 0.f}, v1 = v0;
                 if (k < CIN) v0 = *reinterpret_cast<const f32x4*>(Xc + xoff[i] + k);
                 if (k + 4 < CIN) v1 = *reinterpret_cast<const f32x4*>(Xc + xoff[i] + k + 4);
-                split_half8(v0, v1, xhi[i][kg], xlo[i][kg]);
+                MX::split(v0, v1, xhi[i][kg], xlo[i][kg]);
             }
         }
     }
@@ -2039,13 +2067,13 @@ __global__ __launch_bounds__(64 * NW, MINW) void ir_tile_h_kernel(IrT2Args t) {
         if (EXPAND) __syncthreads();
         // ---- phase A
         if (EXPAND) {
-            h8 wf[2][KG > 0 ? KG : 1];
+            V8 wf[2][KG > 0 ? KG : 1];
             f32x4 bias[2];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 bias[nt] = *reinterpret_cast<const f32x4*>(wa + 2 * KG * 256 + nt * 16 + lk * 4);
 #pragma unroll
-                for (int kg = 0; kg < KG; ++kg) wf[nt][kg] = *reinterpret_cast<const h8*>(wa + (nt * KG + kg) * 256 + lane * 4);
+                for (int kg = 0; kg < KG; ++kg) wf[nt][kg] = *reinterpret_cast<const V8*>(wa + (nt * KG + kg) * 256 + lane * 4);
             }
 #pragma unroll
             for (int i = 0; i < MTA; ++i) {
@@ -2055,8 +2083,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ir_tile_h_kernel(IrT2Args t) {
                     f32x4 acc = bias[nt];
 #pragma unroll
                     for (int kg = 0; kg < KG; ++kg) {
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt][kg], xhi[i][kg], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt][kg], xlo[i][kg], acc, 0, 0, 0);
+                        acc = MX::mma(wf[nt][kg], xhi[i][kg], xlo[i][kg], acc);
                     }
                     acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
                     if (eoff[i] >= 0) *reinterpret_cast<f32x4*>(E + eoff[i] + nt * 16 + lk * 4) = acc;
@@ -2077,7 +2104,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ir_tile_h_kernel(IrT2Args t) {
         // ---- phase B: fp32 depthwise, 8 channels per lane
         const float* wd = wb + NTP * 256 + lk * 8;
         const float* Ebase = E + ((r0 * ST) * IWR + (seg * 16 + li) * ST) * ES + lk * 8;
-        h8 dhi[MTC], dlo[MTC];
+        V8 dhi[MTC], dlo[MTC];
         if (ST == 1) {
 #pragma unroll
             for (int pr = 0; pr < MTC / 2; ++pr) {        // output rows 2pr, 2pr+1 in one 8-wide accumulator per half
@@ -2112,7 +2139,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ir_tile_h_kernel(IrT2Args t) {
                         q0.x = fmaxf(q0.x, 0.f); q0.y = fmaxf(q0.y, 0.f); q0.z = fmaxf(q0.z, 0.f); q0.w = fmaxf(q0.w, 0.f);
                         q1.x = fmaxf(q1.x, 0.f); q1.y = fmaxf(q1.y, 0.f); q1.z = fmaxf(q1.z, 0.f); q1.w = fmaxf(q1.w, 0.f);
                     }
-                    split_half8(q0, q1, dhi[2 * pr + rr], dlo[2 * pr + rr]);
+                    MX::split(q0, q1, dhi[2 * pr + rr], dlo[2 * pr + rr]);
                 }
             }
         } else {
@@ -2133,16 +2160,15 @@ __global__ __launch_bounds__(64 * NW, MINW) void ir_tile_h_kernel(IrT2Args t) {
                     d[h].x = fmaxf(d[h].x, 0.f); d[h].y = fmaxf(d[h].y, 0.f); d[h].z = fmaxf(d[h].z, 0.f); d[h].w = fmaxf(d[h].w, 0.f);
                 }
             }
-            split_half8(d[0], d[1], dhi[0], dlo[0]);
+            MX::split(d[0], d[1], dhi[0], dlo[0]);
         }
         // ---- phase C
 #pragma unroll
         for (int nt = 0; nt < NTP; ++nt) {
-            const h8 wp = *reinterpret_cast<const h8*>(wb + nt * 256 + lane * 4);
+            const V8 wp = *reinterpret_cast<const V8*>(wb + nt * 256 + lane * 4);
 #pragma unroll
             for (int r = 0; r < MTC; ++r) {
-                accp[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wp, dhi[r], accp[r][nt], 0, 0, 0);
-                accp[r][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wp, dlo[r], accp[r][nt], 0, 0, 0);
+                accp[r][nt] = MX::mma(wp, dhi[r], dlo[r], accp[r][nt]);
             }
         }
         if (c + 1 < NCHUNK) store_w(c + 1);

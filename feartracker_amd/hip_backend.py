@@ -24,6 +24,7 @@ from .constants import TARGET_CLASSIFICATION_KEY, TARGET_REGRESSION_LABEL_KEY
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FEAR_LIB", os.path.join(_PKG, "libfear_hip.so"))   # FEAR_LIB: development builds (tools/)
 DEFAULT_WEIGHTS = os.path.join(_PKG, "weights", "fear_xs_noembs.fearw")
+WEIGHTS_FEAR_M = os.path.join(_PKG, "weights", "fear_m_synth.fearw")   # synthetic deeper trunk (tools/make_fear_m.py), random weights
 
 FEAR_OPT_MAX_BATCH = 1
 FEAR_OPT_PROFILE = 2
@@ -179,7 +180,8 @@ class FEARNetHIP:
         self._check(self._lib.fear_set_option(self._h, FEAR_OPT_PLAN_CROPS, int(crops)))
 
     def set_math(self, mode: int) -> None:
-        """0: exact fp32 MFMA (default); 1: fp16 hi+lo split operands on the matrix pipe, fp32 accumulate."""
+        """0: exact fp32 MFMA (default); 1: fp16 hi+lo split operands on the matrix pipe, fp32 accumulate (fp32-grade);
+        2: bf16 operands, fp32 accumulate (reduced precision: the bf16 MFMA pointwise-conv path of BASELINE configs[3])."""
         self._check(self._lib.fear_set_option(self._h, FEAR_OPT_MATH, int(mode)))
 
     def set_profile(self, on: bool, op: int = -1) -> None:

@@ -110,6 +110,8 @@ int fear_crop_normalize(fear_handle* h, const uint8_t* frame_u8, int frame_h, in
                                /*   0 (default) fp32 operands, v_mfma_f32_16x16x4_f32 (exact fp32) */
                                /*   1 fp32 activations split into fp16 hi+lo, exact-fp16 weights,  */
                                /*     v_mfma_f32_16x16x32_f16 on the matrix pipe, fp32 accumulate  */
+                               /*   2 activations and weights rounded to bf16, v_mfma_f32_16x16x32_bf16,*/
+                               /*     fp32 accumulate: reduced precision (BASELINE config "bf16")  */
 #define FEAR_OPT_CHAIN 6       /* 1 (default): stride-16 trunk stage + neck as one register-resident chain kernel */
                                /*   (fp32 mode); 0: one fused kernel per block                                 */
 #define FEAR_OPT_SMALL_PASS 7  /* passes of at most this many crops (default 96; 0 = never) run the small-batch plan:      */

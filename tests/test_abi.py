@@ -141,7 +141,7 @@ def test_error_codes_and_options_on_device():
     assert lib.fear_decode(h, None, None, 3, 0, 16, 256, None, None, None, st) == SHAPE
     assert lib.fear_decode_smooth(h, None, None, 0, 16, 16, 256, None, None, 0.1, 0.3, 0.3, None, None, None, st) == OK
     assert lib.fear_decode_smooth(h, None, None, 2, 16, 16, 256, None, None, 0.1, 0.3, 0.3, None, None, None, st) == NULL
-    for opt, good, bad in ((hb.FEAR_OPT_MAX_BATCH, 17, 0), (hb.FEAR_OPT_MATH, 1, 2), (hb.FEAR_OPT_CHAIN, 0, 5),
+    for opt, good, bad in ((hb.FEAR_OPT_MAX_BATCH, 17, 0), (hb.FEAR_OPT_MATH, 2, 3), (hb.FEAR_OPT_CHAIN, 0, 5),
                            (hb.FEAR_OPT_SMALL_PASS, 12, -1), (hb.FEAR_OPT_FUSE, 0, 3), (hb.FEAR_OPT_PLAN_CROPS, 3, -2)):
         assert lib.fear_set_option(h, opt, good) == OK and lib.fear_get_option(h, opt) == good
         assert lib.fear_set_option(h, opt, bad) == SHAPE and lib.fear_get_option(h, opt) == good

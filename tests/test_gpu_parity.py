@@ -667,3 +667,45 @@ def test_calls_on_two_streams_are_ordered(hip_net):
     torch.cuda.synchronize()
     for b, c in outs:
         assert torch.equal(b, b0) and torch.equal(c, c0)
+
+
+def test_fear_m_synthetic_deeper_trunk_all_math_modes():
+    """BASELINE configs[3] ("FEAR-M, deeper FBNet, bf16"): the reference defines no such model, so the synthetic deeper trunk
+    of tools/make_fear_m.py (every residual block of FEAR-XS twice: 28 IR blocks, seeded random weights) stands in.  The
+    engine is weight-file driven: every block must land on a fused kernel; fp32 and the fp16-split mode must match the
+    oracle on the same file at the path's 1e-3; the bf16 mode (FEAR_OPT_MATH=2: operands rounded to 8 mantissa bits, fp32
+    accumulate) is reduced precision by construction — its stated tolerance against the fp32 path is 8e-2 relative on the
+    ltrb maps and 0.15 absolute on the logits (measured 2.7e-2 / 5.4e-2), and it must keep the arg-max cell wherever the
+    fp32 top-2 logit margin exceeds twice the observed logit deviation."""
+    from feartracker_amd import FEARNetHIP
+    from feartracker_amd.hip_backend import WEIGHTS_FEAR_M
+    from oracle.fear_oracle import OracleNet
+    net = FEARNetHIP(WEIGHTS_FEAR_M, device=0, max_batch=64)
+    net.set_small_pass(0)
+    ora = OracleNet(WEIGHTS_FEAR_M)
+    names = [n for n, _, _ in net.plan(256, True)]
+    assert sum(n.startswith(("irt_", "stem_irt")) for n in names) == 15 and sum(n.startswith("ir16_") for n in names) == 13
+    assert not any(n.startswith(("pw_", "dw")) for n in names)           # nothing fell back to the layer-wise kernels
+    g = torch.Generator().manual_seed(6)
+    x = norm_u8(torch.randint(0, 256, (4, 3, 256, 256), dtype=torch.uint8, generator=g))
+    t = norm_u8(torch.randint(0, 256, (4, 3, 128, 128), dtype=torch.uint8, generator=g))
+    zr = ora.get_features(t)
+    ref = ora.track(x, zr)
+    maps = {}
+    for mode in (0, 1, 2):
+        net.set_math(mode)
+        z = net.get_features(t.cuda())
+        assert_features_close(z, zr)
+        maps[mode] = net.track_maps(x.cuda(), z)
+        if mode < 2:
+            assert_maps_close(maps[mode][0], maps[mode][1], ref["TARGET_REGRESSION_LABEL_KEY"], ref["TARGET_CLASSIFICATION_KEY"])
+    b0, c0 = maps[0]
+    b2, c2 = maps[2]
+    dev_b = float(((b2 - b0).abs() / b0.abs()).max())
+    dev_c = float((c2 - c0).abs().max())
+    print(f"bf16 vs fp32 on FEAR-M: bbox {dev_b:.2e} rel, cls {dev_c:.2e} abs")
+    assert 1e-4 < dev_b < 8e-2 and 1e-4 < dev_c < 0.15                    # really bf16, and no worse than bf16
+    flat = c0.reshape(4, -1)
+    top2 = torch.topk(flat, 2, dim=1).values
+    need = (top2[:, 0] - top2[:, 1]) > 2 * dev_c
+    assert torch.equal(c2.reshape(4, -1).argmax(dim=1)[need], flat.argmax(dim=1)[need])
