@@ -11,8 +11,10 @@ import subprocess
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(PKG_DIR, "csrc", "fear_engine.hip")
-DEPS = [SRC, os.path.join(PKG_DIR, "csrc", "fear_kernels.h"),
+SRC_TRAIN = os.path.join(PKG_DIR, "csrc", "fear_train.hip")       # head training-step operators, #included by fear_engine.hip
+DEPS = [SRC, SRC_TRAIN, os.path.join(PKG_DIR, "csrc", "fear_kernels.h"),
         os.path.join(os.path.dirname(PKG_DIR), "include", "fear_hip.h"),
+        os.path.join(os.path.dirname(PKG_DIR), "include", "fear_train.h"),
         os.path.join(os.path.dirname(PKG_DIR), "include", "fearw_format.h")]
 LIB = os.path.join(PKG_DIR, "libfear_hip.so")
 

@@ -1637,3 +1637,6 @@ size_t fear_workspace_bytes(fear_handle* h) { return h ? h->workspace_floats * s
 int fear_last_hip_error(fear_handle* h) { return h ? h->last_hip_error : 0; }
 
 }  // extern "C"
+
+// the head training-step operators (include/fear_train.h) share this translation unit
+#include "fear_train.hip"

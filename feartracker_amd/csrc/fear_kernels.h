@@ -57,8 +57,8 @@ struct PwArgs {
     int M, K, N;
     int relu;
     int nchw_hw;         // >0: store Y as [M / hw][N][hw] (NCHW), hw = pixels per crop
-    int rows_per_crop;   // WKN only: pixels per crop (selects the crop's weight matrix)
-    long w_crop_stride;  // WKN only: floats between consecutive crops' weights
+    int rows_per_crop;   // > 0: every block of this many rows (one crop's pixels) has its own weight matrix ...
+    long w_crop_stride;  // ... this many floats after the previous one (the correlation and its gradients); 0: shared weights
 };
 
 template <int MT, int NT, bool WKN>
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(PwArgs a) {
     if (m_wave >= a.M) return;
 
     const float* Wp = a.W;
-    if (WKN) Wp += (long)(m_wave / a.rows_per_crop) * a.w_crop_stride;
+    if (a.rows_per_crop > 0) Wp += (long)(m_wave / a.rows_per_crop) * a.w_crop_stride;   // per-crop weight matrices
 
     const float* xrow[MT];
     bool mvalid[MT];

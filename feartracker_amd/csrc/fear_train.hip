@@ -1,0 +1,827 @@
+// fear_train.hip — gfx950 operators of the FEAR head TRAINING step (BASELINE.json configs[4]):
+// forward in train mode (BatchNorm on batch statistics) and backward of everything `BoxTower.forward` is made of
+//     SepConv            model_training/model/blocks.py:45-72    depthwise 3x3 (+bias) -> pointwise 1x1 (+bias)
+//     BatchNorm2d + ReLU model/blocks.py:98-101,115-119,150-158  (nn.BatchNorm2d, training=True)
+//     MobileCorrelation  model/blocks.py:121-126                 s = z^T x, cat[x, s]
+//     exp(adjust*x+bias) / 0.1*cls   model/blocks.py:186-192
+//     FEARLoss           model_training/train/loss.py:13-96      BCE-with-logits (pos / neg halves) + (1 - IoU) on the weighted cells
+// Host code (feartracker_amd/train_head.py) composes them; the reference relies on torch autograd + cuDNN for all of this.
+//
+// Layout: fp32 NHWC "rows x channels" ([M = batch*H*W][ld], channels contiguous) like the inference engine, so that a 1x1
+// convolution's three GEMMs all run on v_mfma_f32_16x16x4_f32:
+//     forward   Y[m][n]  = sum_k X[m][k]  W[n][k]          (pw_mfma_kernel, fear_kernels.h)
+//     dgrad     dX[m][k] = sum_n dY[m][n] W[n][k]          (the same kernel, W read K-major: WKN = true)
+//     wgrad     dW[n][k] = sum_m dY[m][n] X[m][k]          (pw_wgrad_kernel below: reduction over the pixels, split over row
+//                                                           slices -> partial [slice][N][K] -> deterministic final sum)
+// Every reduction over the batch (BN statistics, bias / BN-affine / depthwise-weight gradients, the loss) is two-stage and
+// fixed-order: no atomics, bit-reproducible.
+//
+// This file is the second half of the library's single translation unit: fear_engine.hip includes it (the kernels of
+// fear_kernels.h it reuses — pw_mfma_kernel, dw_conv_kernel — are then instantiated once).
+#include "../../include/fear_train.h"
+
+namespace {
+
+using namespace fear;
+
+#define LAUNCH_CHECK()                                        \
+    do {                                                      \
+        if (hipGetLastError() != hipSuccess) return FEAR_TRAIN_ERR_HIP; \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// Column reductions over rows: per-channel sums.  Block = 256 threads = (C/4 channel quads) x (R row lanes); a block reduces
+// ROWS_PER_BLOCK rows into partial[block][2][C]; col_finalize_kernel adds the partials in double, in block order.
+//   MODE 0: s1 = sum x,        s2 = sum x^2                                  (BatchNorm forward statistics)
+//   MODE 1: g = relu ? (y > 0 ? dy : 0) : dy;  s1 = sum g,  s2 = sum g * xhat,  xhat = (x - mean) * rstd   (BatchNorm backward)
+//   MODE 2: s1 = sum dy                                                      (bias gradients)
+constexpr int ROWS_PER_BLOCK = 256;
+
+struct ColArgs {
+    const float* A;      // x (mode 0) / dy (modes 1, 2)
+    const float* Yact;   // mode 1: activation output (ReLU mask) or nullptr
+    const float* X;      // mode 1: the BatchNorm input
+    const float* mean;   // mode 1
+    const float* rstd;   // mode 1
+    float* partial;      // [blocks][2][C]
+    long M;
+    int C, lda, ldy, ldx;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void col_reduce_kernel(ColArgs a) {
+    __shared__ f32x4 red[2][256];
+    const int c4n = a.C >> 2;
+    const int R = 256 / c4n;
+    const int cq = threadIdx.x % c4n, rl = threadIdx.x / c4n;
+    f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f}, s2 = s1;
+    const long r0 = (long)blockIdx.x * ROWS_PER_BLOCK;
+    const long r1 = r0 + ROWS_PER_BLOCK < a.M ? r0 + ROWS_PER_BLOCK : a.M;
+    if (rl < R) {
+        f32x4 mu = s1, rs = s1;
+        if (MODE == 1) {
+            mu = *reinterpret_cast<const f32x4*>(a.mean + cq * 4);
+            rs = *reinterpret_cast<const f32x4*>(a.rstd + cq * 4);
+        }
+        for (long r = r0 + rl; r < r1; r += R) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(a.A + r * a.lda + cq * 4);
+            if (MODE == 0) {
+                s1 += v;
+                s2 += v * v;
+            } else if (MODE == 1) {
+                if (a.Yact) {
+                    const f32x4 y = *reinterpret_cast<const f32x4*>(a.Yact + r * a.ldy + cq * 4);
+                    v.x = y.x > 0.f ? v.x : 0.f; v.y = y.y > 0.f ? v.y : 0.f; v.z = y.z > 0.f ? v.z : 0.f; v.w = y.w > 0.f ? v.w : 0.f;
+                }
+                const f32x4 xh = (*reinterpret_cast<const f32x4*>(a.X + r * a.ldx + cq * 4) - mu) * rs;
+                s1 += v;
+                s2 += v * xh;
+            } else {
+                s1 += v;
+            }
+        }
+    }
+    red[0][threadIdx.x] = s1;
+    red[1][threadIdx.x] = s2;
+    __syncthreads();
+    if (rl == 0) {
+        for (int j = 1; j < R; ++j) {          // fixed order
+            s1 += red[0][j * c4n + cq];
+            s2 += red[1][j * c4n + cq];
+        }
+        float* p = a.partial + (long)blockIdx.x * 2 * a.C;
+        *reinterpret_cast<f32x4*>(p + cq * 4) = s1;
+        *reinterpret_cast<f32x4*>(p + a.C + cq * 4) = s2;
+    }
+}
+
+// mode 0: mean / rstd (+ running statistics, torch semantics: biased variance normalises, unbiased one is tracked);
+// mode 1: the two sums as they are (sum g -> out1, sum g*xhat -> out2);  mode 2: out1 only
+struct ColFinArgs {
+    const float* partial;
+    float* out1;
+    float* out2;
+    float* running_mean;   // mode 0, optional
+    float* running_var;
+    int blocks, C, mode;
+    double M, eps, momentum;
+};
+
+__global__ __launch_bounds__(256) void col_finalize_kernel(ColFinArgs a) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < a.blocks; ++b) {
+        s1 += (double)a.partial[(long)b * 2 * a.C + c];
+        s2 += (double)a.partial[(long)b * 2 * a.C + a.C + c];
+    }
+    if (a.mode == 0) {
+        const double mean = s1 / a.M;
+        double var = s2 / a.M - mean * mean;
+        if (var < 0.0) var = 0.0;
+        a.out1[c] = (float)mean;
+        a.out2[c] = (float)(1.0 / sqrt(var + a.eps));
+        if (a.running_mean) {
+            a.running_mean[c] = (float)((1.0 - a.momentum) * (double)a.running_mean[c] + a.momentum * mean);
+            const double unbiased = a.M > 1.0 ? var * a.M / (a.M - 1.0) : var;
+            a.running_var[c] = (float)((1.0 - a.momentum) * (double)a.running_var[c] + a.momentum * unbiased);
+        }
+    } else {
+        a.out1[c] = (float)s1;
+        if (a.out2) a.out2[c] = (float)s2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm apply (+ReLU) and its input gradient, elementwise over float4s.
+struct BnApplyArgs {
+    const float* X;
+    const float* mean;
+    const float* rstd;
+    const float* gamma;
+    const float* beta;
+    float* Y;
+    long M;
+    int C, ldx, ldy, relu;
+};
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs a) {
+    const int c4n = a.C >> 2;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.M * c4n) return;
+    const long r = i / c4n;
+    const int c = (int)(i % c4n) * 4;
+    const f32x4 x = *reinterpret_cast<const f32x4*>(a.X + r * a.ldx + c);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + c), rs = *reinterpret_cast<const f32x4*>(a.rstd + c);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(a.gamma + c), b = *reinterpret_cast<const f32x4*>(a.beta + c);
+    f32x4 y = (x - mu) * rs * g + b;
+    if (a.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+    *reinterpret_cast<f32x4*>(a.Y + r * a.ldy + c) = y;
+}
+
+struct BnBwdArgs {
+    const float* dY;
+    const float* Yact;   // ReLU mask source or nullptr
+    const float* X;
+    const float* mean;
+    const float* rstd;
+    const float* gamma;
+    const float* sum_g;      // [C] sum g
+    const float* sum_gx;     // [C] sum g * xhat
+    float* dX;
+    long M;
+    int C, lddy, ldy, ldx, lddx;
+};
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
+    const int c4n = a.C >> 2;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.M * c4n) return;
+    const long r = i / c4n;
+    const int c = (int)(i % c4n) * 4;
+    f32x4 g = *reinterpret_cast<const f32x4*>(a.dY + r * a.lddy + c);
+    if (a.Yact) {
+        const f32x4 y = *reinterpret_cast<const f32x4*>(a.Yact + r * a.ldy + c);
+        g.x = y.x > 0.f ? g.x : 0.f; g.y = y.y > 0.f ? g.y : 0.f; g.z = y.z > 0.f ? g.z : 0.f; g.w = y.w > 0.f ? g.w : 0.f;
+    }
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + c), rs = *reinterpret_cast<const f32x4*>(a.rstd + c);
+    const f32x4 xh = (*reinterpret_cast<const f32x4*>(a.X + r * a.ldx + c) - mu) * rs;
+    const float inv_m = 1.0f / (float)a.M;
+    const f32x4 sg = *reinterpret_cast<const f32x4*>(a.sum_g + c) * inv_m;
+    const f32x4 sgx = *reinterpret_cast<const f32x4*>(a.sum_gx + c) * inv_m;
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + c);
+    *reinterpret_cast<f32x4*>(a.dX + r * a.lddx + c) = gm * rs * (g - sg - xh * sgx);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pointwise-conv weight gradient on the matrix cores: dW[n][k] = sum_m dY[m][n] X[m][k].
+// One wavefront owns a 16 (n) x 64 (k) strip of dW for one slice of rows (and one crop when batched): per step of 4 rows,
+// lane (li, lk) loads dY[m + lk][n0 + li] (A operand: i = n) and the float4 X[m + lk][k0 + 4 li .. +3]; MFMA q uses component
+// q as its B operand, i.e. output column j = li of MFMA q is k = k0 + 4 li + q — a column permutation undone at the store.
+struct WgradArgs {
+    const float* dY;     // [M][lddy]   (per crop: + crop * dy_crop_stride)
+    const float* X;      // [M][ldx]
+    float* P;            // partial [slices][crops][N][K]
+    long rows_per_slice, M;      // M = rows per crop when batched
+    long dy_crop_stride, x_crop_stride;
+    int N, K, lddy, ldx, n_strips, k_strips, crops;
+};
+
+__global__ __launch_bounds__(64) void pw_wgrad_kernel(WgradArgs a) {
+    const int lane = threadIdx.x, li = lane & 15, lk = lane >> 4;
+    const int strip = blockIdx.x;
+    const int ns = strip / a.k_strips, ks = strip % a.k_strips;
+    const int slice = blockIdx.y, crop = blockIdx.z;
+    const int n = ns * 16 + li;
+    const int k = ks * 64 + li * 4;
+    const bool nv = n < a.N, kv = k < a.K;      // K is a multiple of 4
+    const float* dy = a.dY + (long)crop * a.dy_crop_stride + (nv ? n : 0);
+    const float* x = a.X + (long)crop * a.x_crop_stride + (kv ? k : 0);
+    f32x4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const long m0 = (long)slice * a.rows_per_slice;
+    const long m1 = m0 + a.rows_per_slice < a.M ? m0 + a.rows_per_slice : a.M;
+    for (long m = m0; m < m1; m += 16) {
+        float av[4];
+        f32x4 bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long r = m + u * 4 + lk;
+            const bool rv = r < m1;
+            av[u] = rv && nv ? dy[r * a.lddy] : 0.f;
+            bv[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (rv && kv) bv[u] = *reinterpret_cast<const f32x4*>(x + r * a.ldx);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u][q], acc[q], 0, 0, 0);
+    }
+    // acc[q] lane (li, lk), component r  =  dW[ns*16 + 4 lk + r][ks*64 + 4 li + q]
+    float* P = a.P + (((long)slice * a.crops + crop) * a.N) * a.K;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int nn = ns * 16 + lk * 4 + r;
+        if (nn < a.N && kv) {
+            const f32x4 v = (f32x4){acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+            *reinterpret_cast<f32x4*>(P + (long)nn * a.K + k) = v;
+        }
+    }
+}
+
+// out[i] = sum over slices of P[s][i], fixed order (i over crops*N*K)
+__global__ __launch_bounds__(256) void slice_sum_kernel(const float* P, float* out, long count, int slices) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= count) return;
+    f32x4 s = *reinterpret_cast<const f32x4*>(P + i);
+    for (int j = 1; j < slices; ++j) s += *reinterpret_cast<const f32x4*>(P + (long)j * count + i);
+    *reinterpret_cast<f32x4*>(out + i) = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Depthwise-conv weight gradient (stride 1, pad k/2): dW[t][c] = sum_{b,y,x} dY[b,y,x,c] * X[b, y+ky-P, x+kx-P, c].
+// Block = (C/4 quads) x R pixel lanes over a slice of output pixels; partial [block][KS*KS][C] -> slice_sum_kernel.
+struct DwWgradArgs {
+    const float* dY;
+    const float* X;
+    float* partial;
+    long pixels;          // B*H*W
+    int H, W, C, lddy, ldx;
+};
+
+template <int KS>
+__global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgradArgs a) {
+    constexpr int P = KS / 2, KK = KS * KS;
+    __shared__ f32x4 red[256];
+    const int c4n = a.C >> 2;
+    const int R = 256 / c4n;
+    const int cq = threadIdx.x % c4n, rl = threadIdx.x / c4n;
+    f32x4 acc[KK];
+#pragma unroll
+    for (int t = 0; t < KK; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const long p0 = (long)blockIdx.x * ROWS_PER_BLOCK;
+    const long p1 = p0 + ROWS_PER_BLOCK < a.pixels ? p0 + ROWS_PER_BLOCK : a.pixels;
+    if (rl < R) {
+        for (long p = p0 + rl; p < p1; p += R) {
+            const int x = (int)(p % a.W);
+            const int y = (int)((p / a.W) % a.H);
+            const f32x4 g = *reinterpret_cast<const f32x4*>(a.dY + p * a.lddy + cq * 4);
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky) {
+                const int yy = y + ky - P;
+                if (yy < 0 || yy >= a.H) continue;
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) {
+                    const int xx = x + kx - P;
+                    if (xx < 0 || xx >= a.W) continue;
+                    const long q = p + (long)(ky - P) * a.W + (kx - P);
+                    acc[ky * KS + kx] += g * *reinterpret_cast<const f32x4*>(a.X + q * a.ldx + cq * 4);
+                }
+            }
+        }
+    }
+    float* out = a.partial + (long)blockIdx.x * KK * a.C;
+    for (int t = 0; t < KK; ++t) {
+        __syncthreads();
+        red[threadIdx.x] = acc[t];
+        __syncthreads();
+        if (rl == 0) {
+            f32x4 s = acc[t];
+            for (int j = 1; j < R; ++j) s += red[j * c4n + cq];
+            *reinterpret_cast<f32x4*>(out + (long)t * a.C + cq * 4) = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Box head: bbox = exp(adjust * p + bias[c]) (blocks.py:186-187) forward, and backward
+//   dp = dbbox * bbox * adjust;  d adjust = sum dbbox * bbox * p;  d bias[c] = sum dbbox * bbox
+// p, bbox, dbbox, dp: NHWC rows of 4.  The two reductions reuse col_reduce (mode 0 style) through a staging tensor:
+//   T[m][0..3] = dbbox*bbox (-> d bias),  U[m][0..3] = dbbox*bbox*p (-> d adjust = sum over m and c).
+struct ExpHeadArgs {
+    const float* P;      // [M][4]
+    const float* adjust; // [1]
+    const float* bias;   // [4]
+    float* bbox;         // [M][4]
+    const float* dbbox;  // bwd
+    float* dP;           // bwd
+    float* T;            // bwd [M][4]
+    float* U;            // bwd [M][4]
+    long M;
+};
+
+__global__ __launch_bounds__(256) void exp_head_fwd_kernel(ExpHeadArgs a) {
+    const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= a.M) return;
+    const f32x4 p = *reinterpret_cast<const f32x4*>(a.P + m * 4);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias);
+    const float s = a.adjust[0];
+    *reinterpret_cast<f32x4*>(a.bbox + m * 4) = (f32x4){expf(s * p.x + b.x), expf(s * p.y + b.y), expf(s * p.z + b.z), expf(s * p.w + b.w)};
+}
+
+__global__ __launch_bounds__(256) void exp_head_bwd_kernel(ExpHeadArgs a) {
+    const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= a.M) return;
+    const f32x4 p = *reinterpret_cast<const f32x4*>(a.P + m * 4);
+    const f32x4 y = *reinterpret_cast<const f32x4*>(a.bbox + m * 4);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(a.dbbox + m * 4) * y;
+    *reinterpret_cast<f32x4*>(a.T + m * 4) = g;
+    *reinterpret_cast<f32x4*>(a.U + m * 4) = g * p;
+    *reinterpret_cast<f32x4*>(a.dP + m * 4) = g * a.adjust[0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// FEARLoss (train/loss.py:45-96) forward + gradient, on the head's own NHWC rows:
+//   classification: BCEWithLogits, mean over the cells with label 1 and mean over those with label 0, 0.5 each
+//   regression:     mean over the cells with weight > 0 of 1 - (I + 1) / (U + 1)     (calc_iou, smooth = 1)
+// Pass 1 (loss_partial_kernel): per block {n_pos, n_neg, n_reg, sum bce_pos, sum bce_neg, sum (1 - iou)};
+// finalize (one thread): totals -> losses[2] and the three normalisers; pass 2 (loss_grad_kernel): gradients.
+struct LossArgs {
+    const float* bbox;     // [M][4]  predicted ltrb (after exp)
+    const float* cls;      // [M]     logits (after the 0.1 factor)
+    const float* gt_reg;   // [M][4]
+    const float* gt_cls;   // [M]
+    const float* gt_w;     // [M]
+    float* partial;        // [blocks][8]
+    float* totals;         // [8]: n_pos, n_neg, n_reg, loss_cls, loss_reg
+    float* dbbox;          // [M][4]
+    float* dcls;           // [M]
+    long M;
+    int blocks;
+    float coef_cls, coef_reg;
+};
+
+__device__ __forceinline__ float bce_logits(float x, float y) {      // max(x,0) - x*y + log(1 + exp(-|x|)), like torch
+    return fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
+}
+
+__global__ __launch_bounds__(256) void loss_partial_kernel(LossArgs a) {
+    __shared__ float red[6][256];
+    float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < a.M) {
+        const float x = a.cls[m], y = a.gt_cls[m];
+        if (y == 1.f) { v[0] = 1.f; v[3] = bce_logits(x, y); }
+        else if (y == 0.f) { v[1] = 1.f; v[4] = bce_logits(x, y); }
+        if (a.gt_w[m] > 0.f) {
+            const f32x4 p = *reinterpret_cast<const f32x4*>(a.bbox + m * 4);
+            const f32x4 t = *reinterpret_cast<const f32x4*>(a.gt_reg + m * 4);
+            const float ta = (t.x + t.z) * (t.y + t.w), pa = (p.x + p.z) * (p.y + p.w);
+            const float wi = fminf(p.x, t.x) + fminf(p.z, t.z), hi = fminf(p.w, t.w) + fminf(p.y, t.y);
+            const float inter = wi * hi, uni = ta + pa - inter;
+            v[2] = 1.f;
+            v[5] = 1.f - (inter + 1.f) / (uni + 1.f);
+        }
+    }
+    for (int j = 0; j < 6; ++j) red[j][threadIdx.x] = v[j];
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float s = 0.f;
+        for (int i = 0; i < 256; ++i) s += red[threadIdx.x][i];     // fixed order
+        a.partial[(long)blockIdx.x * 8 + threadIdx.x] = s;
+    }
+}
+
+__global__ void loss_finalize_kernel(LossArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s[6] = {0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < a.blocks; ++b)
+        for (int j = 0; j < 6; ++j) s[j] += (double)a.partial[(long)b * 8 + j];
+    // _weighted_cls_loss: mean over the selected cells (nn.BCEWithLogitsLoss of an empty selection is NaN in torch; the
+    // reference's batches always hold both kinds, and so must the caller's)
+    const double lp = s[0] > 0 ? s[3] / s[0] : 0.0, ln = s[1] > 0 ? s[4] / s[1] : 0.0;
+    const double lr = s[2] > 0 ? s[5] / s[2] : 0.0;
+    a.totals[0] = (float)s[0]; a.totals[1] = (float)s[1]; a.totals[2] = (float)s[2];
+    a.totals[3] = (float)((0.5 * lp + 0.5 * ln) * a.coef_cls);
+    a.totals[4] = (float)(lr * a.coef_reg);
+}
+
+__global__ __launch_bounds__(256) void loss_grad_kernel(LossArgs a) {
+    const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= a.M) return;
+    const float n_pos = a.totals[0], n_neg = a.totals[1], n_reg = a.totals[2];
+    const float x = a.cls[m], y = a.gt_cls[m];
+    const float sg = 1.f / (1.f + expf(-x));
+    float dc = 0.f;
+    if (y == 1.f) dc = 0.5f * a.coef_cls * (sg - 1.f) / n_pos;
+    else if (y == 0.f) dc = 0.5f * a.coef_cls * sg / n_neg;
+    a.dcls[m] = dc;
+    f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.gt_w[m] > 0.f) {
+        const f32x4 p = *reinterpret_cast<const f32x4*>(a.bbox + m * 4);
+        const f32x4 t = *reinterpret_cast<const f32x4*>(a.gt_reg + m * 4);
+        const float pw = p.x + p.z, ph = p.y + p.w;
+        const float ta = (t.x + t.z) * (t.y + t.w), pa = pw * ph;
+        const float wi = fminf(p.x, t.x) + fminf(p.z, t.z), hi = fminf(p.w, t.w) + fminf(p.y, t.y);
+        const float inter = wi * hi, uni = ta + pa - inter;
+        // d(1 - (I+1)/(U+1)) = -[dI (U+1) - (I+1) dU] / (U+1)^2,  dU = dPa - dI;  min(p, t) passes the gradient to p where
+        // p < t (and half of it on an exact tie, like torch.min's backward)
+        auto dmin = [](float pp, float tt) { return pp < tt ? 1.f : (pp == tt ? 0.5f : 0.f); };
+        const float dI[4] = {dmin(p.x, t.x) * hi, dmin(p.y, t.y) * wi, dmin(p.z, t.z) * hi, dmin(p.w, t.w) * wi};
+        const float dPa[4] = {ph, pw, ph, pw};
+        const float den = (uni + 1.f) * (uni + 1.f);
+        const float sc = a.coef_reg / n_reg;
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = -sc * (dI[j] * (uni + 1.f) - (inter + 1.f) * (dPa[j] - dI[j])) / den;
+        d = (f32x4){o[0], o[1], o[2], o[3]};
+    }
+    *reinterpret_cast<f32x4*>(a.dbbox + m * 4) = d;
+}
+
+// ------------------------------------------------------------------------------------------------
+// NCHW <-> NHWC at the boundary (the reference's tensors are NCHW): one thread per element, coalesced on the NHWC side.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* in, float* out, long n, int C, int HW, int ldo, int off) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * C * HW) return;
+    const int c = (int)(i % C);
+    const long r = i / C;
+    const long b = r / HW, p = r % HW;
+    out[r * ldo + off + c] = in[(b * C + c) * HW + p];
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* in, float* out, long n, int C, int HW, int ldi, int off) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * C * HW) return;
+    const int p = (int)(i % HW);
+    const long r = i / HW;
+    const long b = r / C;
+    const int c = (int)(r % C);
+    out[i] = in[(b * HW + p) * ldi + off + c];
+}
+
+__global__ void sum4_kernel(const float* in, float* out) { out[0] = (in[0] + in[1]) + (in[2] + in[3]); }
+
+// out[m * ld_out + col_out] = scale * in[m * ld_in + col_in]   (cls = 0.1 * cls_pred(c), blocks.py:192, and its gradient)
+__global__ __launch_bounds__(256) void scale_column_kernel(const float* in, int ld_in, int col_in, float scale, float* out,
+                                                           int ld_out, int col_out, long M) {
+    const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < M) out[m * ld_out + col_out] = scale * in[m * ld_in + col_in];
+}
+
+// gradient accumulation where two paths meet (the two branches of the head read the same features): out = a + b
+__global__ __launch_bounds__(256) void add_kernel(const float* x, const float* y, float* out, long n) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) *reinterpret_cast<f32x4*>(out + i) = *reinterpret_cast<const f32x4*>(x + i) + *reinterpret_cast<const f32x4*>(y + i);
+    else for (long j = i; j < n; ++j) out[j] = x[j] + y[j];
+}
+
+int train_pick_nt(int n_tiles) {
+    for (int nt : {8, 7, 6, 4, 3, 2, 1})
+        if (n_tiles % nt == 0) return nt;
+    return 1;
+}
+
+template <bool WKN>
+void launch_pw(int nt, dim3 grid, hipStream_t s, const PwArgs& a) {
+    switch (nt) {
+        case 1: hipLaunchKernelGGL((pw_mfma_kernel<2, 1, WKN>), grid, dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((pw_mfma_kernel<2, 2, WKN>), grid, dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL((pw_mfma_kernel<2, 3, WKN>), grid, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((pw_mfma_kernel<2, 4, WKN>), grid, dim3(256), 0, s, a); break;
+        case 6: hipLaunchKernelGGL((pw_mfma_kernel<2, 6, WKN>), grid, dim3(256), 0, s, a); break;
+        case 7: hipLaunchKernelGGL((pw_mfma_kernel<2, 7, WKN>), grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((pw_mfma_kernel<2, 8, WKN>), grid, dim3(256), 0, s, a); break;
+    }
+}
+
+int col_blocks(long M) { return (int)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK); }
+
+}  // namespace
+
+extern "C" {
+
+size_t fear_train_workspace_bytes(long rows, int max_channels) {
+    // the largest user: pw wgrad partials [slices][N][K] with slices = ceil(rows / 1024) and N, K <= max_channels;
+    // column reductions need [rows / 256][2][C]; depthwise wgrad [rows / 256][25][C]
+    const size_t slices = (size_t)((rows + 1023) / 1024);
+    const size_t a = slices * (size_t)max_channels * max_channels;
+    const size_t b = (size_t)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK) * 25 * (size_t)max_channels;
+    return ((a > b ? a : b) + 1024) * sizeof(float);
+}
+
+int fear_pw_forward(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, long M, int K, int N,
+                    void* stream) {
+    if (M == 0) return FEAR_TRAIN_OK;
+    if (!x || !w || !y) return FEAR_TRAIN_ERR_NULL;
+    if (M < 0 || K < 4 || K % 4 || N < 4 || N % 4 || M > 0x7fffffffL) return FEAR_TRAIN_ERR_SHAPE;
+    PwArgs a{};
+    a.X = x; a.ldx = ldx; a.W = w; a.bias = bias; a.Y = y; a.ldy = ldy; a.M = (int)M; a.K = K; a.N = N;
+    dim3 grid((unsigned)((M + 127) / 128));
+    launch_pw<false>(train_pick_nt((N + 15) / 16), grid, static_cast<hipStream_t>(stream), a);
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+int fear_pw_backward_data(const float* dy, int lddy, const float* w, const float* add, int ldadd, float* dx, int lddx, long M,
+                          int K, int N, void* stream) {
+    if (M == 0) return FEAR_TRAIN_OK;
+    if (!dy || !w || !dx) return FEAR_TRAIN_ERR_NULL;
+    if (M < 0 || K < 4 || K % 4 || N < 4 || N % 4 || M > 0x7fffffffL) return FEAR_TRAIN_ERR_SHAPE;
+    // dX[m][k] = sum_n dY[m][n] W[n][k]: a pointwise conv with "input channels" N, "output channels" K and the weight matrix
+    // read K-major (W[n][k] row-major IS the K-major layout of that conv)
+    PwArgs a{};
+    a.X = dy; a.ldx = lddy; a.W = w; a.Y = dx; a.ldy = lddx; a.M = (int)M; a.K = N; a.N = K;
+    a.R = add; a.ldr = ldadd;
+    a.rows_per_crop = (int)M; a.w_crop_stride = 0;
+    dim3 grid((unsigned)((M + 127) / 128));
+    launch_pw<true>(train_pick_nt((K + 15) / 16), grid, static_cast<hipStream_t>(stream), a);
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+static int wgrad_impl(const float* dy, int lddy, long dy_crop_stride, const float* x, int ldx, long x_crop_stride, float* dw,
+                      float* workspace, size_t ws_bytes, long M, int K, int N, int crops, hipStream_t s) {
+    WgradArgs a{};
+    a.dY = dy; a.X = x; a.lddy = lddy; a.ldx = ldx; a.N = N; a.K = K; a.M = M; a.crops = crops;
+    a.dy_crop_stride = dy_crop_stride; a.x_crop_stride = x_crop_stride;
+    a.n_strips = (N + 15) / 16; a.k_strips = (K + 63) / 64;
+    a.rows_per_slice = crops > 1 ? M : 1024;
+    const int slices = (int)((M + a.rows_per_slice - 1) / a.rows_per_slice);
+    const size_t need = (size_t)slices * crops * N * K * sizeof(float);
+    if (slices == 1) {
+        a.P = dw;
+    } else {
+        if (!workspace || ws_bytes < need) return FEAR_TRAIN_ERR_WORKSPACE;
+        a.P = workspace;
+    }
+    hipLaunchKernelGGL(pw_wgrad_kernel, dim3(a.n_strips * a.k_strips, slices, crops), dim3(64), 0, s, a);
+    if (slices > 1) {
+        const long count = (long)crops * N * K;
+        hipLaunchKernelGGL(slice_sum_kernel, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, s, workspace, dw, count, slices);
+    }
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+int fear_pw_backward_weight(const float* dy, int lddy, const float* x, int ldx, float* dw, float* workspace, size_t ws_bytes,
+                            long M, int K, int N, void* stream) {
+    if (!dy || !x || !dw) return FEAR_TRAIN_ERR_NULL;
+    if (M <= 0 || K < 4 || K % 4 || N < 1) return FEAR_TRAIN_ERR_SHAPE;
+    return wgrad_impl(dy, lddy, 0, x, ldx, 0, dw, workspace, ws_bytes, M, K, N, 1, static_cast<hipStream_t>(stream));
+}
+
+int fear_col_sum(const float* dy, int lddy, float* out, float* workspace, size_t ws_bytes, long M, int C, void* stream) {
+    if (!dy || !out || !workspace) return FEAR_TRAIN_ERR_NULL;
+    if (M <= 0 || C < 4 || C % 4 || C > 1024) return FEAR_TRAIN_ERR_SHAPE;
+    const int blocks = col_blocks(M);
+    if (ws_bytes < (size_t)blocks * 2 * C * sizeof(float)) return FEAR_TRAIN_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ColArgs a{};
+    a.A = dy; a.lda = lddy; a.partial = workspace; a.M = M; a.C = C;
+    hipLaunchKernelGGL(col_reduce_kernel<2>, dim3(blocks), dim3(256), 0, s, a);
+    ColFinArgs f{};
+    f.partial = workspace; f.out1 = out; f.out2 = nullptr; f.blocks = blocks; f.C = C; f.mode = 2; f.M = (double)M;
+    hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, f);
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+static int dw_impl(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int B, int H, int W, int C,
+                   int k, hipStream_t s) {
+    DwArgs a{};
+    a.X = x; a.ldx = ldx; a.Wt = w; a.bias = bias; a.Y = y; a.ldy = ldy;
+    a.B = B; a.H = H; a.W = W; a.C = C; a.Ho = H; a.Wo = W; a.relu = 0;
+    const long strips = (H + 3) / 4;
+    const long total = (long)B * strips * W * (C / 4);
+    dim3 grid((unsigned)((total + 255) / 256));
+    if (k == 3) hipLaunchKernelGGL((dw_conv_kernel<3, 1, 4>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((dw_conv_kernel<5, 1, 4>), grid, dim3(256), 0, s, a);
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+int fear_dw_forward(const float* x, int ldx, const float* w_taps, const float* bias, float* y, int ldy, int B, int H, int W,
+                    int C, int k, void* stream) {
+    if (B == 0) return FEAR_TRAIN_OK;
+    if (!x || !w_taps || !y) return FEAR_TRAIN_ERR_NULL;
+    if (B < 0 || H < 1 || W < 1 || C < 4 || C % 4 || (k != 3 && k != 5)) return FEAR_TRAIN_ERR_SHAPE;
+    return dw_impl(x, ldx, w_taps, bias, y, ldy, B, H, W, C, k, static_cast<hipStream_t>(stream));
+}
+
+int fear_dw_backward_data(const float* dy, int lddy, const float* w_taps_flipped, float* dx, int lddx, int B, int H, int W,
+                          int C, int k, void* stream) {
+    // stride 1, pad k/2: dX = depthwise conv of dY with the taps reversed (the caller passes w[k*k-1-t][c])
+    if (B == 0) return FEAR_TRAIN_OK;
+    if (!dy || !w_taps_flipped || !dx) return FEAR_TRAIN_ERR_NULL;
+    if (B < 0 || H < 1 || W < 1 || C < 4 || C % 4 || (k != 3 && k != 5)) return FEAR_TRAIN_ERR_SHAPE;
+    return dw_impl(dy, lddy, w_taps_flipped, nullptr, dx, lddx, B, H, W, C, k, static_cast<hipStream_t>(stream));
+}
+
+int fear_dw_backward_weight(const float* dy, int lddy, const float* x, int ldx, float* dw_taps, float* workspace,
+                            size_t ws_bytes, int B, int H, int W, int C, int k, void* stream) {
+    if (!dy || !x || !dw_taps || !workspace) return FEAR_TRAIN_ERR_NULL;
+    if (B < 1 || H < 1 || W < 1 || C < 4 || C % 4 || C > 1024 || (k != 3 && k != 5)) return FEAR_TRAIN_ERR_SHAPE;
+    const long pixels = (long)B * H * W;
+    const int blocks = col_blocks(pixels);
+    const long count = (long)k * k * C;
+    if (ws_bytes < (size_t)blocks * count * sizeof(float)) return FEAR_TRAIN_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DwWgradArgs a{};
+    a.dY = dy; a.X = x; a.partial = workspace; a.pixels = pixels; a.H = H; a.W = W; a.C = C; a.lddy = lddy; a.ldx = ldx;
+    if (k == 3) hipLaunchKernelGGL(dw_wgrad_kernel<3>, dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(dw_wgrad_kernel<5>, dim3(blocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(slice_sum_kernel, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, s, workspace, dw_taps, count, blocks);
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+int fear_bn_train_forward(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, float* mean,
+                          float* rstd, float* running_mean, float* running_var, double momentum, double eps, long M, int C,
+                          int relu, float* workspace, size_t ws_bytes, void* stream) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd || !workspace) return FEAR_TRAIN_ERR_NULL;
+    if (M <= 0 || C < 4 || C % 4 || C > 1024) return FEAR_TRAIN_ERR_SHAPE;
+    const int blocks = col_blocks(M);
+    if (ws_bytes < (size_t)blocks * 2 * C * sizeof(float)) return FEAR_TRAIN_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ColArgs a{};
+    a.A = x; a.lda = ldx; a.partial = workspace; a.M = M; a.C = C;
+    hipLaunchKernelGGL(col_reduce_kernel<0>, dim3(blocks), dim3(256), 0, s, a);
+    ColFinArgs f{};
+    f.partial = workspace; f.out1 = mean; f.out2 = rstd; f.running_mean = running_mean; f.running_var = running_var;
+    f.blocks = blocks; f.C = C; f.mode = 0; f.M = (double)M; f.eps = eps; f.momentum = momentum;
+    hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, f);
+    BnApplyArgs b{};
+    b.X = x; b.mean = mean; b.rstd = rstd; b.gamma = gamma; b.beta = beta; b.Y = y; b.M = M; b.C = C; b.ldx = ldx; b.ldy = ldy;
+    b.relu = relu;
+    const long n4 = M * (C / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, b);
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+int fear_bn_train_backward(const float* dy, int lddy, const float* y_act, int ldy, const float* x, int ldx, const float* mean,
+                           const float* rstd, const float* gamma, float* dx, int lddx, float* dgamma, float* dbeta, long M,
+                           int C, float* workspace, size_t ws_bytes, void* stream) {
+    if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !workspace) return FEAR_TRAIN_ERR_NULL;
+    if (M <= 0 || C < 4 || C % 4 || C > 1024) return FEAR_TRAIN_ERR_SHAPE;
+    const int blocks = col_blocks(M);
+    if (ws_bytes < (size_t)blocks * 2 * C * sizeof(float)) return FEAR_TRAIN_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ColArgs a{};
+    a.A = dy; a.lda = lddy; a.Yact = y_act; a.ldy = ldy; a.X = x; a.ldx = ldx; a.mean = mean; a.rstd = rstd;
+    a.partial = workspace; a.M = M; a.C = C;
+    hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(blocks), dim3(256), 0, s, a);
+    ColFinArgs f{};
+    f.partial = workspace; f.out1 = dbeta; f.out2 = dgamma; f.blocks = blocks; f.C = C; f.mode = 1; f.M = (double)M;
+    hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, f);
+    BnBwdArgs b{};
+    b.dY = dy; b.Yact = y_act; b.X = x; b.mean = mean; b.rstd = rstd; b.gamma = gamma; b.sum_g = dbeta; b.sum_gx = dgamma;
+    b.dX = dx; b.M = M; b.C = C; b.lddy = lddy; b.ldy = ldy; b.ldx = ldx; b.lddx = lddx;
+    const long n4 = M * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, b);
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+int fear_xcorr_forward(const float* x, int ldx, const float* z_nchw, float* s_out, int lds, int B, int P, int C, int J,
+                       void* stream) {
+    // s[b][p][j] = sum_c x[b][p][c] z[b][c][j]   (MobileCorrelation, blocks.py:121-123); z is the caller's NCHW (C, J) block
+    if (B == 0) return FEAR_TRAIN_OK;
+    if (!x || !z_nchw || !s_out) return FEAR_TRAIN_ERR_NULL;
+    if (B < 0 || P < 1 || C % 4 || J % 4) return FEAR_TRAIN_ERR_SHAPE;
+    PwArgs a{};
+    a.X = x; a.ldx = ldx; a.W = z_nchw; a.Y = s_out; a.ldy = lds; a.M = B * P; a.K = C; a.N = J;
+    a.rows_per_crop = P; a.w_crop_stride = (long)C * J;
+    dim3 grid((unsigned)((a.M + 127) / 128));
+    launch_pw<true>(train_pick_nt((J + 15) / 16), grid, static_cast<hipStream_t>(stream), a);
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+int fear_xcorr_backward(const float* ds, int ldds, const float* x, int ldx, const float* z_nchw, const float* dx_add, int ldadd,
+                        float* dx, int lddx, float* dz_nchw, int B, int P, int C, int J, void* stream) {
+    // dx[b][p][c] = dx_add[b][p][c] + sum_j ds[b][p][j] z[b][c][j];   dz[b][c][j] = sum_p x[b][p][c] ds[b][p][j]
+    if (B == 0) return FEAR_TRAIN_OK;
+    if (!ds || !x || !z_nchw || !dx || !dz_nchw) return FEAR_TRAIN_ERR_NULL;
+    if (B < 0 || P < 1 || P % 128 || C % 4 || J % 4) return FEAR_TRAIN_ERR_SHAPE;      // a 128-row tile must not straddle crops
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    PwArgs a{};
+    a.X = ds; a.ldx = ldds; a.W = z_nchw; a.Y = dx; a.ldy = lddx; a.M = B * P; a.K = J; a.N = C;
+    a.R = dx_add; a.ldr = ldadd;
+    a.rows_per_crop = P; a.w_crop_stride = (long)C * J;      // per-crop [N = C][K = J] row-major weights = z as it is
+    dim3 grid((unsigned)((a.M + 127) / 128));
+    launch_pw<false>(train_pick_nt((C + 15) / 16), grid, s, a);
+    LAUNCH_CHECK();
+    return wgrad_impl(x, ldx, (long)P * ldx, ds, ldds, (long)P * ldds, dz_nchw, nullptr, 0, P, J, C, B, s);
+}
+
+int fear_exp_head_forward(const float* p, const float* adjust, const float* bias4, float* bbox, long M, void* stream) {
+    if (M == 0) return FEAR_TRAIN_OK;
+    if (!p || !adjust || !bias4 || !bbox) return FEAR_TRAIN_ERR_NULL;
+    ExpHeadArgs a{};
+    a.P = p; a.adjust = adjust; a.bias = bias4; a.bbox = bbox; a.M = M;
+    hipLaunchKernelGGL(exp_head_fwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+int fear_exp_head_backward(const float* p, const float* adjust, const float* bbox, const float* dbbox, float* dp, float* dadjust,
+                           float* dbias4, float* workspace, size_t ws_bytes, long M, void* stream) {
+    if (!p || !adjust || !bbox || !dbbox || !dp || !dadjust || !dbias4 || !workspace) return FEAR_TRAIN_ERR_NULL;
+    if (M <= 0) return FEAR_TRAIN_ERR_SHAPE;
+    const int blocks = col_blocks(M);
+    const size_t stage = (size_t)M * 4;
+    if (ws_bytes < (2 * stage + (size_t)blocks * 8 + 8) * sizeof(float)) return FEAR_TRAIN_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* T = workspace;
+    float* U = workspace + stage;
+    float* part = U + stage;
+    float* u4 = part + (size_t)blocks * 8;
+    ExpHeadArgs a{};
+    a.P = p; a.adjust = adjust; a.bbox = const_cast<float*>(bbox); a.dbbox = dbbox; a.dP = dp; a.T = T; a.U = U; a.M = M;
+    hipLaunchKernelGGL(exp_head_bwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, a);
+    for (int pass = 0; pass < 2; ++pass) {
+        ColArgs c{};
+        c.A = pass == 0 ? T : U; c.lda = 4; c.partial = part; c.M = M; c.C = 4;
+        hipLaunchKernelGGL(col_reduce_kernel<2>, dim3(blocks), dim3(256), 0, s, c);
+        ColFinArgs f{};
+        f.partial = part; f.out1 = pass == 0 ? dbias4 : u4; f.blocks = blocks; f.C = 4; f.mode = 2; f.M = (double)M;
+        hipLaunchKernelGGL(col_finalize_kernel, dim3(1), dim3(256), 0, s, f);
+    }
+    // d adjust = the four per-channel sums of dbbox * bbox * p added up (adjust is one scalar shared by the four channels)
+    hipLaunchKernelGGL(sum4_kernel, dim3(1), dim3(1), 0, s, u4, dadjust);
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+int fear_head_loss(const float* bbox, const float* cls, const float* gt_reg, const float* gt_cls, const float* gt_weight,
+                   float coef_cls, float coef_reg, float* losses2, float* dbbox, float* dcls, float* workspace, size_t ws_bytes,
+                   long M, void* stream) {
+    if (!bbox || !cls || !gt_reg || !gt_cls || !gt_weight || !losses2 || !dbbox || !dcls || !workspace) return FEAR_TRAIN_ERR_NULL;
+    if (M <= 0) return FEAR_TRAIN_ERR_SHAPE;
+    const int blocks = (int)((M + 255) / 256);
+    if (ws_bytes < ((size_t)blocks * 8 + 8) * sizeof(float)) return FEAR_TRAIN_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    LossArgs a{};
+    a.bbox = bbox; a.cls = cls; a.gt_reg = gt_reg; a.gt_cls = gt_cls; a.gt_w = gt_weight;
+    a.partial = workspace; a.totals = workspace + (size_t)blocks * 8; a.dbbox = dbbox; a.dcls = dcls; a.M = M; a.blocks = blocks;
+    a.coef_cls = coef_cls; a.coef_reg = coef_reg;
+    hipLaunchKernelGGL(loss_partial_kernel, dim3(blocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(loss_grad_kernel, dim3(blocks), dim3(256), 0, s, a);
+    if (hipMemcpyAsync(losses2, a.totals + 3, 2 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return FEAR_TRAIN_ERR_HIP;
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+int fear_nchw_to_nhwc(const float* in, float* out, long n, int C, int HW, int ld_out, int ch_off, void* stream) {
+    if (n == 0) return FEAR_TRAIN_OK;
+    if (!in || !out) return FEAR_TRAIN_ERR_NULL;
+    const long total = n * C * HW;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), in, out,
+                       n, C, HW, ld_out, ch_off);
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+int fear_nhwc_to_nchw(const float* in, float* out, long n, int C, int HW, int ld_in, int ch_off, void* stream) {
+    if (n == 0) return FEAR_TRAIN_OK;
+    if (!in || !out) return FEAR_TRAIN_ERR_NULL;
+    const long total = n * C * HW;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), in, out,
+                       n, C, HW, ld_in, ch_off);
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+int fear_scale_column(const float* in, int ld_in, int col_in, float scale, float* out, int ld_out, int col_out, long M,
+                      void* stream) {
+    if (M == 0) return FEAR_TRAIN_OK;
+    if (!in || !out) return FEAR_TRAIN_ERR_NULL;
+    hipLaunchKernelGGL(scale_column_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), in, ld_in,
+                       col_in, scale, out, ld_out, col_out, M);
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+int fear_add(const float* a, const float* b, float* out, long n, void* stream) {
+    if (n == 0) return FEAR_TRAIN_OK;
+    if (!a || !b || !out) return FEAR_TRAIN_ERR_NULL;
+    hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), a, b, out, n);
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+}  // extern "C"

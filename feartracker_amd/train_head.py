@@ -1,0 +1,300 @@
+"""Training step of the FEAR correlation head on MI355X (SURVEY.md §8f N3 — first slice of BASELINE.json configs[4]).
+
+`BoxTowerTrainHIP` is the training-mode counterpart of the reference's `BoxTower` (model_training/model/blocks.py:129-194)
+followed by `FEARLoss` (model_training/train/loss.py:45-96): forward with BatchNorm on batch statistics, the two losses,
+and the gradient of every parameter and of both inputs — what `FEARLightningModel._training_step` + `loss.backward()` do for
+this part of the network (train/fear_lightning_model.py:60-66).  Every FLOP runs in the hand-written HIP operators of
+include/fear_train.h (MFMA GEMMs for the pointwise convs' forward / dgrad / wgrad and the pixel-wise correlation and its two
+gradients, fixed-order two-stage reductions for BatchNorm, bias and depthwise-weight gradients and the loss); this module
+only sequences them and keeps the parameters, like the reference's Python does around torch.  torch is the allocator, the
+stream provider and — for several ranks — the RCCL all-reduce of the flat gradient buffer (`allreduce_gradients`; the
+reference uses Lightning DDP, train/trainer.py:50-52).  Parameter and gradient names are the reference's `state_dict` keys.
+
+Not in this slice: the trunk's backward (the FBNet blocks need the unfolded, un-recoverable `mobile_cv` BatchNorm
+parameters), SyncBatchNorm across ranks, the optimiser.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from .hip_backend import load_library
+
+_P = ctypes.c_void_p
+_i, _l, _f, _d, _sz = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double, ctypes.c_size_t
+
+TRAIN_SYMBOLS = {
+    "fear_train_workspace_bytes": ([_l, _i], _sz),
+    "fear_pw_forward": ([_P, _i, _P, _P, _P, _i, _l, _i, _i, _P], _i),
+    "fear_pw_backward_data": ([_P, _i, _P, _P, _i, _P, _i, _l, _i, _i, _P], _i),
+    "fear_pw_backward_weight": ([_P, _i, _P, _i, _P, _P, _sz, _l, _i, _i, _P], _i),
+    "fear_col_sum": ([_P, _i, _P, _P, _sz, _l, _i, _P], _i),
+    "fear_dw_forward": ([_P, _i, _P, _P, _P, _i, _i, _i, _i, _i, _i, _P], _i),
+    "fear_dw_backward_data": ([_P, _i, _P, _P, _i, _i, _i, _i, _i, _i, _P], _i),
+    "fear_dw_backward_weight": ([_P, _i, _P, _i, _P, _P, _sz, _i, _i, _i, _i, _i, _P], _i),
+    "fear_bn_train_forward": ([_P, _i, _P, _P, _P, _i, _P, _P, _P, _P, _d, _d, _l, _i, _i, _P, _sz, _P], _i),
+    "fear_bn_train_backward": ([_P, _i, _P, _i, _P, _i, _P, _P, _P, _P, _i, _P, _P, _l, _i, _P, _sz, _P], _i),
+    "fear_xcorr_forward": ([_P, _i, _P, _P, _i, _i, _i, _i, _i, _P], _i),
+    "fear_xcorr_backward": ([_P, _i, _P, _i, _P, _P, _i, _P, _i, _P, _i, _i, _i, _i, _P], _i),
+    "fear_exp_head_forward": ([_P, _P, _P, _P, _l, _P], _i),
+    "fear_exp_head_backward": ([_P, _P, _P, _P, _P, _P, _P, _P, _sz, _l, _P], _i),
+    "fear_head_loss": ([_P, _P, _P, _P, _P, _f, _f, _P, _P, _P, _P, _sz, _l, _P], _i),
+    "fear_nchw_to_nhwc": ([_P, _P, _l, _i, _i, _i, _i, _P], _i),
+    "fear_nhwc_to_nchw": ([_P, _P, _l, _i, _i, _i, _i, _P], _i),
+    "fear_scale_column": ([_P, _i, _i, _f, _P, _i, _i, _l, _P], _i),
+    "fear_add": ([_P, _P, _P, _l, _P], _i),
+}
+
+_bound = None
+
+
+def load_train_library() -> ctypes.CDLL:
+    """The training operators live in the same libfear_hip.so; declare their prototypes (include/fear_train.h)."""
+    global _bound
+    if _bound is None:
+        lib = load_library()
+        for name, (args, res) in TRAIN_SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.argtypes, fn.restype = args, res
+        _bound = lib
+    return _bound
+
+
+class TrainError(RuntimeError):
+    pass
+
+
+def _p(t: Optional[torch.Tensor], offset: int = 0):
+    return None if t is None else ctypes.c_void_p(t.data_ptr() + 4 * offset)
+
+
+class _Sep:
+    """One SepConv (+ optional BatchNorm + ReLU) with its parameters in kernel layout and its saved activations."""
+
+    def __init__(self, owner, prefix: str, bn_prefix: Optional[str], sd: Dict[str, torch.Tensor], pad_out_to: int = 0):
+        dev = owner.device
+        dw = sd[prefix + ".depthwise.weight"].float()
+        pw = sd[prefix + ".pointwise.weight"].float()
+        self.prefix, self.bn_prefix = prefix, bn_prefix
+        self.cin, self.cout = dw.shape[0], pw.shape[0]
+        self.n = max(self.cout, pad_out_to)                     # pointwise rows padded to a multiple of 4 (cls_pred: 1 -> 4)
+        self.taps = dw.reshape(self.cin, 9).t().contiguous().to(dev)                       # [9][C]
+        self.dw_bias = sd[prefix + ".depthwise.bias"].float().to(dev) if prefix + ".depthwise.bias" in sd else None
+        w = torch.zeros(self.n, self.cin)
+        w[: self.cout] = pw.reshape(self.cout, self.cin)
+        self.w = w.to(dev)
+        self.pw_bias = None
+        if prefix + ".pointwise.bias" in sd:
+            b = torch.zeros(self.n)
+            b[: self.cout] = sd[prefix + ".pointwise.bias"].float()
+            self.pw_bias = b.to(dev)
+        if bn_prefix:
+            self.gamma = sd[bn_prefix + ".weight"].float().to(dev)
+            self.beta = sd[bn_prefix + ".bias"].float().to(dev)
+            self.running_mean = sd[bn_prefix + ".running_mean"].float().clone().to(dev)
+            self.running_var = sd[bn_prefix + ".running_var"].float().clone().to(dev)
+
+
+class BoxTowerTrainHIP:
+    """BoxTower(towernum=2, inchannels=256, outchannels=256, mobile=True) in training mode + FEARLoss, on HIP operators."""
+
+    S, TZ = 16, 8           # search feature map 16x16, template feature map 8x8 (256 / 128 px crops, stride 16)
+
+    def __init__(self, state_dict: Dict[str, "np.ndarray | torch.Tensor"], device: int = 0, momentum: float = 0.1,
+                 eps: float = 1e-5, coef_cls: float = 1.0, coef_reg: float = 1.0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("BoxTowerTrainHIP needs a ROCm GPU; there is no CPU fallback")
+        self.lib = load_train_library()
+        self.device = torch.device(f"cuda:{int(device)}")
+        self.momentum, self.eps, self.coef_cls, self.coef_reg = momentum, eps, coef_cls, coef_reg
+        sd = {k: torch.as_tensor(np.asarray(v)) if not isinstance(v, torch.Tensor) else v.detach().cpu() for k, v in state_dict.items()}
+        self.branches = {}
+        for name, enc, corr, tower, pred in (("cls", "cls_encode.matrix11_s", "cls_dw.enc", "cls_tower", "cls_pred"),
+                                             ("reg", "reg_encode.matrix11_s", "reg_dw.enc", "bbox_tower", "bbox_pred")):
+            self.branches[name] = dict(
+                enc=_Sep(self, enc + ".0", enc + ".1", sd), corr=_Sep(self, corr + ".0", corr + ".1", sd),
+                tower=[_Sep(self, f"{tower}.0", f"{tower}.1", sd), _Sep(self, f"{tower}.3", f"{tower}.4", sd)],
+                pred=_Sep(self, pred, None, sd, pad_out_to=4))
+        self.adjust = sd["adjust"].float().reshape(1).to(self.device)
+        self.bias4 = sd["bias"].float().reshape(4).to(self.device)
+        self._ws = None
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, st: int) -> None:
+        if st != 0:
+            raise TrainError(f"libfear_hip training operator failed with status {st}")
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _new(self, *shape) -> torch.Tensor:
+        return torch.empty(shape, dtype=torch.float32, device=self.device)
+
+    def _workspace(self, rows: int):
+        need = int(self.lib.fear_train_workspace_bytes(rows, 320))
+        need = max(need, (8 * rows + 4096) * 4)
+        if self._ws is None or self._ws.numel() * 4 < need:
+            self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
+        return _p(self._ws), self._ws.numel() * 4
+
+    # ------------------------------------------------------------------ one SepConv [+ BN + ReLU]
+    def _sep_forward(self, L: _Sep, x: torch.Tensor, ldx: int, B: int, out: Optional[torch.Tensor] = None, ld_out: int = 0):
+        lib, st, M = self.lib, self._stream(), B * self.S * self.S
+        ws, wsb = self._workspace(M)
+        L.x, L.ldx = x, ldx
+        L.d = self._new(M, L.cin)
+        self._check(lib.fear_dw_forward(_p(x), ldx, _p(L.taps), _p(L.dw_bias), _p(L.d), L.cin, B, self.S, self.S, L.cin, 3, st))
+        L.p = self._new(M, L.n)
+        self._check(lib.fear_pw_forward(_p(L.d), L.cin, _p(L.w), _p(L.pw_bias), _p(L.p), L.n, M, L.cin, L.n, st))
+        if not L.bn_prefix:
+            return L.p
+        L.mean, L.rstd = self._new(L.cout), self._new(L.cout)
+        if out is None:
+            out, ld_out = self._new(M, L.cout), L.cout
+        L.y, L.ldy = out, ld_out
+        self._check(lib.fear_bn_train_forward(_p(L.p), L.n, _p(L.gamma), _p(L.beta), _p(out), ld_out, _p(L.mean), _p(L.rstd),
+                                              _p(L.running_mean), _p(L.running_var), self.momentum, self.eps, M, L.cout, 1,
+                                              ws, wsb, st))
+        return out
+
+    def _sep_backward(self, L: _Sep, dy: torch.Tensor, lddy: int, B: int, grads: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """dy = gradient w.r.t. the layer's output (after BN+ReLU when it has them); returns d(input) as [M][cin]."""
+        lib, st, M = self.lib, self._stream(), B * self.S * self.S
+        ws, wsb = self._workspace(M)
+        if L.bn_prefix:
+            dp = self._new(M, L.n)
+            dgamma, dbeta = self._new(L.cout), self._new(L.cout)
+            self._check(lib.fear_bn_train_backward(_p(dy), lddy, _p(L.y), L.ldy, _p(L.p), L.n, _p(L.mean), _p(L.rstd), _p(L.gamma),
+                                                   _p(dp), L.n, _p(dgamma), _p(dbeta), M, L.cout, ws, wsb, st))
+            grads[L.bn_prefix + ".weight"], grads[L.bn_prefix + ".bias"] = dgamma, dbeta
+            lddp = L.n
+        else:
+            dp, lddp = dy, lddy
+        dw = self._new(L.n, L.cin)
+        self._check(lib.fear_pw_backward_weight(_p(dp), lddp, _p(L.d), L.cin, _p(dw), ws, wsb, M, L.cin, L.n, st))
+        grads[L.prefix + ".pointwise.weight"] = dw[: L.cout].reshape(L.cout, L.cin, 1, 1)
+        if L.pw_bias is not None:
+            db = self._new(L.n)
+            self._check(lib.fear_col_sum(_p(dp), lddp, _p(db), ws, wsb, M, L.n, st))
+            grads[L.prefix + ".pointwise.bias"] = db[: L.cout]
+        dd = self._new(M, L.cin)
+        self._check(lib.fear_pw_backward_data(_p(dp), lddp, _p(L.w), None, 0, _p(dd), L.cin, M, L.cin, L.n, st))
+        dtaps = self._new(9, L.cin)
+        self._check(lib.fear_dw_backward_weight(_p(dd), L.cin, _p(L.x), L.ldx, _p(dtaps), ws, wsb, B, self.S, self.S, L.cin, 3, st))
+        grads[L.prefix + ".depthwise.weight"] = dtaps.t().reshape(L.cin, 1, 3, 3)
+        if L.dw_bias is not None:
+            dbd = self._new(L.cin)
+            self._check(lib.fear_col_sum(_p(dd), L.cin, _p(dbd), ws, wsb, M, L.cin, st))
+            grads[L.prefix + ".depthwise.bias"] = dbd
+        dx = self._new(M, L.cin)
+        flipped = torch.flip(L.taps, dims=[0]).contiguous()         # parameter re-layout: taps reversed
+        self._check(lib.fear_dw_backward_data(_p(dd), L.cin, _p(flipped), _p(dx), L.cin, B, self.S, self.S, L.cin, 3, st))
+        return dx
+
+    # ------------------------------------------------------------------ the step
+    @torch.no_grad()
+    def step(self, search_feats: torch.Tensor, template_feats: torch.Tensor, gt_reg: torch.Tensor, gt_cls: torch.Tensor,
+             gt_weight: torch.Tensor) -> Dict[str, object]:
+        """search_feats (B,256,16,16), template_feats (B,256,8,8) NCHW fp32 (the neck's outputs); gt_* as the reference's
+        dataset emits them (siam_dataset.py:53-56): regression map (B,4,16,16), label (B,1,16,16), weight (B,16,16).
+        Returns {"loss_cls", "loss_reg", "bbox", "cls", "grads": {reference parameter name: tensor}, "grad_search",
+        "grad_template"}."""
+        lib, dev = self.lib, self.device
+        xs = search_feats.to(dev, torch.float32).contiguous()
+        zs = template_feats.to(dev, torch.float32).contiguous()
+        B = xs.shape[0]
+        if tuple(xs.shape[1:]) != (256, self.S, self.S) or tuple(zs.shape) != (B, 256, self.TZ, self.TZ):
+            raise ValueError("expected search features (B,256,16,16) and template features (B,256,8,8)")
+        M, P, J = B * self.S * self.S, self.S * self.S, self.TZ * self.TZ
+        with torch.cuda.device(dev):
+            st = self._stream()
+            ws, wsb = self._workspace(M)
+            x = self._new(M, 256)
+            self._check(lib.fear_nchw_to_nhwc(_p(xs), _p(x), B, 256, P, 256, 0, st))
+            saved = {}
+            pred_out = {}
+            for name, br in self.branches.items():
+                cat = self._new(M, 320)                                   # [encode output | correlation] without a concat kernel
+                self._sep_forward(br["enc"], x, 256, B, out=cat, ld_out=320)
+                self._check(lib.fear_xcorr_forward(_p(cat), 320, _p(zs), _p(cat, 256), 320, B, P, 256, J, st))
+                a = self._sep_forward(br["corr"], cat, 320, B)
+                for L in br["tower"]:
+                    a = self._sep_forward(L, a, 256, B)
+                pred_out[name] = self._sep_forward(br["pred"], a, 256, B)   # [M][4] (cls: column 0 is real)
+                saved[name] = cat
+            bbox_rows = self._new(M, 4)
+            self._check(lib.fear_exp_head_forward(_p(pred_out["reg"]), _p(self.adjust), _p(self.bias4), _p(bbox_rows), M, st))
+            cls_rows = self._new(M)
+            self._check(lib.fear_scale_column(_p(pred_out["cls"]), 4, 0, 0.1, _p(cls_rows), 1, 0, M, st))   # cls = 0.1 * cls_pred(c)
+            # ---- loss + its gradient
+            gr = self._new(M, 4)
+            self._check(lib.fear_nchw_to_nhwc(_p(gt_reg.to(dev, torch.float32).contiguous()), _p(gr), B, 4, P, 4, 0, st))
+            gc = gt_cls.to(dev, torch.float32).contiguous().reshape(M)
+            gw = gt_weight.to(dev, torch.float32).contiguous().reshape(M)
+            losses, dbbox, dcls = self._new(2), self._new(M, 4), self._new(M)
+            self._check(lib.fear_head_loss(_p(bbox_rows), _p(cls_rows), _p(gr), _p(gc), _p(gw), self.coef_cls, self.coef_reg,
+                                           _p(losses), _p(dbbox), _p(dcls), ws, wsb, M, st))
+            # ---- backward
+            grads: Dict[str, torch.Tensor] = {}
+            dpred = {}
+            dp_reg, dadj, dbias = self._new(M, 4), self._new(1), self._new(4)
+            self._check(lib.fear_exp_head_backward(_p(pred_out["reg"]), _p(self.adjust), _p(bbox_rows), _p(dbbox), _p(dp_reg),
+                                                   _p(dadj), _p(dbias), ws, wsb, M, st))
+            grads["adjust"], grads["bias"] = dadj, dbias.reshape(1, 4, 1, 1)
+            dpred["reg"] = dp_reg
+            dp_cls = torch.zeros((M, 4), dtype=torch.float32, device=dev)
+            self._check(lib.fear_scale_column(_p(dcls), 1, 0, 0.1, _p(dp_cls), 4, 0, M, st))
+            dpred["cls"] = dp_cls
+            dx_total, dz_total = None, None
+            for name, br in self.branches.items():
+                da = self._sep_backward(br["pred"], dpred[name], 4, B, grads)
+                for L in reversed(br["tower"]):
+                    da = self._sep_backward(L, da, 256, B, grads)
+                dcat = self._sep_backward(br["corr"], da, 256, B, grads)            # [M][320]
+                cat = saved[name]
+                denc, dz = self._new(M, 256), self._new(B, 256, self.TZ, self.TZ)
+                self._check(lib.fear_xcorr_backward(_p(dcat, 256), 320, _p(cat), 320, _p(zs), _p(dcat), 320, _p(denc), 256, _p(dz),
+                                                    B, P, 256, J, st))
+                dx = self._sep_backward(br["enc"], denc, 256, B, grads)
+                if dx_total is None:
+                    dx_total, dz_total = dx, dz
+                else:
+                    self._check(lib.fear_add(_p(dx_total), _p(dx), _p(dx_total), dx.numel(), st))
+                    self._check(lib.fear_add(_p(dz_total), _p(dz), _p(dz_total), dz.numel(), st))
+            grad_search = self._new(B, 256, self.S, self.S)
+            self._check(lib.fear_nhwc_to_nchw(_p(dx_total), _p(grad_search), B, 256, P, 256, 0, st))
+            bbox = self._new(B, 4, self.S, self.S)
+            self._check(lib.fear_nhwc_to_nchw(_p(bbox_rows), _p(bbox), B, 4, P, 4, 0, st))
+        return {"loss_cls": losses[0], "loss_reg": losses[1], "bbox": bbox, "cls": cls_rows.reshape(B, 1, self.S, self.S),
+                "grads": grads, "grad_search": grad_search, "grad_template": dz_total}
+
+    # ------------------------------------------------------------------ several ranks
+    @staticmethod
+    def allreduce_gradients(grads: Dict[str, torch.Tensor], group=None) -> Dict[str, torch.Tensor]:
+        """Data-parallel gradient averaging as ONE collective: the gradients are flattened into one buffer (0.65 M floats for
+        the head), all-reduced (RCCL over xGMI with the "nccl" backend; gloo in the CPU tests) and divided by the world size —
+        what Lightning DDP does bucket by bucket for the reference (train/trainer.py:50-52)."""
+        import torch.distributed as dist
+        if not dist.is_initialized() or dist.get_world_size(group) == 1:
+            return grads
+        names = sorted(grads)
+        flat = torch.cat([grads[n].reshape(-1) for n in names])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat /= dist.get_world_size(group)
+        out, off = {}, 0
+        for n in names:
+            k = grads[n].numel()
+            out[n] = flat[off: off + k].reshape(grads[n].shape)
+            off += k
+        return out
+
+    def running_stats(self) -> Dict[str, torch.Tensor]:
+        out = {}
+        for br in self.branches.values():
+            for L in [br["enc"], br["corr"]] + br["tower"]:
+                out[L.bn_prefix + ".running_mean"] = L.running_mean
+                out[L.bn_prefix + ".running_var"] = L.running_var
+        return out

@@ -1,0 +1,101 @@
+/*
+ * fear_train.h — C ABI of the MI355X (gfx950) operators of the FEAR head TRAINING step (SURVEY.md §8f N3,
+ * BASELINE.json configs[4] "training step: backbone + xcorr fwd/bwd"; first slice = BoxTower + FEARLoss).
+ *
+ * What the reference does with torch autograd + cuDNN is spelled out here as explicit forward / backward operators:
+ *     SepConv (depthwise 3x3 -> pointwise 1x1)         model_training/model/blocks.py:45-72
+ *     nn.BatchNorm2d in training mode (+ ReLU)         model/blocks.py:98-101, 115-119, 150-158
+ *     MobileCorrelation  s = z^T x, cat[x, s]          model/blocks.py:121-126
+ *     exp(adjust * x + bias), 0.1 * cls                model/blocks.py:186-192
+ *     FEARLoss (BCE-with-logits halves + 1 - IoU)      model_training/train/loss.py:13-96
+ * feartracker_amd/train_head.py composes them into `BoxTower.forward` + loss + backward (host code stays Python, like the
+ * reference's Lightning step train/fear_lightning_model.py:60-66); gradients of all ranks are averaged by ONE RCCL
+ * all-reduce of the flat gradient buffer (the reference: Lightning DDP, train/trainer.py:50-52).
+ *
+ * Conventions: plain C; every tensor pointer is a DEVICE pointer, fp32, "rows x channels" NHWC ([M = batch*H*W][ld], channels
+ * contiguous, ld = row stride in floats) unless it says NCHW; `stream` is a hipStream_t passed as void*; calls are
+ * asynchronous on it; 0 on success, negative FEAR_TRAIN_ERR_* otherwise.  `workspace` is caller-owned scratch of at least
+ * fear_train_workspace_bytes(rows, max_channels) bytes; every reduction is two-stage in a fixed order (no atomics).
+ */
+#ifndef FEAR_TRAIN_H
+#define FEAR_TRAIN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FEAR_TRAIN_OK 0
+#define FEAR_TRAIN_ERR_NULL (-1)
+#define FEAR_TRAIN_ERR_SHAPE (-2)
+#define FEAR_TRAIN_ERR_HIP (-4)
+#define FEAR_TRAIN_ERR_WORKSPACE (-7)   /* workspace missing or too small */
+
+size_t fear_train_workspace_bytes(long rows, int max_channels);
+
+/* nn.Conv2d(K, N, 1): y[m][n] = sum_k x[m][k] w[n][k] (+ bias[n]); K, N multiples of 4 (v_mfma_f32_16x16x4_f32) */
+int fear_pw_forward(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, long M, int K, int N,
+                    void* stream);
+/* its input gradient dx[m][k] = (add ? add[m][k] : 0) + sum_n dy[m][n] w[n][k] */
+int fear_pw_backward_data(const float* dy, int lddy, const float* w, const float* add, int ldadd, float* dx, int lddx, long M,
+                          int K, int N, void* stream);
+/* its weight gradient dw[n][k] = sum_m dy[m][n] x[m][k] (MFMA, reduction over the rows) */
+int fear_pw_backward_weight(const float* dy, int lddy, const float* x, int ldx, float* dw, float* workspace, size_t ws_bytes,
+                            long M, int K, int N, void* stream);
+/* bias gradients: out[c] = sum_m dy[m][c] */
+int fear_col_sum(const float* dy, int lddy, float* out, float* workspace, size_t ws_bytes, long M, int C, void* stream);
+
+/* nn.Conv2d(C, C, k, groups=C, padding=k/2), stride 1: taps laid out [k*k][C] (tap-major, channels contiguous) */
+int fear_dw_forward(const float* x, int ldx, const float* w_taps, const float* bias, float* y, int ldy, int B, int H, int W,
+                    int C, int k, void* stream);
+/* input gradient = the same convolution of dy with the taps reversed: pass w_taps_flipped[t][c] = w_taps[k*k-1-t][c] */
+int fear_dw_backward_data(const float* dy, int lddy, const float* w_taps_flipped, float* dx, int lddx, int B, int H, int W,
+                          int C, int k, void* stream);
+/* weight gradient dw_taps[t][c] = sum_{b,y,x} dy[b,y,x,c] * x[b, y+ky-k/2, x+kx-k/2, c] */
+int fear_dw_backward_weight(const float* dy, int lddy, const float* x, int ldx, float* dw_taps, float* workspace,
+                            size_t ws_bytes, int B, int H, int W, int C, int k, void* stream);
+
+/* nn.BatchNorm2d(C) in training mode (+ optional ReLU): batch statistics over the M rows; mean / rstd are saved for the
+ * backward; running_mean / running_var (may be NULL) follow torch: (1 - momentum) * running + momentum * stat, unbiased var */
+int fear_bn_train_forward(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, float* mean,
+                          float* rstd, float* running_mean, float* running_var, double momentum, double eps, long M, int C,
+                          int relu, float* workspace, size_t ws_bytes, void* stream);
+/* backward through (ReLU o BatchNorm): y_act = the forward output when a ReLU followed (its mask), else NULL */
+int fear_bn_train_backward(const float* dy, int lddy, const float* y_act, int ldy, const float* x, int ldx, const float* mean,
+                           const float* rstd, const float* gamma, float* dx, int lddx, float* dgamma, float* dbeta, long M,
+                           int C, float* workspace, size_t ws_bytes, void* stream);
+
+/* MobileCorrelation (blocks.py:121-123): s[b][p][j] = sum_c x[b][p][c] z[b][c][j]; z_nchw = (B, C, J) as the reference holds it */
+int fear_xcorr_forward(const float* x, int ldx, const float* z_nchw, float* s_out, int lds, int B, int P, int C, int J,
+                       void* stream);
+/* dx[b][p][c] = (dx_add ? dx_add[b][p][c] : 0) + sum_j ds[b][p][j] z[b][c][j];   dz[b][c][j] = sum_p x[b][p][c] ds[b][p][j] */
+int fear_xcorr_backward(const float* ds, int ldds, const float* x, int ldx, const float* z_nchw, const float* dx_add, int ldadd,
+                        float* dx, int lddx, float* dz_nchw, int B, int P, int C, int J, void* stream);
+
+/* bbox = exp(adjust * p + bias[c]) on rows of 4 (blocks.py:186-187), and its backward (dp, d adjust, d bias) */
+int fear_exp_head_forward(const float* p, const float* adjust, const float* bias4, float* bbox, long M, void* stream);
+int fear_exp_head_backward(const float* p, const float* adjust, const float* bbox, const float* dbbox, float* dp, float* dadjust,
+                           float* dbias4, float* workspace, size_t ws_bytes, long M, void* stream);
+
+/* FEARLoss forward + gradient (train/loss.py:45-96): bbox / gt_reg rows of 4 (ltrb), cls / gt_cls / gt_weight one value per row.
+ * losses2 = {classification, regression} (each times its coefficient); dbbox / dcls = d(sum of both) / d(bbox, cls).       */
+int fear_head_loss(const float* bbox, const float* cls, const float* gt_reg, const float* gt_cls, const float* gt_weight,
+                   float coef_cls, float coef_reg, float* losses2, float* dbbox, float* dcls, float* workspace, size_t ws_bytes,
+                   long M, void* stream);
+
+/* boundary layout changes (the reference's tensors are NCHW): out[(b*HW + p)*ld_out + ch_off + c] = in[(b*C + c)*HW + p], and back */
+int fear_nchw_to_nhwc(const float* in, float* out, long n, int C, int HW, int ld_out, int ch_off, void* stream);
+int fear_nhwc_to_nchw(const float* in, float* out, long n, int C, int HW, int ld_in, int ch_off, void* stream);
+
+/* out[m*ld_out + col_out] = scale * in[m*ld_in + col_in]  (cls = 0.1 * cls_pred(c), blocks.py:192, forward and backward) */
+int fear_scale_column(const float* in, int ld_in, int col_in, float scale, float* out, int ld_out, int col_out, long M,
+                      void* stream);
+/* out = a + b over n floats: gradient accumulation where the two branches of the head meet */
+int fear_add(const float* a, const float* b, float* out, long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FEAR_TRAIN_H */

@@ -110,3 +110,43 @@ def test_rccl_gather_of_hip_maps_single_rank():
         assert torch.equal(b2, bbox) and torch.equal(c2, cls)
     finally:
         dist.destroy_process_group()
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from feartracker_amd.train_head import BoxTowerTrainHIP
+    g = torch.Generator().manual_seed(100 + rank)
+    grads = {"b.weight": torch.randn(7, 3, generator=g), "a.bias": torch.randn(5, generator=g), "adjust": torch.randn(1, generator=g)}
+    out = BoxTowerTrainHIP.allreduce_gradients(grads)
+    q.put((rank, {k: v.numpy() for k, v in out.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_averages_over_ranks():
+    """N3 / BASELINE configs[4] data parallelism: the head's gradients are averaged over the ranks by ONE all-reduce of the
+    flat gradient buffer (`BoxTowerTrainHIP.allreduce_gradients`; RCCL on the GPUs, gloo here) — every rank ends up with
+    the mean, shapes and names preserved."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = {}
+    for r in range(world):
+        g = torch.Generator().manual_seed(100 + r)
+        for k, shape in (("b.weight", (7, 3)), ("a.bias", (5,)), ("adjust", (1,))):
+            want[k] = want.get(k, 0) + torch.randn(*shape, generator=g) / world
+    for r in range(world):
+        assert set(results[r]) == set(want)
+        for k in want:
+            assert results[r][k].shape == tuple(want[k].shape)
+            assert torch.allclose(torch.from_numpy(results[r][k]), want[k], rtol=0, atol=1e-6)

@@ -1,0 +1,188 @@
+"""N3: one training step of the correlation head on the HIP operators of include/fear_train.h against the
+fixture produced by the REFERENCE's own BoxTower (train mode) + FEARLoss + torch autograd (tools/make_golden.py section 11):
+outputs, both losses, the gradient of every parameter and of both inputs, BatchNorm running statistics."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fear_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_training_operators_are_exported():
+    """The C-ABI library exports every symbol include/fear_train.h declares, and the Python binding declares them all."""
+    from feartracker_amd.train_head import TRAIN_SYMBOLS, load_train_library
+    lib = load_train_library()
+    declared = _declared("fear_train.h")
+    assert len(declared) >= 18 and set(declared) == set(TRAIN_SYMBOLS)
+    for sym in declared:
+        assert hasattr(lib, sym)
+    assert lib.fear_train_workspace_bytes(1024, 320) >= 320 * 320 * 4
+    # null / shape errors need no GPU
+    assert lib.fear_pw_forward(None, 0, None, None, None, 0, 16, 8, 8, None) == -1
+    assert lib.fear_pw_backward_weight(None, 0, None, 0, None, None, 0, 16, 8, 8, None) == -1
+    assert lib.fear_bn_train_forward(None, 0, None, None, None, 0, None, None, None, None, 0.1, 1e-5, 16, 8, 1, None, 0, None) == -1
+
+
+def test_fixture_is_self_consistent(golden_dir):
+    """The reference-generated fixture itself: FEARLoss recomputed from its stored outputs/targets with plain numpy."""
+    d = np.load(f"{golden_dir}/head_train_step.npz")
+    cls, lab = d["out_cls"].reshape(-1).astype(np.float64), d["gt_cls"].reshape(-1)
+    bce = np.maximum(cls, 0) - cls * lab + np.log1p(np.exp(-np.abs(cls)))
+    np.testing.assert_allclose(0.5 * bce[lab == 1].mean() + 0.5 * bce[lab == 0].mean(), d["loss_cls"], rtol=1e-6)
+    p = d["out_bbox"].transpose(0, 2, 3, 1).reshape(-1, 4).astype(np.float64)
+    t = d["gt_reg"].transpose(0, 2, 3, 1).reshape(-1, 4).astype(np.float64)
+    sel = d["gt_weight"].reshape(-1) > 0
+    p, t = p[sel], t[sel]
+    inter = (np.minimum(p[:, 0], t[:, 0]) + np.minimum(p[:, 2], t[:, 2])) * (np.minimum(p[:, 3], t[:, 3]) + np.minimum(p[:, 1], t[:, 1]))
+    union = (t[:, 0] + t[:, 2]) * (t[:, 1] + t[:, 3]) + (p[:, 0] + p[:, 2]) * (p[:, 1] + p[:, 3]) - inter
+    np.testing.assert_allclose((1 - (inter + 1) / (union + 1)).mean(), d["loss_reg"], rtol=1e-6)
+    assert sel.sum() == 3 * 13 and (d["gt_cls"][3] == 0).all()
+
+
+def _close(got, ref, what, rel=1e-3):
+    """|got - ref| <= rel * max|ref| + 1e-9 element-wise (gradient tensors span many magnitudes; the tensor's own scale is
+    the yardstick, and biases in front of a BatchNorm have an exactly-zero true gradient)."""
+    got = torch.as_tensor(got).detach().double().cpu().reshape(-1)
+    ref = torch.as_tensor(ref).double().reshape(-1)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    tol = rel * float(ref.abs().max()) + 1e-9
+    err = float((got - ref).abs().max())
+    assert err <= tol, f"{what}: max abs err {err:.3e} > {tol:.3e} (max |ref| {float(ref.abs().max()):.3e})"
+    return err / max(float(ref.abs().max()), 1e-30)
+
+
+@pytest.mark.gpu
+def test_head_training_step_matches_reference_autograd(golden_dir):
+    from feartracker_amd.train_head import BoxTowerTrainHIP
+    d = np.load(f"{golden_dir}/head_train_step.npz")
+    sd = {k[len("param."):]: d[k] for k in d.files if k.startswith("param.")}
+    net = BoxTowerTrainHIP(sd, device=0)
+    out = net.step(torch.from_numpy(d["in_search"]), torch.from_numpy(d["in_template"]), torch.from_numpy(d["gt_reg"]),
+                   torch.from_numpy(d["gt_cls"]), torch.from_numpy(d["gt_weight"]))
+    torch.cuda.synchronize()
+    # forward in train mode (BatchNorm on batch statistics)
+    _close(out["bbox"], d["out_bbox"], "bbox")
+    _close(out["cls"], d["out_cls"], "cls")
+    assert abs(float(out["loss_cls"]) - float(d["loss_cls"])) <= 1e-5 * abs(float(d["loss_cls"]))
+    assert abs(float(out["loss_reg"]) - float(d["loss_reg"])) <= 1e-5 * abs(float(d["loss_reg"]))
+    # every parameter gradient, by reference name
+    names = [k[len("grad."):] for k in d.files if k.startswith("grad.")]
+    assert set(names) == set(out["grads"]) and len(names) == 54
+    worst = {}
+    for n in names:
+        pre_bn_bias = n.endswith(".bias") and ("depthwise" in n or "pointwise" in n) and "pred" not in n
+        ref = d["grad." + n]
+        if pre_bn_bias:
+            # a bias that feeds a BatchNorm has zero gradient; autograd returns rounding noise (1e-10), so do we
+            assert float(np.abs(ref).max()) < 1e-8 and float(out["grads"][n].abs().max()) < 1e-7
+            continue
+        worst[n] = _close(out["grads"][n], ref, "grad " + n)
+    # gradients w.r.t. the inputs (what the trunk's backward would receive)
+    _close(out["grad_search"], d["grad_in_search"], "grad search features")
+    _close(out["grad_template"], d["grad_in_template"], "grad template features")
+    # BatchNorm running statistics after the step
+    for k, v in net.running_stats().items():
+        _close(v, d["after." + k], "running stat " + k, rel=1e-5)
+    print("worst relative gradient errors:", sorted(worst.items(), key=lambda kv: -kv[1])[:3])
+    # deterministic: the same step again gives bit-identical gradients (fixed-order reductions, no atomics)
+    net2 = BoxTowerTrainHIP(sd, device=0)
+    out2 = net2.step(torch.from_numpy(d["in_search"]), torch.from_numpy(d["in_template"]), torch.from_numpy(d["gt_reg"]),
+                     torch.from_numpy(d["gt_cls"]), torch.from_numpy(d["gt_weight"]))
+    for n in names:
+        assert torch.equal(out["grads"][n], out2["grads"][n]), n
+
+
+@pytest.mark.gpu
+def test_training_operators_individually_vs_torch():
+    """Each heavy operator against the same operator written with torch ops on the GPU tensors' CPU copies (fp32 reference
+    of the same op): pointwise forward / dgrad / wgrad, depthwise dgrad / wgrad, BatchNorm train forward / backward, the
+    correlation's two gradients — at sizes that are not the fixture's (ragged row counts, 320 channels, 5x5 taps)."""
+    import torch.nn.functional as F
+    from feartracker_amd.train_head import _p, load_train_library
+    lib = load_train_library()
+    dev = torch.device("cuda:0")
+    st = None
+    g = torch.Generator().manual_seed(3)
+    ws = torch.empty(lib.fear_train_workspace_bytes(4096, 320) // 4 + 1024, device=dev)
+    wsb = ws.numel() * 4
+    for M, K, N in ((1000, 320, 256), (2304, 256, 4), (130, 64, 112)):
+        x, w, dy = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.1, torch.randn(M, N, generator=g)
+        b = torch.randn(N, generator=g)
+        xd, wd, dyd, bd = x.to(dev), w.to(dev), dy.to(dev), b.to(dev)
+        y = torch.empty(M, N, device=dev)
+        assert lib.fear_pw_forward(_p(xd), K, _p(wd), _p(bd), _p(y), N, M, K, N, st) == 0
+        _close(y, x @ w.t() + b, "pw forward", 1e-5)
+        dx = torch.empty(M, K, device=dev)
+        assert lib.fear_pw_backward_data(_p(dyd), N, _p(wd), None, 0, _p(dx), K, M, K, N, st) == 0
+        _close(dx, dy @ w, "pw dgrad", 1e-5)
+        dw = torch.empty(N, K, device=dev)
+        assert lib.fear_pw_backward_weight(_p(dyd), N, _p(xd), K, _p(dw), _p(ws), wsb, M, K, N, st) == 0
+        _close(dw, dy.t() @ x, "pw wgrad", 1e-5)
+        db = torch.empty(N, device=dev)
+        assert lib.fear_col_sum(_p(dyd), N, _p(db), _p(ws), wsb, M, N, st) == 0
+        _close(db, dy.sum(0), "bias grad", 1e-5)
+    for B, H, C, k in ((3, 16, 320, 3), (2, 8, 64, 5)):
+        x = torch.randn(B, C, H, H, generator=g, requires_grad=True)
+        w = torch.randn(C, 1, k, k, generator=g, requires_grad=True)
+        y = F.conv2d(x, w, None, padding=k // 2, groups=C)
+        dy = torch.randn(y.shape, generator=g)
+        y.backward(dy)
+        rows = lambda t: t.detach().permute(0, 2, 3, 1).reshape(-1, C).contiguous().to(dev)
+        taps = w.detach().reshape(C, k * k).t().contiguous().to(dev)
+        yd = torch.empty(B * H * H, C, device=dev)
+        assert lib.fear_dw_forward(_p(rows(x)), C, _p(taps), None, _p(yd), C, B, H, H, C, k, st) == 0
+        _close(yd, rows(y).cpu(), "dw forward", 1e-5)
+        dxd = torch.empty(B * H * H, C, device=dev)
+        assert lib.fear_dw_backward_data(_p(rows(dy)), C, _p(torch.flip(taps, [0]).contiguous()), _p(dxd), C, B, H, H, C, k, st) == 0
+        _close(dxd, rows(x.grad).cpu(), "dw dgrad", 1e-5)
+        dtaps = torch.empty(k * k, C, device=dev)
+        assert lib.fear_dw_backward_weight(_p(rows(dy)), C, _p(rows(x)), C, _p(dtaps), _p(ws), wsb, B, H, H, C, k, st) == 0
+        _close(dtaps, w.grad.reshape(C, k * k).t(), "dw wgrad", 1e-5)
+    for M, C, relu in ((1024, 256, 1), (777, 112, 0)):
+        x = (torch.randn(M, C, generator=g) * 2 + 0.5).requires_grad_(True)
+        gamma, beta = (torch.rand(C, generator=g) + 0.5).requires_grad_(True), torch.randn(C, generator=g).requires_grad_(True)
+        rm, rv = torch.zeros(C), torch.ones(C)
+        y = F.batch_norm(x, rm, rv, gamma, beta, training=True, momentum=0.1, eps=1e-5)
+        y = F.relu(y) if relu else y
+        dy = torch.randn(M, C, generator=g)
+        y.backward(dy)
+        xd, yd = x.detach().to(dev), torch.empty(M, C, device=dev)
+        mean, rstd = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        rmd, rvd = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        assert lib.fear_bn_train_forward(_p(xd), C, _p(gamma.detach().to(dev)), _p(beta.detach().to(dev)), _p(yd), C, _p(mean), _p(rstd),
+                                         _p(rmd), _p(rvd), 0.1, 1e-5, M, C, relu, _p(ws), wsb, st) == 0
+        _close(yd, y.detach(), "bn forward", 1e-5)
+        _close(rmd, rm, "running mean", 1e-5)
+        _close(rvd, rv, "running var", 1e-5)
+        dxd, dg, db = torch.empty(M, C, device=dev), torch.empty(C, device=dev), torch.empty(C, device=dev)
+        assert lib.fear_bn_train_backward(_p(dy.to(dev)), C, _p(yd) if relu else None, C, _p(xd), C, _p(mean), _p(rstd),
+                                          _p(gamma.detach().to(dev)), _p(dxd), C, _p(dg), _p(db), M, C, _p(ws), wsb, st) == 0
+        _close(dxd, x.grad, "bn dx", 1e-4)
+        _close(dg, gamma.grad, "bn dgamma", 1e-4)
+        _close(db, beta.grad, "bn dbeta", 1e-4)
+    B, P, C, J = 3, 256, 256, 64
+    x = torch.randn(B, P, C, generator=g, requires_grad=True)
+    z = torch.randn(B, C, J, generator=g, requires_grad=True)
+    s = torch.matmul(x, z)
+    ds = torch.randn(s.shape, generator=g)
+    s.backward(ds)
+    xd, zd = x.detach().reshape(B * P, C).to(dev), z.detach().to(dev)
+    sd_ = torch.empty(B * P, J, device=dev)
+    assert lib.fear_xcorr_forward(_p(xd), C, _p(zd), _p(sd_), J, B, P, C, J, st) == 0
+    _close(sd_, s.detach().reshape(B * P, J), "xcorr forward", 1e-5)
+    dxd, dzd = torch.empty(B * P, C, device=dev), torch.empty(B, C, J, device=dev)
+    add = torch.randn(B * P, C, generator=g)
+    assert lib.fear_xcorr_backward(_p(ds.reshape(B * P, J).to(dev)), J, _p(xd), C, _p(zd), _p(add.to(dev)), C, _p(dxd), C, _p(dzd),
+                                   B, P, C, J, st) == 0
+    torch.cuda.synchronize()
+    _close(dxd, x.grad.reshape(B * P, C) + add, "xcorr dx", 1e-5)
+    _close(dzd, z.grad, "xcorr dz", 1e-5)
