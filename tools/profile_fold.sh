@@ -15,4 +15,5 @@ done
 cp $P/r${N}_per_op_math0.csv $P/r${N}_per_op.csv
 python tools/pmc_to_traffic.py $O/pmc_FETCH_SIZE/p_counter_collection.csv $O/pmc_WRITE_SIZE/p_counter_collection.csv > $P/r${N}_traffic.json
 tail -1 $O/latency.json > $P/r${N}_latency_batch1.json
+tail -1 $O/bench_force_dist.json > $P/r${N}_bench_force_dist_1gpu.json
 ls -la $P
