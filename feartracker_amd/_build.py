@@ -64,5 +64,34 @@ def check_spills(remarks: str):
     return out
 
 
+def build_debug_library(verbose: bool = False) -> str:
+    """Debug target: the same translation unit with the device code built exactly like the product (-O3) and the
+    HOST side at -O1 -g, instrumented — UndefinedBehavior-
+    Sanitizer (bounds, integer overflow, null, alignment; traps instead of recovering) and libstdc++'s container assertions
+    (every std::vector operator[] of the engine's model / plan / workspace bookkeeping is range-checked) — written next to the
+    product library as libfear_hip_debug.so (git-ignored).  On the GPU box:
+        FEAR_LIB=feartracker_amd/libfear_hip_debug.so python -m pytest tests -m gpu -x -q
+    (FEAR_LIB selects the library hip_backend loads).  AddressSanitizer was tried first and is NOT usable here: ROCm's
+    compiler-rt intercepts hsa_amd_memory_pool_allocate and aborts inside torch's stock libamdhip64 (it needs an xnack+
+    ASan build of the whole runtime); device code is the same in both builds."""
+    out = os.path.join(PKG_DIR, "libfear_hip_debug.so")
+    # (-fsanitize=function instruments the entry of every function and breaks the launch of HIP kernels through the function
+    # pointers the engine's kernel tables hold: wrong maps, no trap — excluded)
+    host = ["-O1", "-g", "-fsanitize=undefined", "-fno-sanitize=function,vptr", "-fsanitize-trap=undefined", "-fno-omit-frame-pointer"]
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-fno-honor-nans",
+           "-D_GLIBCXX_ASSERTIONS", "-Xarch_device", "-O3"]
+    for f in host:
+        cmd += ["-Xarch_host", f]
+    cmd += ["-o", out, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    return out
+
+
 if __name__ == "__main__":
-    print(build_library(force=True, verbose=True))
+    import sys
+    if "--debug" in sys.argv:
+        print(build_debug_library(verbose=True))
+    else:
+        print(build_library(force=True, verbose=True))
