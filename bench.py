@@ -320,6 +320,7 @@ def main() -> None:
                     help="crops per internal engine pass (workspace / cache footprint)")
     ap.add_argument("--math", type=int, default=int(os.environ.get("FEAR_MATH", "0")), choices=[0, 1],
                     help="0: fp32 MFMA (exact fp32, default); 1: fp16 hi+lo split operands on the matrix pipe, fp32 accumulate")
+    ap.add_argument("--dual-head", action="store_true", help="A/B: the head's two branches on two streams (FEAR_OPT_DUAL_HEAD)")
     ap.add_argument("--no-chain", action="store_true", help="A/B: one fused kernel per stride-16 block instead of the chain kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-math", action="store_true",
@@ -374,6 +375,8 @@ def main() -> None:
     net.set_math(args.math)
     if args.no_chain:
         net.set_chain(False)
+    if args.dual_head:
+        net.set_dual_head(True)
     search_u8, tmpl_u8 = synth_batch(B, rank)
     search = norm_u8(search_u8.to(dev)).contiguous()
     tmpl_feats = net.get_features(norm_u8(tmpl_u8.to(dev)).contiguous())

@@ -170,6 +170,9 @@ struct fear_handle {
     std::vector<float*> weight_allocs;    // per-conv weights: live as long as the handle
     std::vector<float*> plan_allocs;      // weights packed for the fused kernels of the cached plans: freed with the plans
     bool building_plan = false;           // upload() books into plan_allocs while a plan is being built
+    int dual_head = 0;                    // FEAR_OPT_DUAL_HEAD: throughput plan runs the head's two branches on two streams (A/B option:
+                                          // measured 104.3 k vs 104.8 k crops/s single-stream — the 16x16 kernels are ALU-bound, a second
+                                          // resident workgroup per CU buys nothing: kbench 512 vs 2 x 256 crops, +2 %)
     int plan_crops = 0;                   // FEAR_OPT_PLAN_CROPS: crop count whose plan the introspection calls describe (0: max_batch)
     hipStream_t last_stream = nullptr;    // the caller stream of the previous call: a call on another stream first waits for it
     bool last_stream_valid = false;       // (the workspace and the branch stream are shared by all calls on a handle)
@@ -1004,7 +1007,9 @@ int build_plan_uncached(fear_handle* h, int hw, bool with_head, int mode, Plan**
         };
         // Small batches (one workgroup per crop leaves most CUs idle): the two branches are independent, so the bbox branch is
         // planned on buffers of its own and run_plan puts it on a second stream next to the cls branch.
-        const bool dual = small;
+        // The throughput plan does the same when FEAR_OPT_DUAL_HEAD is on (off by default): a sep16 workgroup needs 77 KB of LDS and
+        // 116 VGPRs, so one workgroup of each branch fits on a CU at the same time — measured: no gain, the kernels are ALU-bound.
+        const bool dual = small || (h->dual_head && h->fuse && !h->math);
         const size_t head_first = ops.size();
         pool.hold = dual;
         int st = branch(role[FEARW_CLS_ENCODE], role[FEARW_CLS_CORR], cls_tower, role[FEARW_CLS_PRED], true);
@@ -1131,7 +1136,9 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
     const size_t slab = p.buf_floats_per_crop * pass_cap(h, p);
     auto buf = [&](int id) -> float* { return h->workspace + (size_t)id * slab; };
     // head branches on two streams (plans built for small passes only; per-op profiling keeps everything on one stream)
-    const bool dual = p.head_first >= 0 && !h->profile;
+    // (bracketing ONE op with events keeps the two streams — the events go to the stream the op runs on; the all-ops table of
+    // FEAR_OPT_PROFILE_OP = -1 serialises the plan so that per-op times do not overlap)
+    const bool dual = p.head_first >= 0 && !(h->profile && h->profile_op < 0);
     if (dual && !h->branch_stream) {
         HIP_TRY(h, hipStreamCreateWithFlags(&h->branch_stream, hipStreamNonBlocking));
         HIP_TRY(h, hipEventCreateWithFlags(&h->branch_fork, hipEventDisableTiming));
@@ -1430,6 +1437,10 @@ int fear_set_option(fear_handle* h, int option, int64_t value) {
             if (value < 0 || value > 65536) return FEAR_ERR_SHAPE;
             h->plan_crops = (int)value;
             return FEAR_OK;
+        case FEAR_OPT_DUAL_HEAD:
+            if (value != 0 && value != 1) return FEAR_ERR_SHAPE;
+            if (h->dual_head != (int)value) { h->dual_head = (int)value; return drop_plans(h); }
+            return FEAR_OK;
         default: return FEAR_ERR_SHAPE;
     }
 }
@@ -1445,6 +1456,7 @@ int64_t fear_get_option(fear_handle* h, int option) {
         case FEAR_OPT_CHAIN: return h->chain;
         case FEAR_OPT_SMALL_PASS: return h->small_pass;
         case FEAR_OPT_PLAN_CROPS: return h->plan_crops;
+        case FEAR_OPT_DUAL_HEAD: return h->dual_head;
         default: return FEAR_ERR_SHAPE;
     }
 }

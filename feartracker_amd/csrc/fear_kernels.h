@@ -725,6 +725,13 @@ __device__ __forceinline__ void pk_fma4(f32x4& d, const f32x4& a, const f32x4& b
     d = __builtin_shufflevector(dl, dh, 0, 1, 2, 3);
 }
 
+// hipcc's hazard recognizer does not look inside inline asm: an MFMA whose A/B operand is a VGPR written by the v_pk_fma_f32
+// right in front of it gets NO wait states and reads a stale value (found with tools/sepcheck.hip: the last tap of the
+// prediction head's last channel chunk was dropped from one output row — 5e-3 relative — as soon as a re-layout of the LDS
+// tile let the scheduler place the chain's last FMA directly before the MFMAs).  Call this after the last pk_fma4 of a chain
+// whose results feed MFMAs: it pins eight wait states between the two (once per chunk: noise).
+__device__ __forceinline__ void pk_fma_settle(f32x4& a, f32x4& b) { asm volatile("s_nop 7" : "+v"(a), "+v"(b)); }
+
 // One barrier interval of the fused 16x16 block kernels (ir16v2_fused_kernel, chain16_block): depthwise + projection of
 // chunk c from E / wb, and (HAS_A) the expansion of chunk c + 1 from wa into En.
 // The depthwise is a chain of KS*(KS+1) tap steps (kx outer, iy inner, so the weight of (iy, kx) feeds row 0 now and
@@ -798,6 +805,7 @@ __device__ __forceinline__ void ir16_interval(const float* __restrict__ E, float
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    pk_fma_settle(d0, d1);
     f32x4 wpq[2];
     wpq[0] = *reinterpret_cast<const f32x4*>(wb + lane * 4);
     if (HAS_A) {
@@ -1030,9 +1038,14 @@ __global__ __launch_bounds__(512) void ir16v2_fused_kernel(Ir2Args a) {
 // Packed weights: the BC-part layout of Ir2Args (AP = 0): per chunk NTP fragments x 256 | Wd[KS*KS][16] | bd[16].
 template <int CIN, int COUT, int KS, bool CORR = false>
 struct Sep16Geom {
-    static constexpr int S = 16, P = KS / 2, PW = S + 2 * P, ES = 24, NCHUNK = CIN / 16, NTP = COUT / 16;
+    static constexpr int S = 16, P = KS / 2, PW = S + 2 * P, NCHUNK = CIN / 16, NTP = COUT / 16;
     static constexpr int WPF = NTP * 256, WDF = KS * KS * 16 + 16, CST = WPF + WDF;
-    static constexpr int EBUF = PW * PW * ES;
+    // LDS tile of one 16-channel chunk: four planes (one per channel quad) of [pixel][4], a multiple of 64 floats apart —
+    // conflict free for the stride-1 ds_read_b128 pattern and for the stores, nothing padded (see IrT2Geom).  16 instead of
+    // 24 floats per pixel brings the kernel from 96 to 77 KB of LDS: two workgroups per CU when the two head branches run
+    // side by side.
+    static constexpr int EP = 4, EQ = (PW * PW * 4 + 63) / 64 * 64;
+    static constexpr int EBUF = 4 * EQ;
     static constexpr int ZF = CORR ? COUT * 64 : 0;            // the crop's template features, resident for the epilogue
     static constexpr int LDS_BYTES = (2 * EBUF + 2 * WPF + 2 * WDF + ZF) * 4;
 };
@@ -1051,7 +1064,7 @@ __global__ __launch_bounds__(512) void sep16_kernel(Ir2Args a) {
     using G = Sep16Geom<CIN, COUT, KS, CORR>;
     static_assert(!(CORR && PRED) && !(SPLITK && (CORR || PRED)), "one epilogue at a time");
     static_assert(SPLITK == 0 || (SPLITK >= 2 && G::NCHUNK % SPLITK == 0), "SPLITK = chunks per workgroup (compile time)");
-    constexpr int S = G::S, P = G::P, PW = G::PW, ES = G::ES, NTP = G::NTP;
+    constexpr int S = G::S, P = G::P, PW = G::PW, EP = G::EP, EQ = G::EQ, NTP = G::NTP;
     constexpr int NCHUNK = SPLITK ? SPLITK : G::NCHUNK;         // split-K: this workgroup's share of the input chunks
     const int c_base = SPLITK ? (int)blockIdx.y * SPLITK : 0;
     constexpr int WPF = G::WPF, WDF = G::WDF, CST = G::CST, EBUF = G::EBUF;
@@ -1082,7 +1095,7 @@ __global__ __launch_bounds__(512) void sep16_kernel(Ir2Args a) {
     auto store_x = [&](int c) {
         float* E = Ebuf + (c & 1) * EBUF;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) *reinterpret_cast<f32x4*>(E + ((y0 + mt + P) * PW + li + P) * ES + lk * 4) = rx[mt];
+        for (int mt = 0; mt < 2; ++mt) *reinterpret_cast<f32x4*>(E + ((y0 + mt + P) * PW + li + P) * EP + lk * EQ) = rx[mt];
     };
     // weights go global -> LDS directly (asynchronous, no registers): the projection fragments of chunk c into WP[c & 1],
     // the depthwise taps + bias into WD[c & 1]
@@ -1103,7 +1116,7 @@ __global__ __launch_bounds__(512) void sep16_kernel(Ir2Args a) {
         if (FEAR_ABL & 64) { d0 = d1 = rx[0]; }
         const int cd = PROJ ? c + 1 : c;
         const float* wd = WD + (cd & 1) * WDF + lk * 4;
-        const float* e0 = Ebuf + (cd & 1) * EBUF + (y0 * PW + li) * ES + lk * 4;
+        const float* e0 = Ebuf + (cd & 1) * EBUF + (y0 * PW + li) * EP + lk * EQ;
         const float* wp = WP + (c & 1) * WPF;
         f32x4 n0, n1, ev[D], wv[D], wprev = (f32x4){0.f, 0.f, 0.f, 0.f}, wpq[2];
         if (PROJ) wpq[0] = *reinterpret_cast<const f32x4*>(wp + lane * 4);
@@ -1112,7 +1125,7 @@ __global__ __launch_bounds__(512) void sep16_kernel(Ir2Args a) {
 #pragma unroll
             for (int t = 0; t < D; ++t) {
                 const int kx = t / (KS + 1), iy = t % (KS + 1);
-                ev[t] = *reinterpret_cast<const f32x4*>(e0 + (iy * PW + kx) * ES);
+                ev[t] = *reinterpret_cast<const f32x4*>(e0 + (iy * PW + kx) * EP);
                 if (iy < KS) wv[t] = *reinterpret_cast<const f32x4*>(wd + (iy * KS + kx) * 16);
             }
         }
@@ -1125,7 +1138,7 @@ __global__ __launch_bounds__(512) void sep16_kernel(Ir2Args a) {
                 e = ev[t % D]; w = wv[t % D];
                 if (t + D < NS) {
                     const int kx2 = (t + D) / (KS + 1), iy2 = (t + D) % (KS + 1);
-                    ev[t % D] = *reinterpret_cast<const f32x4*>(e0 + (iy2 * PW + kx2) * ES);
+                    ev[t % D] = *reinterpret_cast<const f32x4*>(e0 + (iy2 * PW + kx2) * EP);
                     if (iy2 < KS) wv[t % D] = *reinterpret_cast<const f32x4*>(wd + (iy2 * KS + kx2) * 16);
                 }
             }
@@ -1146,6 +1159,7 @@ __global__ __launch_bounds__(512) void sep16_kernel(Ir2Args a) {
             __builtin_amdgcn_sched_barrier(0);
         }
         if (DW) {
+            pk_fma_settle(n0, n1);
             if (a.relu_dw) {
                 n0.x = fmaxf(n0.x, 0.f); n0.y = fmaxf(n0.y, 0.f); n0.z = fmaxf(n0.z, 0.f); n0.w = fmaxf(n0.w, 0.f);
                 n1.x = fmaxf(n1.x, 0.f); n1.y = fmaxf(n1.y, 0.f); n1.z = fmaxf(n1.z, 0.f); n1.w = fmaxf(n1.w, 0.f);
@@ -1211,18 +1225,18 @@ __global__ __launch_bounds__(512) void sep16_kernel(Ir2Args a) {
                 v0.x = fmaxf(v0.x, 0.f); v0.y = fmaxf(v0.y, 0.f); v0.z = fmaxf(v0.z, 0.f); v0.w = fmaxf(v0.w, 0.f);
                 v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); v1.z = fmaxf(v1.z, 0.f); v1.w = fmaxf(v1.w, 0.f);
             }
-            *reinterpret_cast<f32x4*>(E + ((y0 + P) * PW + li + P) * ES + lk * 4) = v0;
-            *reinterpret_cast<f32x4*>(E + ((y0 + 1 + P) * PW + li + P) * ES + lk * 4) = v1;
+            *reinterpret_cast<f32x4*>(E + ((y0 + P) * PW + li + P) * EP + lk * EQ) = v0;
+            *reinterpret_cast<f32x4*>(E + ((y0 + 1 + P) * PW + li + P) * EP + lk * EQ) = v1;
             __syncthreads();                                   // (first pass: also completes the weight copy)
             const float* wpk = WP + c * PCH;
             const float* wd = wpk + 256 + lk * 4;
-            const float* e0 = E + (y0 * PW + li) * ES + lk * 4;
+            const float* e0 = E + (y0 * PW + li) * EP + lk * EQ;
             f32x4 n0 = *reinterpret_cast<const f32x4*>(wd + KS * KS * 16), n1 = n0, wprev = (f32x4){0.f, 0.f, 0.f, 0.f};
             f32x4 ev[D], wv[D];
 #pragma unroll
             for (int t = 0; t < D; ++t) {
                 const int kx = t / (KS + 1), iy = t % (KS + 1);
-                ev[t] = *reinterpret_cast<const f32x4*>(e0 + (iy * PW + kx) * ES);
+                ev[t] = *reinterpret_cast<const f32x4*>(e0 + (iy * PW + kx) * EP);
                 if (iy < KS) wv[t] = *reinterpret_cast<const f32x4*>(wd + (iy * KS + kx) * 16);
             }
 #pragma unroll
@@ -1231,7 +1245,7 @@ __global__ __launch_bounds__(512) void sep16_kernel(Ir2Args a) {
                 const f32x4 e = ev[t % D], w = wv[t % D];
                 if (t + D < NS) {
                     const int kx2 = (t + D) / (KS + 1), iy2 = (t + D) % (KS + 1);
-                    ev[t % D] = *reinterpret_cast<const f32x4*>(e0 + (iy2 * PW + kx2) * ES);
+                    ev[t % D] = *reinterpret_cast<const f32x4*>(e0 + (iy2 * PW + kx2) * EP);
                     if (iy2 < KS) wv[t % D] = *reinterpret_cast<const f32x4*>(wd + (iy2 * KS + kx2) * 16);
                 }
                 if (iy < KS) pk_fma4(n0, e, w);
@@ -1239,6 +1253,7 @@ __global__ __launch_bounds__(512) void sep16_kernel(Ir2Args a) {
                 wprev = w;
             }
             // (no activation between the head's depthwise and its 1x1: SepConv = dw -> pw, as in the towers)
+            pk_fma_settle(n0, n1);
             const f32x4 wf = *reinterpret_cast<const f32x4*>(wpk + lane * 4);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {

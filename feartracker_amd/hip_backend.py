@@ -34,6 +34,7 @@ FEAR_OPT_MATH = 5
 FEAR_OPT_CHAIN = 6
 FEAR_OPT_SMALL_PASS = 7
 FEAR_OPT_PLAN_CROPS = 8
+FEAR_OPT_DUAL_HEAD = 9
 
 _lib = None
 
@@ -174,6 +175,10 @@ class FEARNetHIP:
     def set_small_pass(self, crops: int) -> None:
         """Passes of at most `crops` crops run the small-batch plan (split-K 16x16 kernels, two-stream head); 0 = never."""
         self._check(self._lib.fear_set_option(self._h, FEAR_OPT_SMALL_PASS, int(crops)))
+
+    def set_dual_head(self, on: bool) -> None:
+        """Throughput plan: the head's two branches on two streams (default) vs one."""
+        self._check(self._lib.fear_set_option(self._h, FEAR_OPT_DUAL_HEAD, 1 if on else 0))
 
     def set_plan_crops(self, crops: int) -> None:
         """Crop count whose launch plan `plan()` / `profile_read()` describe (0 = a full pass of max_batch crops)."""

@@ -120,6 +120,8 @@ int fear_crop_normalize(fear_handle* h, const uint8_t* frame_u8, int frame_h, in
 #define FEAR_OPT_PLAN_CROPS 8  /* crop count whose launch plan fear_plan_size / fear_plan_op / fear_profile_read describe (a    */
                                /*   pass of <= FEAR_OPT_SMALL_PASS crops runs another plan than a full one); 0 (default) =     */
                                /*   FEAR_OPT_MAX_BATCH, i.e. the plan of a full pass                                           */
+#define FEAR_OPT_DUAL_HEAD 9   /* 1: the throughput plan runs the head's cls and bbox branches on two streams (one workgroup   */
+                               /*   of each fits on a CU); 0 (default): one stream — measured equal, the kernels are ALU-bound */
 int fear_set_option(fear_handle* h, int option, int64_t value);
 int64_t fear_get_option(fear_handle* h, int option);
 

@@ -45,7 +45,8 @@ def test_option_ids_match_header():
     text = open(os.path.join(ROOT, "include", "fear_hip.h")).read()
     ids = dict(re.findall(r"#define (FEAR_OPT_[A-Z_]+) (\d+)", text))
     assert ids == {"FEAR_OPT_MAX_BATCH": "1", "FEAR_OPT_PROFILE": "2", "FEAR_OPT_PROFILE_OP": "3", "FEAR_OPT_FUSE": "4",
-                   "FEAR_OPT_MATH": "5", "FEAR_OPT_CHAIN": "6", "FEAR_OPT_SMALL_PASS": "7", "FEAR_OPT_PLAN_CROPS": "8"}
+                   "FEAR_OPT_MATH": "5", "FEAR_OPT_CHAIN": "6", "FEAR_OPT_SMALL_PASS": "7", "FEAR_OPT_PLAN_CROPS": "8",
+                   "FEAR_OPT_DUAL_HEAD": "9"}
     for name, val in ids.items():
         assert getattr(hip_backend, name) == int(val)
 
@@ -142,7 +143,7 @@ def test_error_codes_and_options_on_device():
     assert lib.fear_decode_smooth(h, None, None, 0, 16, 16, 256, None, None, 0.1, 0.3, 0.3, None, None, None, st) == OK
     assert lib.fear_decode_smooth(h, None, None, 2, 16, 16, 256, None, None, 0.1, 0.3, 0.3, None, None, None, st) == NULL
     for opt, good, bad in ((hb.FEAR_OPT_MAX_BATCH, 17, 0), (hb.FEAR_OPT_MATH, 2, 3), (hb.FEAR_OPT_CHAIN, 0, 5),
-                           (hb.FEAR_OPT_SMALL_PASS, 12, -1), (hb.FEAR_OPT_FUSE, 0, 3), (hb.FEAR_OPT_PLAN_CROPS, 3, -2)):
+                           (hb.FEAR_OPT_SMALL_PASS, 12, -1), (hb.FEAR_OPT_FUSE, 0, 3), (hb.FEAR_OPT_PLAN_CROPS, 3, -2), (hb.FEAR_OPT_DUAL_HEAD, 1, 2)):
         assert lib.fear_set_option(h, opt, good) == OK and lib.fear_get_option(h, opt) == good
         assert lib.fear_set_option(h, opt, bad) == SHAPE and lib.fear_get_option(h, opt) == good
     assert lib.fear_set_option(h, 999, 1) == SHAPE

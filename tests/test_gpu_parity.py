@@ -709,3 +709,21 @@ def test_fear_m_synthetic_deeper_trunk_all_math_modes():
     top2 = torch.topk(flat, 2, dim=1).values
     need = (top2[:, 0] - top2[:, 1]) > 2 * dev_c
     assert torch.equal(c2.reshape(4, -1).argmax(dim=1)[need], flat.argmax(dim=1)[need])
+
+
+def test_dual_stream_head_in_the_throughput_plan(hip_net):
+    """FEAR_OPT_DUAL_HEAD: the head's two branches on two streams in the throughput plan too (disjoint scratch, fork / join
+    events) — the same kernels in the same per-branch order, so the maps are bit-identical to the single-stream plan."""
+    from feartracker_amd import FEARNetHIP
+    from conftest import WEIGHTS
+    g = torch.Generator().manual_seed(12)
+    x = norm_u8(torch.randint(0, 256, (6, 3, 256, 256), dtype=torch.uint8, generator=g)).cuda()
+    z = hip_net.get_features(norm_u8(torch.randint(0, 256, (6, 3, 128, 128), dtype=torch.uint8, generator=g)).cuda())
+    one, two = FEARNetHIP(WEIGHTS, device=0, max_batch=8), FEARNetHIP(WEIGHTS, device=0, max_batch=8)
+    for n in (one, two):
+        n.set_small_pass(0)
+    two.set_dual_head(True)
+    b1, c1 = one.track_maps(x, z)
+    for _ in range(10):
+        b2, c2 = two.track_maps(x, z)
+        assert torch.equal(b1, b2) and torch.equal(c1, c2)
