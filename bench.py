@@ -255,7 +255,8 @@ def latency_batch1(weights, frames_cap: int = 120):
         return {k: 1e3 * v / n for k, v in t.items() if v > 0}, np.stack(boxes)
 
     sync = torch.cuda.synchronize
-    host_ms, host_boxes = loop(FEARTracker(net, cuda_id=torch.cuda.current_device(), **DEFAULT_TRACKING_CONFIG), sync, True)
+    host_ms, host_boxes = loop(FEARTracker(net, cuda_id=torch.cuda.current_device(),
+                                           **dict(DEFAULT_TRACKING_CONFIG, device_crop=False, device_postprocess=False)), sync, True)
     dev_ms, dev_boxes = loop(FEARTracker(net, cuda_id=torch.cuda.current_device(),
                                          **dict(DEFAULT_TRACKING_CONFIG, device_crop=True, device_postprocess=True)), sync, False)
     from oracle.fear_oracle import OracleNet  # CPU baseline leg only

@@ -70,7 +70,7 @@ def main():
     from feartracker_amd import FEARNetHIP
     net = FEARNetHIP(DEFAULT_WEIGHTS, device=0, max_batch=1)
     net.set_math(args.math)
-    hip = FEARTracker(net, cuda_id=0, **DEFAULT_TRACKING_CONFIG)
+    hip = FEARTracker(net, cuda_id=0, **dict(DEFAULT_TRACKING_CONFIG, device_crop=False, device_postprocess=False))
     hip_ms, hip_boxes = run(hip, frames, init_box, args.repeats, torch.cuda.synchronize)
 
     # device crop path (fear_crop_normalize) and device crop + device post-processing (fear_decode): whole update() timed,

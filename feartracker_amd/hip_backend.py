@@ -107,7 +107,10 @@ class FearError(RuntimeError):
 
 
 class FEARNetHIP:
-    """FEAR network running on one MI355X through libfear_hip.so."""
+    """FEAR network running on one MI355X through libfear_hip.so.
+
+    One handle = one device, one workspace: calls are ordered on the device even when they are issued on different torch
+    streams (the engine makes a call on a new stream wait for the previous call's work); the object is not thread-safe."""
 
     def __init__(self, weights_path: str = DEFAULT_WEIGHTS, device: int = 0, max_batch: int = 64):
         self._lib = load_library()
@@ -341,6 +344,8 @@ class FEARNetHIP:
         the GPU, ctx_xywh (n,4) int context boxes, pad_rgb_u8 (n,3) uint8 border colours -> (n,3,out_hw,out_hw) fp32."""
         if frame_u8.dtype != torch.uint8 or frame_u8.dim() != 3 or frame_u8.shape[2] != 3:
             raise ValueError("frame must be uint8 (H,W,3)")
+        # (a host frame goes up with one plain .to(): a reused pinned staging buffer was tried — ADVICE r1 — and measured
+        # 10x SLOWER per frame on the 256-core host, torch's CPU->pinned copy_ costs milliseconds there)
         frame_u8 = frame_u8.to(self.device).contiguous()
         ctx = torch.as_tensor(ctx_xywh, dtype=torch.int32).reshape(-1, 4).to(self.device).contiguous()
         pad = torch.as_tensor(pad_rgb_u8, dtype=torch.uint8).reshape(-1, 3).to(self.device).contiguous()

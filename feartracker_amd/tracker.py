@@ -200,9 +200,11 @@ class FEARTracker(Tracker):
         self._template_features = self.get_template_features(image, rect)
 
     def _device_crop(self) -> bool:
-        """`device_crop=True` in the tracking config moves crop + border + resize + normalise to the GPU
-        (`fear_crop_normalize`); bit-identical to the host path, not part of the reference config."""
-        return bool(self.tracking_config.get("device_crop", False)) and hasattr(self.net, "crop_normalize")
+        """Crop + border + resize + normalise on the GPU (`fear_crop_normalize`) whenever the model offers
+        it — bit-identical to the host path (tests/test_gpu_parity.py: same floats, same boxes on both clips) and 7x faster
+        per frame (bench.py `latency_batch1`: 0.7 vs 4.8 ms) — unless the tracking config says `device_crop=False` (not a key
+        of the reference config; the reference always crops on the host with cv2, utils.py:215-253)."""
+        return bool(self.tracking_config.get("device_crop", True)) and hasattr(self.net, "crop_normalize")
 
     def get_template_features(self, image: np.ndarray, rect: np.ndarray):
         cfg = self.tracking_config
@@ -245,9 +247,11 @@ class FEARTracker(Tracker):
 
     def _postprocess(self, track_result: Dict[str, torch.Tensor]):
         cfg = self.tracking_config
-        if cfg.get("device_postprocess", False) and hasattr(self.net, "decode_smooth"):
+        if cfg.get("device_postprocess", True) and hasattr(self.net, "decode_smooth") and \
+                getattr(track_result.get(TARGET_CLASSIFICATION_KEY), "is_cuda", False):
             # whole post-processing in one device kernel (fear_decode / fear_decode_smooth), one 40-byte D2H; identical
-            # boxes to the host path below (tests/test_gpu_parity.py); not a key of the reference config
+            # boxes to the host path below (tests/test_gpu_parity.py); default whenever the model offers it, switched off
+            # with `device_postprocess=False` (not a key of the reference config)
             cls_map, reg_map = track_result[TARGET_CLASSIFICATION_KEY], track_result[TARGET_REGRESSION_LABEL_KEY]
             if cfg.get("smooth", False):
                 _, xywh, score = self.net.decode_smooth(

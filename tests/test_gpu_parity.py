@@ -177,7 +177,8 @@ def test_tracker_clip_through_drop_in_api(hip_net, golden_dir):
     reference tracker produced on the synthetic clip (fixture: tools/make_golden.py §8)."""
     from feartracker_amd import DEFAULT_TRACKING_CONFIG, FEARTracker
     d = np.load(f"{golden_dir}/clip_synth.npz")
-    trk = FEARTracker(hip_net, cuda_id=0, **DEFAULT_TRACKING_CONFIG)
+    trk = FEARTracker(hip_net, cuda_id=0, **DEFAULT_TRACKING_CONFIG)      # default: device crop + device post-processing
+    assert trk._device_crop()
     frames = d["frames"]
     trk.initialize(frames[0], d["init_bbox"])
     assert trk._template_features.is_cuda
