@@ -21,7 +21,7 @@ Prints ONE JSON line (rank 0).  Extra objects:
   cpu_baseline the CPU oracle (torch fp32, best thread count on the host) timed on a bounded sample of the same workload,
                with the B=1 and B=32 legs of BASELINE.md §3.2 and the host's lscpu model string.
   config4_fear_m_bf16  BASELINE configs[3]: synthetic deeper trunk (no reference definition), bf16 MFMA pointwise path, B=512.
-  config5_head_train_step  BASELINE configs[4], first slice: the correlation head's training step (fwd + loss + bwd) per rank.
+  config5_train_step  BASELINE configs[4]: the whole network's training step (fwd in train mode + FEARLoss + bwd) per rank.
   latency_batch1  BASELINE configs[0] stand-in: the drop-in tracker's update() at batch 1 on the 480x256 demo-geometry clip
                (no H.264 decoder exists on the box, profiles/r02_box_probe.txt), ms/frame for the reference-style host crop
                path and for device crop + device post-processing, the CPU-oracle tracker beside it, boxes compared.
@@ -156,52 +156,39 @@ def config4_fear_m(dev, steps: int = 20, warmup: int = 5, batch: int = 512):
             "tflops_bf16_path": res["bf16"]["value"] * flops / 1e12, "bf16": res["bf16"], "fp32_same_model": res["fp32"]}
 
 
-def config5_head_train_step(dev, batch: int = 128, steps: int = 10, warmup: int = 3):
-    """BASELINE.json configs[4] ("training step: backbone+xcorr fwd/bwd, random-init, batch=1024 on 8xMI355X"), first slice
-    (SURVEY.md §8f N3): ONE data-parallel rank's share (1024 / 8 = 128 pairs) of the correlation head's training step —
-    BoxTower forward in train mode + FEARLoss + backward to every head parameter and to both feature inputs — on the HIP
-    operators of include/fear_train.h, random-init parameters, synthetic features/targets.  The trunk's backward is not
-    built (its un-folded BatchNorm parameters are not recoverable); correctness: tests/test_train_head.py
-    (gradients vs the reference's autograd)."""
-    from feartracker_amd.train_head import BoxTowerTrainHIP
+def config5_train_step(dev, batch: int = 128, steps: int = 5, warmup: int = 2):
+    """BASELINE.json configs[4] ("training step: backbone+xcorr fwd/bwd, random-init, batch=1024 on 8xMI355X"): ONE data-parallel
+    rank's share (1024 / 8 = 128 template/search pairs) of the full training step — FEARNet.forward((template, search)) in train
+    mode (both crops through the trunk + neck, BatchNorm on batch statistics), FEARLoss, backward to all 195 parameter tensors —
+    on the HIP operators of include/fear_train.h (feartracker_amd/train_net.py), random init, synthetic crops and targets.  With
+    several ranks the gradients are averaged by one all-reduce of the flat 1.37 M-float buffer (not part of this 1-GPU number).
+    Correctness: tests/test_train_head.py (every gradient vs autograd; the head additionally vs the reference's own classes).
+    These operators are a first, unfused implementation (one kernel per layer and direction): the number is a baseline."""
+    from feartracker_amd.train_net import FEARNetTrainHIP, random_init_state
     g = torch.Generator().manual_seed(7)
-    sd = {}
-    for br, enc, corr, tower, pred, pc in (("cls", "cls_encode.matrix11_s", "cls_dw.enc", "cls_tower", "cls_pred", 1),
-                                           ("reg", "reg_encode.matrix11_s", "reg_dw.enc", "bbox_tower", "bbox_pred", 4)):
-        for name, cin, cout, bias, bn in ((enc + ".0", 256, 256, False, enc + ".1"), (corr + ".0", 320, 256, True, corr + ".1"),
-                                          (tower + ".0", 256, 256, True, tower + ".1"), (tower + ".3", 256, 256, True, tower + ".4"),
-                                          (pred, 256, pc, True, None)):
-            sd[name + ".depthwise.weight"] = torch.randn(cin, 1, 3, 3, generator=g) / 3.0
-            sd[name + ".pointwise.weight"] = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
-            if bias:
-                sd[name + ".depthwise.bias"] = torch.zeros(cin)
-                sd[name + ".pointwise.bias"] = torch.zeros(cout)
-            if bn:
-                sd[bn + ".weight"], sd[bn + ".bias"] = torch.ones(cout), torch.zeros(cout)
-                sd[bn + ".running_mean"], sd[bn + ".running_var"] = torch.zeros(cout), torch.ones(cout)
-    sd["adjust"], sd["bias"] = 0.1 * torch.ones(1), torch.ones(1, 4, 1, 1)
-    net = BoxTowerTrainHIP(sd, device=dev.index)
-    xs = torch.randn(batch, 256, 16, 16, generator=g).to(dev)
-    zs = torch.randn(batch, 256, 8, 8, generator=g).to(dev)
+    net = FEARNetTrainHIP(random_init_state(3), device=dev.index)
+    tmpl = torch.randn(batch, 3, 128, 128, generator=g).to(dev)
+    srch = torch.randn(batch, 3, 256, 256, generator=g).to(dev)
     gt_reg = (torch.rand(batch, 4, 16, 16, generator=g) * 60 + 1).to(dev)
     gt_cls = (torch.rand(batch, 1, 16, 16, generator=g) > 0.8).float().to(dev)
     gt_w = (torch.rand(batch, 16, 16, generator=g) > 0.9).float().to(dev)
     for _ in range(warmup):
-        out = net.step(xs, zs, gt_reg, gt_cls, gt_w)
+        out = net.step(tmpl, srch, gt_reg, gt_cls, gt_w)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        out = net.step(xs, zs, gt_reg, gt_cls, gt_w)
+        out = net.step(tmpl, srch, gt_reg, gt_cls, gt_w)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    head_macs = 157_515_776                      # BASELINE.md §2: head MACs per search crop (forward)
-    return {"workload": f"BoxTower (train mode, BatchNorm on batch statistics) + FEARLoss forward + backward, batch={batch} "
-                        "pairs per rank (configs[4]: 1024 over 8 ranks), random init, synthetic features and targets; trunk "
-                        "backward not built",
+    fwd_macs = 461_393_920 + 75_970_000           # BASELINE.md §2: search path + template path, forward MACs per pair
+    nparams = sum(v.numel() for v in out["grads"].values())
+    return {"workload": f"FEARNet training step (trunk + neck on both crops, correlation head, FEARLoss; forward in train mode + "
+                        f"backward), batch={batch} pairs per rank (configs[4]: 1024 over 8 ranks), fp32, random init, synthetic data",
             "value": batch / dt, "unit": "pairs/s per GPU", "ms_per_step": 1e3 * dt, "steps": steps, "warmup": warmup,
-            "approx_tflops": 3 * 2 * head_macs * batch / dt / 1e12,
+            "approx_tflops": 3 * 2 * fwd_macs * batch / dt / 1e12,
             "loss": [float(out["loss_cls"]), float(out["loss_reg"])], "dtype": "f32",
-            "parameters_with_gradients": len(out["grads"])}
+            "parameter_tensors_with_gradients": len(out["grads"]), "parameters": nparams,
+            "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
 
 
 def latency_batch1(weights, frames_cap: int = 120):
@@ -545,7 +532,8 @@ def main() -> None:
             out["config4_fear_m_bf16"] = config4_fear_m(dev)
             net = search = tmpl_feats = None
         if not args.no_train and world == 1 and not use_dist:
-            out["config5_head_train_step"] = config5_head_train_step(dev)
+            out["config5_train_step"] = config5_train_step(dev)
+            torch.cuda.empty_cache()
         if not args.no_latency and world == 1 and not use_dist:
             del net, search, tmpl_feats
             torch.cuda.empty_cache()

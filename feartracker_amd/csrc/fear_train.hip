@@ -32,7 +32,7 @@ using namespace fear;
 // ------------------------------------------------------------------------------------------------
 // Column reductions over rows: per-channel sums.  Block = 256 threads = (C/4 channel quads) x (R row lanes); a block reduces
 // ROWS_PER_BLOCK rows into partial[block][2][C]; col_finalize_kernel adds the partials in double, in block order.
-//   MODE 0: s1 = sum x,        s2 = sum x^2                                  (BatchNorm forward statistics)
+//   MODE 0: s1 = sum x,        s2 = sum (x - block mean)^2                   (BatchNorm forward statistics)
 //   MODE 1: g = relu ? (y > 0 ? dy : 0) : dy;  s1 = sum g,  s2 = sum g * xhat,  xhat = (x - mean) * rstd   (BatchNorm backward)
 //   MODE 2: s1 = sum dy                                                      (bias gradients)
 constexpr int ROWS_PER_BLOCK = 256;
@@ -43,22 +43,30 @@ struct ColArgs {
     const float* X;      // mode 1: the BatchNorm input
     const float* mean;   // mode 1
     const float* rstd;   // mode 1
-    float* partial;      // [blocks][2][C]
+    double* partial;     // [blocks][2][C] float64
     long M;
     int C, lda, ldy, ldx;
 };
 
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f64x4 to_f64(const f32x4& v) { return (f64x4){(double)v.x, (double)v.y, (double)v.z, (double)v.w}; }
+
+// Accumulation is in float64 end to end (per thread, across the row lanes, the per-block partials, the final sum): these sums
+// feed gradients that are themselves small differences of large sums (a BatchNorm's d beta is sum(dy) of a tensor whose
+// channel sums nearly cancel), and a coherent 1e-6 error per element — what fp32 accumulation over 64 rows leaves — shows up
+// as a 1e-2 error two layers further down.  Measured against float64 autograd: 2.5e-2 -> 1e-5 (tests/test_train_head.py).
 template <int MODE>
 __global__ __launch_bounds__(256) void col_reduce_kernel(ColArgs a) {
-    __shared__ f32x4 red[2][256];
+    __shared__ f64x4 red[2][256];
     const int c4n = a.C >> 2;
     const int R = 256 / c4n;
     const int cq = threadIdx.x % c4n, rl = threadIdx.x / c4n;
-    f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f}, s2 = s1;
+    const f64x4 zero = (f64x4){0.0, 0.0, 0.0, 0.0};
+    f64x4 s1 = zero, s2 = zero;
     const long r0 = (long)blockIdx.x * ROWS_PER_BLOCK;
     const long r1 = r0 + ROWS_PER_BLOCK < a.M ? r0 + ROWS_PER_BLOCK : a.M;
     if (rl < R) {
-        f32x4 mu = s1, rs = s1;
+        f32x4 mu = (f32x4){0.f, 0.f, 0.f, 0.f}, rs = mu;
         if (MODE == 1) {
             mu = *reinterpret_cast<const f32x4*>(a.mean + cq * 4);
             rs = *reinterpret_cast<const f32x4*>(a.rstd + cq * 4);
@@ -66,20 +74,34 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(ColArgs a) {
         for (long r = r0 + rl; r < r1; r += R) {
             f32x4 v = *reinterpret_cast<const f32x4*>(a.A + r * a.lda + cq * 4);
             if (MODE == 0) {
-                s1 += v;
-                s2 += v * v;
+                s1 += to_f64(v);
             } else if (MODE == 1) {
                 if (a.Yact) {
                     const f32x4 y = *reinterpret_cast<const f32x4*>(a.Yact + r * a.ldy + cq * 4);
                     v.x = y.x > 0.f ? v.x : 0.f; v.y = y.y > 0.f ? v.y : 0.f; v.z = y.z > 0.f ? v.z : 0.f; v.w = y.w > 0.f ? v.w : 0.f;
                 }
                 const f32x4 xh = (*reinterpret_cast<const f32x4*>(a.X + r * a.ldx + cq * 4) - mu) * rs;
-                s1 += v;
-                s2 += v * xh;
+                s1 += to_f64(v);
+                s2 += to_f64(v) * to_f64(xh);
             } else {
-                s1 += v;
+                s1 += to_f64(v);
             }
         }
+    }
+    if (MODE == 0) {
+        // variance around THIS block's mean (no E[x^2] - mean^2 cancellation); blocks are combined by Chan's formula in
+        // col_finalize_kernel
+        red[0][threadIdx.x] = s1;
+        __syncthreads();
+        f64x4 bsum = red[0][cq];
+        for (int j = 1; j < R; ++j) bsum += red[0][j * c4n + cq];
+        const f64x4 bmean = bsum / (double)(r1 - r0);
+        if (rl < R)
+            for (long r = r0 + rl; r < r1; r += R) {
+                const f64x4 dv = to_f64(*reinterpret_cast<const f32x4*>(a.A + r * a.lda + cq * 4)) - bmean;
+                s2 += dv * dv;
+            }
+        __syncthreads();
     }
     red[0][threadIdx.x] = s1;
     red[1][threadIdx.x] = s2;
@@ -89,16 +111,16 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(ColArgs a) {
             s1 += red[0][j * c4n + cq];
             s2 += red[1][j * c4n + cq];
         }
-        float* p = a.partial + (long)blockIdx.x * 2 * a.C;
-        *reinterpret_cast<f32x4*>(p + cq * 4) = s1;
-        *reinterpret_cast<f32x4*>(p + a.C + cq * 4) = s2;
+        double* p = a.partial + (long)blockIdx.x * 2 * a.C;
+        *reinterpret_cast<f64x4*>(p + cq * 4) = s1;
+        *reinterpret_cast<f64x4*>(p + a.C + cq * 4) = s2;
     }
 }
 
 // mode 0: mean / rstd (+ running statistics, torch semantics: biased variance normalises, unbiased one is tracked);
 // mode 1: the two sums as they are (sum g -> out1, sum g*xhat -> out2);  mode 2: out1 only
 struct ColFinArgs {
-    const float* partial;
+    const double* partial;
     float* out1;
     float* out2;
     float* running_mean;   // mode 0, optional
@@ -112,12 +134,19 @@ __global__ __launch_bounds__(256) void col_finalize_kernel(ColFinArgs a) {
     if (c >= a.C) return;
     double s1 = 0.0, s2 = 0.0;
     for (int b = 0; b < a.blocks; ++b) {
-        s1 += (double)a.partial[(long)b * 2 * a.C + c];
-        s2 += (double)a.partial[(long)b * 2 * a.C + a.C + c];
+        s1 += a.partial[(long)b * 2 * a.C + c];
+        s2 += a.partial[(long)b * 2 * a.C + a.C + c];
     }
     if (a.mode == 0) {
+        // partial[b] = (sum_b, M2_b = sum (x - mean_b)^2): M2 = sum_b M2_b + n_b (mean_b - mean)^2
         const double mean = s1 / a.M;
-        double var = s2 / a.M - mean * mean;
+        double m2 = s2;
+        for (int b = 0; b < a.blocks; ++b) {
+            const double nb = (double)((long)(b + 1) * ROWS_PER_BLOCK <= (long)a.M ? ROWS_PER_BLOCK : (long)a.M - (long)b * ROWS_PER_BLOCK);
+            const double db = a.partial[(long)b * 2 * a.C + c] / nb - mean;
+            m2 += nb * db * db;
+        }
+        double var = m2 / a.M;
         if (var < 0.0) var = 0.0;
         a.out1[c] = (float)mean;
         a.out2[c] = (float)(1.0 / sqrt(var + a.eps));
@@ -260,17 +289,17 @@ __global__ __launch_bounds__(256) void slice_sum_kernel(const float* P, float* o
 }
 
 // ------------------------------------------------------------------------------------------------
-// Depthwise-conv weight gradient (stride 1, pad k/2): dW[t][c] = sum_{b,y,x} dY[b,y,x,c] * X[b, y+ky-P, x+kx-P, c].
-// Block = (C/4 quads) x R pixel lanes over a slice of output pixels; partial [block][KS*KS][C] -> slice_sum_kernel.
+// Depthwise-conv weight gradient (stride S, pad k/2): dW[t][c] = sum_{b,oy,ox} dY[b,oy,ox,c] * X[b, oy*S+ky-P, ox*S+kx-P, c].
+// Block = (C/4 quads) x R pixel lanes over a slice of OUTPUT pixels; partial [block][KS*KS][C] -> slice_sum_kernel.
 struct DwWgradArgs {
     const float* dY;
     const float* X;
     float* partial;
-    long pixels;          // B*H*W
-    int H, W, C, lddy, ldx;
+    long pixels;          // B*Ho*Wo
+    int H, W, Ho, Wo, C, lddy, ldx;
 };
 
-template <int KS>
+template <int KS, int S>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgradArgs a) {
     constexpr int P = KS / 2, KK = KS * KS;
     __shared__ f32x4 red[256];
@@ -284,19 +313,20 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgradArgs a) {
     const long p1 = p0 + ROWS_PER_BLOCK < a.pixels ? p0 + ROWS_PER_BLOCK : a.pixels;
     if (rl < R) {
         for (long p = p0 + rl; p < p1; p += R) {
-            const int x = (int)(p % a.W);
-            const int y = (int)((p / a.W) % a.H);
+            const int ox = (int)(p % a.Wo);
+            const int oy = (int)((p / a.Wo) % a.Ho);
+            const long b = p / ((long)a.Wo * a.Ho);
             const f32x4 g = *reinterpret_cast<const f32x4*>(a.dY + p * a.lddy + cq * 4);
+            const float* xb = a.X + b * a.H * a.W * a.ldx + cq * 4;
 #pragma unroll
             for (int ky = 0; ky < KS; ++ky) {
-                const int yy = y + ky - P;
+                const int yy = oy * S + ky - P;
                 if (yy < 0 || yy >= a.H) continue;
 #pragma unroll
                 for (int kx = 0; kx < KS; ++kx) {
-                    const int xx = x + kx - P;
+                    const int xx = ox * S + kx - P;
                     if (xx < 0 || xx >= a.W) continue;
-                    const long q = p + (long)(ky - P) * a.W + (kx - P);
-                    acc[ky * KS + kx] += g * *reinterpret_cast<const f32x4*>(a.X + q * a.ldx + cq * 4);
+                    acc[ky * KS + kx] += g * *reinterpret_cast<const f32x4*>(xb + ((long)yy * a.W + xx) * a.ldx);
                 }
             }
         }
@@ -312,6 +342,68 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgradArgs a) {
             *reinterpret_cast<f32x4*>(out + (long)t * a.C + cq * 4) = s;
         }
     }
+}
+
+// Depthwise-conv input gradient for any stride (gather form, one thread per input pixel and channel quad):
+// dX[b,y,x,c] = sum over taps (ky,kx) with (y + P - ky) = S*oy and (x + P - kx) = S*ox of dY[b,oy,ox,c] * W[ky*KS+kx][c]
+struct DwDgradArgs {
+    const float* dY;
+    const float* Wt;      // [KS*KS][C]
+    float* dX;
+    long total;           // B*H*W*(C/4)
+    int H, W, Ho, Wo, C, lddy, lddx;
+};
+
+template <int KS, int S>
+__global__ __launch_bounds__(256) void dw_dgrad_kernel(DwDgradArgs a) {
+    constexpr int P = KS / 2;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.total) return;
+    const int c4n = a.C >> 2;
+    const int c = (int)(idx % c4n) * 4; idx /= c4n;
+    const int x = (int)(idx % a.W); idx /= a.W;
+    const int y = (int)(idx % a.H);
+    const long b = idx / a.H;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* gy = a.dY + b * a.Ho * a.Wo * a.lddy + c;
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky) {
+        const int ty = y + P - ky;
+        if (ty < 0 || ty % S != 0 || ty / S >= a.Ho) continue;
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+            const int tx = x + P - kx;
+            if (tx < 0 || tx % S != 0 || tx / S >= a.Wo) continue;
+            acc += *reinterpret_cast<const f32x4*>(gy + ((long)(ty / S) * a.Wo + tx / S) * a.lddy) *
+                   *reinterpret_cast<const f32x4*>(a.Wt + (long)(ky * KS + kx) * a.C + c);
+        }
+    }
+    *reinterpret_cast<f32x4*>(a.dX + ((b * a.H + y) * a.W + x) * a.lddx + c) = acc;
+}
+
+// Stem conv 3x3 stride 2 pad 1 (3 -> 16, fbnet_c stages[0]) as a GEMM for training: im2col of the caller's NCHW image into
+// rows of 28 floats (k = (ci*3 + ky)*3 + kx, column 27 = 0), so that forward and weight gradient are fear_pw_forward /
+// fear_pw_backward_weight with K = 28 (the image needs no gradient).
+__global__ __launch_bounds__(256) void stem_im2col_kernel(const float* X, float* out, long n, int H, int W) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * Ho * Wo * 7) return;
+    const int q = (int)(i % 7);                 // 7 float4 per row
+    const long p = i / 7;
+    const int ox = (int)(p % Wo), oy = (int)((p / Wo) % Ho);
+    const long b = p / ((long)Wo * Ho);
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = q * 4 + j;
+        v[j] = 0.f;
+        if (k < 27) {
+            const int ci = k / 9, ky = (k % 9) / 3, kx = k % 3;
+            const int y = oy * 2 - 1 + ky, x = ox * 2 - 1 + kx;
+            if (y >= 0 && y < H && x >= 0 && x < W) v[j] = X[((b * 3 + ci) * H + y) * W + x];
+        }
+    }
+    *reinterpret_cast<f32x4*>(out + p * 28 + q * 4) = (f32x4){v[0], v[1], v[2], v[3]};
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -508,15 +600,23 @@ void launch_pw(int nt, dim3 grid, hipStream_t s, const PwArgs& a) {
 
 int col_blocks(long M) { return (int)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK); }
 
+// row slices of the pointwise weight gradient: 1024 rows each, but never more than 256 slices (the partials are
+// [slices][N][K] floats; at the trunk's 128x128 maps a batch has millions of rows)
+long wgrad_rows_per_slice(long M) {
+    long r = 1024;
+    while ((M + r - 1) / r > 256) r *= 2;
+    return r;
+}
+int wgrad_slices(long M) { const long r = wgrad_rows_per_slice(M); return (int)((M + r - 1) / r); }
+
 }  // namespace
 
 extern "C" {
 
 size_t fear_train_workspace_bytes(long rows, int max_channels) {
-    // the largest user: pw wgrad partials [slices][N][K] with slices = ceil(rows / 1024) and N, K <= max_channels;
-    // column reductions need [rows / 256][2][C]; depthwise wgrad [rows / 256][25][C]
-    const size_t slices = (size_t)((rows + 1023) / 1024);
-    const size_t a = slices * (size_t)max_channels * max_channels;
+    // the largest users: pw wgrad partials [slices][N][K] (slices = ceil(rows / rows_per_slice), see wgrad_slices) with
+    // N * K <= max_channels^2; column reductions [rows / 256][2][C]; depthwise wgrad [rows / 256][25][C]
+    const size_t a = (size_t)wgrad_slices(rows) * (size_t)max_channels * max_channels;
     const size_t b = (size_t)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK) * 25 * (size_t)max_channels;
     return ((a > b ? a : b) + 1024) * sizeof(float);
 }
@@ -557,7 +657,7 @@ static int wgrad_impl(const float* dy, int lddy, long dy_crop_stride, const floa
     a.dY = dy; a.X = x; a.lddy = lddy; a.ldx = ldx; a.N = N; a.K = K; a.M = M; a.crops = crops;
     a.dy_crop_stride = dy_crop_stride; a.x_crop_stride = x_crop_stride;
     a.n_strips = (N + 15) / 16; a.k_strips = (K + 63) / 64;
-    a.rows_per_slice = crops > 1 ? M : 1024;
+    a.rows_per_slice = crops > 1 ? M : wgrad_rows_per_slice(M);
     const int slices = (int)((M + a.rows_per_slice - 1) / a.rows_per_slice);
     const size_t need = (size_t)slices * crops * N * K * sizeof(float);
     if (slices == 1) {
@@ -586,63 +686,93 @@ int fear_col_sum(const float* dy, int lddy, float* out, float* workspace, size_t
     if (!dy || !out || !workspace) return FEAR_TRAIN_ERR_NULL;
     if (M <= 0 || C < 4 || C % 4 || C > 1024) return FEAR_TRAIN_ERR_SHAPE;
     const int blocks = col_blocks(M);
-    if (ws_bytes < (size_t)blocks * 2 * C * sizeof(float)) return FEAR_TRAIN_ERR_WORKSPACE;
+    if (ws_bytes < (size_t)blocks * 2 * C * sizeof(double)) return FEAR_TRAIN_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     ColArgs a{};
-    a.A = dy; a.lda = lddy; a.partial = workspace; a.M = M; a.C = C;
+    a.A = dy; a.lda = lddy; a.partial = reinterpret_cast<double*>(workspace); a.M = M; a.C = C;
     hipLaunchKernelGGL(col_reduce_kernel<2>, dim3(blocks), dim3(256), 0, s, a);
     ColFinArgs f{};
-    f.partial = workspace; f.out1 = out; f.out2 = nullptr; f.blocks = blocks; f.C = C; f.mode = 2; f.M = (double)M;
+    f.partial = reinterpret_cast<const double*>(workspace); f.out1 = out; f.out2 = nullptr; f.blocks = blocks; f.C = C; f.mode = 2; f.M = (double)M;
     hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, f);
     LAUNCH_CHECK();
     return FEAR_TRAIN_OK;
 }
 
 static int dw_impl(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int B, int H, int W, int C,
-                   int k, hipStream_t s) {
+                   int k, int stride, hipStream_t s) {
     DwArgs a{};
     a.X = x; a.ldx = ldx; a.Wt = w; a.bias = bias; a.Y = y; a.ldy = ldy;
-    a.B = B; a.H = H; a.W = W; a.C = C; a.Ho = H; a.Wo = W; a.relu = 0;
-    const long strips = (H + 3) / 4;
-    const long total = (long)B * strips * W * (C / 4);
+    a.B = B; a.H = H; a.W = W; a.C = C; a.Ho = H / stride; a.Wo = W / stride; a.relu = 0;
+    const long strips = (a.Ho + 3) / 4;
+    const long total = (long)B * strips * a.Wo * (C / 4);
     dim3 grid((unsigned)((total + 255) / 256));
-    if (k == 3) hipLaunchKernelGGL((dw_conv_kernel<3, 1, 4>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((dw_conv_kernel<5, 1, 4>), grid, dim3(256), 0, s, a);
+    if (k == 3 && stride == 1) hipLaunchKernelGGL((dw_conv_kernel<3, 1, 4>), grid, dim3(256), 0, s, a);
+    else if (k == 3) hipLaunchKernelGGL((dw_conv_kernel<3, 2, 4>), grid, dim3(256), 0, s, a);
+    else if (stride == 1) hipLaunchKernelGGL((dw_conv_kernel<5, 1, 4>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((dw_conv_kernel<5, 2, 4>), grid, dim3(256), 0, s, a);
     LAUNCH_CHECK();
     return FEAR_TRAIN_OK;
 }
 
-int fear_dw_forward(const float* x, int ldx, const float* w_taps, const float* bias, float* y, int ldy, int B, int H, int W,
-                    int C, int k, void* stream) {
-    if (B == 0) return FEAR_TRAIN_OK;
-    if (!x || !w_taps || !y) return FEAR_TRAIN_ERR_NULL;
-    if (B < 0 || H < 1 || W < 1 || C < 4 || C % 4 || (k != 3 && k != 5)) return FEAR_TRAIN_ERR_SHAPE;
-    return dw_impl(x, ldx, w_taps, bias, y, ldy, B, H, W, C, k, static_cast<hipStream_t>(stream));
+static bool dw_shape_ok(int B, int H, int W, int C, int k, int stride) {
+    return B >= 0 && H >= 1 && W >= 1 && C >= 4 && C % 4 == 0 && C <= 1024 && (k == 3 || k == 5) && (stride == 1 || stride == 2) &&
+           H % stride == 0 && W % stride == 0;
 }
 
-int fear_dw_backward_data(const float* dy, int lddy, const float* w_taps_flipped, float* dx, int lddx, int B, int H, int W,
-                          int C, int k, void* stream) {
-    // stride 1, pad k/2: dX = depthwise conv of dY with the taps reversed (the caller passes w[k*k-1-t][c])
+int fear_dw_forward(const float* x, int ldx, const float* w_taps, const float* bias, float* y, int ldy, int B, int H, int W,
+                    int C, int k, int stride, void* stream) {
     if (B == 0) return FEAR_TRAIN_OK;
-    if (!dy || !w_taps_flipped || !dx) return FEAR_TRAIN_ERR_NULL;
-    if (B < 0 || H < 1 || W < 1 || C < 4 || C % 4 || (k != 3 && k != 5)) return FEAR_TRAIN_ERR_SHAPE;
-    return dw_impl(dy, lddy, w_taps_flipped, nullptr, dx, lddx, B, H, W, C, k, static_cast<hipStream_t>(stream));
+    if (!x || !w_taps || !y) return FEAR_TRAIN_ERR_NULL;
+    if (!dw_shape_ok(B, H, W, C, k, stride)) return FEAR_TRAIN_ERR_SHAPE;
+    return dw_impl(x, ldx, w_taps, bias, y, ldy, B, H, W, C, k, stride, static_cast<hipStream_t>(stream));
+}
+
+int fear_dw_backward_data(const float* dy, int lddy, const float* w_taps, float* dx, int lddx, int B, int H, int W, int C, int k,
+                          int stride, void* stream) {
+    if (B == 0) return FEAR_TRAIN_OK;
+    if (!dy || !w_taps || !dx) return FEAR_TRAIN_ERR_NULL;
+    if (!dw_shape_ok(B, H, W, C, k, stride)) return FEAR_TRAIN_ERR_SHAPE;
+    DwDgradArgs a{};
+    a.dY = dy; a.Wt = w_taps; a.dX = dx; a.H = H; a.W = W; a.Ho = H / stride; a.Wo = W / stride; a.C = C; a.lddy = lddy; a.lddx = lddx;
+    a.total = (long)B * H * W * (C / 4);
+    dim3 grid((unsigned)((a.total + 255) / 256));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (k == 3 && stride == 1) hipLaunchKernelGGL((dw_dgrad_kernel<3, 1>), grid, dim3(256), 0, s, a);
+    else if (k == 3) hipLaunchKernelGGL((dw_dgrad_kernel<3, 2>), grid, dim3(256), 0, s, a);
+    else if (stride == 1) hipLaunchKernelGGL((dw_dgrad_kernel<5, 1>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((dw_dgrad_kernel<5, 2>), grid, dim3(256), 0, s, a);
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
 }
 
 int fear_dw_backward_weight(const float* dy, int lddy, const float* x, int ldx, float* dw_taps, float* workspace,
-                            size_t ws_bytes, int B, int H, int W, int C, int k, void* stream) {
+                            size_t ws_bytes, int B, int H, int W, int C, int k, int stride, void* stream) {
     if (!dy || !x || !dw_taps || !workspace) return FEAR_TRAIN_ERR_NULL;
-    if (B < 1 || H < 1 || W < 1 || C < 4 || C % 4 || C > 1024 || (k != 3 && k != 5)) return FEAR_TRAIN_ERR_SHAPE;
-    const long pixels = (long)B * H * W;
+    if (B < 1 || !dw_shape_ok(B, H, W, C, k, stride)) return FEAR_TRAIN_ERR_SHAPE;
+    const int Ho = H / stride, Wo = W / stride;
+    const long pixels = (long)B * Ho * Wo;
     const int blocks = col_blocks(pixels);
     const long count = (long)k * k * C;
     if (ws_bytes < (size_t)blocks * count * sizeof(float)) return FEAR_TRAIN_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     DwWgradArgs a{};
-    a.dY = dy; a.X = x; a.partial = workspace; a.pixels = pixels; a.H = H; a.W = W; a.C = C; a.lddy = lddy; a.ldx = ldx;
-    if (k == 3) hipLaunchKernelGGL(dw_wgrad_kernel<3>, dim3(blocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(dw_wgrad_kernel<5>, dim3(blocks), dim3(256), 0, s, a);
+    a.dY = dy; a.X = x; a.partial = workspace; a.pixels = pixels; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.C = C; a.lddy = lddy; a.ldx = ldx;
+    if (k == 3 && stride == 1) hipLaunchKernelGGL((dw_wgrad_kernel<3, 1>), dim3(blocks), dim3(256), 0, s, a);
+    else if (k == 3) hipLaunchKernelGGL((dw_wgrad_kernel<3, 2>), dim3(blocks), dim3(256), 0, s, a);
+    else if (stride == 1) hipLaunchKernelGGL((dw_wgrad_kernel<5, 1>), dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((dw_wgrad_kernel<5, 2>), dim3(blocks), dim3(256), 0, s, a);
     hipLaunchKernelGGL(slice_sum_kernel, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, s, workspace, dw_taps, count, blocks);
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+int fear_stem_im2col(const float* x_nchw, float* rows28, long n, int H, int W, void* stream) {
+    if (n == 0) return FEAR_TRAIN_OK;
+    if (!x_nchw || !rows28) return FEAR_TRAIN_ERR_NULL;
+    if (n < 0 || H < 2 || W < 2 || H % 2 || W % 2) return FEAR_TRAIN_ERR_SHAPE;
+    const long total = n * (H / 2) * (W / 2) * 7;
+    hipLaunchKernelGGL(stem_im2col_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x_nchw,
+                       rows28, n, H, W);
     LAUNCH_CHECK();
     return FEAR_TRAIN_OK;
 }
@@ -653,13 +783,13 @@ int fear_bn_train_forward(const float* x, int ldx, const float* gamma, const flo
     if (!x || !gamma || !beta || !y || !mean || !rstd || !workspace) return FEAR_TRAIN_ERR_NULL;
     if (M <= 0 || C < 4 || C % 4 || C > 1024) return FEAR_TRAIN_ERR_SHAPE;
     const int blocks = col_blocks(M);
-    if (ws_bytes < (size_t)blocks * 2 * C * sizeof(float)) return FEAR_TRAIN_ERR_WORKSPACE;
+    if (ws_bytes < (size_t)blocks * 2 * C * sizeof(double)) return FEAR_TRAIN_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     ColArgs a{};
-    a.A = x; a.lda = ldx; a.partial = workspace; a.M = M; a.C = C;
+    a.A = x; a.lda = ldx; a.partial = reinterpret_cast<double*>(workspace); a.M = M; a.C = C;
     hipLaunchKernelGGL(col_reduce_kernel<0>, dim3(blocks), dim3(256), 0, s, a);
     ColFinArgs f{};
-    f.partial = workspace; f.out1 = mean; f.out2 = rstd; f.running_mean = running_mean; f.running_var = running_var;
+    f.partial = reinterpret_cast<const double*>(workspace); f.out1 = mean; f.out2 = rstd; f.running_mean = running_mean; f.running_var = running_var;
     f.blocks = blocks; f.C = C; f.mode = 0; f.M = (double)M; f.eps = eps; f.momentum = momentum;
     hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, f);
     BnApplyArgs b{};
@@ -677,14 +807,14 @@ int fear_bn_train_backward(const float* dy, int lddy, const float* y_act, int ld
     if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !workspace) return FEAR_TRAIN_ERR_NULL;
     if (M <= 0 || C < 4 || C % 4 || C > 1024) return FEAR_TRAIN_ERR_SHAPE;
     const int blocks = col_blocks(M);
-    if (ws_bytes < (size_t)blocks * 2 * C * sizeof(float)) return FEAR_TRAIN_ERR_WORKSPACE;
+    if (ws_bytes < (size_t)blocks * 2 * C * sizeof(double)) return FEAR_TRAIN_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     ColArgs a{};
     a.A = dy; a.lda = lddy; a.Yact = y_act; a.ldy = ldy; a.X = x; a.ldx = ldx; a.mean = mean; a.rstd = rstd;
-    a.partial = workspace; a.M = M; a.C = C;
+    a.partial = reinterpret_cast<double*>(workspace); a.M = M; a.C = C;
     hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(blocks), dim3(256), 0, s, a);
     ColFinArgs f{};
-    f.partial = workspace; f.out1 = dbeta; f.out2 = dgamma; f.blocks = blocks; f.C = C; f.mode = 1; f.M = (double)M;
+    f.partial = reinterpret_cast<const double*>(workspace); f.out1 = dbeta; f.out2 = dgamma; f.blocks = blocks; f.C = C; f.mode = 1; f.M = (double)M;
     hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, f);
     BnBwdArgs b{};
     b.dY = dy; b.Yact = y_act; b.X = x; b.mean = mean; b.rstd = rstd; b.gamma = gamma; b.sum_g = dbeta; b.sum_gx = dgamma;
@@ -743,12 +873,12 @@ int fear_exp_head_backward(const float* p, const float* adjust, const float* bbo
     if (M <= 0) return FEAR_TRAIN_ERR_SHAPE;
     const int blocks = col_blocks(M);
     const size_t stage = (size_t)M * 4;
-    if (ws_bytes < (2 * stage + (size_t)blocks * 8 + 8) * sizeof(float)) return FEAR_TRAIN_ERR_WORKSPACE;
+    if (ws_bytes < (2 * stage + (size_t)blocks * 16 + 8) * sizeof(float)) return FEAR_TRAIN_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* T = workspace;
     float* U = workspace + stage;
-    float* part = U + stage;
-    float* u4 = part + (size_t)blocks * 8;
+    double* part = reinterpret_cast<double*>(U + stage);      // [blocks][2][4] float64 partials (stage is a multiple of 4 floats)
+    float* u4 = U + stage + (size_t)blocks * 16;
     ExpHeadArgs a{};
     a.P = p; a.adjust = adjust; a.bbox = const_cast<float*>(bbox); a.dbbox = dbbox; a.dP = dp; a.T = T; a.U = U; a.M = M;
     hipLaunchKernelGGL(exp_head_bwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, a);

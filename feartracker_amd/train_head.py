@@ -32,9 +32,10 @@ TRAIN_SYMBOLS = {
     "fear_pw_backward_data": ([_P, _i, _P, _P, _i, _P, _i, _l, _i, _i, _P], _i),
     "fear_pw_backward_weight": ([_P, _i, _P, _i, _P, _P, _sz, _l, _i, _i, _P], _i),
     "fear_col_sum": ([_P, _i, _P, _P, _sz, _l, _i, _P], _i),
-    "fear_dw_forward": ([_P, _i, _P, _P, _P, _i, _i, _i, _i, _i, _i, _P], _i),
-    "fear_dw_backward_data": ([_P, _i, _P, _P, _i, _i, _i, _i, _i, _i, _P], _i),
-    "fear_dw_backward_weight": ([_P, _i, _P, _i, _P, _P, _sz, _i, _i, _i, _i, _i, _P], _i),
+    "fear_dw_forward": ([_P, _i, _P, _P, _P, _i, _i, _i, _i, _i, _i, _i, _P], _i),
+    "fear_dw_backward_data": ([_P, _i, _P, _P, _i, _i, _i, _i, _i, _i, _i, _P], _i),
+    "fear_dw_backward_weight": ([_P, _i, _P, _i, _P, _P, _sz, _i, _i, _i, _i, _i, _i, _P], _i),
+    "fear_stem_im2col": ([_P, _P, _l, _i, _i, _P], _i),
     "fear_bn_train_forward": ([_P, _i, _P, _P, _P, _i, _P, _P, _P, _P, _d, _d, _l, _i, _i, _P, _sz, _P], _i),
     "fear_bn_train_backward": ([_P, _i, _P, _i, _P, _i, _P, _P, _P, _P, _i, _P, _P, _l, _i, _P, _sz, _P], _i),
     "fear_xcorr_forward": ([_P, _i, _P, _P, _i, _i, _i, _i, _i, _P], _i),
@@ -135,7 +136,7 @@ class BoxTowerTrainHIP:
 
     def _workspace(self, rows: int):
         need = int(self.lib.fear_train_workspace_bytes(rows, 320))
-        need = max(need, (8 * rows + 4096) * 4)
+        need = max(need, (8 * rows + rows // 8 + 4096) * 4)
         if self._ws is None or self._ws.numel() * 4 < need:
             self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
         return _p(self._ws), self._ws.numel() * 4
@@ -146,7 +147,7 @@ class BoxTowerTrainHIP:
         ws, wsb = self._workspace(M)
         L.x, L.ldx = x, ldx
         L.d = self._new(M, L.cin)
-        self._check(lib.fear_dw_forward(_p(x), ldx, _p(L.taps), _p(L.dw_bias), _p(L.d), L.cin, B, self.S, self.S, L.cin, 3, st))
+        self._check(lib.fear_dw_forward(_p(x), ldx, _p(L.taps), _p(L.dw_bias), _p(L.d), L.cin, B, self.S, self.S, L.cin, 3, 1, st))
         L.p = self._new(M, L.n)
         self._check(lib.fear_pw_forward(_p(L.d), L.cin, _p(L.w), _p(L.pw_bias), _p(L.p), L.n, M, L.cin, L.n, st))
         if not L.bn_prefix:
@@ -183,15 +184,14 @@ class BoxTowerTrainHIP:
         dd = self._new(M, L.cin)
         self._check(lib.fear_pw_backward_data(_p(dp), lddp, _p(L.w), None, 0, _p(dd), L.cin, M, L.cin, L.n, st))
         dtaps = self._new(9, L.cin)
-        self._check(lib.fear_dw_backward_weight(_p(dd), L.cin, _p(L.x), L.ldx, _p(dtaps), ws, wsb, B, self.S, self.S, L.cin, 3, st))
+        self._check(lib.fear_dw_backward_weight(_p(dd), L.cin, _p(L.x), L.ldx, _p(dtaps), ws, wsb, B, self.S, self.S, L.cin, 3, 1, st))
         grads[L.prefix + ".depthwise.weight"] = dtaps.t().reshape(L.cin, 1, 3, 3)
         if L.dw_bias is not None:
             dbd = self._new(L.cin)
             self._check(lib.fear_col_sum(_p(dd), L.cin, _p(dbd), ws, wsb, M, L.cin, st))
             grads[L.prefix + ".depthwise.bias"] = dbd
         dx = self._new(M, L.cin)
-        flipped = torch.flip(L.taps, dims=[0]).contiguous()         # parameter re-layout: taps reversed
-        self._check(lib.fear_dw_backward_data(_p(dd), L.cin, _p(flipped), _p(dx), L.cin, B, self.S, self.S, L.cin, 3, st))
+        self._check(lib.fear_dw_backward_data(_p(dd), L.cin, _p(L.taps), _p(dx), L.cin, B, self.S, self.S, L.cin, 3, 1, st))
         return dx
 
     # ------------------------------------------------------------------ the step

@@ -1,0 +1,303 @@
+"""Training step of the whole FEAR network on MI355X — BASELINE.json configs[4] "backbone + xcorr fwd/bwd, random-init".
+
+`FEARNetTrainHIP.step(template, search, targets)` is `FEARNet.forward((template, search))` in training mode
+(model_training/model/fear_net.py:83-88: both crops through the shared trunk + AdjustLayer neck, template first, BatchNorm
+on the statistics of each pass; then `BoxTower`), `FEARLoss` (train/loss.py:45-96) and the backward pass to EVERY
+parameter — what `FEARLightningModel._training_step` + `loss.backward()` compute (train/fear_lightning_model.py:60-66).
+The head, the loss and their backward are `train_head.BoxTowerTrainHIP`; this module adds the trunk and the neck on the
+same hand-written HIP operators (include/fear_train.h): 1x1 convolutions as MFMA GEMMs (forward / dgrad / wgrad), the
+stem conv as im2col + the same GEMMs, depthwise 3x3 / 5x5 stride 1 / 2 forward, dgrad and wgrad, train-mode BatchNorm
+forward / backward with fixed-order reductions.  Host code only sequences kernels and owns the parameters.
+
+Trunk definition: the reference takes it from the un-vendored `mobile_cv` package (fbnet_c, model/blocks.py:22-35) and
+ships only the BatchNorm-folded inference trace, so the TRAINING form of the trunk is restated — block table of SURVEY.md
+Appendix A, every convolution bias-free and followed by a BatchNorm (expand 1x1 + BN + ReLU, depthwise + BN + ReLU,
+project 1x1 + BN, residual where the block keeps shape) — with parameter names `stem.{conv,bn}`, `trunk.<i>.{pw,dw,pwl}.
+{conv,bn}`, `neck.downsample.{0,1}`, `connect_model.*`.  Its gradient parity is pinned by torch autograd on the same graph
+(the CPU checker under tests/), NOT by the reference; the head's is pinned by the reference itself.  Random initialisation is
+the only use (configs[4] says so): trained `mobile_cv` checkpoints cannot be loaded without their key names.
+
+Several ranks: every rank runs `step` on its share of the batch and `allreduce_gradients` averages the flat gradient buffer
+with ONE RCCL all-reduce (≈1.37 M floats); BatchNorm statistics stay per rank (the reference's `sync_bn` option,
+config/backend/*.yaml, is not built).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from .train_head import BoxTowerTrainHIP, TrainError, _p, load_train_library
+
+# (cin, cexp, cout, k, stride, expand, residual): fbnet_c stages[1:18]
+TRUNK_BLOCKS = [
+    (16, 16, 16, 3, 1, False, True), (16, 96, 24, 3, 2, True, False), (24, 24, 24, 3, 1, False, True),
+    (24, 24, 24, 3, 1, False, True), (24, 144, 32, 5, 2, True, False), (32, 96, 32, 5, 1, True, True),
+    (32, 192, 32, 5, 1, True, True), (32, 192, 32, 3, 1, True, True), (32, 192, 64, 5, 2, True, False),
+    (64, 192, 64, 5, 1, True, True), (64, 384, 64, 5, 1, True, True), (64, 384, 64, 5, 1, True, True),
+    (64, 384, 112, 5, 1, True, False), (112, 672, 112, 5, 1, True, True), (112, 672, 112, 5, 1, True, True),
+    (112, 336, 112, 5, 1, True, True),
+]
+
+
+def random_init_state(seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Seeded random initialisation of every parameter of the training graph (BASELINE configs[4]: "random-init"):
+    He-normal convolutions, BatchNorm weight 1 / bias 0 / running statistics 0 / 1, adjust = 0.1, bias = 1 like
+    BoxTower.__init__ (blocks.py:170-172).  Keys as documented in the module docstring."""
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+
+    def conv(key, cout, cin_g, k):
+        sd[key] = torch.randn(cout, cin_g, k, k, generator=g) * (2.0 / (cin_g * k * k)) ** 0.5
+
+    def bn(prefix, c):
+        sd[prefix + ".weight"], sd[prefix + ".bias"] = torch.ones(c), torch.zeros(c)
+        sd[prefix + ".running_mean"], sd[prefix + ".running_var"] = torch.zeros(c), torch.ones(c)
+
+    conv("stem.conv.weight", 16, 3, 3)
+    bn("stem.bn", 16)
+    for i, (cin, cexp, cout, k, stride, expand, residual) in enumerate(TRUNK_BLOCKS):
+        if expand:
+            conv(f"trunk.{i}.pw.conv.weight", cexp, cin, 1)
+            bn(f"trunk.{i}.pw.bn", cexp)
+        conv(f"trunk.{i}.dw.conv.weight", cexp, 1, k)
+        bn(f"trunk.{i}.dw.bn", cexp)
+        conv(f"trunk.{i}.pwl.conv.weight", cout, cexp, 1)
+        bn(f"trunk.{i}.pwl.bn", cout)
+    conv("neck.downsample.0.weight", 256, 112, 1)
+    bn("neck.downsample.1", 256)
+    for enc, corr, tower, pred, pc in (("cls_encode.matrix11_s", "cls_dw.enc", "cls_tower", "cls_pred", 1),
+                                       ("reg_encode.matrix11_s", "reg_dw.enc", "bbox_tower", "bbox_pred", 4)):
+        for name, cin, cout, bias, bnp in ((enc + ".0", 256, 256, False, enc + ".1"), (corr + ".0", 320, 256, True, corr + ".1"),
+                                           (tower + ".0", 256, 256, True, tower + ".1"), (tower + ".3", 256, 256, True, tower + ".4"),
+                                           (pred, 256, pc, True, None)):
+            h = "connect_model." + name
+            conv(h + ".depthwise.weight", cin, 1, 3)
+            conv(h + ".pointwise.weight", cout, cin, 1)
+            if bias:
+                sd[h + ".depthwise.bias"], sd[h + ".pointwise.bias"] = torch.zeros(cin), torch.zeros(cout)
+            if bnp:
+                bn("connect_model." + bnp, cout)
+    sd["connect_model.adjust"], sd["connect_model.bias"] = 0.1 * torch.ones(1), torch.ones(1, 4, 1, 1)
+    return sd
+
+
+class _ConvBN:
+    """conv (stem / pointwise / depthwise, no bias) + BatchNorm2d (train mode) [+ ReLU]: parameters in kernel layout."""
+
+    def __init__(self, name: str, kind: str, sd: Dict[str, torch.Tensor], dev, k: int = 1, stride: int = 1, relu: bool = True,
+                 conv_key: str = ".conv.weight", bn_key: str = ".bn"):
+        self.name, self.kind, self.k, self.stride, self.relu = name, kind, k, stride, relu
+        self.conv_key, self.bn_key = name + conv_key, name + bn_key
+        w = sd[self.conv_key].float()
+        self.cout = w.shape[0]
+        if kind == "dw":
+            self.cin = self.cout
+            self.w = w.reshape(self.cout, k * k).t().contiguous().to(dev)                 # taps [k*k][C]
+        elif kind == "stem":
+            self.cin = 28
+            w28 = torch.zeros(self.cout, 28)
+            w28[:, :27] = w.reshape(self.cout, 27)
+            self.w = w28.to(dev)
+        else:
+            self.cin = w.shape[1]
+            self.w = w.reshape(self.cout, self.cin).contiguous().to(dev)
+        self.gamma = sd[self.bn_key + ".weight"].float().to(dev)
+        self.beta = sd[self.bn_key + ".bias"].float().to(dev)
+        self.running_mean = sd[self.bn_key + ".running_mean"].float().clone().to(dev)
+        self.running_var = sd[self.bn_key + ".running_var"].float().clone().to(dev)
+
+
+class FEARNetTrainHIP:
+    def __init__(self, state_dict: Dict[str, "np.ndarray | torch.Tensor"], device: int = 0, momentum: float = 0.1, eps: float = 1e-5,
+                 coef_cls: float = 1.0, coef_reg: float = 1.0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("FEARNetTrainHIP needs a ROCm GPU; there is no CPU fallback")
+        self.lib = load_train_library()
+        self.device = torch.device(f"cuda:{int(device)}")
+        self.momentum, self.eps = momentum, eps
+        sd = {k: torch.as_tensor(np.asarray(v)) if not isinstance(v, torch.Tensor) else v.detach().cpu() for k, v in state_dict.items()}
+        dev = self.device
+        self.stem = _ConvBN("stem", "stem", sd, dev, k=3, stride=2)
+        self.blocks: List[dict] = []
+        for i, (cin, cexp, cout, k, stride, expand, residual) in enumerate(TRUNK_BLOCKS):
+            self.blocks.append(dict(
+                pw=_ConvBN(f"trunk.{i}.pw", "pw", sd, dev) if expand else None,
+                dw=_ConvBN(f"trunk.{i}.dw", "dw", sd, dev, k=k, stride=stride),
+                pwl=_ConvBN(f"trunk.{i}.pwl", "pw", sd, dev, relu=False), residual=residual))
+        self.neck = _ConvBN("neck.downsample", "pw", sd, dev, relu=False, conv_key=".0.weight", bn_key=".1")
+        self.head = BoxTowerTrainHIP({k[len("connect_model."):]: v for k, v in sd.items() if k.startswith("connect_model.")},
+                                     device=device, momentum=momentum, eps=eps, coef_cls=coef_cls, coef_reg=coef_reg)
+        self._ws = None
+        self.last_contexts = None
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, st: int) -> None:
+        if st != 0:
+            raise TrainError(f"libfear_hip training operator failed with status {st}")
+
+    def _stream(self):
+        import ctypes
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _new(self, *shape) -> torch.Tensor:
+        return torch.empty(shape, dtype=torch.float32, device=self.device)
+
+    def _workspace(self, rows: int):
+        need = int(self.lib.fear_train_workspace_bytes(rows, 672))
+        if self._ws is None or self._ws.numel() * 4 < need:
+            self._ws = None
+            self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
+        return _p(self._ws), self._ws.numel() * 4
+
+    # ------------------------------------------------------------------ one conv + BN [+ ReLU]
+    def _fwd(self, L: _ConvBN, x: torch.Tensor, B: int, H: int, saved: list) -> torch.Tensor:
+        """x: NHWC rows [B*H*H][cin] (stem: the im2col rows of the output grid).  Returns the activation rows."""
+        lib, st = self.lib, self._stream()
+        Ho = H // L.stride if L.kind == "dw" else H
+        M = B * Ho * Ho
+        ws, wsb = self._workspace(max(M, B * H * H))
+        pre = self._new(M, L.cout)
+        if L.kind == "dw":
+            self._check(lib.fear_dw_forward(_p(x), L.cin, _p(L.w), None, _p(pre), L.cout, B, H, H, L.cin, L.k, L.stride, st))
+        else:
+            self._check(lib.fear_pw_forward(_p(x), L.cin, _p(L.w), None, _p(pre), L.cout, M, L.cin, L.cout, st))
+        out, mean, rstd = self._new(M, L.cout), self._new(L.cout), self._new(L.cout)
+        self._check(lib.fear_bn_train_forward(_p(pre), L.cout, _p(L.gamma), _p(L.beta), _p(out), L.cout, _p(mean), _p(rstd),
+                                              _p(L.running_mean), _p(L.running_var), self.momentum, self.eps, M, L.cout,
+                                              1 if L.relu else 0, ws, wsb, st))
+        saved.append((L, x, pre, out, mean, rstd, B, H))
+        return out
+
+    def _bwd(self, rec, dy: torch.Tensor, grads: Dict[str, torch.Tensor], need_dx: bool = True) -> Optional[torch.Tensor]:
+        L, x, pre, out, mean, rstd, B, H = rec
+        lib, st = self.lib, self._stream()
+        Ho = H // L.stride if L.kind == "dw" else H
+        M = B * Ho * Ho
+        ws, wsb = self._workspace(max(M, B * H * H))
+        dpre, dgamma, dbeta = self._new(M, L.cout), self._new(L.cout), self._new(L.cout)
+        self._check(lib.fear_bn_train_backward(_p(dy), L.cout, _p(out) if L.relu else None, L.cout, _p(pre), L.cout, _p(mean), _p(rstd),
+                                               _p(L.gamma), _p(dpre), L.cout, _p(dgamma), _p(dbeta), M, L.cout, ws, wsb, st))
+        self._acc(grads, L.bn_key + ".weight", dgamma)
+        self._acc(grads, L.bn_key + ".bias", dbeta)
+        dx = None
+        if L.kind == "dw":
+            dtaps = self._new(L.k * L.k, L.cout)
+            self._check(lib.fear_dw_backward_weight(_p(dpre), L.cout, _p(x), L.cin, _p(dtaps), ws, wsb, B, H, H, L.cin, L.k, L.stride, st))
+            self._acc(grads, L.conv_key, dtaps.t().reshape(L.cout, 1, L.k, L.k))
+            if need_dx:
+                dx = self._new(B * H * H, L.cin)
+                self._check(lib.fear_dw_backward_data(_p(dpre), L.cout, _p(L.w), _p(dx), L.cin, B, H, H, L.cin, L.k, L.stride, st))
+        else:
+            dw = self._new(L.cout, L.cin)
+            self._check(lib.fear_pw_backward_weight(_p(dpre), L.cout, _p(x), L.cin, _p(dw), ws, wsb, M, L.cin, L.cout, st))
+            if L.kind == "stem":
+                self._acc(grads, L.conv_key, dw[:, :27].reshape(L.cout, 3, 3, 3))
+            else:
+                self._acc(grads, L.conv_key, dw.reshape(L.cout, L.cin, 1, 1))
+                if need_dx:
+                    dx = self._new(M, L.cin)
+                    self._check(lib.fear_pw_backward_data(_p(dpre), L.cout, _p(L.w), None, 0, _p(dx), L.cin, M, L.cin, L.cout, st))
+        return dx
+
+    def _acc(self, grads: Dict[str, torch.Tensor], key: str, g: torch.Tensor) -> None:
+        """The trunk runs twice per step (template, search): gradients of the shared parameters add up."""
+        if key in grads:
+            a = grads[key]
+            gc = g.contiguous()
+            self._check(self.lib.fear_add(_p(a), _p(gc), _p(a), a.numel(), self._stream()))
+        else:
+            grads[key] = g.contiguous()
+
+    def _add(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        out = self._new(*a.shape)
+        self._check(self.lib.fear_add(_p(a), _p(b), _p(out), a.numel(), self._stream()))
+        return out
+
+    # ------------------------------------------------------------------ trunk + neck
+    def _features_forward(self, img: torch.Tensor):
+        """img (B,3,H,H) NCHW -> (feature rows [B*(H/16)^2][256], saved records for the backward)."""
+        B, H = img.shape[0], img.shape[2]
+        saved: list = []
+        h = H // 2
+        col = self._new(B * h * h, 28)
+        self._check(self.lib.fear_stem_im2col(_p(img), _p(col), B, H, H, self._stream()))
+        x = self._fwd(self.stem, col, B, h, saved)
+        block_recs = []
+        for blk in self.blocks:
+            start = len(saved)
+            y = x
+            if blk["pw"] is not None:
+                y = self._fwd(blk["pw"], y, B, h, saved)
+            y = self._fwd(blk["dw"], y, B, h, saved)
+            h = h // blk["dw"].stride
+            y = self._fwd(blk["pwl"], y, B, h, saved)
+            if blk["residual"]:
+                y = self._add(x, y)
+            block_recs.append((start, len(saved), blk["residual"]))
+            x = y
+        feats = self._fwd(self.neck, x, B, h, saved)
+        return feats, (saved, block_recs, B, h)
+
+    def _features_backward(self, ctx, dfeat: torch.Tensor, grads: Dict[str, torch.Tensor]) -> None:
+        saved, block_recs, B, h = ctx
+        d = self._bwd(saved[-1], dfeat, grads)                       # neck
+        for start, end, residual in reversed(block_recs):
+            dres = d
+            for i in range(end - 1, start - 1, -1):
+                d = self._bwd(saved[i], d, grads)
+            if residual:
+                d = self._add(d, dres)
+        self._bwd(saved[0], d, grads, need_dx=False)                 # stem: the image needs no gradient
+
+    # ------------------------------------------------------------------ the step
+    @torch.no_grad()
+    def step(self, template: torch.Tensor, search: torch.Tensor, gt_reg: torch.Tensor, gt_cls: torch.Tensor,
+             gt_weight: torch.Tensor) -> Dict[str, object]:
+        """template (B,3,128,128), search (B,3,256,256) normalised fp32 NCHW; targets as `BoxTowerTrainHIP.step`.
+        Returns {"loss_cls", "loss_reg", "bbox", "cls", "grads": {parameter name: gradient}}."""
+        dev = self.device
+        t = template.to(dev, torch.float32).contiguous()
+        s = search.to(dev, torch.float32).contiguous()
+        B = s.shape[0]
+        if tuple(t.shape) != (B, 3, 128, 128) or tuple(s.shape) != (B, 3, 256, 256):
+            raise ValueError("expected template (B,3,128,128) and search (B,3,256,256)")
+        with torch.cuda.device(dev):
+            st = self._stream()
+            zrows, zctx = self._features_forward(t)                  # template first, like FEARNet.forward
+            xrows, xctx = self._features_forward(s)
+            z = self._new(B, 256, 8, 8)
+            x = self._new(B, 256, 16, 16)
+            self._check(self.lib.fear_nhwc_to_nchw(_p(zrows), _p(z), B, 256, 64, 256, 0, st))
+            self._check(self.lib.fear_nhwc_to_nchw(_p(xrows), _p(x), B, 256, 256, 256, 0, st))
+            out = self.head.step(x, z, gt_reg, gt_cls, gt_weight)
+            grads = {"connect_model." + k: v for k, v in out["grads"].items()}
+            dx = self._new(B * 256, 256)
+            dz = self._new(B * 64, 256)
+            self._check(self.lib.fear_nchw_to_nhwc(_p(out["grad_search"]), _p(dx), B, 256, 256, 256, 0, st))
+            self._check(self.lib.fear_nchw_to_nhwc(_p(out["grad_template"].contiguous()), _p(dz), B, 256, 64, 256, 0, st))
+            self._features_backward(xctx, dx, grads)
+            self._features_backward(zctx, dz, grads)
+            self.last_contexts = (zctx, xctx)          # saved activations of the two trunk passes (tests read the ReLU patterns)
+        return {"loss_cls": out["loss_cls"], "loss_reg": out["loss_reg"], "bbox": out["bbox"], "cls": out["cls"], "grads": grads}
+
+    allreduce_gradients = staticmethod(BoxTowerTrainHIP.allreduce_gradients)
+
+    def relu_patterns(self) -> Dict[str, List[torch.Tensor]]:
+        """{conv name: [template-pass mask, search-pass mask]} (bool, NCHW, CPU) of every ReLU of the last `step`'s trunk passes,
+        and {head layer prefix: [mask]} for the head — which elements the forward treated as active."""
+        out: Dict[str, List[torch.Tensor]] = {}
+        for ctx in self.last_contexts:
+            saved = ctx[0]
+            for (L, x, pre, act, mean, rstd, B, H) in saved:
+                if not L.relu:
+                    continue
+                Ho = H // L.stride if L.kind == "dw" else H
+                out.setdefault(L.name, []).append((act > 0).reshape(B, Ho, Ho, L.cout).permute(0, 3, 1, 2).cpu())
+        for bname, br in self.head.branches.items():
+            for L in [br["enc"], br["corr"]] + br["tower"]:
+                m = (L.y.reshape(-1, L.ldy)[:, : L.cout] > 0)
+                Bn = m.shape[0] // 256
+                out[L.bn_prefix] = [m.reshape(Bn, 16, 16, L.cout).permute(0, 3, 1, 2).cpu()]
+        return out

@@ -47,15 +47,19 @@ int fear_pw_backward_weight(const float* dy, int lddy, const float* x, int ldx, 
 /* bias gradients: out[c] = sum_m dy[m][c] */
 int fear_col_sum(const float* dy, int lddy, float* out, float* workspace, size_t ws_bytes, long M, int C, void* stream);
 
-/* nn.Conv2d(C, C, k, groups=C, padding=k/2), stride 1: taps laid out [k*k][C] (tap-major, channels contiguous) */
+/* nn.Conv2d(C, C, k, groups=C, padding=k/2, stride=stride), k in {3,5}, stride in {1,2}: taps laid out [k*k][C] (tap-major) */
 int fear_dw_forward(const float* x, int ldx, const float* w_taps, const float* bias, float* y, int ldy, int B, int H, int W,
-                    int C, int k, void* stream);
-/* input gradient = the same convolution of dy with the taps reversed: pass w_taps_flipped[t][c] = w_taps[k*k-1-t][c] */
-int fear_dw_backward_data(const float* dy, int lddy, const float* w_taps_flipped, float* dx, int lddx, int B, int H, int W,
-                          int C, int k, void* stream);
-/* weight gradient dw_taps[t][c] = sum_{b,y,x} dy[b,y,x,c] * x[b, y+ky-k/2, x+kx-k/2, c] */
+                    int C, int k, int stride, void* stream);
+/* input gradient (B, H, W = the INPUT map; dy is the (H/stride, W/stride) output-side gradient) */
+int fear_dw_backward_data(const float* dy, int lddy, const float* w_taps, float* dx, int lddx, int B, int H, int W, int C, int k,
+                          int stride, void* stream);
+/* weight gradient dw_taps[t][c] = sum_{b,oy,ox} dy[b,oy,ox,c] * x[b, oy*stride+ky-k/2, ox*stride+kx-k/2, c] */
 int fear_dw_backward_weight(const float* dy, int lddy, const float* x, int ldx, float* dw_taps, float* workspace,
-                            size_t ws_bytes, int B, int H, int W, int C, int k, void* stream);
+                            size_t ws_bytes, int B, int H, int W, int C, int k, int stride, void* stream);
+
+/* stem conv 3x3 stride 2 pad 1 (3 -> 16) as a GEMM: im2col of an NCHW image batch into rows of 28 floats
+ * (k = (ci*3+ky)*3+kx, column 27 zero) -> fear_pw_forward / fear_pw_backward_weight with K = 28 */
+int fear_stem_im2col(const float* x_nchw, float* rows28, long n, int H, int W, void* stream);
 
 /* nn.BatchNorm2d(C) in training mode (+ optional ReLU): batch statistics over the M rows; mean / rstd are saved for the
  * backward; running_mean / running_var (may be NULL) follow torch: (1 - momentum) * running + momentum * stat, unbiased var */

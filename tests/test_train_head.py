@@ -1,6 +1,7 @@
 """N3: one training step of the correlation head on the HIP operators of include/fear_train.h against the
 fixture produced by the REFERENCE's own BoxTower (train mode) + FEARLoss + torch autograd (tools/make_golden.py section 11):
 outputs, both losses, the gradient of every parameter and of both inputs, BatchNorm running statistics."""
+import copy
 import os
 import re
 
@@ -111,6 +112,12 @@ def test_training_operators_individually_vs_torch():
     lib = load_train_library()
     dev = torch.device("cuda:0")
     st = None
+    keep = []                     # device tensors handed to the C ABI by pointer must outlive the (asynchronous) calls
+
+    def D(t):
+        keep.append(t.detach().to(dev).contiguous())
+        return keep[-1]
+
     g = torch.Generator().manual_seed(3)
     ws = torch.empty(lib.fear_train_workspace_bytes(4096, 320) // 4 + 1024, device=dev)
     wsb = ws.numel() * 4
@@ -130,22 +137,23 @@ def test_training_operators_individually_vs_torch():
         db = torch.empty(N, device=dev)
         assert lib.fear_col_sum(_p(dyd), N, _p(db), _p(ws), wsb, M, N, st) == 0
         _close(db, dy.sum(0), "bias grad", 1e-5)
-    for B, H, C, k in ((3, 16, 320, 3), (2, 8, 64, 5)):
+    for B, H, C, k, st_ in ((3, 16, 320, 3, 1), (2, 8, 64, 5, 1), (2, 32, 96, 3, 2), (2, 16, 144, 5, 2)):
         x = torch.randn(B, C, H, H, generator=g, requires_grad=True)
         w = torch.randn(C, 1, k, k, generator=g, requires_grad=True)
-        y = F.conv2d(x, w, None, padding=k // 2, groups=C)
+        y = F.conv2d(x, w, None, stride=st_, padding=k // 2, groups=C)
+        Ho = H // st_
         dy = torch.randn(y.shape, generator=g)
         y.backward(dy)
-        rows = lambda t: t.detach().permute(0, 2, 3, 1).reshape(-1, C).contiguous().to(dev)
-        taps = w.detach().reshape(C, k * k).t().contiguous().to(dev)
-        yd = torch.empty(B * H * H, C, device=dev)
-        assert lib.fear_dw_forward(_p(rows(x)), C, _p(taps), None, _p(yd), C, B, H, H, C, k, st) == 0
-        _close(yd, rows(y).cpu(), "dw forward", 1e-5)
+        rows = lambda t: t.detach().permute(0, 2, 3, 1).reshape(-1, C).contiguous()
+        taps = D(w.detach().reshape(C, k * k).t())
+        yd = torch.empty(B * Ho * Ho, C, device=dev)
+        assert lib.fear_dw_forward(_p(D(rows(x))), C, _p(taps), None, _p(yd), C, B, H, H, C, k, st_, st) == 0
+        _close(yd, rows(y), "dw forward", 1e-5)
         dxd = torch.empty(B * H * H, C, device=dev)
-        assert lib.fear_dw_backward_data(_p(rows(dy)), C, _p(torch.flip(taps, [0]).contiguous()), _p(dxd), C, B, H, H, C, k, st) == 0
-        _close(dxd, rows(x.grad).cpu(), "dw dgrad", 1e-5)
+        assert lib.fear_dw_backward_data(_p(D(rows(dy))), C, _p(taps), _p(dxd), C, B, H, H, C, k, st_, st) == 0
+        _close(dxd, rows(x.grad), "dw dgrad", 1e-5)
         dtaps = torch.empty(k * k, C, device=dev)
-        assert lib.fear_dw_backward_weight(_p(rows(dy)), C, _p(rows(x)), C, _p(dtaps), _p(ws), wsb, B, H, H, C, k, st) == 0
+        assert lib.fear_dw_backward_weight(_p(D(rows(dy))), C, _p(D(rows(x))), C, _p(dtaps), _p(ws), wsb, B, H, H, C, k, st_, st) == 0
         _close(dtaps, w.grad.reshape(C, k * k).t(), "dw wgrad", 1e-5)
     for M, C, relu in ((1024, 256, 1), (777, 112, 0)):
         x = (torch.randn(M, C, generator=g) * 2 + 0.5).requires_grad_(True)
@@ -158,17 +166,35 @@ def test_training_operators_individually_vs_torch():
         xd, yd = x.detach().to(dev), torch.empty(M, C, device=dev)
         mean, rstd = torch.empty(C, device=dev), torch.empty(C, device=dev)
         rmd, rvd = torch.zeros(C, device=dev), torch.ones(C, device=dev)
-        assert lib.fear_bn_train_forward(_p(xd), C, _p(gamma.detach().to(dev)), _p(beta.detach().to(dev)), _p(yd), C, _p(mean), _p(rstd),
+        assert lib.fear_bn_train_forward(_p(xd), C, _p(D(gamma)), _p(D(beta)), _p(yd), C, _p(mean), _p(rstd),
                                          _p(rmd), _p(rvd), 0.1, 1e-5, M, C, relu, _p(ws), wsb, st) == 0
         _close(yd, y.detach(), "bn forward", 1e-5)
         _close(rmd, rm, "running mean", 1e-5)
         _close(rvd, rv, "running var", 1e-5)
         dxd, dg, db = torch.empty(M, C, device=dev), torch.empty(C, device=dev), torch.empty(C, device=dev)
-        assert lib.fear_bn_train_backward(_p(dy.to(dev)), C, _p(yd) if relu else None, C, _p(xd), C, _p(mean), _p(rstd),
-                                          _p(gamma.detach().to(dev)), _p(dxd), C, _p(dg), _p(db), M, C, _p(ws), wsb, st) == 0
+        assert lib.fear_bn_train_backward(_p(D(dy)), C, _p(yd) if relu else None, C, _p(xd), C, _p(mean), _p(rstd),
+                                          _p(D(gamma)), _p(dxd), C, _p(dg), _p(db), M, C, _p(ws), wsb, st) == 0
         _close(dxd, x.grad, "bn dx", 1e-4)
         _close(dg, gamma.grad, "bn dgamma", 1e-4)
         _close(db, beta.grad, "bn dbeta", 1e-4)
+    # stem conv 3x3 s2 (3 -> 16) as im2col + GEMM: forward and weight gradient
+    img = torch.randn(2, 3, 64, 64, generator=g)
+    ws_ = torch.randn(16, 3, 3, 3, generator=g, requires_grad=True)
+    ys = F.conv2d(img, ws_, None, stride=2, padding=1)
+    dys = torch.randn(ys.shape, generator=g)
+    ys.backward(dys)
+    Ms = 2 * 32 * 32
+    col = torch.empty(Ms, 28, device=dev)
+    assert lib.fear_stem_im2col(_p(D(img)), _p(col), 2, 64, 64, st) == 0
+    w28 = torch.zeros(16, 28)
+    w28[:, :27] = ws_.detach().reshape(16, 27)
+    yd = torch.empty(Ms, 16, device=dev)
+    assert lib.fear_pw_forward(_p(col), 28, _p(D(w28)), None, _p(yd), 16, Ms, 28, 16, st) == 0
+    _close(yd, ys.detach().permute(0, 2, 3, 1).reshape(Ms, 16), "stem forward", 1e-5)
+    dw28 = torch.empty(16, 28, device=dev)
+    assert lib.fear_pw_backward_weight(_p(D(dys.permute(0, 2, 3, 1).reshape(Ms, 16))), 16, _p(col), 28, _p(dw28), _p(ws),
+                                       wsb, Ms, 28, 16, st) == 0
+    _close(dw28[:, :27], ws_.grad.reshape(16, 27), "stem wgrad", 1e-5)
     B, P, C, J = 3, 256, 256, 64
     x = torch.randn(B, P, C, generator=g, requires_grad=True)
     z = torch.randn(B, C, J, generator=g, requires_grad=True)
@@ -181,8 +207,92 @@ def test_training_operators_individually_vs_torch():
     _close(sd_, s.detach().reshape(B * P, J), "xcorr forward", 1e-5)
     dxd, dzd = torch.empty(B * P, C, device=dev), torch.empty(B, C, J, device=dev)
     add = torch.randn(B * P, C, generator=g)
-    assert lib.fear_xcorr_backward(_p(ds.reshape(B * P, J).to(dev)), J, _p(xd), C, _p(zd), _p(add.to(dev)), C, _p(dxd), C, _p(dzd),
+    assert lib.fear_xcorr_backward(_p(D(ds.reshape(B * P, J))), J, _p(xd), C, _p(zd), _p(D(add)), C, _p(dxd), C, _p(dzd),
                                    B, P, C, J, st) == 0
     torch.cuda.synchronize()
     _close(dxd, x.grad.reshape(B * P, C) + add, "xcorr dx", 1e-5)
     _close(dzd, z.grad, "xcorr dz", 1e-5)
+
+
+def test_training_oracle_head_matches_reference_fixture(golden_dir):
+    """Pins oracle/fear_train_oracle.py's head + loss restatement against the REFERENCE's BoxTower + FEARLoss + autograd
+    (fixture of tools/make_golden.py section 11): same outputs, losses and gradients on CPU."""
+    from oracle.fear_train_oracle import BoxTowerOracle, fear_loss
+    d = np.load(f"{golden_dir}/head_train_step.npz")
+    net = BoxTowerOracle().train()
+    sd = {k[len("param."):]: torch.from_numpy(d[k]) for k in d.files if k.startswith("param.")}
+    missing = net.load_state_dict(sd, strict=True)
+    xs = torch.from_numpy(d["in_search"]).requires_grad_(True)
+    zs = torch.from_numpy(d["in_template"]).requires_grad_(True)
+    bbox, cls = net(xs, zs)
+    lc, lr = fear_loss(bbox, cls, torch.from_numpy(d["gt_reg"]), torch.from_numpy(d["gt_cls"]), torch.from_numpy(d["gt_weight"]))
+    (lc + lr).backward()
+    np.testing.assert_allclose(bbox.detach().numpy(), d["out_bbox"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(cls.detach().numpy(), d["out_cls"], rtol=1e-5, atol=1e-7)
+    assert abs(float(lc) - float(d["loss_cls"])) < 1e-6 and abs(float(lr) - float(d["loss_reg"])) < 1e-6
+    for n, p in net.named_parameters():
+        _close(p.grad, d["grad." + n], "oracle grad " + n, 1e-4)
+    _close(xs.grad, d["grad_in_search"], "oracle grad search", 1e-4)
+    _close(zs.grad, d["grad_in_template"], "oracle grad template", 1e-4)
+
+
+@pytest.mark.gpu
+def test_whole_network_training_step_matches_autograd():
+    """BASELINE configs[4] "backbone + xcorr fwd/bwd, random-init": FEARNet.forward((template, search)) in train mode +
+    FEARLoss + backward to all 195 parameter tensors on the HIP operators vs torch autograd on the restated graph
+    (oracle/fear_train_oracle.py: head pinned by the reference fixture, trunk = FBNet-C blocks with a BatchNorm after every
+    conv — the reference's own trunk code is the absent mobile_cv package).  Tolerance 1e-3 of each tensor's max-norm."""
+    from feartracker_amd.train_net import FEARNetTrainHIP
+    from oracle.fear_train_oracle import FEARNetTrainOracle, fear_loss, random_init_state
+    sd = random_init_state(5)
+    ora = FEARNetTrainOracle().train()
+    ora.load_state_dict(sd, strict=False)
+    g = torch.Generator().manual_seed(9)
+    B = 2
+    tmpl = torch.randn(B, 3, 128, 128, generator=g)
+    srch = torch.randn(B, 3, 256, 256, generator=g)
+    gt_reg = torch.rand(B, 4, 16, 16, generator=g) * 60 + 1
+    gt_cls = (torch.rand(B, 1, 16, 16, generator=g) > 0.8).float()
+    gt_w = (torch.rand(B, 16, 16, generator=g) > 0.85).float()
+    net = FEARNetTrainHIP(sd, device=0)
+    out = net.step(tmpl, srch, gt_reg, gt_cls, gt_w)
+    torch.cuda.synchronize()
+    # the oracle's backward runs on the HIP forward's ReLU activity pattern (oracle/fear_train_oracle.py::MaskableReLU: the
+    # derivative at a pre-activation within rounding of 0 is a tie-break, not arithmetic); the two forwards must agree first
+    with torch.no_grad():
+        bbox0, cls0 = copy.deepcopy(ora)(tmpl, srch)
+    _close(out["bbox"], bbox0, "bbox (plain forward)", 1e-4)
+    _close(out["cls"], cls0, "cls (plain forward)", 1e-4)
+    pats = net.relu_patterns()
+    n_relu = 0
+
+    def resolve(root, dotted):
+        for part in dotted.split("."):
+            root = root[int(part)] if part.isdigit() else getattr(root, part)
+        return root
+
+    for name, masks in pats.items():
+        if name == "stem" or name.startswith("trunk."):
+            target = resolve(ora, name).act                      # ConvBN of the trunk
+        else:                                                    # head: name = the BatchNorm inside BoxTower, its ReLU is the next module
+            parent, idx = name.rsplit(".", 1)
+            target = resolve(ora.connect_model, parent)[int(idx) + 1]
+        target.masks = list(masks)
+        n_relu += len(masks)
+    assert n_relu == 2 * 30 + 8                    # stem + 13 expand + 16 depthwise ReLUs per trunk pass, 8 in the head
+    bbox, cls = ora(tmpl, srch)
+    lc, lr = fear_loss(bbox, cls, gt_reg, gt_cls, gt_w)
+    (lc + lr).backward()
+    _close(out["bbox"], bbox.detach(), "bbox")
+    _close(out["cls"], cls.detach(), "cls")
+    assert abs(float(out["loss_cls"]) - float(lc.detach())) <= 1e-4 * abs(float(lc.detach()))
+    assert abs(float(out["loss_reg"]) - float(lr.detach())) <= 1e-4 * abs(float(lr.detach()))
+    ref = {n: p.grad for n, p in ora.named_parameters()}
+    assert set(ref) == set(out["grads"]) and len(ref) == 195, set(ref) ^ set(out["grads"])
+    worst = {}
+    for n, gr in ref.items():
+        if float(gr.abs().max()) < 1e-8:                     # biases in front of a BatchNorm: exactly-zero true gradient
+            assert float(out["grads"][n].abs().max()) < 1e-6
+            continue
+        worst[n] = _close(out["grads"][n], gr, "grad " + n)
+    print("worst relative gradient errors:", sorted(worst.items(), key=lambda kv: -kv[1])[:4])
