@@ -31,11 +31,11 @@ using namespace fear;
 
 // ------------------------------------------------------------------------------------------------
 // Column reductions over rows: per-channel sums.  Block = 256 threads = (C/4 channel quads) x (R row lanes); a block reduces
-// ROWS_PER_BLOCK rows into partial[block][2][C]; col_finalize_kernel adds the partials in double, in block order.
-//   MODE 0: s1 = sum x,        s2 = sum (x - block mean)^2                   (BatchNorm forward statistics)
+// `rpb` rows (col_rows_per_block: 64, doubled until there are at most 1024 blocks) into partial[block][2][C];
+// col_finalize_kernel adds the partials in double, 16 lanes per column in a fixed order.
+//   MODE 0: s1 = sum x,        s2 = sum x^2   (float64)                      (BatchNorm forward statistics)
 //   MODE 1: g = relu ? (y > 0 ? dy : 0) : dy;  s1 = sum g,  s2 = sum g * xhat,  xhat = (x - mean) * rstd   (BatchNorm backward)
 //   MODE 2: s1 = sum dy                                                      (bias gradients)
-constexpr int ROWS_PER_BLOCK = 256;
 
 struct ColArgs {
     const float* A;      // x (mode 0) / dy (modes 1, 2)
@@ -45,7 +45,7 @@ struct ColArgs {
     const float* rstd;   // mode 1
     double* partial;     // [blocks][2][C] float64
     long M;
-    int C, lda, ldy, ldx;
+    int C, lda, ldy, ldx, rpb;
 };
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -63,8 +63,8 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(ColArgs a) {
     const int cq = threadIdx.x % c4n, rl = threadIdx.x / c4n;
     const f64x4 zero = (f64x4){0.0, 0.0, 0.0, 0.0};
     f64x4 s1 = zero, s2 = zero;
-    const long r0 = (long)blockIdx.x * ROWS_PER_BLOCK;
-    const long r1 = r0 + ROWS_PER_BLOCK < a.M ? r0 + ROWS_PER_BLOCK : a.M;
+    const long r0 = (long)blockIdx.x * a.rpb;
+    const long r1 = r0 + a.rpb < a.M ? r0 + a.rpb : a.M;
     if (rl < R) {
         f32x4 mu = (f32x4){0.f, 0.f, 0.f, 0.f}, rs = mu;
         if (MODE == 1) {
@@ -74,7 +74,9 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(ColArgs a) {
         for (long r = r0 + rl; r < r1; r += R) {
             f32x4 v = *reinterpret_cast<const f32x4*>(a.A + r * a.lda + cq * 4);
             if (MODE == 0) {
-                s1 += to_f64(v);
+                const f64x4 d = to_f64(v);
+                s1 += d;
+                s2 += d * d;
             } else if (MODE == 1) {
                 if (a.Yact) {
                     const f32x4 y = *reinterpret_cast<const f32x4*>(a.Yact + r * a.ldy + cq * 4);
@@ -87,21 +89,6 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(ColArgs a) {
                 s1 += to_f64(v);
             }
         }
-    }
-    if (MODE == 0) {
-        // variance around THIS block's mean (no E[x^2] - mean^2 cancellation); blocks are combined by Chan's formula in
-        // col_finalize_kernel
-        red[0][threadIdx.x] = s1;
-        __syncthreads();
-        f64x4 bsum = red[0][cq];
-        for (int j = 1; j < R; ++j) bsum += red[0][j * c4n + cq];
-        const f64x4 bmean = bsum / (double)(r1 - r0);
-        if (rl < R)
-            for (long r = r0 + rl; r < r1; r += R) {
-                const f64x4 dv = to_f64(*reinterpret_cast<const f32x4*>(a.A + r * a.lda + cq * 4)) - bmean;
-                s2 += dv * dv;
-            }
-        __syncthreads();
     }
     red[0][threadIdx.x] = s1;
     red[1][threadIdx.x] = s2;
@@ -125,27 +112,33 @@ struct ColFinArgs {
     float* out2;
     float* running_mean;   // mode 0, optional
     float* running_var;
-    int blocks, C, mode;
+    int blocks, C, mode, rpb;
     double M, eps, momentum;
 };
 
 __global__ __launch_bounds__(256) void col_finalize_kernel(ColFinArgs a) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= a.C) return;
+    // block = 16 columns x 16 lanes; lane j adds partials j, j+16, ... in order, the 16 lane sums are then added in lane order
+    __shared__ double red[2][16][17];
+    const int cl = threadIdx.x & 15, j = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    const bool ok = c < a.C;
     double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < a.blocks; ++b) {
-        s1 += a.partial[(long)b * 2 * a.C + c];
-        s2 += a.partial[(long)b * 2 * a.C + a.C + c];
-    }
-    if (a.mode == 0) {
-        // partial[b] = (sum_b, M2_b = sum (x - mean_b)^2): M2 = sum_b M2_b + n_b (mean_b - mean)^2
-        const double mean = s1 / a.M;
-        double m2 = s2;
-        for (int b = 0; b < a.blocks; ++b) {
-            const double nb = (double)((long)(b + 1) * ROWS_PER_BLOCK <= (long)a.M ? ROWS_PER_BLOCK : (long)a.M - (long)b * ROWS_PER_BLOCK);
-            const double db = a.partial[(long)b * 2 * a.C + c] / nb - mean;
-            m2 += nb * db * db;
+    if (ok)
+        for (int b = j; b < a.blocks; b += 16) {
+            s1 += a.partial[(long)b * 2 * a.C + c];
+            s2 += a.partial[(long)b * 2 * a.C + a.C + c];
         }
+    red[0][j][cl] = s1;
+    red[1][j][cl] = s2;
+    __syncthreads();
+    s1 = 0.0; s2 = 0.0;
+    for (int l = 0; l < 16; ++l) { s1 += red[0][l][cl]; s2 += red[1][l][cl]; }
+    if (a.mode == 0) {
+        // single pass, float64 sums of x and x^2: the E[x^2] - mean^2 cancellation costs mean^2 / var * 2^-53 relative, far
+        // below the fp32 inputs' own rounding for any activation a network produces
+        const double mean = s1 / a.M;
+        if (j != 0 || !ok) return;
+        const double m2 = s2 - s1 * mean;
         double var = m2 / a.M;
         if (var < 0.0) var = 0.0;
         a.out1[c] = (float)mean;
@@ -155,7 +148,7 @@ __global__ __launch_bounds__(256) void col_finalize_kernel(ColFinArgs a) {
             const double unbiased = a.M > 1.0 ? var * a.M / (a.M - 1.0) : var;
             a.running_var[c] = (float)((1.0 - a.momentum) * (double)a.running_var[c] + a.momentum * unbiased);
         }
-    } else {
+    } else if (j == 0 && ok) {
         a.out1[c] = (float)s1;
         if (a.out2) a.out2[c] = (float)s2;
     }
@@ -279,13 +272,29 @@ __global__ __launch_bounds__(64) void pw_wgrad_kernel(WgradArgs a) {
     }
 }
 
-// out[i] = sum over slices of P[s][i], fixed order (i over crops*N*K)
-__global__ __launch_bounds__(256) void slice_sum_kernel(const float* P, float* out, long count, int slices) {
-    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i >= count) return;
-    f32x4 s = *reinterpret_cast<const f32x4*>(P + i);
-    for (int j = 1; j < slices; ++j) s += *reinterpret_cast<const f32x4*>(P + (long)j * count + i);
-    *reinterpret_cast<f32x4*>(out + i) = s;
+// out[i] = sum over slices of P[s][i], fixed order (i over crops*N*K): `lanes` threads per float4 (lane l adds slices l, l+lanes,
+// ... in order, then the lane sums are added in lane order); lanes = 1 for a handful of slices, 16 for the long reductions
+__global__ __launch_bounds__(256) void slice_sum_kernel(const float* P, float* out, long count, int slices, int lanes) {
+    __shared__ f32x4 red[256];
+    const int per = 256 / lanes;
+    const int o = threadIdx.x % per, l = threadIdx.x / per;
+    const long i = ((long)blockIdx.x * per + o) * 4;
+    f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (i < count)
+        for (int j = l; j < slices; j += lanes) s += *reinterpret_cast<const f32x4*>(P + (long)j * count + i);
+    if (lanes > 1) {
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (l == 0)
+            for (int k = 1; k < lanes; ++k) s += red[k * per + o];
+    }
+    if (l == 0 && i < count) *reinterpret_cast<f32x4*>(out + i) = s;
+}
+
+void launch_slice_sum(const float* P, float* out, long count, int slices, hipStream_t s) {
+    const int lanes = slices >= 64 ? 16 : 1;
+    const int per = 256 / lanes;
+    hipLaunchKernelGGL(slice_sum_kernel, dim3((unsigned)((count / 4 + per - 1) / per)), dim3(256), 0, s, P, out, count, slices, lanes);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -296,7 +305,7 @@ struct DwWgradArgs {
     const float* X;
     float* partial;
     long pixels;          // B*Ho*Wo
-    int H, W, Ho, Wo, C, lddy, ldx;
+    int H, W, Ho, Wo, C, lddy, ldx, rpb;
 };
 
 template <int KS, int S>
@@ -309,9 +318,40 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgradArgs a) {
     f32x4 acc[KK];
 #pragma unroll
     for (int t = 0; t < KK; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const long p0 = (long)blockIdx.x * ROWS_PER_BLOCK;
-    const long p1 = p0 + ROWS_PER_BLOCK < a.pixels ? p0 + ROWS_PER_BLOCK : a.pixels;
-    if (rl < R) {
+    const long p0 = (long)blockIdx.x * a.rpb;
+    const long p1 = p0 + a.rpb < a.pixels ? p0 + a.rpb : a.pixels;
+    constexpr int T = S == 1 ? 8 : 4, WIN = S * (T - 1) + KS;
+    if (a.Wo % T == 0) {
+        // runs of T output pixels of one row: the KS input rows are walked once as a WIN-wide register window instead of KS*KS
+        // loads per pixel (the loads, not the FMAs, bound this kernel: 25 of them per pixel and channel quad)
+        if (rl < R)
+            for (long u = p0 / T + rl; u < p1 / T; u += R) {
+                const long p = u * T;
+                const int ox0 = (int)(p % a.Wo);
+                const int oy = (int)((p / a.Wo) % a.Ho);
+                const long b = p / ((long)a.Wo * a.Ho);
+                f32x4 g[T];
+#pragma unroll
+                for (int i = 0; i < T; ++i) g[i] = *reinterpret_cast<const f32x4*>(a.dY + (p + i) * a.lddy + cq * 4);
+                const float* xb = a.X + b * a.H * a.W * a.ldx + cq * 4;
+#pragma unroll
+                for (int ky = 0; ky < KS; ++ky) {
+                    const int yy = oy * S + ky - P;
+                    if (yy < 0 || yy >= a.H) continue;
+                    f32x4 xr[WIN];
+#pragma unroll
+                    for (int i = 0; i < WIN; ++i) {
+                        const int xx = ox0 * S + i - P;
+                        xr[i] = (xx >= 0 && xx < a.W) ? *reinterpret_cast<const f32x4*>(xb + ((long)yy * a.W + xx) * a.ldx)
+                                                      : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                    for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+                        for (int i = 0; i < T; ++i) acc[ky * KS + kx] += g[i] * xr[i * S + kx];
+                }
+            }
+    } else if (rl < R) {
         for (long p = p0 + rl; p < p1; p += R) {
             const int ox = (int)(p % a.Wo);
             const int oy = (int)((p / a.Wo) % a.Ho);
@@ -598,7 +638,12 @@ void launch_pw(int nt, dim3 grid, hipStream_t s, const PwArgs& a) {
     }
 }
 
-int col_blocks(long M) { return (int)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK); }
+int col_rows_per_block(long M) {
+    int r = 64;
+    while ((M + r - 1) / r > 1024) r *= 2;
+    return r;
+}
+int col_blocks(long M) { const int r = col_rows_per_block(M); return (int)((M + r - 1) / r); }
 
 // row slices of the pointwise weight gradient: 1024 rows each, but never more than 256 slices (the partials are
 // [slices][N][K] floats; at the trunk's 128x128 maps a batch has millions of rows)
@@ -615,9 +660,9 @@ extern "C" {
 
 size_t fear_train_workspace_bytes(long rows, int max_channels) {
     // the largest users: pw wgrad partials [slices][N][K] (slices = ceil(rows / rows_per_slice), see wgrad_slices) with
-    // N * K <= max_channels^2; column reductions [rows / 256][2][C]; depthwise wgrad [rows / 256][25][C]
+    // N * K <= max_channels^2; column reductions [blocks <= 1024][2][C] float64; depthwise wgrad [blocks][25][C]
     const size_t a = (size_t)wgrad_slices(rows) * (size_t)max_channels * max_channels;
-    const size_t b = (size_t)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK) * 25 * (size_t)max_channels;
+    const size_t b = (size_t)col_blocks(rows) * 25 * (size_t)max_channels;      // <= 1024 blocks; col partials are 2 doubles = 4 floats
     return ((a > b ? a : b) + 1024) * sizeof(float);
 }
 
@@ -669,7 +714,7 @@ static int wgrad_impl(const float* dy, int lddy, long dy_crop_stride, const floa
     hipLaunchKernelGGL(pw_wgrad_kernel, dim3(a.n_strips * a.k_strips, slices, crops), dim3(64), 0, s, a);
     if (slices > 1) {
         const long count = (long)crops * N * K;
-        hipLaunchKernelGGL(slice_sum_kernel, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, s, workspace, dw, count, slices);
+        launch_slice_sum(workspace, dw, count, slices, s);
     }
     LAUNCH_CHECK();
     return FEAR_TRAIN_OK;
@@ -689,11 +734,11 @@ int fear_col_sum(const float* dy, int lddy, float* out, float* workspace, size_t
     if (ws_bytes < (size_t)blocks * 2 * C * sizeof(double)) return FEAR_TRAIN_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     ColArgs a{};
-    a.A = dy; a.lda = lddy; a.partial = reinterpret_cast<double*>(workspace); a.M = M; a.C = C;
+    a.A = dy; a.lda = lddy; a.partial = reinterpret_cast<double*>(workspace); a.M = M; a.C = C; a.rpb = col_rows_per_block(M);
     hipLaunchKernelGGL(col_reduce_kernel<2>, dim3(blocks), dim3(256), 0, s, a);
     ColFinArgs f{};
-    f.partial = reinterpret_cast<const double*>(workspace); f.out1 = out; f.out2 = nullptr; f.blocks = blocks; f.C = C; f.mode = 2; f.M = (double)M;
-    hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, f);
+    f.partial = reinterpret_cast<const double*>(workspace); f.out1 = out; f.out2 = nullptr; f.blocks = blocks; f.C = C; f.mode = 2; f.M = (double)M; f.rpb = col_rows_per_block(M);
+    hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, s, f);
     LAUNCH_CHECK();
     return FEAR_TRAIN_OK;
 }
@@ -756,12 +801,12 @@ int fear_dw_backward_weight(const float* dy, int lddy, const float* x, int ldx, 
     if (ws_bytes < (size_t)blocks * count * sizeof(float)) return FEAR_TRAIN_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     DwWgradArgs a{};
-    a.dY = dy; a.X = x; a.partial = workspace; a.pixels = pixels; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.C = C; a.lddy = lddy; a.ldx = ldx;
+    a.dY = dy; a.X = x; a.partial = workspace; a.pixels = pixels; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.C = C; a.lddy = lddy; a.ldx = ldx; a.rpb = col_rows_per_block(pixels);
     if (k == 3 && stride == 1) hipLaunchKernelGGL((dw_wgrad_kernel<3, 1>), dim3(blocks), dim3(256), 0, s, a);
     else if (k == 3) hipLaunchKernelGGL((dw_wgrad_kernel<3, 2>), dim3(blocks), dim3(256), 0, s, a);
     else if (stride == 1) hipLaunchKernelGGL((dw_wgrad_kernel<5, 1>), dim3(blocks), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((dw_wgrad_kernel<5, 2>), dim3(blocks), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(slice_sum_kernel, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, s, workspace, dw_taps, count, blocks);
+    launch_slice_sum(workspace, dw_taps, count, blocks, s);
     LAUNCH_CHECK();
     return FEAR_TRAIN_OK;
 }
@@ -786,12 +831,12 @@ int fear_bn_train_forward(const float* x, int ldx, const float* gamma, const flo
     if (ws_bytes < (size_t)blocks * 2 * C * sizeof(double)) return FEAR_TRAIN_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     ColArgs a{};
-    a.A = x; a.lda = ldx; a.partial = reinterpret_cast<double*>(workspace); a.M = M; a.C = C;
+    a.A = x; a.lda = ldx; a.partial = reinterpret_cast<double*>(workspace); a.M = M; a.C = C; a.rpb = col_rows_per_block(M);
     hipLaunchKernelGGL(col_reduce_kernel<0>, dim3(blocks), dim3(256), 0, s, a);
     ColFinArgs f{};
     f.partial = reinterpret_cast<const double*>(workspace); f.out1 = mean; f.out2 = rstd; f.running_mean = running_mean; f.running_var = running_var;
-    f.blocks = blocks; f.C = C; f.mode = 0; f.M = (double)M; f.eps = eps; f.momentum = momentum;
-    hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, f);
+    f.blocks = blocks; f.C = C; f.mode = 0; f.M = (double)M; f.rpb = col_rows_per_block(M); f.eps = eps; f.momentum = momentum;
+    hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, s, f);
     BnApplyArgs b{};
     b.X = x; b.mean = mean; b.rstd = rstd; b.gamma = gamma; b.beta = beta; b.Y = y; b.M = M; b.C = C; b.ldx = ldx; b.ldy = ldy;
     b.relu = relu;
@@ -811,11 +856,11 @@ int fear_bn_train_backward(const float* dy, int lddy, const float* y_act, int ld
     hipStream_t s = static_cast<hipStream_t>(stream);
     ColArgs a{};
     a.A = dy; a.lda = lddy; a.Yact = y_act; a.ldy = ldy; a.X = x; a.ldx = ldx; a.mean = mean; a.rstd = rstd;
-    a.partial = reinterpret_cast<double*>(workspace); a.M = M; a.C = C;
+    a.partial = reinterpret_cast<double*>(workspace); a.M = M; a.C = C; a.rpb = col_rows_per_block(M);
     hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(blocks), dim3(256), 0, s, a);
     ColFinArgs f{};
-    f.partial = reinterpret_cast<const double*>(workspace); f.out1 = dbeta; f.out2 = dgamma; f.blocks = blocks; f.C = C; f.mode = 1; f.M = (double)M;
-    hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, f);
+    f.partial = reinterpret_cast<const double*>(workspace); f.out1 = dbeta; f.out2 = dgamma; f.blocks = blocks; f.C = C; f.mode = 1; f.M = (double)M; f.rpb = col_rows_per_block(M);
+    hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, s, f);
     BnBwdArgs b{};
     b.dY = dy; b.Yact = y_act; b.X = x; b.mean = mean; b.rstd = rstd; b.gamma = gamma; b.sum_g = dbeta; b.sum_gx = dgamma;
     b.dX = dx; b.M = M; b.C = C; b.lddy = lddy; b.ldy = ldy; b.ldx = ldx; b.lddx = lddx;
@@ -884,10 +929,10 @@ int fear_exp_head_backward(const float* p, const float* adjust, const float* bbo
     hipLaunchKernelGGL(exp_head_bwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, a);
     for (int pass = 0; pass < 2; ++pass) {
         ColArgs c{};
-        c.A = pass == 0 ? T : U; c.lda = 4; c.partial = part; c.M = M; c.C = 4;
+        c.A = pass == 0 ? T : U; c.lda = 4; c.partial = part; c.M = M; c.C = 4; c.rpb = col_rows_per_block(M);
         hipLaunchKernelGGL(col_reduce_kernel<2>, dim3(blocks), dim3(256), 0, s, c);
         ColFinArgs f{};
-        f.partial = part; f.out1 = pass == 0 ? dbias4 : u4; f.blocks = blocks; f.C = 4; f.mode = 2; f.M = (double)M;
+        f.partial = part; f.out1 = pass == 0 ? dbias4 : u4; f.blocks = blocks; f.C = 4; f.mode = 2; f.M = (double)M; f.rpb = col_rows_per_block(M);
         hipLaunchKernelGGL(col_finalize_kernel, dim3(1), dim3(256), 0, s, f);
     }
     // d adjust = the four per-channel sums of dbbox * bbox * p added up (adjust is one scalar shared by the four channels)
