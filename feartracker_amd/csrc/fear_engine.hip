@@ -110,9 +110,10 @@ struct Op {
     int pred_fused = 0;       // OP_IR16 (sep16): the prediction SepConv that consumes this layer runs in its epilogue
     float* pred_packed = nullptr;
     int pred_conv_p = -1;
-    int small_tiles = 0;      // OP_IRTILE: use kFusedTileSmall (small-batch plan)
+    int small_tiles = 0;      // OP_IRTILE: 1 = kFusedTileSmall (small-batch plan), 2 = kFusedTileTiny (a handful of crops)
     int pw_split = 0;         // OP_PW / OP_CORR: spread the output-channel passes over gridDim.y workgroups (small-batch plan)
     int splitk = 0;           // OP_IR16: > 0 = workgroups per crop (split over expansion chunks) + a reduce launch
+    int nsplit = 0;           // OP_IR16 (sep16): > 0 = 16-channel output slices, one workgroup each (Ir2Args::nsplit_wstride)
     int part_buf = -1;        //          scratch buffer of the partial projections
     int lane = 0;             // 1: bbox branch of the head, may run on the handle's second stream (small batches)
     int corr_fused = 0;       // OP_IR16 (sep16): the pixel-wise correlation runs in this kernel's epilogue
@@ -312,6 +313,7 @@ const Fused16 kFused16[] = {
     FUSED16(112, 672, 112, 5, 1), FUSED16(112, 336, 112, 5, 1),
     SEP16(256, 256, 3, 4), SEP16(320, 256, 3, 4),
     SEP16(256, 16, 3, 2),              // bbox_pred / cls_pred: 4 / 1 output channels padded to one 16-channel tile
+    SEP16(320, 16, 3, 2),              // N-split slices of the 320 -> 256 SepConv (very small batches)
 };
 
 // Spatially tiled fused block kernels (ir_tile_fused_kernel) for the high-resolution trunk stages.
@@ -385,6 +387,42 @@ const FusedTile kFusedTileSmall[] = {
     FTILE(32, 192, 192, 64, 5, 2, 16, 8, 1, 2, 32),    // 2 instead of 1
 };
 static_assert(sizeof(kFusedTileSmall) == sizeof(kFusedTile), "same blocks, same order");
+// a handful of crops (tiny plan): the smallest tiles the kernel supports, a tile's chunk loop is the latency that counts
+const FusedTile kFusedTileTiny[] = {
+    FTILE(16, 16, 16, 16, 3, 1, 32, 16, 0, 4, 128),
+    FTILE(16, 96, 96, 24, 3, 2, 16, 8, 1, 4, 128),
+    FTILE(24, 24, 32, 24, 3, 1, 16, 16, 0, 4, 64),
+    FTILE(24, 144, 144, 32, 5, 2, 16, 8, 1, 4, 64),
+    FTILE(32, 96, 96, 32, 5, 1, 16, 8, 1, 2, 32),      // 8 tiles per crop
+    FTILE(32, 192, 192, 32, 5, 1, 16, 8, 1, 2, 32),    // 8
+    FTILE(32, 192, 192, 32, 3, 1, 16, 8, 1, 2, 32),    // 8
+    FTILE(32, 192, 192, 64, 5, 2, 16, 8, 1, 2, 32),
+};
+static_assert(sizeof(kFusedTileTiny) == sizeof(kFusedTile), "same blocks, same order");
+// split-K variants of tiny-plan tiles (ir_tile_v2_kernel<..., KSPLIT>): the blocks whose chunk loop is the longest serial
+// stretch of a one-crop pass get gridDim.y workgroups per tile + a splitk_reduce launch
+struct TileKSplit {
+    int id, k;                                  // index into kFusedTileTiny, chunks per workgroup
+    void (*kernel)(IrT2Args);
+    int lds_bytes;
+};
+#define TKSPLIT(ID, K, CIN, CEXP, COUT, KS, ST, TW, TH, MINW) \
+    {ID, K, ir_tile_v2_kernel<CIN, CEXP, COUT, KS, ST, TW, TH, true, MINW, false, K>, IrT2Geom<CIN, CEXP, COUT, KS, ST, TW, TH, true>::LDS_BYTES}
+const TileKSplit kTileKSplit[] = {
+    TKSPLIT(3, 3, 24, 144, 32, 5, 2, 16, 8, 4),     // stage 6:  9 chunks -> 3 workgroups per tile
+    TKSPLIT(4, 2, 32, 96, 32, 5, 1, 16, 8, 2),      // stage 7:  6 chunks -> 3
+    TKSPLIT(5, 3, 32, 192, 32, 5, 1, 16, 8, 2),     // stage 8: 12 chunks -> 4
+    TKSPLIT(6, 3, 32, 192, 32, 3, 1, 16, 8, 2),     // stage 9: 12 chunks -> 4
+    TKSPLIT(7, 2, 32, 192, 64, 5, 2, 16, 8, 2),     // stage 10: 12 chunks -> 6 (two tiles per crop)
+};
+const TileKSplit* find_tile_ksplit(int id) {
+    for (const TileKSplit& t : kTileKSplit)
+        if (t.id == id) return &t;
+    return nullptr;
+}
+const FusedTile& fp32_tile(int small_tiles, int id) {
+    return small_tiles == 2 ? kFusedTileTiny[id] : small_tiles ? kFusedTileSmall[id] : kFusedTile[id];
+}
 
 int find_fused_tile(int cin, int cexp, int cout, int ks, int st, int expand, int hw) {
     for (size_t i = 0; i < sizeof(kFusedTile) / sizeof(kFusedTile[0]); ++i) {
@@ -404,6 +442,7 @@ const Fused16 kFused16H[] = {
     FUSED16H(112, 672, 112, 5, 1), FUSED16H(112, 336, 112, 5, 1),
     FUSED16H(256, 256, 256, 3, 0), FUSED16H(320, 320, 256, 3, 0),
     FUSED16H(256, 256, 16, 3, 0),
+    FUSED16H(320, 320, 16, 3, 0),
 };
 static_assert(sizeof(kFused16H) == sizeof(kFused16), "the two tables must list the same shapes in the same order");
 #define FUSED16B(CIN, CEXP, COUT, KS, EXP) \
@@ -414,6 +453,7 @@ const Fused16 kFused16B[] = {
     FUSED16B(112, 672, 112, 5, 1), FUSED16B(112, 336, 112, 5, 1),
     FUSED16B(256, 256, 256, 3, 0), FUSED16B(320, 320, 256, 3, 0),
     FUSED16B(256, 256, 16, 3, 0),
+    FUSED16B(320, 320, 16, 3, 0),
 };
 static_assert(sizeof(kFused16B) == sizeof(kFused16), "same shapes, same order");
 
@@ -477,6 +517,24 @@ int pack_fused16(fear_handle* h, int ce, int cd, int cp, float** out) {
     return upload(h, buf, out);
 }
 
+
+// N-split packing of a SepConv (Ir2Args::nsplit_wstride): one weight set per 16-channel output slice, each in the layout
+// sep16_kernel<CIN, 16, KS> stages — per 16-channel input chunk [1 projection fragment | Wd[k*k][16] | bd[16]].
+int pack_sep16_nsplit(fear_handle* h, int cd, int cp, float** out) {
+    const Conv& d = h->convs[cd];
+    const Conv& p = h->convs[cp];
+    const int cin = d.cout, cout = p.cout, kk = d.k * d.k;
+    std::vector<float> buf;
+    for (int n0 = 0; n0 < cout; n0 += 16)
+        for (int c0 = 0; c0 < cin; c0 += 16) {
+            for (int l = 0; l < 64; ++l)
+                for (int i = 0; i < 4; ++i) buf.push_back(p.w[(size_t)(n0 + (l & 15)) * cin + c0 + (l >> 4) * 4 + i]);
+            for (int t = 0; t < kk; ++t)
+                for (int ch = 0; ch < 16; ++ch) buf.push_back(d.w[(size_t)(c0 + ch) * kk + t]);
+            for (int ch = 0; ch < 16; ++ch) buf.push_back(d.has_bias ? d.b[c0 + ch] : 0.f);
+        }
+    return upload(h, buf, out);
+}
 
 // Packed weights for the matrix-pipe (fp16-split) fused kernels, per 32-channel chunk (IrHGeom layout):
 //   [A-part: 2 n-tiles x KG32 fragments of 64 lanes x 8 halfs | be[32] fp32]
@@ -655,7 +713,15 @@ int build_plan_uncached(fear_handle* h, int hw, bool with_head, int mode, Plan**
         Op op{};
         op.type = OP_IR16; op.fused_id = id; op.conv_e = ce; op.conv_d = cd; op.conv_p = cp;
         op.math = h->math;
-        if ((h->math ? pack_fused_h(h, ce, cd, cp, &op.d_packed, h->math == 2) : pack_fused16(h, ce, cd, cp, &op.d_packed)) != FEAR_OK)
+        // a handful of crops: a SepConv runs as COUT/16 independent 16-channel output slices, one workgroup each, every one
+        // with the whole (cheap) depthwise — finished outputs from one launch instead of split-K partials + a reduce launch
+        const int id16 = (mode == 2 && !h->math && ce < 0 && p.cout > 16 && p.cout % 16 == 0 && d.cout % 16 == 0)
+                             ? find_fused16(cin, d.cout, 16, d.k, 0) : -1;
+        if (id16 >= 0) {
+            op.nsplit = p.cout / 16;
+            op.fused_id = id16;
+            if (pack_sep16_nsplit(h, cd, cp, &op.d_packed) != FEAR_OK) return false;
+        } else if ((h->math ? pack_fused_h(h, ce, cd, cp, &op.d_packed, h->math == 2) : pack_fused16(h, ce, cd, cp, &op.d_packed)) != FEAR_OK)
             return false;
         op.in_buf = in.buf; op.in_ld = in.ld; op.in_off = in.off;
         op.H = 16; op.W = 16; op.Ho = 16; op.Wo = 16; op.C = cin; op.N = p.cout;
@@ -665,7 +731,7 @@ int build_plan_uncached(fear_handle* h, int hw, bool with_head, int mode, Plan**
         if (res) { op.res_buf = res->buf; op.res_ld = res->ld; }
         // small passes: one workgroup per crop leaves the GPU idle — split the expansion chunks of a crop over several
         // workgroups (each projects its own chunks), then add the partial projections up
-        if (!h->math && small && kFused16[id].kernel_splitk) {
+        if (!h->math && small && !op.nsplit && kFused16[id].kernel_splitk) {
             const int nchunk = d.cout / 16;
             int w = 0;
             if (kFused16[id].splitk_kc > 0) {
@@ -681,7 +747,8 @@ int build_plan_uncached(fear_handle* h, int hw, bool with_head, int mode, Plan**
                 pool.release(op.part_buf);          // only alive inside this op (the next acquire may reuse it)
             }
         }
-        snprintf(op.name, sizeof(op.name), op.splitk ? "%s_splitk_%dx%dx%d_k%d" : "%s_%dx%dx%d_k%d", tag, cin, d.cout, p.cout, d.k);
+        snprintf(op.name, sizeof(op.name), op.splitk ? "%s_splitk_%dx%dx%d_k%d" : op.nsplit ? "%s_nsplit_%dx%dx%d_k%d" : "%s_%dx%dx%d_k%d", tag, cin,
+                 d.cout, p.cout, d.k);
         op.flops = 2.0 * 256 * ((ce >= 0 ? (double)cin * d.cout : 0.0) + (double)d.cout * d.k * d.k + (double)d.cout * p.cout);
         op.bytes = 4.0 * 256 * (cin + p.cout + (res ? p.cout : 0));
         ops.push_back(op);
@@ -720,15 +787,15 @@ int build_plan_uncached(fear_handle* h, int hw, bool with_head, int mode, Plan**
         const int id = find_fused_tile(cin, d.cout, p.cout, d.k, d.stride, ce >= 0 ? 1 : 0, in.H);
         if (id < 0) return false;
         const int use_h = ce >= 0 ? h->math : 0;   // e1 blocks (no expand GEMM) stay on the fp32 kernel
-        const bool small_tiles = small && !use_h;
-        const FusedTile& f = use_h == 2 ? kFusedTileB[id] : use_h ? kFusedTileH[id] : (small_tiles ? kFusedTileSmall[id] : kFusedTile[id]);
+        const int small_tiles = small && !use_h ? (mode == 2 ? 2 : 1) : 0;
+        const FusedTile& f = use_h == 2 ? kFusedTileB[id] : use_h ? kFusedTileH[id] : fp32_tile(small_tiles, id);
         const int ho = in.H / d.stride;
         if (ho % f.th != 0 || ho % f.tw != 0) return false;
         if (!p.has_bias) return false;
         Op op{};
         op.type = OP_IRTILE; op.fused_id = id; op.conv_e = ce; op.conv_d = cd; op.conv_p = cp;
         op.math = use_h;
-        op.small_tiles = small_tiles ? 1 : 0;
+        op.small_tiles = small_tiles;
         if ((use_h ? pack_fused_h(h, ce, cd, cp, &op.d_packed, use_h == 2) : pack_fused16(h, ce, cd, cp, &op.d_packed)) != FEAR_OK)
             return false;
         op.in_buf = in.buf; op.in_ld = in.ld; op.in_off = in.off;
@@ -737,7 +804,17 @@ int build_plan_uncached(fear_handle* h, int hw, bool with_head, int mode, Plan**
         outT.buf = pool.acquire(); outT.ld = p.cout; outT.off = 0; outT.C = p.cout; outT.H = ho; outT.W = ho;
         op.out_buf = outT.buf; op.out_ld = outT.ld;
         if (res) { op.res_buf = res->buf; op.res_ld = res->ld; }
-        snprintf(op.name, sizeof(op.name), "irt_%dx%dx%d_k%ds%d_hw%d", cin, d.cout, p.cout, d.k, d.stride, in.H);
+        if (small_tiles == 2 && ce >= 0) {
+            if (const TileKSplit* ks = find_tile_ksplit(id)) {
+                op.splitk = d.cout / 16 / ks->k;
+                const size_t pe = (size_t)op.splitk * ho * ho * p.cout;
+                if (pe > max_elems) max_elems = pe;
+                op.part_buf = pool.acquire();
+                pool.release(op.part_buf);          // only alive inside this op
+            }
+        }
+        snprintf(op.name, sizeof(op.name), op.splitk ? "irt_splitk_%dx%dx%d_k%ds%d_hw%d" : "irt_%dx%dx%d_k%ds%d_hw%d", cin, d.cout, p.cout, d.k,
+                 d.stride, in.H);
         op.flops = 2.0 * ((ce >= 0 ? (double)in.H * in.W * cin * d.cout : 0.0) +
                           (double)ho * ho * d.cout * d.k * d.k + (double)ho * ho * d.cout * p.cout);
         op.bytes = 4.0 * ((double)in.H * in.W * cin + (double)ho * ho * p.cout * (res ? 2 : 1));
@@ -1106,6 +1183,12 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
         for (const FusedTile& f : kFusedTileSmall)
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(f.kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, f.lds_bytes));
+        for (const FusedTile& f : kFusedTileTiny)
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(f.kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, f.lds_bytes));
+        for (const TileKSplit& f : kTileKSplit)
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(f.kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, f.lds_bytes));
         for (const FusedTile& f : kFusedTileH)
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(f.kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, f.lds_bytes));
@@ -1243,7 +1326,11 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
                     a.Y = op.out_external == 3 ? ext.cls_out : ext.bbox_out;
                     a.pred_stride = op.out_external == 3 ? ext.cls_stride : ext.bbox_stride;
                 }
-                if (op.splitk) {
+                if (op.nsplit) {
+                    const Conv& dconv = h->convs[op.conv_d];
+                    a.nsplit_wstride = (long)(dconv.cout / 16) * (256 + dconv.k * dconv.k * 16 + 16);
+                    hipLaunchKernelGGL(f.kernel, dim3(n, op.nsplit), dim3(512), f.lds_bytes, s, a);
+                } else if (op.splitk) {
                     // several workgroups per crop, each over its own chunk range -> partial projections -> reduce
                     Ir2Args pa = a;
                     const Conv& dconv = h->convs[op.conv_d];
@@ -1270,7 +1357,7 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
             }
             case OP_IRTILE: {
                 const FusedTile& f = op.stem ? kStemTile : (op.math == 2 ? kFusedTileB[op.fused_id] : op.math ? kFusedTileH[op.fused_id] :
-                                                            (op.small_tiles ? kFusedTileSmall[op.fused_id] : kFusedTile[op.fused_id]));
+                                                            fp32_tile(op.small_tiles, op.fused_id));
                 IrT2Args ta{};
                 Ir2Args& a = ta.b;
                 if (op.stem) { a.X = ext.img; a.ldx = 0; }
@@ -1280,6 +1367,19 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
                 a.Y = buf(op.out_buf); a.ldy = op.out_ld;
                 a.relu_dw = op.relu_dw; a.relu_out = op.relu;
                 ta.H = op.H; ta.W = op.W; ta.tiles_x = op.Wo / f.tw; ta.tiles_y = op.Ho / f.th;
+                if (op.splitk) {
+                    const TileKSplit* ks = find_tile_ksplit(op.fused_id);
+                    SplitKReduceArgs ra{};
+                    ra.bias = a.bp; ra.R = a.R; ra.Y = a.Y; ra.W = op.splitk; ra.M = n * op.Ho * op.Wo; ra.N = op.N; ra.ldp = op.N;
+                    ra.ldr = a.ldr; ra.ldy = a.ldy; ra.relu = a.relu_out;
+                    ra.part_stride = (long)ra.M * op.N;
+                    a.Y = buf(op.part_buf); a.ldy = op.N; a.R = nullptr; a.kc_part_stride = ra.part_stride;
+                    ra.P = a.Y;
+                    hipLaunchKernelGGL(ks->kernel, dim3((unsigned)n * ta.tiles_x * ta.tiles_y, op.splitk), dim3(512), ks->lds_bytes, s, ta);
+                    const long total = (long)ra.M * (ra.N / 4);
+                    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ra);
+                    break;
+                }
                 hipLaunchKernelGGL(f.kernel, dim3((unsigned)n * ta.tiles_x * ta.tiles_y), dim3(64 * f.nw), f.lds_bytes, s, ta);
                 break;
             }

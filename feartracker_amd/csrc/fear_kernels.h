@@ -677,6 +677,11 @@ struct Ir2Args {
     // to Y + y * kc_part_stride; splitk_reduce_kernel adds the partials up
     int kc_count;
     long kc_part_stride;
+    // N-split (sep16_kernel<CIN, 16, KS> at very small batches): the layer's COUT_total = 16 * gridDim.y output channels are
+    // cut into 16-channel slices, workgroup y runs the whole depthwise and projects onto slice y — finished outputs (bias,
+    // ReLU), no partials and no reduce launch; the depthwise is recomputed per slice, which costs nothing when the GPU is
+    // otherwise idle.  nsplit_wstride = floats between the packed weight sets of two slices (0 = not an N-split launch).
+    long nsplit_wstride;
 };
 
 template <int CIN, int CEXP, int COUT, int KS, bool EXPAND>
@@ -1082,6 +1087,11 @@ __global__ __launch_bounds__(512) void sep16_kernel(Ir2Args a) {
     const long crop = blockIdx.x;
     const float* Xc = a.X + crop * 256 * a.ldx;
     const int y0 = wave * 2;
+    if (!SPLITK && !CORR && !PRED && a.nsplit_wstride) {      // N-split: this workgroup's 16-channel output slice
+        a.Wpk += (long)blockIdx.y * a.nsplit_wstride;
+        a.bp += blockIdx.y * COUT;
+        a.Y += blockIdx.y * COUT;
+    }
 
     for (int i = tid * 4; i < 2 * EBUF; i += 512 * 4) *reinterpret_cast<f32x4*>(lds + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (CORR) lds_copy_async<G::ZF>(a.Z + crop * a.z_stride, ZL, wave, lane);
@@ -1380,15 +1390,19 @@ struct IrT2Args {
 // STEM = true fuses the network stem in front of an e1 block: phase A is then the stem's 3x3 stride-2 conv as an
 // implicit GEMM (K = 27 -> 32) gathered straight from the caller's NCHW image (a.X), producing the stem output
 // (= the block input) only in LDS; the block's residual is read back from that LDS tile.  CIN must be 27.
-template <int CIN, int CEXPP, int COUT, int KS, int ST, int TW, int TH, bool EXPAND, int MINW, bool STEM = false>
+// KSPLIT = k > 0 (a handful of crops): gridDim.y workgroups per tile, workgroup y running the k expansion chunks from chunk
+// y*k on and writing its RAW partial projection to Y + y * kc_part_stride (splitk_reduce_kernel adds bias / residual / ReLU).
+template <int CIN, int CEXPP, int COUT, int KS, int ST, int TW, int TH, bool EXPAND, int MINW, bool STEM = false, int KSPLIT = 0>
 __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
     static_assert(!STEM || (EXPAND && CIN == 27 && ST == 1 && CEXPP == 16), "stem mode");
+    static_assert(KSPLIT == 0 || (!STEM && EXPAND && KSPLIT >= 2 && (CEXPP / 16) % KSPLIT == 0), "KSPLIT = chunks per workgroup");
     using G = IrT2Geom<CIN, CEXPP, COUT, KS, ST, TW, TH, EXPAND>;
     const Ir2Args& a = t.b;
     constexpr int P = G::P, IWR = G::IWR, IHR = G::IHR, ES = G::ES, SEG = G::SEG, MTC = G::MTC, MTA = G::MTA;
-    constexpr int NCHUNK = G::NCHUNK, NTP = G::NTP, KG = G::KG, AP = G::AP, BP = G::BP, EBUF = G::EBUF, EPX = G::EPX;
+    constexpr int NCHUNK = KSPLIT ? KSPLIT : G::NCHUNK, NTP = G::NTP, KG = G::KG, AP = G::AP, BP = G::BP, EBUF = G::EBUF, EPX = G::EPX;
     constexpr bool KHALF = G::KHALF;
     constexpr int CST = AP + BP, W4 = CST / 4, NRW = (W4 + 511) / 512;
+    const int c_base = KSPLIT ? (int)blockIdx.y * KSPLIT : 0;         // first chunk of this workgroup
     static_assert(G::NMT_OUT % 8 == 0 && (SEG == 1 || SEG == 2), "tile shape");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* const E = lds;               // [EBUF]
@@ -1419,7 +1433,7 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
 #pragma unroll
         for (int r = 0; r < NRW; ++r) {
             const int idx = tid + r * 512;
-            if (idx < W4) rw[r] = *reinterpret_cast<const f32x4*>(a.Wpk + (long)c * CST + idx * 4);
+            if (idx < W4) rw[r] = *reinterpret_cast<const f32x4*>(a.Wpk + (long)(c_base + c) * CST + idx * 4);
         }
     };
     auto store_w = [&](int c) {
@@ -1623,6 +1637,20 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
     }
     const long long tk_loop_end = (FEAR_ABL & 4096) ? wall_clock64() : 0;
 
+    if (KSPLIT) {
+        float* Yp = a.Y + (long)blockIdx.y * a.kc_part_stride;
+#pragma unroll
+        for (int nt = 0; nt < NTP; ++nt) {
+            const int n = nt * 16 + lk * 4;
+            if (n >= COUT) continue;
+#pragma unroll
+            for (int r = 0; r < MTC; ++r) {
+                const long m = (crop * Ho + oy0 + r0 + r) * Wo + ox0 + seg * 16 + li;
+                *reinterpret_cast<f32x4*>(Yp + m * a.ldy + n) = accp[r][nt];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int nt = 0; nt < NTP; ++nt) {
         const int n = nt * 16 + lk * 4;

@@ -456,6 +456,18 @@ def test_small_batch_plan_vs_oracle_and_clip(oracle_net, golden_dir):
     for _ in range(20):                      # the two streams and the partial-sum scratch must not race
         b2, c2 = net.track_maps(x.cuda(), net.get_features(t.cuda()))
         assert torch.equal(b, b2) and torch.equal(c, c2)
+    # 9..96 crops: the small-batch plan proper (split-K head, 16x16 / 16x8 tiles); the <= 8-crop pass above ran the tiny plan
+    # (N-split head slices, 16x8 tiles everywhere)
+    net12 = FEARNetHIP(WEIGHTS, device=0, max_batch=12)
+    names12 = [n for n, _, _ in net12.plan(256, True)]
+    assert any("sep16_splitk" in n for n in names12) and not any("nsplit" in n for n in names12)
+    assert any("sep16_nsplit" in n for n, _, _ in net.plan(256, True))
+    x12 = norm_u8(torch.randint(0, 256, (12, 3, 256, 256), dtype=torch.uint8, generator=g))
+    t12 = norm_u8(torch.randint(0, 256, (12, 3, 128, 128), dtype=torch.uint8, generator=g))
+    ref12 = oracle_net.track(x12, oracle_net.get_features(t12))
+    b12, c12 = net12.track_maps(x12.cuda(), net12.get_features(t12.cuda()))
+    assert_maps_close(b12, c12, ref12["TARGET_REGRESSION_LABEL_KEY"], ref12["TARGET_CLASSIFICATION_KEY"])
+    assert_argmax_identity(net12, b12, c12, ref12["TARGET_CLASSIFICATION_KEY"])
     d = np.load(f"{golden_dir}/clip_synth.npz")
     trk = FEARTracker(FEARNetHIP(WEIGHTS, device=0, max_batch=1), cuda_id=0, **DEFAULT_TRACKING_CONFIG)
     trk.initialize(d["frames"][0], d["init_bbox"])
@@ -612,9 +624,14 @@ def test_plan_introspection_follows_the_pass_size():
     counts_full = [c for _, c in net.profile_read(256, True)]
     net.set_profile(False)
     assert all(c == 1 for c in counts_one) and all(c == 0 for c in counts_full)
-    # a pass of 20 crops takes the small-batch plan with the shallower split: same op list, fewer workgroups per crop
+    # a pass of 20 crops takes the small-batch plan: same blocks, but the head's SepConvs are split over input chunks
+    # (partials + reduce) where the one-crop plan cuts them into 16-channel output slices (finished outputs, no reduce), and
+    # the one-crop plan also splits the expansion chunks of the 32x32-map tiles over several workgroups
     net.set_plan_crops(20)
-    assert [n for n, _, _ in net.plan(256, True)] == one
+    twenty = [n for n, _, _ in net.plan(256, True)]
+    assert [n.replace("_nsplit_", "_splitk_").replace("irt_splitk_", "irt_") for n in one] == twenty
+    assert any("sep16_nsplit" in n for n in one) and not any("nsplit" in n for n in twenty)
+    assert any(n.startswith("irt_splitk_") for n in one) and not any(n.startswith("irt_splitk_") for n in twenty)
 
 
 def test_option_toggles_do_not_leak_device_memory():
