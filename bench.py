@@ -315,6 +315,7 @@ def main() -> None:
                     help="skip the supplementary run in the other arithmetic mode (profiling runs: keeps the trace to one plan)")
     ap.add_argument("--dump-ops", action="store_true", help="print the per-kernel time table to stderr")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 tracker latency object")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the two-handles-on-two-streams supplementary number")
     ap.add_argument("--no-train", action="store_true", help="skip the BASELINE configs[4] object (head training step, first slice)")
     ap.add_argument("--no-fear-m", action="store_true", help="skip the BASELINE configs[3] object (synthetic FEAR-M, bf16, B=512)")
     args = ap.parse_args()
@@ -446,6 +447,33 @@ def main() -> None:
         barrier()
         gather_ms = 1e3 * (time.perf_counter() - tg) / args.steps
 
+    # supplementary: the same K steps dealt alternately to TWO engine handles on two HIP streams (each step is still one whole
+    # batch of B crops through one handle; consecutive independent batches overlap, so one batch's kernel tails are filled by
+    # the other's kernels).  What a serving loop with two batches in flight gets; never `value`.
+    elapsed_pipe = None
+    if not args.no_pipelined and not use_dist:
+        net_b = FEARNetHIP(DEFAULT_WEIGHTS, device=local_rank, max_batch=args.max_batch)
+        net_b.set_math(args.math)
+        bbox_b, cls_b = torch.empty_like(bbox), torch.empty_like(cls)
+        streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        lanes = [(net, bbox, cls), (net_b, bbox_b, cls_b)]
+
+        def pipelined(k):
+            for i in range(k):
+                nn, bb, cc = lanes[i & 1]
+                with torch.cuda.stream(streams[i & 1]):
+                    nn.track_maps(search, tmpl_feats, out=(bb, cc))
+        torch.cuda.synchronize()
+        pipelined(max(4, args.warmup // 2))
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        pipelined(args.steps)
+        torch.cuda.synchronize()
+        elapsed_pipe = time.perf_counter() - tp
+        same = bool(torch.equal(bbox, bbox_b) and torch.equal(cls, cls_b))
+        del net_b, lanes
+        torch.cuda.empty_cache()
+
     # the same K steps in the other arithmetic mode (supplementary number, same protocol)
     other = 1 - args.math
     elapsed_other = None
@@ -521,6 +549,12 @@ def main() -> None:
                          "fp32 MFMA (exact fp32)"),
                 "value": world * B * args.steps / elapsed_other, "unit": "crops/s",
                 "ms_per_step": 1e3 * elapsed_other / args.steps}
+        if elapsed_pipe is not None:
+            out["pipelined_two_streams"] = {
+                "what": "the same K batches dealt alternately to two engine handles on two HIP streams (two independent batches in "
+                        "flight); supplementary, never `value`",
+                "value": B * args.steps / elapsed_pipe, "unit": "crops/s", "ms_per_step": 1e3 * elapsed_pipe / args.steps,
+                "outputs_identical_between_handles": same}
         if use_dist:
             out["collective"] = {"backend": "nccl (RCCL)", "ranks": world, "op": "all_gather_into_tensor",
                                  "bytes_per_rank": B * 5 * 16 * 16 * 4, "ms_alone": gather_ms}

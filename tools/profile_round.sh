@@ -13,11 +13,11 @@ cd /tmp && export TMPDIR=/tmp
 python "$R/bench.py" > "$O/bench.json" 2> "$O/bench.err"
 for m in 0 1; do
   rocprofv3 --kernel-trace --stats -d "$O/trace_math$m" -o p --output-format csv -- \
-    python "$R/bench.py" --steps 20 --warmup 5 --math $m --no-cpu-baseline --no-other-math --no-latency --no-fear-m --no-train --dump-ops > "$O/trace_math$m.json" 2> "$O/trace_math$m.err"
+    python "$R/bench.py" --steps 20 --warmup 5 --math $m --no-cpu-baseline --no-other-math --no-pipelined --no-latency --no-fear-m --no-train --dump-ops > "$O/trace_math$m.json" 2> "$O/trace_math$m.err"
 done
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c -d "$O/pmc_$c" -o p --output-format csv -- \
-    python "$R/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-other-math --no-latency --no-fear-m --no-train > "$O/pmc_$c.json" 2> "$O/pmc_$c.err"
+    python "$R/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-other-math --no-pipelined --no-latency --no-fear-m --no-train > "$O/pmc_$c.json" 2> "$O/pmc_$c.err"
 done
 python "$R/bench_latency.py" > "$O/latency.json" 2> "$O/latency.err"
 # the distributed code path (RCCL process group, barriers, fear_track_packed + all-gather) with the one rank a 1-GPU box has

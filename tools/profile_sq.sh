@@ -13,6 +13,6 @@ for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU
            "SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $set -d "$O/pass$i" -o p --output-format csv -- \
-    python "$R/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-other-math --no-latency --no-fear-m --no-train > "$O/pass$i.json" 2> "$O/pass$i.err"
+    python "$R/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-other-math --no-pipelined --no-latency --no-fear-m --no-train > "$O/pass$i.json" 2> "$O/pass$i.err"
 done
 ls "$O"
