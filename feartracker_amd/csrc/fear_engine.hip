@@ -209,8 +209,15 @@ int parse_model(fear_handle* h, const uint8_t* blob, size_t nbytes) {
     if (nbytes < sizeof(FearwHeader)) return FEAR_ERR_FORMAT;
     FearwHeader hd;
     memcpy(&hd, blob, sizeof(hd));
-    if (memcmp(hd.magic, FEARW_MAGIC, 8) != 0 || hd.version != FEARW_VERSION || hd.payload_dtype != 0)
+    if (memcmp(hd.magic, FEARW_MAGIC, 8) != 0 || hd.version != FEARW_VERSION || hd.payload_dtype > FEARW_PAYLOAD_F32)
         return FEAR_ERR_FORMAT;
+    const size_t esz = hd.payload_dtype == FEARW_PAYLOAD_F32 ? 4 : 2;
+    auto read_elems = [&](const uint8_t* src, size_t n, std::vector<float>& dst) {
+        dst.resize(n);
+        if (esz == 4) memcpy(dst.data(), src, n * 4);
+        else
+            for (size_t j = 0; j < n; ++j) { uint16_t v; memcpy(&v, src + 2 * j, 2); dst[j] = half_to_float(v); }
+    };
     const size_t tables = sizeof(FearwHeader) + (size_t)hd.n_convs * sizeof(FearwConv) +
                           (size_t)hd.n_blocks * sizeof(FearwBlock);
     if (tables > nbytes || hd.payload_bytes > nbytes - tables) return FEAR_ERR_FORMAT;
@@ -230,16 +237,12 @@ int parse_model(fear_handle* h, const uint8_t* blob, size_t nbytes) {
             (c.k != 1 && c.k != 3 && c.k != 5))
             return FEAR_ERR_FORMAT;
         const size_t nw = (size_t)c.cout * c.cin_g * c.k * c.k;
-        if (fc.w_off > hd.payload_bytes || nw * 2 > hd.payload_bytes - fc.w_off) return FEAR_ERR_FORMAT;
+        if (fc.w_off > hd.payload_bytes || nw * esz > hd.payload_bytes - fc.w_off) return FEAR_ERR_FORMAT;
         if (c.pad != c.k / 2 || (c.stride != 1 && c.stride != 2)) return FEAR_ERR_FORMAT;
-        c.w.resize(nw);
-        const uint16_t* src = reinterpret_cast<const uint16_t*>(payload + fc.w_off);
-        for (size_t j = 0; j < nw; ++j) c.w[j] = half_to_float(src[j]);
+        read_elems(payload + fc.w_off, nw, c.w);
         if (c.has_bias) {
-            if (fc.b_off > hd.payload_bytes || (size_t)c.cout * 2 > hd.payload_bytes - fc.b_off) return FEAR_ERR_FORMAT;
-            c.b.resize(c.cout);
-            const uint16_t* bs = reinterpret_cast<const uint16_t*>(payload + fc.b_off);
-            for (int j = 0; j < c.cout; ++j) c.b[j] = half_to_float(bs[j]);
+            if (fc.b_off > hd.payload_bytes || (size_t)c.cout * esz > hd.payload_bytes - fc.b_off) return FEAR_ERR_FORMAT;
+            read_elems(payload + fc.b_off, (size_t)c.cout, c.b);
         }
     }
     h->blocks.resize(hd.n_blocks);

@@ -284,6 +284,18 @@ class FEARNetTrainHIP:
 
     allreduce_gradients = staticmethod(BoxTowerTrainHIP.allreduce_gradients)
 
+    def running_stats(self) -> Dict[str, torch.Tensor]:
+        """{"<bn>.running_mean" / "<bn>.running_var": device tensor} of every BatchNorm, as updated by the `step` calls so far
+        (template pass first, then the search pass, like two forward calls of the shared trunk) — what `export.py` folds."""
+        out = {"connect_model." + k: v for k, v in self.head.running_stats().items()}
+        layers = [self.stem, self.neck]
+        for blk in self.blocks:
+            layers += [L for L in (blk["pw"], blk["dw"], blk["pwl"]) if L is not None]
+        for L in layers:
+            out[L.bn_key + ".running_mean"] = L.running_mean
+            out[L.bn_key + ".running_var"] = L.running_var
+        return out
+
     def relu_patterns(self) -> Dict[str, List[torch.Tensor]]:
         """{conv name: [template-pass mask, search-pass mask]} (bool, NCHW, CPU) of every ReLU of the last `step`'s trunk passes,
         and {head layer prefix: [mask]} for the head — which elements the forward treated as active."""

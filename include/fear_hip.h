@@ -110,6 +110,9 @@ int fear_crop_normalize(fear_handle* h, const uint8_t* frame_u8, int frame_h, in
                                /*   0 (default) fp32 operands, v_mfma_f32_16x16x4_f32 (exact fp32) */
                                /*   1 fp32 activations split into fp16 hi+lo, exact-fp16 weights,  */
                                /*     v_mfma_f32_16x16x32_f16 on the matrix pipe, fp32 accumulate  */
+                               /*     (fp32-grade for an fp16 payload — every shipped model; the    */
+                               /*     weights of an fp32 payload, fearw_format.h, are ROUNDED to    */
+                               /*     fp16 in this mode)                                            */
                                /*   2 activations and weights rounded to bf16, v_mfma_f32_16x16x32_bf16,*/
                                /*     fp32 accumulate: reduced precision (BASELINE config "bf16")  */
 #define FEAR_OPT_CHAIN 6       /* 1 (default): stride-16 trunk stage + neck as one register-resident chain kernel */

@@ -8,7 +8,8 @@
  *
  *   [FearwHeader 64 B][FearwConv x n_convs][FearwBlock x n_blocks][payload]
  *
- * Payload holds IEEE fp16 values exactly as stored in the .mlmodel: conv weights in
+ * Payload holds IEEE fp16 values exactly as stored in the .mlmodel (payload_dtype 0) — or fp32 values
+ * (payload_dtype 1: weights exported from a training state, feartracker_amd/export.py) —: conv weights in
  * [Cout][Cin/groups][kH][kW] order followed by Cout biases when has_bias is set.
  * Offsets are bytes from the start of the payload, 16-byte aligned per conv.
  */
@@ -38,6 +39,8 @@ enum FearwRole {
     FEARW_BBOX_PRED = 7,  FEARW_CLS_PRED = 8
 };
 
+enum FearwPayload { FEARW_PAYLOAD_F16 = 0, FEARW_PAYLOAD_F32 = 1 };
+
 enum FearwAct { FEARW_ACT_NONE = 0, FEARW_ACT_RELU = 1, FEARW_ACT_EXP = 2 };
 
 typedef struct FearwHeader {
@@ -45,7 +48,7 @@ typedef struct FearwHeader {
     uint32_t version;
     uint32_t n_convs;
     uint32_t n_blocks;
-    uint32_t payload_dtype; /* 0 = fp16 */
+    uint32_t payload_dtype; /* 0 = fp16, 1 = fp32 (FearwPayload) */
     uint64_t payload_bytes;
     uint8_t  reserved[32];
 } FearwHeader; /* 64 bytes */

@@ -50,8 +50,9 @@ def load_fearw(path: str) -> Dict:
     with open(path, "rb") as fh:
         buf = fh.read()
     magic, version, n_convs, n_blocks, dtype, payload_bytes = struct.unpack_from("<8s4IQ", buf, 0)
-    if magic != b"FEARW1\0\0" or version != 1 or dtype != 0:
-        raise ValueError(f"{path}: not a FEARW1/fp16 file")
+    if magic != b"FEARW1\0\0" or version != 1 or dtype not in (0, 1):
+        raise ValueError(f"{path}: not a FEARW1 file with an fp16 / fp32 payload")
+    ety = "<f4" if dtype == 1 else "<f2"
     off = 64
     convs = []
     entries = []
@@ -69,11 +70,11 @@ def load_fearw(path: str) -> Dict:
         raise ValueError(f"{path}: truncated payload")
     for cout, cin_g, groups, k, stride, pad, relu, has_bias, w_off, b_off, name in entries:
         nw = cout * cin_g * k * k
-        w = np.frombuffer(payload, dtype="<f2", count=nw, offset=w_off).astype(np.float32)
+        w = np.frombuffer(payload, dtype=ety, count=nw, offset=w_off).astype(np.float32)
         w = torch.from_numpy(w.reshape(cout, cin_g, k, k).copy())
         b = None
         if has_bias:
-            b = torch.from_numpy(np.frombuffer(payload, dtype="<f2", count=cout, offset=b_off).astype(np.float32).copy())
+            b = torch.from_numpy(np.frombuffer(payload, dtype=ety, count=cout, offset=b_off).astype(np.float32).copy())
         convs.append(dict(w=w, b=b, groups=groups, k=k, stride=stride, pad=pad, relu=bool(relu),
                           name=name.rstrip(b"\0").decode()))
     return dict(convs=convs, blocks=blocks)

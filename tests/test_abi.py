@@ -95,6 +95,12 @@ def test_malformed_tables_are_rejected_not_followed():
     bad = bytearray(blob)
     struct.pack_into("<I", bad, conv0 + 12, 7)                        # kernel size 7
     assert create(bad) == -3
+    bad = bytearray(blob)
+    struct.pack_into("<I", bad, 20, 2)                                # payload_dtype: only 0 (fp16) and 1 (fp32) exist
+    assert create(bad) == -3
+    bad = bytearray(blob)
+    struct.pack_into("<I", bad, 20, 1)                                # an fp16 payload declared fp32: the last convs run past it
+    assert create(bad) == -3
 
 
 def test_product_fails_loudly_without_gpu():
