@@ -619,6 +619,30 @@ __global__ __launch_bounds__(256) void add_kernel(const float* x, const float* y
     else for (long j = i; j < n; ++j) out[j] = x[j] + y[j];
 }
 
+// torch.optim.Adam (no amsgrad), one element per thread: the reference's optimiser (train/base_lightning_model.py:63-64)
+struct AdamArgs {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    long n;
+    float lr_over_bc1, beta1, beta2, eps, weight_decay, bc2_sqrt;
+};
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    float g = a.g[i];
+    const float p = a.p[i];
+    if (a.weight_decay != 0.f) g += a.weight_decay * p;
+    const float m = a.m[i] + (g - a.m[i]) * (1.f - a.beta1);          // exp_avg.lerp_(grad, 1 - beta1)
+    const float v = a.v[i] * a.beta2 + (1.f - a.beta2) * g * g;       // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+    a.m[i] = m;
+    a.v[i] = v;
+    a.p[i] = p - a.lr_over_bc1 * (m / denom);
+}
+
 int train_pick_nt(int n_tiles) {
     for (int nt : {8, 7, 6, 4, 3, 2, 1})
         if (n_tiles % nt == 0) return nt;
@@ -995,6 +1019,21 @@ int fear_add(const float* a, const float* b, float* out, long n, void* stream) {
     if (n == 0) return FEAR_TRAIN_OK;
     if (!a || !b || !out) return FEAR_TRAIN_ERR_NULL;
     hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), a, b, out, n);
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+int fear_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, double lr, double beta1, double beta2,
+                   double eps, double weight_decay, int step, void* stream) {
+    if (n == 0) return FEAR_TRAIN_OK;
+    if (!param || !grad || !exp_avg || !exp_avg_sq) return FEAR_TRAIN_ERR_NULL;
+    if (n < 0 || step < 1 || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0)) return FEAR_TRAIN_ERR_SHAPE;
+    AdamArgs a{};
+    a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.n = n;
+    a.beta1 = (float)beta1; a.beta2 = (float)beta2; a.eps = (float)eps; a.weight_decay = (float)weight_decay;
+    a.lr_over_bc1 = (float)(lr / (1.0 - pow(beta1, step)));           // step_size = lr / bias_correction1
+    a.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, step));
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     LAUNCH_CHECK();
     return FEAR_TRAIN_OK;
 }

@@ -47,6 +47,7 @@ TRAIN_SYMBOLS = {
     "fear_nhwc_to_nchw": ([_P, _P, _l, _i, _i, _i, _i, _P], _i),
     "fear_scale_column": ([_P, _i, _i, _f, _P, _i, _i, _l, _P], _i),
     "fear_add": ([_P, _P, _P, _l, _P], _i),
+    "fear_adam_step": ([_P, _P, _P, _P, _l, _d, _d, _d, _d, _d, _i, _P], _i),
 }
 
 _bound = None
@@ -290,6 +291,40 @@ class BoxTowerTrainHIP:
             out[n] = flat[off: off + k].reshape(grads[n].shape)
             off += k
         return out
+
+    def parameter_slots(self) -> Dict[str, tuple]:
+        """{parameter name: (storage tensor, to_storage, to_torch)}: the device tensor the kernels read (kernel layout: depthwise
+        taps [9][C], pointwise rows padded to a multiple of 4), a function mapping a gradient / value in the reference's
+        layout onto it, and its inverse.  What `optim.AdamHIP` updates and `state_dict` reads."""
+        slots: Dict[str, tuple] = {}
+
+        def add_sep(L: _Sep):
+            C, N, n = L.cin, L.cout, L.n
+            slots[L.prefix + ".depthwise.weight"] = (L.taps, lambda g, C=C: g.reshape(C, 9).t().contiguous(),
+                                                     lambda t, C=C: t.t().reshape(C, 1, 3, 3))
+            if L.dw_bias is not None:
+                slots[L.prefix + ".depthwise.bias"] = (L.dw_bias, lambda g: g.contiguous(), lambda t: t.clone())
+
+            def pad_rows(g, N=N, n=n, C=C):
+                out = torch.zeros(n, C, dtype=torch.float32, device=g.device)
+                out[:N] = g.reshape(N, C)
+                return out
+            slots[L.prefix + ".pointwise.weight"] = (L.w, pad_rows, lambda t, N=N, C=C: t[:N].reshape(N, C, 1, 1).clone())
+            if L.pw_bias is not None:
+                def pad_vec(g, N=N, n=n):
+                    out = torch.zeros(n, dtype=torch.float32, device=g.device)
+                    out[:N] = g.reshape(N)
+                    return out
+                slots[L.prefix + ".pointwise.bias"] = (L.pw_bias, pad_vec, lambda t, N=N: t[:N].clone())
+            if L.bn_prefix:
+                slots[L.bn_prefix + ".weight"] = (L.gamma, lambda g: g.contiguous(), lambda t: t.clone())
+                slots[L.bn_prefix + ".bias"] = (L.beta, lambda g: g.contiguous(), lambda t: t.clone())
+        for br in self.branches.values():
+            for L in [br["enc"], br["corr"]] + br["tower"] + [br["pred"]]:
+                add_sep(L)
+        slots["adjust"] = (self.adjust, lambda g: g.reshape(1).contiguous(), lambda t: t.reshape(1).clone())
+        slots["bias"] = (self.bias4, lambda g: g.reshape(4).contiguous(), lambda t: t.reshape(1, 4, 1, 1).clone())
+        return slots
 
     def running_stats(self) -> Dict[str, torch.Tensor]:
         out = {}

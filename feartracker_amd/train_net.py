@@ -284,6 +284,37 @@ class FEARNetTrainHIP:
 
     allreduce_gradients = staticmethod(BoxTowerTrainHIP.allreduce_gradients)
 
+    def parameter_slots(self) -> Dict[str, tuple]:
+        """{parameter name: (storage tensor, to_storage, to_torch)} of every trainable parameter (see
+        `BoxTowerTrainHIP.parameter_slots`): depthwise weights live as taps [k*k][C], the stem as [16][28] rows."""
+        slots = {"connect_model." + k: v for k, v in self.head.parameter_slots().items()}
+        layers = [self.stem, self.neck]
+        for blk in self.blocks:
+            layers += [L for L in (blk["pw"], blk["dw"], blk["pwl"]) if L is not None]
+        for L in layers:
+            N, K, k = L.cout, L.cin, L.k
+            if L.kind == "dw":
+                slots[L.conv_key] = (L.w, lambda g, N=N, k=k: g.reshape(N, k * k).t().contiguous(),
+                                     lambda t, N=N, k=k: t.t().reshape(N, 1, k, k))
+            elif L.kind == "stem":
+                def pad28(g, N=N):
+                    out = torch.zeros(N, 28, dtype=torch.float32, device=g.device)
+                    out[:, :27] = g.reshape(N, 27)
+                    return out
+                slots[L.conv_key] = (L.w, pad28, lambda t, N=N: t[:, :27].reshape(N, 3, 3, 3).clone())
+            else:
+                slots[L.conv_key] = (L.w, lambda g, N=N, K=K: g.reshape(N, K).contiguous(), lambda t, N=N, K=K: t.reshape(N, K, 1, 1).clone())
+            slots[L.bn_key + ".weight"] = (L.gamma, lambda g: g.contiguous(), lambda t: t.clone())
+            slots[L.bn_key + ".bias"] = (L.beta, lambda g: g.contiguous(), lambda t: t.clone())
+        return slots
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        """Current parameters and BatchNorm running statistics in the reference's layouts (CPU tensors, the keys of
+        `random_init_state`): what `export.export_training_state` turns into inference weights."""
+        out = {name: to_torch(t).cpu() for name, (t, _, to_torch) in self.parameter_slots().items()}
+        out.update({k: v.cpu().clone() for k, v in self.running_stats().items()})
+        return out
+
     def running_stats(self) -> Dict[str, torch.Tensor]:
         """{"<bn>.running_mean" / "<bn>.running_var": device tensor} of every BatchNorm, as updated by the `step` calls so far
         (template pass first, then the search pass, like two forward calls of the shared trunk) — what `export.py` folds."""

@@ -99,6 +99,12 @@ int fear_scale_column(const float* in, int ld_in, int col_in, float scale, float
 /* out = a + b over n floats: gradient accumulation where the two branches of the head meet */
 int fear_add(const float* a, const float* b, float* out, long n, void* stream);
 
+/* One torch.optim.Adam update (no amsgrad; weight_decay is the L2 form added to the gradient) of n parameters in place — the
+ * reference's optimiser is Adam(lr = 1e-4) (train/base_lightning_model.py:63-64).  `step` counts from 1 (bias corrections
+ * 1 - beta^step are taken in double on the host, like torch's Python scalars); exp_avg / exp_avg_sq start at zero. */
+int fear_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, double lr, double beta1, double beta2,
+                   double eps, double weight_decay, int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
