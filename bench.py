@@ -163,7 +163,7 @@ def config5_train_step(dev, batch: int = 128, steps: int = 5, warmup: int = 2):
     on the HIP operators of include/fear_train.h (feartracker_amd/train_net.py), random init, synthetic crops and targets.  With
     several ranks the gradients are averaged by one all-reduce of the flat 1.37 M-float buffer (not part of this 1-GPU number).
     Correctness: tests/test_train_head.py (every gradient vs autograd; the head additionally vs the reference's own classes).
-    These operators are a first, unfused implementation (one kernel per layer and direction): the number is a baseline."""
+    One kernel per layer and direction (HBM-bound passes; DESIGN.md §7 N3 lists what fusing them would save)."""
     from feartracker_amd.train_net import FEARNetTrainHIP, random_init_state
     g = torch.Generator().manual_seed(7)
     net = FEARNetTrainHIP(random_init_state(3), device=dev.index)
@@ -180,6 +180,16 @@ def config5_train_step(dev, batch: int = 128, steps: int = 5, warmup: int = 2):
         out = net.step(tmpl, srch, gt_reg, gt_cls, gt_w)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    # the optimiser update of the reference (Adam, lr 1e-4) on the same parameters, timed on its own (not part of "fwd/bwd")
+    from feartracker_amd.optim import AdamHIP
+    opt = AdamHIP(net)
+    opt.step(out["grads"])
+    torch.cuda.synchronize()
+    ta = time.perf_counter()
+    for _ in range(steps):
+        opt.step(out["grads"])
+    torch.cuda.synchronize()
+    adam_ms = 1e3 * (time.perf_counter() - ta) / steps
     fwd_macs = 461_393_920 + 75_970_000           # search path + template path, forward MACs per pair
     nparams = sum(v.numel() for v in out["grads"].values())
     return {"workload": f"FEARNet training step (trunk + neck on both crops, correlation head, FEARLoss; forward in train mode + "
@@ -187,7 +197,7 @@ def config5_train_step(dev, batch: int = 128, steps: int = 5, warmup: int = 2):
             "value": batch / dt, "unit": "pairs/s per GPU", "ms_per_step": 1e3 * dt, "steps": steps, "warmup": warmup,
             "approx_tflops": 3 * 2 * fwd_macs * batch / dt / 1e12,
             "loss": [float(out["loss_cls"]), float(out["loss_reg"])], "dtype": "f32",
-            "parameter_tensors_with_gradients": len(out["grads"]), "parameters": nparams,
+            "parameter_tensors_with_gradients": len(out["grads"]), "parameters": nparams, "adam_update_ms": adam_ms,
             "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
 
 
