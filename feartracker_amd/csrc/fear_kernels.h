@@ -1382,6 +1382,17 @@ struct IrT2Geom {
     static constexpr int LDS_BYTES = (EBUF + NSTAGE * (AP + BP) + DUMMY) * 4;
 };
 
+// Workgroups of a 1-D grid are dealt round-robin to the 8 XCDs (workgroup b runs on XCD b % 8), each with its own L2.  The tile
+// kernels want neighbouring tiles of a crop — which share their halo rows and columns — behind the SAME L2: logical tile
+// index = (b % 8) * (n / 8) + b / 8 hands every XCD one contiguous eighth of the tile list (whole crops), walked in order.
+// FEAR_XCD_SWIZZLE=0 keeps the linear order (tools/kbench A/B).
+#ifndef FEAR_XCD_SWIZZLE
+#define FEAR_XCD_SWIZZLE 1
+#endif
+__device__ __forceinline__ unsigned xcd_tile_index(unsigned b, unsigned n) {
+    return (FEAR_XCD_SWIZZLE && n % 8 == 0) ? (b & 7) * (n >> 3) + (b >> 3) : b;
+}
+
 struct IrT2Args {
     Ir2Args b;
     int H, W, tiles_x, tiles_y;
@@ -1412,8 +1423,9 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int tiles = t.tiles_x * t.tiles_y;
-    const long crop = blockIdx.x / tiles;
-    const int tile = blockIdx.x % tiles;
+    const unsigned tix = xcd_tile_index(blockIdx.x, gridDim.x);
+    const long crop = tix / tiles;
+    const int tile = tix % tiles;
     const int ox0 = (tile % t.tiles_x) * TW, oy0 = (tile / t.tiles_x) * TH;
     const int ix0 = ox0 * ST - P, iy0 = oy0 * ST - P;
     const int cx_lo = max(ix0, 0), cy_lo = max(iy0, 0);
@@ -2028,8 +2040,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void ir_tile_h_kernel(IrT2Args t) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int tiles = t.tiles_x * t.tiles_y;
-    const long crop = blockIdx.x / tiles;
-    const int tile = blockIdx.x % tiles;
+    const unsigned tix = xcd_tile_index(blockIdx.x, gridDim.x);
+    const long crop = tix / tiles;
+    const int tile = tix % tiles;
     const int ox0 = (tile % t.tiles_x) * TW, oy0 = (tile / t.tiles_x) * TH;
     const int ix0 = ox0 * ST - P, iy0 = oy0 * ST - P;
     const int cx_lo = max(ix0, 0), cy_lo = max(iy0, 0);
