@@ -325,6 +325,8 @@ def main() -> None:
                     help="skip the supplementary run in the other arithmetic mode (profiling runs: keeps the trace to one plan)")
     ap.add_argument("--dump-ops", action="store_true", help="print the per-kernel time table to stderr")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 tracker latency object")
+    ap.add_argument("--no-overlap", action="store_true", help="multi-GPU: blocking all-gather inside the step instead of the "
+                    "double-buffered collective that overlaps the next batch")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the two-handles-on-two-streams supplementary number")
     ap.add_argument("--no-train", action="store_true", help="skip the BASELINE configs[4] object (head training step, first slice)")
     ap.add_argument("--no-fear-m", action="store_true", help="skip the BASELINE configs[3] object (synthetic FEAR-M, bf16, B=512)")
@@ -367,7 +369,7 @@ def main() -> None:
             torch.cuda.synchronize()
 
     from feartracker_amd import FEARNetHIP, DEFAULT_WEIGHTS
-    from feartracker_amd.sharding import gather_packed
+    from feartracker_amd.sharding import OverlappedGather, gather_packed
 
     B = args.batch
     net = FEARNetHIP(DEFAULT_WEIGHTS, device=local_rank, max_batch=args.max_batch)
@@ -383,16 +385,24 @@ def main() -> None:
     bbox = torch.empty((B, 4, 16, 16), dtype=torch.float32, device=dev)
     cls = torch.empty((B, 1, 16, 16), dtype=torch.float32, device=dev)
     gathered = torch.empty((world * B, 5, 16, 16), dtype=torch.float32, device=dev) if use_dist else None
+    # the all-gather of batch i travels over xGMI while batch i+1 computes (two send/receive slots); --no-overlap keeps the
+    # blocking collective in the step for an A/B
+    overlap = OverlappedGather(B, 16, device=dev) if use_dist and not args.no_overlap else None
 
     def step():
-        if use_dist:
+        if overlap is not None:
             # the engine writes (bbox | cls) straight into the packed send buffer: the step is its kernels + ONE collective
+            net.track_packed(search, tmpl_feats, out=overlap.slot())
+            overlap.launch()
+        elif use_dist:
             net.track_packed(search, tmpl_feats, out=packed)
             gather_packed(packed, gathered)
         else:
             net.track_maps(search, tmpl_feats, out=(bbox, cls))
 
     def barrier():
+        if overlap is not None:
+            overlap.finish()               # every collective of the timed region has completed before the clock stops
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -567,7 +577,8 @@ def main() -> None:
                 "outputs_identical_between_handles": same}
         if use_dist:
             out["collective"] = {"backend": "nccl (RCCL)", "ranks": world, "op": "all_gather_into_tensor",
-                                 "bytes_per_rank": B * 5 * 16 * 16 * 4, "ms_alone": gather_ms}
+                                 "bytes_per_rank": B * 5 * 16 * 16 * 4, "ms_alone": gather_ms,
+                                 "overlapped_with_next_batch": overlap is not None}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(search_u8, tmpl_u8, DEFAULT_WEIGHTS)
         if not args.no_fear_m and world == 1 and not use_dist:

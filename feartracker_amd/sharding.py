@@ -56,6 +56,46 @@ def gather_packed(packed: torch.Tensor, gathered: Optional[torch.Tensor] = None,
     return gathered
 
 
+class OverlappedGather:
+    """Double-buffered all-gather of packed maps that overlaps with the NEXT batch's kernels.
+
+    `slot()` hands out the send buffer the engine should write batch i into (`FEARNetHIP.track_packed(..., out=buf)`),
+    after making the compute stream wait for the collective that last read that buffer; `launch()` starts the all-gather of
+    the slot asynchronously (RCCL runs it on its own stream, ordered after the kernels enqueued so far) and returns at once, so
+    the caller's next `track_packed` — into the other slot — runs while the maps travel over xGMI.  `finish()` waits for
+    everything in flight and returns the most recent gathered tensor; result i is valid after `finish()` or once `slot()`
+    has handed the same slot out again.  Two slots = at most one collective in flight behind the compute."""
+
+    def __init__(self, shard_crops: int, map_size: int = 16, device=None, dtype=torch.float32, group=None, slots: int = 2):
+        self.group = group
+        world = dist.get_world_size(group)
+        self.packed = [torch.empty((shard_crops, 5, map_size, map_size), dtype=dtype, device=device) for _ in range(slots)]
+        self.gathered = [torch.empty((world * shard_crops, 5, map_size, map_size), dtype=dtype, device=device) for _ in range(slots)]
+        self.work = [None] * slots
+        self.i = 0
+        self.last = None
+
+    def slot(self) -> torch.Tensor:
+        j = self.i % len(self.packed)
+        if self.work[j] is not None:
+            self.work[j].wait()            # compute stream waits for the collective that still reads packed[j]
+            self.work[j] = None
+        return self.packed[j]
+
+    def launch(self) -> None:
+        j = self.i % len(self.packed)
+        self.work[j] = dist.all_gather_into_tensor(self.gathered[j], self.packed[j], group=self.group, async_op=True)
+        self.last = j
+        self.i += 1
+
+    def finish(self) -> Optional[torch.Tensor]:
+        for j, w in enumerate(self.work):
+            if w is not None:
+                w.wait()
+                self.work[j] = None
+        return None if self.last is None else self.gathered[self.last]
+
+
 def track_sharded(net, search: torch.Tensor, template_features: torch.Tensor, group=None):
     """Run `net.track` on this rank's contiguous shard of a replicated global batch and all-gather.
 

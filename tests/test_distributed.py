@@ -73,6 +73,47 @@ def test_sharded_track_equals_single_process(n):
             assert torch.equal(g2[:, 4:], ref["TARGET_CLASSIFICATION_KEY"])
 
 
+def _overlap_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from feartracker_amd.sharding import OverlappedGather
+    og = OverlappedGather(3, map_size=4, device="cpu")
+    outs = []
+    for step in range(5):                                  # 5 batches through 2 slots: every slot is reused
+        buf = og.slot()
+        buf.copy_(torch.full((3, 5, 4, 4), float(10 * step + rank)))
+        og.launch()
+        if step >= 1:                                      # result of step - 1 is complete once its slot is asked for again...
+            pass
+    last = og.finish().clone()                             # ...or after finish()
+    # replay synchronously to get every step's expected result
+    for step in range(5):
+        outs.append(torch.cat([torch.full((3, 5, 4, 4), float(10 * step + r)) for r in range(world)]))
+    q.put((rank, last.numpy(), outs[-1].numpy(), og.gathered[0].numpy(), outs[4].numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_gather_double_buffering():
+    """sharding.OverlappedGather (what bench.py's multi-GPU step uses): asynchronous all-gathers through two slots give the
+    same rank-major result as the blocking collective, including after slot reuse."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, last, expect_last, slot0, expect_slot0 in results:
+        assert (last == expect_last).all()
+        assert (slot0 == expect_slot0).all()               # step 4 went through slot 0 (after steps 0 and 2)
+
+
 def test_shard_range_covers_everything():
     for n in (0, 1, 7, 8, 2048, 2049):
         for world in (1, 2, 4, 8):
