@@ -741,7 +741,7 @@ int build_plan_uncached(fear_handle* h, int hw, bool with_head, int mode, Plan**
                 w = nchunk / kFused16[id].splitk_kc;              // the variant's chunk count per workgroup is compiled in
             } else {
                 for (int cand = splitk_max; cand >= 2 && !w; --cand)
-                    if (nchunk % cand == 0 && nchunk / cand >= 2) w = cand;
+                    if (nchunk % cand == 0 && nchunk / cand >= (mode == 2 ? 1 : 2)) w = cand;
             }
             if (w) {
                 op.splitk = w;
