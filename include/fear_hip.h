@@ -119,7 +119,9 @@ int fear_crop_normalize(fear_handle* h, const uint8_t* frame_u8, int frame_h, in
                                /*   (fp32 mode); 0: one fused kernel per block                                 */
 #define FEAR_OPT_SMALL_PASS 7  /* passes of at most this many crops (default 96; 0 = never) run the small-batch plan:      */
                                /*   several workgroups per crop in the 16x16 kernels (split over channel chunks, partial   */
-                               /*   sums reduced afterwards), the head's two branches on two streams                       */
+                               /*   sums reduced afterwards), the head's two branches on two streams; passes of <= 8 crops  */
+                               /*   run a third plan (one chunk per workgroup, the head's SepConvs as 16-channel output     */
+                               /*   slices without partial sums, 16x8 tiles split over their expansion chunks)             */
 #define FEAR_OPT_PLAN_CROPS 8  /* crop count whose launch plan fear_plan_size / fear_plan_op / fear_profile_read describe (a    */
                                /*   pass of <= FEAR_OPT_SMALL_PASS crops runs another plan than a full one); 0 (default) =     */
                                /*   FEAR_OPT_MAX_BATCH, i.e. the plan of a full pass                                           */
