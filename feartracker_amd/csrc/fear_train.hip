@@ -216,60 +216,89 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Pointwise-conv weight gradient on the matrix cores: dW[n][k] = sum_m dY[m][n] X[m][k].
-// One wavefront owns a 16 (n) x 64 (k) strip of dW for one slice of rows (and one crop when batched): per step of 4 rows,
-// lane (li, lk) loads dY[m + lk][n0 + li] (A operand: i = n) and the float4 X[m + lk][k0 + 4 li .. +3]; MFMA q uses component
-// q as its B operand, i.e. output column j = li of MFMA q is k = k0 + 4 li + q — a column permutation undone at the store.
+// Pointwise-conv weight gradient on the matrix cores: dW[n][k] = sum_m dY[m][n] X[m][k]  (M in the millions, N and K small:
+// the kernel is bound by reading dY and X, so the point is loads per MFMA and passes over the rows).
+// A workgroup of four wavefronts owns a 64 (n) x 64 (k) tile of dW for one slice of rows (and one crop when batched); the
+// waves take the slice's rows in interleaved groups of 16.  Per step of 4 rows lane (li, lk) loads TWO float4s: dY[m + lk][n0 +
+// 4 li .. +3] and X[m + lk][k0 + 4 li .. +3]; MFMA (p, q) takes component p of the first as its A operand and component q of
+// the second as its B operand, i.e. it computes dW[n0 + 4 i + p][k0 + 4 j + q] for its 16 x 16 (i, j) — sixteen MFMAs per pair
+// of loads, the row/column permutation undone at the store.  (The first version — one wave per 16 x 64 strip with scalar dY
+// loads — issued a load per two MFMAs and re-read X once per 16 output channels.)  The four waves' accumulators are added in
+// a fixed order through LDS: (w0 + w2) + (w1 + w3).
 struct WgradArgs {
     const float* dY;     // [M][lddy]   (per crop: + crop * dy_crop_stride)
     const float* X;      // [M][ldx]
     float* P;            // partial [slices][crops][N][K]
     long rows_per_slice, M;      // M = rows per crop when batched
     long dy_crop_stride, x_crop_stride;
-    int N, K, lddy, ldx, n_strips, k_strips, crops;
+    int N, K, lddy, ldx, n_tiles, k_tiles, crops;      // N and K multiples of 4
 };
 
-__global__ __launch_bounds__(64) void pw_wgrad_kernel(WgradArgs a) {
-    const int lane = threadIdx.x, li = lane & 15, lk = lane >> 4;
-    const int strip = blockIdx.x;
-    const int ns = strip / a.k_strips, ks = strip % a.k_strips;
+__global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs a) {
+    __shared__ f32x4 red[2][16 * 64];                  // two accumulator sets of 16 float4 per lane
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int nt = blockIdx.x / a.k_tiles, kt = blockIdx.x % a.k_tiles;
     const int slice = blockIdx.y, crop = blockIdx.z;
-    const int n = ns * 16 + li;
-    const int k = ks * 64 + li * 4;
-    const bool nv = n < a.N, kv = k < a.K;      // K is a multiple of 4
-    const float* dy = a.dY + (long)crop * a.dy_crop_stride + (nv ? n : 0);
-    const float* x = a.X + (long)crop * a.x_crop_stride + (kv ? k : 0);
-    f32x4 acc[4];
+    const int n4 = nt * 64 + li * 4, k4 = kt * 64 + li * 4;
+    const bool nv = n4 < a.N, kv = k4 < a.K;
+    const float* dy = a.dY + (long)crop * a.dy_crop_stride + (nv ? n4 : 0);
+    const float* x = a.X + (long)crop * a.x_crop_stride + (kv ? k4 : 0);
+    f32x4 acc[4][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[p][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const long m0 = (long)slice * a.rows_per_slice;
     const long m1 = m0 + a.rows_per_slice < a.M ? m0 + a.rows_per_slice : a.M;
-    for (long m = m0; m < m1; m += 16) {
-        float av[4];
-        f32x4 bv[4];
+    const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (long m = m0 + wave * 16; m < m1; m += 64) {
+        f32x4 dv[4], xv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const long r = m + u * 4 + lk;
             const bool rv = r < m1;
-            av[u] = rv && nv ? dy[r * a.lddy] : 0.f;
-            bv[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (rv && kv) bv[u] = *reinterpret_cast<const f32x4*>(x + r * a.ldx);
+            dv[u] = rv && nv ? *reinterpret_cast<const f32x4*>(dy + r * a.lddy) : zero;
+            xv[u] = rv && kv ? *reinterpret_cast<const f32x4*>(x + r * a.ldx) : zero;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u][q], acc[q], 0, 0, 0);
-    }
-    // acc[q] lane (li, lk), component r  =  dW[ns*16 + 4 lk + r][ks*64 + 4 li + q]
-    float* P = a.P + (((long)slice * a.crops + crop) * a.N) * a.K;
+            for (int p = 0; p < 4; ++p)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int nn = ns * 16 + lk * 4 + r;
-        if (nn < a.N && kv) {
-            const f32x4 v = (f32x4){acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-            *reinterpret_cast<f32x4*>(P + (long)nn * a.K + k) = v;
-        }
+                for (int q = 0; q < 4; ++q) acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[u][p], xv[u][q], acc[p][q], 0, 0, 0);
     }
+    // (w0 + w2) + (w1 + w3), fixed order
+    if (wave >= 2) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[wave - 2][i * 64 + lane] = acc[i >> 2][i & 3];
+    }
+    __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i >> 2][i & 3] += red[wave][i * 64 + lane];
+    }
+    __syncthreads();
+    if (wave == 1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[0][i * 64 + lane] = acc[i >> 2][i & 3];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i >> 2][i & 3] += red[0][i * 64 + lane];
+    // acc[p][q] lane (li, lk), component r  =  dW[nt*64 + 16 lk + 4 r + p][kt*64 + 4 li + q]
+    float* P = a.P + (((long)slice * a.crops + crop) * a.N) * a.K;
+    if (!kv) return;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int nn = nt * 64 + lk * 16 + r * 4 + p;
+            if (nn < a.N) {
+                const f32x4 v = (f32x4){acc[p][0][r], acc[p][1][r], acc[p][2][r], acc[p][3][r]};
+                *reinterpret_cast<f32x4*>(P + (long)nn * a.K + k4) = v;
+            }
+        }
 }
 
 // out[i] = sum over slices of P[s][i], fixed order (i over crops*N*K): `lanes` threads per float4 (lane l adds slices l, l+lanes,
@@ -725,7 +754,7 @@ static int wgrad_impl(const float* dy, int lddy, long dy_crop_stride, const floa
     WgradArgs a{};
     a.dY = dy; a.X = x; a.lddy = lddy; a.ldx = ldx; a.N = N; a.K = K; a.M = M; a.crops = crops;
     a.dy_crop_stride = dy_crop_stride; a.x_crop_stride = x_crop_stride;
-    a.n_strips = (N + 15) / 16; a.k_strips = (K + 63) / 64;
+    a.n_tiles = (N + 63) / 64; a.k_tiles = (K + 63) / 64;
     a.rows_per_slice = crops > 1 ? M : wgrad_rows_per_slice(M);
     const int slices = (int)((M + a.rows_per_slice - 1) / a.rows_per_slice);
     const size_t need = (size_t)slices * crops * N * K * sizeof(float);
@@ -735,7 +764,7 @@ static int wgrad_impl(const float* dy, int lddy, long dy_crop_stride, const floa
         if (!workspace || ws_bytes < need) return FEAR_TRAIN_ERR_WORKSPACE;
         a.P = workspace;
     }
-    hipLaunchKernelGGL(pw_wgrad_kernel, dim3(a.n_strips * a.k_strips, slices, crops), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(pw_wgrad_kernel, dim3(a.n_tiles * a.k_tiles, slices, crops), dim3(256), 0, s, a);
     if (slices > 1) {
         const long count = (long)crops * N * K;
         launch_slice_sum(workspace, dw, count, slices, s);
@@ -747,7 +776,7 @@ static int wgrad_impl(const float* dy, int lddy, long dy_crop_stride, const floa
 int fear_pw_backward_weight(const float* dy, int lddy, const float* x, int ldx, float* dw, float* workspace, size_t ws_bytes,
                             long M, int K, int N, void* stream) {
     if (!dy || !x || !dw) return FEAR_TRAIN_ERR_NULL;
-    if (M <= 0 || K < 4 || K % 4 || N < 1) return FEAR_TRAIN_ERR_SHAPE;
+    if (M <= 0 || K < 4 || K % 4 || N < 4 || N % 4 || lddy % 4 || ldx % 4) return FEAR_TRAIN_ERR_SHAPE;    // float4 loads of both operands
     return wgrad_impl(dy, lddy, 0, x, ldx, 0, dw, workspace, ws_bytes, M, K, N, 1, static_cast<hipStream_t>(stream));
 }
 

@@ -41,7 +41,7 @@ int fear_pw_forward(const float* x, int ldx, const float* w, const float* bias, 
 /* its input gradient dx[m][k] = (add ? add[m][k] : 0) + sum_n dy[m][n] w[n][k] */
 int fear_pw_backward_data(const float* dy, int lddy, const float* w, const float* add, int ldadd, float* dx, int lddx, long M,
                           int K, int N, void* stream);
-/* its weight gradient dw[n][k] = sum_m dy[m][n] x[m][k] (MFMA, reduction over the rows) */
+/* its weight gradient dw[n][k] = sum_m dy[m][n] x[m][k] (MFMA, reduction over the rows); N, K, lddy, ldx multiples of 4 */
 int fear_pw_backward_weight(const float* dy, int lddy, const float* x, int ldx, float* dw, float* workspace, size_t ws_bytes,
                             long M, int K, int N, void* stream);
 /* bias gradients: out[c] = sum_m dy[m][c] */
