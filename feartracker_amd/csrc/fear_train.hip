@@ -32,7 +32,7 @@ using namespace fear;
 // ------------------------------------------------------------------------------------------------
 // Column reductions over rows: per-channel sums.  Block = 256 threads = (C/4 channel quads) x (R row lanes); a block reduces
 // `rpb` rows (col_rows_per_block: 64, doubled until there are at most 1024 blocks) into partial[block][2][C];
-// col_finalize_kernel adds the partials in double, 16 lanes per column in a fixed order.
+// col_finalize_kernel adds the partials in double, 64 lanes per column in a fixed order.
 //   MODE 0: s1 = sum x,        s2 = sum x^2   (float64)                      (BatchNorm forward statistics)
 //   MODE 1: g = relu ? (y > 0 ? dy : 0) : dy;  s1 = sum g,  s2 = sum g * xhat,  xhat = (x - mean) * rstd   (BatchNorm backward)
 //   MODE 2: s1 = sum dy                                                      (bias gradients)
@@ -116,28 +116,28 @@ struct ColFinArgs {
     double M, eps, momentum;
 };
 
-__global__ __launch_bounds__(256) void col_finalize_kernel(ColFinArgs a) {
-    // block = 16 columns x 16 lanes; lane j adds partials j, j+16, ... in order, the 16 lane sums are then added in lane order
-    __shared__ double red[2][16][17];
+__global__ __launch_bounds__(1024) void col_finalize_kernel(ColFinArgs a) {
+    // block = 16 columns x 64 lanes; lane j adds partials j, j+64, ... in order, the 64 lane sums are then added in lane order
+    __shared__ double red[2][64][17];
     const int cl = threadIdx.x & 15, j = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
     const bool ok = c < a.C;
     double s1 = 0.0, s2 = 0.0;
     if (ok)
-        for (int b = j; b < a.blocks; b += 16) {
+        for (int b = j; b < a.blocks; b += 64) {
             s1 += a.partial[(long)b * 2 * a.C + c];
             s2 += a.partial[(long)b * 2 * a.C + a.C + c];
         }
     red[0][j][cl] = s1;
     red[1][j][cl] = s2;
     __syncthreads();
+    if (j != 0 || !ok) return;
     s1 = 0.0; s2 = 0.0;
-    for (int l = 0; l < 16; ++l) { s1 += red[0][l][cl]; s2 += red[1][l][cl]; }
+    for (int l = 0; l < 64; ++l) { s1 += red[0][l][cl]; s2 += red[1][l][cl]; }
     if (a.mode == 0) {
         // single pass, float64 sums of x and x^2: the E[x^2] - mean^2 cancellation costs mean^2 / var * 2^-53 relative, far
         // below the fp32 inputs' own rounding for any activation a network produces
         const double mean = s1 / a.M;
-        if (j != 0 || !ok) return;
         const double m2 = s2 - s1 * mean;
         double var = m2 / a.M;
         if (var < 0.0) var = 0.0;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void col_finalize_kernel(ColFinArgs a) {
             const double unbiased = a.M > 1.0 ? var * a.M / (a.M - 1.0) : var;
             a.running_var[c] = (float)((1.0 - a.momentum) * (double)a.running_var[c] + a.momentum * unbiased);
         }
-    } else if (j == 0 && ok) {
+    } else {
         a.out1[c] = (float)s1;
         if (a.out2) a.out2[c] = (float)s2;
     }
@@ -791,7 +791,7 @@ int fear_col_sum(const float* dy, int lddy, float* out, float* workspace, size_t
     hipLaunchKernelGGL(col_reduce_kernel<2>, dim3(blocks), dim3(256), 0, s, a);
     ColFinArgs f{};
     f.partial = reinterpret_cast<const double*>(workspace); f.out1 = out; f.out2 = nullptr; f.blocks = blocks; f.C = C; f.mode = 2; f.M = (double)M; f.rpb = col_rows_per_block(M);
-    hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, s, f);
+    hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, s, f);
     LAUNCH_CHECK();
     return FEAR_TRAIN_OK;
 }
@@ -889,7 +889,7 @@ int fear_bn_train_forward(const float* x, int ldx, const float* gamma, const flo
     ColFinArgs f{};
     f.partial = reinterpret_cast<const double*>(workspace); f.out1 = mean; f.out2 = rstd; f.running_mean = running_mean; f.running_var = running_var;
     f.blocks = blocks; f.C = C; f.mode = 0; f.M = (double)M; f.rpb = col_rows_per_block(M); f.eps = eps; f.momentum = momentum;
-    hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, s, f);
+    hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, s, f);
     BnApplyArgs b{};
     b.X = x; b.mean = mean; b.rstd = rstd; b.gamma = gamma; b.beta = beta; b.Y = y; b.M = M; b.C = C; b.ldx = ldx; b.ldy = ldy;
     b.relu = relu;
@@ -913,7 +913,7 @@ int fear_bn_train_backward(const float* dy, int lddy, const float* y_act, int ld
     hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(blocks), dim3(256), 0, s, a);
     ColFinArgs f{};
     f.partial = reinterpret_cast<const double*>(workspace); f.out1 = dbeta; f.out2 = dgamma; f.blocks = blocks; f.C = C; f.mode = 1; f.M = (double)M; f.rpb = col_rows_per_block(M);
-    hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, s, f);
+    hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, s, f);
     BnBwdArgs b{};
     b.dY = dy; b.Yact = y_act; b.X = x; b.mean = mean; b.rstd = rstd; b.gamma = gamma; b.sum_g = dbeta; b.sum_gx = dgamma;
     b.dX = dx; b.M = M; b.C = C; b.lddy = lddy; b.ldy = ldy; b.ldx = ldx; b.lddx = lddx;
@@ -986,7 +986,7 @@ int fear_exp_head_backward(const float* p, const float* adjust, const float* bbo
         hipLaunchKernelGGL(col_reduce_kernel<2>, dim3(blocks), dim3(256), 0, s, c);
         ColFinArgs f{};
         f.partial = part; f.out1 = pass == 0 ? dbias4 : u4; f.blocks = blocks; f.C = 4; f.mode = 2; f.M = (double)M; f.rpb = col_rows_per_block(M);
-        hipLaunchKernelGGL(col_finalize_kernel, dim3(1), dim3(256), 0, s, f);
+        hipLaunchKernelGGL(col_finalize_kernel, dim3(1), dim3(1024), 0, s, f);
     }
     // d adjust = the four per-channel sums of dbbox * bbox * p added up (adjust is one scalar shared by the four channels)
     hipLaunchKernelGGL(sum4_kernel, dim3(1), dim3(1), 0, s, u4, dadjust);
