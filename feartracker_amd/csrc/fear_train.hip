@@ -112,6 +112,7 @@ struct ColFinArgs {
     float* out2;
     float* running_mean;   // mode 0, optional
     float* running_var;
+    double* dsum;          // mode 3: the two sums as float64 [2][C] (what several ranks all-reduce for SyncBatchNorm)
     int blocks, C, mode, rpb;
     double M, eps, momentum;
 };
@@ -148,10 +149,47 @@ __global__ __launch_bounds__(1024) void col_finalize_kernel(ColFinArgs a) {
             const double unbiased = a.M > 1.0 ? var * a.M / (a.M - 1.0) : var;
             a.running_var[c] = (float)((1.0 - a.momentum) * (double)a.running_var[c] + a.momentum * unbiased);
         }
+    } else if (a.mode == 3) {
+        a.dsum[c] = s1;
+        a.dsum[a.C + c] = s2;
     } else {
         a.out1[c] = (float)s1;
         if (a.out2) a.out2[c] = (float)s2;
     }
+}
+
+// SyncBatchNorm: mean / rstd (+ running statistics) of `count` rows from their float64 sums of x and x^2 (all ranks' sums added)
+struct BnFromSumsArgs {
+    const double* sums;    // [2][C]
+    float* mean;
+    float* rstd;
+    float* running_mean;
+    float* running_var;
+    int C;
+    double count, eps, momentum;
+};
+
+__global__ __launch_bounds__(256) void bn_from_sums_kernel(BnFromSumsArgs a) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.C) return;
+    const double mean = a.sums[c] / a.count;
+    double var = (a.sums[a.C + c] - a.sums[c] * mean) / a.count;
+    if (var < 0.0) var = 0.0;
+    a.mean[c] = (float)mean;
+    a.rstd[c] = (float)(1.0 / sqrt(var + a.eps));
+    if (a.running_mean) {
+        a.running_mean[c] = (float)((1.0 - a.momentum) * (double)a.running_mean[c] + a.momentum * mean);
+        const double unbiased = a.count > 1.0 ? var * a.count / (a.count - 1.0) : var;
+        a.running_var[c] = (float)((1.0 - a.momentum) * (double)a.running_var[c] + a.momentum * unbiased);
+    }
+}
+
+// float64 [2][C] sums -> the float32 [C] vectors bn_bwd_apply_kernel reads (global sums) and d beta / d gamma (local sums)
+__global__ __launch_bounds__(256) void sums_to_float_kernel(const double* sums, float* out1, float* out2, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    out1[c] = (float)sums[c];
+    out2[c] = (float)sums[C + c];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -193,6 +231,7 @@ struct BnBwdArgs {
     float* dX;
     long M;
     int C, lddy, ldy, ldx, lddx;
+    double count;            // rows the sums were taken over (0 = M; SyncBatchNorm: all ranks' rows)
 };
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
@@ -208,7 +247,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
     }
     const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + c), rs = *reinterpret_cast<const f32x4*>(a.rstd + c);
     const f32x4 xh = (*reinterpret_cast<const f32x4*>(a.X + r * a.ldx + c) - mu) * rs;
-    const float inv_m = 1.0f / (float)a.M;
+    const float inv_m = (float)(1.0 / (a.count > 0.0 ? a.count : (double)a.M));
     const f32x4 sg = *reinterpret_cast<const f32x4*>(a.sum_g + c) * inv_m;
     const f32x4 sgx = *reinterpret_cast<const f32x4*>(a.sum_gx + c) * inv_m;
     const f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + c);
@@ -917,6 +956,87 @@ int fear_bn_train_backward(const float* dy, int lddy, const float* y_act, int ld
     BnBwdArgs b{};
     b.dY = dy; b.Yact = y_act; b.X = x; b.mean = mean; b.rstd = rstd; b.gamma = gamma; b.sum_g = dbeta; b.sum_gx = dgamma;
     b.dX = dx; b.M = M; b.C = C; b.lddy = lddy; b.ldy = ldy; b.ldx = ldx; b.lddx = lddx;
+    const long n4 = M * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, b);
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+// ---- SyncBatchNorm (the reference's multi-GPU backends set sync_bn: True, config/backend/*.yaml): the two reductions of a
+// BatchNorm as separate operators, so that the caller can all-reduce the float64 sums between them.
+int fear_bn_reduce(const float* x, int ldx, double* sums, long M, int C, float* workspace, size_t ws_bytes, void* stream) {
+    if (!x || !sums || !workspace) return FEAR_TRAIN_ERR_NULL;
+    if (M <= 0 || C < 4 || C % 4 || C > 1024) return FEAR_TRAIN_ERR_SHAPE;
+    const int blocks = col_blocks(M);
+    if (ws_bytes < (size_t)blocks * 2 * C * sizeof(double)) return FEAR_TRAIN_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ColArgs a{};
+    a.A = x; a.lda = ldx; a.partial = reinterpret_cast<double*>(workspace); a.M = M; a.C = C; a.rpb = col_rows_per_block(M);
+    hipLaunchKernelGGL(col_reduce_kernel<0>, dim3(blocks), dim3(256), 0, s, a);
+    ColFinArgs f{};
+    f.partial = reinterpret_cast<const double*>(workspace); f.dsum = sums; f.blocks = blocks; f.C = C; f.mode = 3; f.M = (double)M;
+    f.rpb = a.rpb;
+    hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, s, f);
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+int fear_bn_forward_from_sums(const float* x, int ldx, const double* sums, double count, const float* gamma, const float* beta,
+                              float* y, int ldy, float* mean, float* rstd, float* running_mean, float* running_var,
+                              double momentum, double eps, long M, int C, int relu, void* stream) {
+    if (!x || !sums || !gamma || !beta || !y || !mean || !rstd) return FEAR_TRAIN_ERR_NULL;
+    if (M <= 0 || C < 4 || C % 4 || C > 1024 || !(count >= (double)M)) return FEAR_TRAIN_ERR_SHAPE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    BnFromSumsArgs f{};
+    f.sums = sums; f.mean = mean; f.rstd = rstd; f.running_mean = running_mean; f.running_var = running_var; f.C = C;
+    f.count = count; f.eps = eps; f.momentum = momentum;
+    hipLaunchKernelGGL(bn_from_sums_kernel, dim3((C + 255) / 256), dim3(256), 0, s, f);
+    BnApplyArgs b{};
+    b.X = x; b.mean = mean; b.rstd = rstd; b.gamma = gamma; b.beta = beta; b.Y = y; b.M = M; b.C = C; b.ldx = ldx; b.ldy = ldy;
+    b.relu = relu;
+    const long n4 = M * (C / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, b);
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+int fear_bn_backward_reduce(const float* dy, int lddy, const float* y_act, int ldy, const float* x, int ldx, const float* mean,
+                            const float* rstd, double* sums, long M, int C, float* workspace, size_t ws_bytes, void* stream) {
+    if (!dy || !x || !mean || !rstd || !sums || !workspace) return FEAR_TRAIN_ERR_NULL;
+    if (M <= 0 || C < 4 || C % 4 || C > 1024) return FEAR_TRAIN_ERR_SHAPE;
+    const int blocks = col_blocks(M);
+    if (ws_bytes < (size_t)blocks * 2 * C * sizeof(double)) return FEAR_TRAIN_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ColArgs a{};
+    a.A = dy; a.lda = lddy; a.Yact = y_act; a.ldy = ldy; a.X = x; a.ldx = ldx; a.mean = mean; a.rstd = rstd;
+    a.partial = reinterpret_cast<double*>(workspace); a.M = M; a.C = C; a.rpb = col_rows_per_block(M);
+    hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(blocks), dim3(256), 0, s, a);
+    ColFinArgs f{};
+    f.partial = reinterpret_cast<const double*>(workspace); f.dsum = sums; f.blocks = blocks; f.C = C; f.mode = 3; f.M = (double)M;
+    f.rpb = a.rpb;
+    hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, s, f);
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+int fear_bn_backward_from_sums(const float* dy, int lddy, const float* y_act, int ldy, const float* x, int ldx, const float* mean,
+                               const float* rstd, const float* gamma, const double* sums_all, double count,
+                               const double* sums_local, float* dx, int lddx, float* dgamma, float* dbeta, float* workspace,
+                               size_t ws_bytes, long M, int C, void* stream) {
+    if (!dy || !x || !mean || !rstd || !gamma || !sums_all || !sums_local || !dx || !dgamma || !dbeta || !workspace)
+        return FEAR_TRAIN_ERR_NULL;
+    if (M <= 0 || C < 4 || C % 4 || C > 1024 || !(count >= (double)M)) return FEAR_TRAIN_ERR_SHAPE;
+    if (ws_bytes < (size_t)2 * C * sizeof(float)) return FEAR_TRAIN_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // the parameter gradients are this rank's sums (data-parallel averaging happens with all the other gradients); the input
+    // gradient needs the sums and the row count of ALL ranks
+    hipLaunchKernelGGL(sums_to_float_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums_local, dbeta, dgamma, C);
+    float* g1 = workspace;
+    float* g2 = workspace + C;
+    hipLaunchKernelGGL(sums_to_float_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums_all, g1, g2, C);
+    BnBwdArgs b{};
+    b.dY = dy; b.Yact = y_act; b.X = x; b.mean = mean; b.rstd = rstd; b.gamma = gamma; b.sum_g = g1; b.sum_gx = g2;
+    b.dX = dx; b.M = M; b.C = C; b.lddy = lddy; b.ldy = ldy; b.ldx = ldx; b.lddx = lddx; b.count = count;
     const long n4 = M * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, b);
     LAUNCH_CHECK();

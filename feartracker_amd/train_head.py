@@ -38,6 +38,10 @@ TRAIN_SYMBOLS = {
     "fear_stem_im2col": ([_P, _P, _l, _i, _i, _P], _i),
     "fear_bn_train_forward": ([_P, _i, _P, _P, _P, _i, _P, _P, _P, _P, _d, _d, _l, _i, _i, _P, _sz, _P], _i),
     "fear_bn_train_backward": ([_P, _i, _P, _i, _P, _i, _P, _P, _P, _P, _i, _P, _P, _l, _i, _P, _sz, _P], _i),
+    "fear_bn_reduce": ([_P, _i, _P, _l, _i, _P, _sz, _P], _i),
+    "fear_bn_forward_from_sums": ([_P, _i, _P, _d, _P, _P, _P, _i, _P, _P, _P, _P, _d, _d, _l, _i, _i, _P], _i),
+    "fear_bn_backward_reduce": ([_P, _i, _P, _i, _P, _i, _P, _P, _P, _l, _i, _P, _sz, _P], _i),
+    "fear_bn_backward_from_sums": ([_P, _i, _P, _i, _P, _i, _P, _P, _P, _P, _d, _P, _P, _i, _P, _P, _P, _sz, _l, _i, _P], _i),
     "fear_xcorr_forward": ([_P, _i, _P, _P, _i, _i, _i, _i, _i, _P], _i),
     "fear_xcorr_backward": ([_P, _i, _P, _i, _P, _P, _i, _P, _i, _P, _i, _i, _i, _i, _P], _i),
     "fear_exp_head_forward": ([_P, _P, _P, _P, _l, _P], _i),
@@ -73,6 +77,49 @@ def _p(t: Optional[torch.Tensor], offset: int = 0):
     return None if t is None else ctypes.c_void_p(t.data_ptr() + 4 * offset)
 
 
+class SyncBN:
+    """SyncBatchNorm across the ranks of a process group (the reference's multi-GPU backends set `sync_bn: True`,
+    config/backend/{2,4}gpu.yaml): every BatchNorm adds its float64 sums over the ranks with one all-reduce in the forward
+    and one in the backward (include/fear_train.h).  Every rank must feed the same number of rows (DDP's equal batches)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.world = dist.get_world_size(group)
+
+    def all_reduce(self, sums: torch.Tensor) -> None:
+        self.dist.all_reduce(sums, op=self.dist.ReduceOp.SUM, group=self.group)
+
+
+def bn_forward(lib, st, ws, wsb, sync: Optional["SyncBN"], x, ldx, gamma, beta, out, ld_out, mean, rstd, running_mean, running_var,
+               momentum, eps, M, C, relu) -> int:
+    if sync is None:
+        return lib.fear_bn_train_forward(_p(x), ldx, _p(gamma), _p(beta), _p(out), ld_out, _p(mean), _p(rstd), _p(running_mean),
+                                         _p(running_var), momentum, eps, M, C, relu, ws, wsb, st)
+    sums = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+    rc = lib.fear_bn_reduce(_p(x), ldx, _p(sums), M, C, ws, wsb, st)
+    if rc != 0:
+        return rc
+    sync.all_reduce(sums)
+    return lib.fear_bn_forward_from_sums(_p(x), ldx, _p(sums), float(M) * sync.world, _p(gamma), _p(beta), _p(out), ld_out, _p(mean),
+                                         _p(rstd), _p(running_mean), _p(running_var), momentum, eps, M, C, relu, st)
+
+
+def bn_backward(lib, st, ws, wsb, sync: Optional["SyncBN"], dy, lddy, y_act, ldy, x, ldx, mean, rstd, gamma, dx, lddx, dgamma, dbeta,
+                M, C) -> int:
+    if sync is None:
+        return lib.fear_bn_train_backward(_p(dy), lddy, _p(y_act), ldy, _p(x), ldx, _p(mean), _p(rstd), _p(gamma), _p(dx), lddx,
+                                          _p(dgamma), _p(dbeta), M, C, ws, wsb, st)
+    sums = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+    rc = lib.fear_bn_backward_reduce(_p(dy), lddy, _p(y_act), ldy, _p(x), ldx, _p(mean), _p(rstd), _p(sums), M, C, ws, wsb, st)
+    if rc != 0:
+        return rc
+    local = sums.clone()
+    sync.all_reduce(sums)
+    return lib.fear_bn_backward_from_sums(_p(dy), lddy, _p(y_act), ldy, _p(x), ldx, _p(mean), _p(rstd), _p(gamma), _p(sums),
+                                          float(M) * sync.world, _p(local), _p(dx), lddx, _p(dgamma), _p(dbeta), ws, wsb, M, C, st)
+
+
 class _Sep:
     """One SepConv (+ optional BatchNorm + ReLU) with its parameters in kernel layout and its saved activations."""
 
@@ -106,10 +153,11 @@ class BoxTowerTrainHIP:
     S, TZ = 16, 8           # search feature map 16x16, template feature map 8x8 (256 / 128 px crops, stride 16)
 
     def __init__(self, state_dict: Dict[str, "np.ndarray | torch.Tensor"], device: int = 0, momentum: float = 0.1,
-                 eps: float = 1e-5, coef_cls: float = 1.0, coef_reg: float = 1.0):
+                 eps: float = 1e-5, coef_cls: float = 1.0, coef_reg: float = 1.0, sync_bn: bool = False, group=None):
         if not torch.cuda.is_available():
             raise RuntimeError("BoxTowerTrainHIP needs a ROCm GPU; there is no CPU fallback")
         self.lib = load_train_library()
+        self.sync = SyncBN(group) if sync_bn else None
         self.device = torch.device(f"cuda:{int(device)}")
         self.momentum, self.eps, self.coef_cls, self.coef_reg = momentum, eps, coef_cls, coef_reg
         sd = {k: torch.as_tensor(np.asarray(v)) if not isinstance(v, torch.Tensor) else v.detach().cpu() for k, v in state_dict.items()}
@@ -157,9 +205,8 @@ class BoxTowerTrainHIP:
         if out is None:
             out, ld_out = self._new(M, L.cout), L.cout
         L.y, L.ldy = out, ld_out
-        self._check(lib.fear_bn_train_forward(_p(L.p), L.n, _p(L.gamma), _p(L.beta), _p(out), ld_out, _p(L.mean), _p(L.rstd),
-                                              _p(L.running_mean), _p(L.running_var), self.momentum, self.eps, M, L.cout, 1,
-                                              ws, wsb, st))
+        self._check(bn_forward(lib, st, ws, wsb, self.sync, L.p, L.n, L.gamma, L.beta, out, ld_out, L.mean, L.rstd,
+                               L.running_mean, L.running_var, self.momentum, self.eps, M, L.cout, 1))
         return out
 
     def _sep_backward(self, L: _Sep, dy: torch.Tensor, lddy: int, B: int, grads: Dict[str, torch.Tensor]) -> torch.Tensor:
@@ -169,8 +216,8 @@ class BoxTowerTrainHIP:
         if L.bn_prefix:
             dp = self._new(M, L.n)
             dgamma, dbeta = self._new(L.cout), self._new(L.cout)
-            self._check(lib.fear_bn_train_backward(_p(dy), lddy, _p(L.y), L.ldy, _p(L.p), L.n, _p(L.mean), _p(L.rstd), _p(L.gamma),
-                                                   _p(dp), L.n, _p(dgamma), _p(dbeta), M, L.cout, ws, wsb, st))
+            self._check(bn_backward(lib, st, ws, wsb, self.sync, dy, lddy, L.y, L.ldy, L.p, L.n, L.mean, L.rstd, L.gamma, dp, L.n,
+                                    dgamma, dbeta, M, L.cout))
             grads[L.bn_prefix + ".weight"], grads[L.bn_prefix + ".bias"] = dgamma, dbeta
             lddp = L.n
         else:

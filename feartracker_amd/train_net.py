@@ -18,8 +18,9 @@ project 1x1 + BN, residual where the block keeps shape) — with parameter names
 the only use (configs[4] says so): trained `mobile_cv` checkpoints cannot be loaded without their key names.
 
 Several ranks: every rank runs `step` on its share of the batch and `allreduce_gradients` averages the flat gradient buffer
-with ONE RCCL all-reduce (≈1.37 M floats); BatchNorm statistics stay per rank (the reference's `sync_bn` option,
-config/backend/*.yaml, is not built).
+with ONE RCCL all-reduce (≈1.37 M floats); `sync_bn=True` makes every BatchNorm a SyncBatchNorm over the group — the
+reference's multi-GPU backends train that way (`sync_bn: True`, config/backend/{2,4}gpu.yaml -> trainer.py:52) — at the price
+of one small float64 all-reduce per BatchNorm and direction; without it the statistics stay per rank.
 """
 from __future__ import annotations
 
@@ -28,7 +29,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
-from .train_head import BoxTowerTrainHIP, TrainError, _p, load_train_library
+from .train_head import BoxTowerTrainHIP, SyncBN, TrainError, _p, bn_backward, bn_forward, load_train_library
 
 # (cin, cexp, cout, k, stride, expand, residual): fbnet_c stages[1:18]
 TRUNK_BLOCKS = [
@@ -111,7 +112,7 @@ class _ConvBN:
 
 class FEARNetTrainHIP:
     def __init__(self, state_dict: Dict[str, "np.ndarray | torch.Tensor"], device: int = 0, momentum: float = 0.1, eps: float = 1e-5,
-                 coef_cls: float = 1.0, coef_reg: float = 1.0):
+                 coef_cls: float = 1.0, coef_reg: float = 1.0, sync_bn: bool = False, group=None):
         if not torch.cuda.is_available():
             raise RuntimeError("FEARNetTrainHIP needs a ROCm GPU; there is no CPU fallback")
         self.lib = load_train_library()
@@ -128,7 +129,9 @@ class FEARNetTrainHIP:
                 pwl=_ConvBN(f"trunk.{i}.pwl", "pw", sd, dev, relu=False), residual=residual))
         self.neck = _ConvBN("neck.downsample", "pw", sd, dev, relu=False, conv_key=".0.weight", bn_key=".1")
         self.head = BoxTowerTrainHIP({k[len("connect_model."):]: v for k, v in sd.items() if k.startswith("connect_model.")},
-                                     device=device, momentum=momentum, eps=eps, coef_cls=coef_cls, coef_reg=coef_reg)
+                                     device=device, momentum=momentum, eps=eps, coef_cls=coef_cls, coef_reg=coef_reg,
+                                     sync_bn=sync_bn, group=group)
+        self.sync = self.head.sync                 # SyncBatchNorm over the data-parallel group (config/backend/*.yaml: sync_bn)
         self._ws = None
         self.last_contexts = None
 
@@ -164,9 +167,8 @@ class FEARNetTrainHIP:
         else:
             self._check(lib.fear_pw_forward(_p(x), L.cin, _p(L.w), None, _p(pre), L.cout, M, L.cin, L.cout, st))
         out, mean, rstd = self._new(M, L.cout), self._new(L.cout), self._new(L.cout)
-        self._check(lib.fear_bn_train_forward(_p(pre), L.cout, _p(L.gamma), _p(L.beta), _p(out), L.cout, _p(mean), _p(rstd),
-                                              _p(L.running_mean), _p(L.running_var), self.momentum, self.eps, M, L.cout,
-                                              1 if L.relu else 0, ws, wsb, st))
+        self._check(bn_forward(lib, st, ws, wsb, self.sync, pre, L.cout, L.gamma, L.beta, out, L.cout, mean, rstd, L.running_mean,
+                               L.running_var, self.momentum, self.eps, M, L.cout, 1 if L.relu else 0))
         saved.append((L, x, pre, out, mean, rstd, B, H))
         return out
 
@@ -177,8 +179,8 @@ class FEARNetTrainHIP:
         M = B * Ho * Ho
         ws, wsb = self._workspace(max(M, B * H * H))
         dpre, dgamma, dbeta = self._new(M, L.cout), self._new(L.cout), self._new(L.cout)
-        self._check(lib.fear_bn_train_backward(_p(dy), L.cout, _p(out) if L.relu else None, L.cout, _p(pre), L.cout, _p(mean), _p(rstd),
-                                               _p(L.gamma), _p(dpre), L.cout, _p(dgamma), _p(dbeta), M, L.cout, ws, wsb, st))
+        self._check(bn_backward(lib, st, ws, wsb, self.sync, dy, L.cout, out if L.relu else None, L.cout, pre, L.cout, mean, rstd,
+                                L.gamma, dpre, L.cout, dgamma, dbeta, M, L.cout))
         self._acc(grads, L.bn_key + ".weight", dgamma)
         self._acc(grads, L.bn_key + ".bias", dbeta)
         dx = None

@@ -71,6 +71,24 @@ int fear_bn_train_backward(const float* dy, int lddy, const float* y_act, int ld
                            const float* rstd, const float* gamma, float* dx, int lddx, float* dgamma, float* dbeta, long M,
                            int C, float* workspace, size_t ws_bytes, void* stream);
 
+/* SyncBatchNorm (the reference's multi-GPU backends train with sync_bn: True, config/backend/{2,4}gpu.yaml -> trainer.py:52):
+ * the same BatchNorm with its two reductions exposed, so that the ranks can add their float64 sums ([2][C] doubles on the
+ * device: forward sum x | sum x^2, backward sum g | sum g * xhat with g = the ReLU-masked dy) with one all-reduce each:
+ *   forward : fear_bn_reduce -> all-reduce(sums) -> fear_bn_forward_from_sums(count = rows of all ranks)
+ *   backward: fear_bn_backward_reduce -> copy = local sums, all-reduce(sums) -> fear_bn_backward_from_sums
+ * d gamma / d beta come from the LOCAL sums (they are averaged with every other gradient), dx from the global ones — the
+ * split torch.nn.SyncBatchNorm makes.  With one rank the pair equals fear_bn_train_forward / _backward. */
+int fear_bn_reduce(const float* x, int ldx, double* sums, long M, int C, float* workspace, size_t ws_bytes, void* stream);
+int fear_bn_forward_from_sums(const float* x, int ldx, const double* sums, double count, const float* gamma, const float* beta,
+                              float* y, int ldy, float* mean, float* rstd, float* running_mean, float* running_var,
+                              double momentum, double eps, long M, int C, int relu, void* stream);
+int fear_bn_backward_reduce(const float* dy, int lddy, const float* y_act, int ldy, const float* x, int ldx, const float* mean,
+                            const float* rstd, double* sums, long M, int C, float* workspace, size_t ws_bytes, void* stream);
+int fear_bn_backward_from_sums(const float* dy, int lddy, const float* y_act, int ldy, const float* x, int ldx, const float* mean,
+                               const float* rstd, const float* gamma, const double* sums_all, double count,
+                               const double* sums_local, float* dx, int lddx, float* dgamma, float* dbeta, float* workspace,
+                               size_t ws_bytes, long M, int C, void* stream);
+
 /* MobileCorrelation (blocks.py:121-123): s[b][p][j] = sum_c x[b][p][c] z[b][c][j]; z_nchw = (B, C, J) as the reference holds it */
 int fear_xcorr_forward(const float* x, int ldx, const float* z_nchw, float* s_out, int lds, int B, int P, int C, int J,
                        void* stream);
