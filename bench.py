@@ -201,6 +201,44 @@ def config5_train_step(dev, batch: int = 128, steps: int = 5, warmup: int = 2):
             "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
 
 
+def config5_train_step_ddp(dev, world: int, batch: int = 128, steps: int = 3, warmup: int = 1):
+    """BASELINE configs[4] with its data parallelism: every rank runs the training step on its own 128 pairs with
+    SyncBatchNorm (the reference's multi-GPU setting, config/backend/*.yaml), the gradients are averaged by ONE RCCL all-reduce
+    of the flat buffer, Adam updates the parameters.  Whole-job pairs/s over all ranks (max step time over ranks)."""
+    import torch.distributed as dist
+    from feartracker_amd.optim import AdamHIP
+    from feartracker_amd.train_net import FEARNetTrainHIP, random_init_state
+    g = torch.Generator().manual_seed(70 + dist.get_rank())
+    net = FEARNetTrainHIP(random_init_state(3), device=dev.index, sync_bn=True)
+    opt = AdamHIP(net)
+    tmpl = torch.randn(batch, 3, 128, 128, generator=g).to(dev)
+    srch = torch.randn(batch, 3, 256, 256, generator=g).to(dev)
+    gt_reg = (torch.rand(batch, 4, 16, 16, generator=g) * 60 + 1).to(dev)
+    gt_cls = (torch.rand(batch, 1, 16, 16, generator=g) > 0.8).float().to(dev)
+    gt_w = (torch.rand(batch, 16, 16, generator=g) > 0.9).float().to(dev)
+
+    def one():
+        out = net.step(tmpl, srch, gt_reg, gt_cls, gt_w)
+        opt.step(net.allreduce_gradients(out["grads"]))
+        return out
+    for _ in range(warmup):
+        out = one()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = one()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t = torch.tensor([(time.perf_counter() - t0) / steps], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    return {"workload": f"FEARNet training step, data parallel over {world} rank(s): {batch} pairs per rank (global batch {world * batch}), "
+                        "SyncBatchNorm, one all-reduce of the flat gradient buffer, Adam; fp32, random init, synthetic data",
+            "value": world * batch / dt, "unit": "pairs/s (all ranks)", "ms_per_step": 1e3 * dt, "steps": steps, "ranks": world,
+            "sync_bn": True, "loss": [float(out["loss_cls"]), float(out["loss_reg"])]}
+
+
 def latency_batch1(weights, frames_cap: int = 120):
     """BASELINE configs[0] / SURVEY §8d config 1 at batch 1: `initialize` + `update` per frame through the drop-in tracker on
     the 480x256 demo-geometry clip (tests/clipgen.py: the init box of demo_video.py:45-46; assets/test.mp4 itself cannot be
@@ -325,6 +363,8 @@ def main() -> None:
                     help="skip the supplementary run in the other arithmetic mode (profiling runs: keeps the trace to one plan)")
     ap.add_argument("--dump-ops", action="store_true", help="print the per-kernel time table to stderr")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 tracker latency object")
+    ap.add_argument("--train-ddp", action="store_true", help="multi-GPU: also time the data-parallel training step (SyncBatchNorm, "
+                    "gradient all-reduce, Adam) -> config5_train_step_data_parallel")
     ap.add_argument("--no-overlap", action="store_true", help="multi-GPU: blocking all-gather inside the step instead of the "
                     "double-buffered collective that overlaps the next batch")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the two-handles-on-two-streams supplementary number")
@@ -515,6 +555,17 @@ def main() -> None:
     if args.no_chain:
         net.set_chain(False)
 
+    # configs[4] with its data parallelism — opt-in (--train-ddp): a rank that failed alone inside it would leave the others
+    # waiting in a collective, and the default multi-GPU run must produce its line whatever happens to a side measurement
+    ddp_train = None
+    if use_dist and args.train_ddp:
+        try:
+            torch.cuda.empty_cache()
+            ddp_train = config5_train_step_ddp(dev, world)
+        except Exception as exc:      # noqa: BLE001 — reported in the JSON line instead
+            ddp_train = {"error": f"{type(exc).__name__}: {exc}"}
+        torch.cuda.empty_cache()
+
     if rank == 0:
         total_crops = world * B * args.steps
         value = total_crops / elapsed
@@ -575,6 +626,8 @@ def main() -> None:
                         "flight); supplementary, never `value`",
                 "value": B * args.steps / elapsed_pipe, "unit": "crops/s", "ms_per_step": 1e3 * elapsed_pipe / args.steps,
                 "outputs_identical_between_handles": same}
+        if ddp_train is not None:
+            out["config5_train_step_data_parallel"] = ddp_train
         if use_dist:
             out["collective"] = {"backend": "nccl (RCCL)", "ranks": world, "op": "all_gather_into_tensor",
                                  "bytes_per_rank": B * 5 * 16 * 16 * 4, "ms_alone": gather_ms,
