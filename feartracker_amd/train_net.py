@@ -134,6 +134,21 @@ class FEARNetTrainHIP:
         self.sync = self.head.sync                 # SyncBatchNorm over the data-parallel group (config/backend/*.yaml: sync_bn)
         self._ws = None
         self.last_contexts = None
+        # the trunk runs twice per step (template, search): each pass writes its parameter gradients into one flat buffer
+        # (kernel layouts, offsets below) and ONE add joins the two — not one add launch per parameter
+        self._goff: Dict[str, int] = {}
+        total = 0
+        for L in self._trunk_layers():
+            for key, n in ((L.conv_key, L.w.numel()), (L.bn_key + ".weight", L.cout), (L.bn_key + ".bias", L.cout)):
+                self._goff[key] = total
+                total += (n + 3) // 4 * 4                      # 16-byte aligned slots
+        self._gtotal = total
+
+    def _trunk_layers(self) -> List["_ConvBN"]:
+        layers = [self.stem]
+        for blk in self.blocks:
+            layers += [L for L in (blk["pw"], blk["dw"], blk["pwl"]) if L is not None]
+        return layers + [self.neck]
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, st: int) -> None:
@@ -172,45 +187,37 @@ class FEARNetTrainHIP:
         saved.append((L, x, pre, out, mean, rstd, B, H))
         return out
 
-    def _bwd(self, rec, dy: torch.Tensor, grads: Dict[str, torch.Tensor], need_dx: bool = True) -> Optional[torch.Tensor]:
+    def _gslot(self, gbuf: torch.Tensor, key: str, *shape) -> torch.Tensor:
+        n = int(np.prod(shape))
+        off = self._goff[key]
+        return gbuf[off: off + n].view(*shape)
+
+    def _bwd(self, rec, dy: torch.Tensor, gbuf: torch.Tensor, need_dx: bool = True) -> Optional[torch.Tensor]:
+        """Backward of one conv + BN [+ ReLU]; the parameter gradients go to their slots of `gbuf` (kernel layouts)."""
         L, x, pre, out, mean, rstd, B, H = rec
         lib, st = self.lib, self._stream()
         Ho = H // L.stride if L.kind == "dw" else H
         M = B * Ho * Ho
         ws, wsb = self._workspace(max(M, B * H * H))
-        dpre, dgamma, dbeta = self._new(M, L.cout), self._new(L.cout), self._new(L.cout)
+        dpre = self._new(M, L.cout)
+        dgamma, dbeta = self._gslot(gbuf, L.bn_key + ".weight", L.cout), self._gslot(gbuf, L.bn_key + ".bias", L.cout)
         self._check(bn_backward(lib, st, ws, wsb, self.sync, dy, L.cout, out if L.relu else None, L.cout, pre, L.cout, mean, rstd,
                                 L.gamma, dpre, L.cout, dgamma, dbeta, M, L.cout))
-        self._acc(grads, L.bn_key + ".weight", dgamma)
-        self._acc(grads, L.bn_key + ".bias", dbeta)
         dx = None
         if L.kind == "dw":
-            dtaps = self._new(L.k * L.k, L.cout)
+            dtaps = self._gslot(gbuf, L.conv_key, L.k * L.k, L.cout)
             self._check(lib.fear_dw_backward_weight(_p(dpre), L.cout, _p(x), L.cin, _p(dtaps), ws, wsb, B, H, H, L.cin, L.k, L.stride, st))
-            self._acc(grads, L.conv_key, dtaps.t().reshape(L.cout, 1, L.k, L.k))
             if need_dx:
                 dx = self._new(B * H * H, L.cin)
                 self._check(lib.fear_dw_backward_data(_p(dpre), L.cout, _p(L.w), _p(dx), L.cin, B, H, H, L.cin, L.k, L.stride, st))
         else:
-            dw = self._new(L.cout, L.cin)
+            dw = self._gslot(gbuf, L.conv_key, L.cout, L.cin)
             self._check(lib.fear_pw_backward_weight(_p(dpre), L.cout, _p(x), L.cin, _p(dw), ws, wsb, M, L.cin, L.cout, st))
-            if L.kind == "stem":
-                self._acc(grads, L.conv_key, dw[:, :27].reshape(L.cout, 3, 3, 3))
-            else:
-                self._acc(grads, L.conv_key, dw.reshape(L.cout, L.cin, 1, 1))
+            if L.kind != "stem":
                 if need_dx:
                     dx = self._new(M, L.cin)
                     self._check(lib.fear_pw_backward_data(_p(dpre), L.cout, _p(L.w), None, 0, _p(dx), L.cin, M, L.cin, L.cout, st))
         return dx
-
-    def _acc(self, grads: Dict[str, torch.Tensor], key: str, g: torch.Tensor) -> None:
-        """The trunk runs twice per step (template, search): gradients of the shared parameters add up."""
-        if key in grads:
-            a = grads[key]
-            gc = g.contiguous()
-            self._check(self.lib.fear_add(_p(a), _p(gc), _p(a), a.numel(), self._stream()))
-        else:
-            grads[key] = g.contiguous()
 
     def _add(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
         out = self._new(*a.shape)
@@ -242,16 +249,16 @@ class FEARNetTrainHIP:
         feats = self._fwd(self.neck, x, B, h, saved)
         return feats, (saved, block_recs, B, h)
 
-    def _features_backward(self, ctx, dfeat: torch.Tensor, grads: Dict[str, torch.Tensor]) -> None:
+    def _features_backward(self, ctx, dfeat: torch.Tensor, gbuf: torch.Tensor) -> None:
         saved, block_recs, B, h = ctx
-        d = self._bwd(saved[-1], dfeat, grads)                       # neck
+        d = self._bwd(saved[-1], dfeat, gbuf)                        # neck
         for start, end, residual in reversed(block_recs):
             dres = d
             for i in range(end - 1, start - 1, -1):
-                d = self._bwd(saved[i], d, grads)
+                d = self._bwd(saved[i], d, gbuf)
             if residual:
                 d = self._add(d, dres)
-        self._bwd(saved[0], d, grads, need_dx=False)                 # stem: the image needs no gradient
+        self._bwd(saved[0], d, gbuf, need_dx=False)                  # stem: the image needs no gradient
 
     # ------------------------------------------------------------------ the step
     @torch.no_grad()
@@ -279,8 +286,20 @@ class FEARNetTrainHIP:
             dz = self._new(B * 64, 256)
             self._check(self.lib.fear_nchw_to_nhwc(_p(out["grad_search"]), _p(dx), B, 256, 256, 256, 0, st))
             self._check(self.lib.fear_nchw_to_nhwc(_p(out["grad_template"].contiguous()), _p(dz), B, 256, 64, 256, 0, st))
-            self._features_backward(xctx, dx, grads)
-            self._features_backward(zctx, dz, grads)
+            gflat = torch.empty(2, self._gtotal, dtype=torch.float32, device=dev)      # fresh per step: the caller keeps `grads`
+            self._features_backward(xctx, dx, gflat[0])
+            self._features_backward(zctx, dz, gflat[1])
+            self._check(self.lib.fear_add(_p(gflat[0]), _p(gflat[1]), _p(gflat[0]), self._gtotal, st))   # shared parameters: the two passes add up
+            for L in self._trunk_layers():
+                gw = self._gslot(gflat[0], L.conv_key, *L.w.shape)
+                if L.kind == "dw":
+                    grads[L.conv_key] = gw.t().reshape(L.cout, 1, L.k, L.k)
+                elif L.kind == "stem":
+                    grads[L.conv_key] = gw[:, :27].reshape(L.cout, 3, 3, 3)
+                else:
+                    grads[L.conv_key] = gw.reshape(L.cout, L.cin, 1, 1)
+                grads[L.bn_key + ".weight"] = self._gslot(gflat[0], L.bn_key + ".weight", L.cout)
+                grads[L.bn_key + ".bias"] = self._gslot(gflat[0], L.bn_key + ".bias", L.cout)
             self.last_contexts = (zctx, xctx)          # saved activations of the two trunk passes (tests read the ReLU patterns)
         return {"loss_cls": out["loss_cls"], "loss_reg": out["loss_reg"], "bbox": out["bbox"], "cls": out["cls"], "grads": grads}
 
