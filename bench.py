@@ -201,6 +201,30 @@ def config5_train_step(dev, batch: int = 128, steps: int = 5, warmup: int = 2):
             "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
 
 
+def clocks_under_load(step_fn, steps: int = 300):
+    """Shader clock and socket power while the GPU is busy with the bench's own step (boxes of this pool differ by ~7 % in
+    throughput at an unchanged kernel mix; the roofline peak is quoted at 2.4 GHz): enqueue `steps` steps, read rocm-smi while
+    they run.  Never fails the bench: any problem gives None."""
+    import re
+    import subprocess
+    try:
+        for _ in range(steps):
+            step_fn()
+        res = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=20)
+        torch.cuda.synchronize()
+        card = next(iter(json.loads(res.stdout).values()))
+        mhz = lambda k: int(re.search(r"(\d+)", card.get(k, "")).group(1)) if re.search(r"(\d+)", card.get(k, "")) else None
+        power = next((float(v) for k, v in card.items() if "Power" in k), None)
+        return {"sclk_mhz": mhz("sclk clock speed:"), "mclk_mhz": mhz("mclk clock speed:"), "socket_power_w": power,
+                "source": "rocm-smi while the step loop runs"}
+    except Exception:      # noqa: BLE001
+        try:
+            torch.cuda.synchronize()
+        except Exception:  # noqa: BLE001
+            pass
+        return None
+
+
 def config5_train_step_ddp(dev, world: int, batch: int = 128, steps: int = 3, warmup: int = 1):
     """BASELINE configs[4] with its data parallelism: every rank runs the training step on its own 128 pairs with
     SyncBatchNorm (the reference's multi-GPU setting, config/backend/*.yaml), the gradients are averaged by ONE RCCL all-reduce
@@ -507,6 +531,8 @@ def main() -> None:
         barrier()
         gather_ms = 1e3 * (time.perf_counter() - tg) / args.steps
 
+    clocks = clocks_under_load(step) if (rank == 0 and not use_dist) else None
+
     # supplementary: the same K steps dealt alternately to TWO engine handles on two HIP streams (each step is still one whole
     # batch of B crops through one handle; consecutive independent batches overlap, so one batch's kernel tails are filled by
     # the other's kernels).  What a serving loop with two batches in flight gets; never `value`.
@@ -620,6 +646,8 @@ def main() -> None:
                          "fp32 MFMA (exact fp32)"),
                 "value": world * B * args.steps / elapsed_other, "unit": "crops/s",
                 "ms_per_step": 1e3 * elapsed_other / args.steps}
+        if clocks is not None:
+            out["device_under_load"] = clocks
         if elapsed_pipe is not None:
             out["pipelined_two_streams"] = {
                 "what": "the same K batches dealt alternately to two engine handles on two HIP streams (two independent batches in "
