@@ -730,6 +730,9 @@ void launch_pw(int nt, dim3 grid, hipStream_t s, const PwArgs& a) {
     }
 }
 
+// rows are read and written as float4s: every leading dimension is a multiple of 4 floats and covers its row
+bool ld_ok(int ld, int cols) { return ld >= cols && ld % 4 == 0; }
+
 int col_rows_per_block(long M) {
     int r = 64;
     while ((M + r - 1) / r > 1024) r *= 2;
@@ -762,7 +765,7 @@ int fear_pw_forward(const float* x, int ldx, const float* w, const float* bias, 
                     void* stream) {
     if (M == 0) return FEAR_TRAIN_OK;
     if (!x || !w || !y) return FEAR_TRAIN_ERR_NULL;
-    if (M < 0 || K < 4 || K % 4 || N < 4 || N % 4 || M > 0x7fffffffL) return FEAR_TRAIN_ERR_SHAPE;
+    if (M < 0 || K < 4 || K % 4 || N < 4 || N % 4 || M > 0x7fffffffL || !ld_ok(ldx, K) || !ld_ok(ldy, N)) return FEAR_TRAIN_ERR_SHAPE;
     PwArgs a{};
     a.X = x; a.ldx = ldx; a.W = w; a.bias = bias; a.Y = y; a.ldy = ldy; a.M = (int)M; a.K = K; a.N = N;
     dim3 grid((unsigned)((M + 127) / 128));
@@ -775,7 +778,8 @@ int fear_pw_backward_data(const float* dy, int lddy, const float* w, const float
                           int K, int N, void* stream) {
     if (M == 0) return FEAR_TRAIN_OK;
     if (!dy || !w || !dx) return FEAR_TRAIN_ERR_NULL;
-    if (M < 0 || K < 4 || K % 4 || N < 4 || N % 4 || M > 0x7fffffffL) return FEAR_TRAIN_ERR_SHAPE;
+    if (M < 0 || K < 4 || K % 4 || N < 4 || N % 4 || M > 0x7fffffffL || !ld_ok(lddy, N) || !ld_ok(lddx, K) || (add && !ld_ok(ldadd, K)))
+        return FEAR_TRAIN_ERR_SHAPE;
     // dX[m][k] = sum_n dY[m][n] W[n][k]: a pointwise conv with "input channels" N, "output channels" K and the weight matrix
     // read K-major (W[n][k] row-major IS the K-major layout of that conv)
     PwArgs a{};
@@ -815,13 +819,14 @@ static int wgrad_impl(const float* dy, int lddy, long dy_crop_stride, const floa
 int fear_pw_backward_weight(const float* dy, int lddy, const float* x, int ldx, float* dw, float* workspace, size_t ws_bytes,
                             long M, int K, int N, void* stream) {
     if (!dy || !x || !dw) return FEAR_TRAIN_ERR_NULL;
-    if (M <= 0 || K < 4 || K % 4 || N < 4 || N % 4 || lddy % 4 || ldx % 4) return FEAR_TRAIN_ERR_SHAPE;    // float4 loads of both operands
+    if (M <= 0 || K < 4 || K % 4 || N < 4 || N % 4 || !ld_ok(lddy, N) || !ld_ok(ldx, K)) return FEAR_TRAIN_ERR_SHAPE;    // float4 loads of both operands
     return wgrad_impl(dy, lddy, 0, x, ldx, 0, dw, workspace, ws_bytes, M, K, N, 1, static_cast<hipStream_t>(stream));
 }
 
 int fear_col_sum(const float* dy, int lddy, float* out, float* workspace, size_t ws_bytes, long M, int C, void* stream) {
     if (!dy || !out || !workspace) return FEAR_TRAIN_ERR_NULL;
     if (M <= 0 || C < 4 || C % 4 || C > 1024) return FEAR_TRAIN_ERR_SHAPE;
+    if (!ld_ok(lddy, C)) return FEAR_TRAIN_ERR_SHAPE;      // float4 rows
     const int blocks = col_blocks(M);
     if (ws_bytes < (size_t)blocks * 2 * C * sizeof(double)) return FEAR_TRAIN_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -861,6 +866,7 @@ int fear_dw_forward(const float* x, int ldx, const float* w_taps, const float* b
     if (B == 0) return FEAR_TRAIN_OK;
     if (!x || !w_taps || !y) return FEAR_TRAIN_ERR_NULL;
     if (!dw_shape_ok(B, H, W, C, k, stride)) return FEAR_TRAIN_ERR_SHAPE;
+    if (!ld_ok(ldx, C) || !ld_ok(ldy, C)) return FEAR_TRAIN_ERR_SHAPE;      // float4 rows
     return dw_impl(x, ldx, w_taps, bias, y, ldy, B, H, W, C, k, stride, static_cast<hipStream_t>(stream));
 }
 
@@ -869,6 +875,7 @@ int fear_dw_backward_data(const float* dy, int lddy, const float* w_taps, float*
     if (B == 0) return FEAR_TRAIN_OK;
     if (!dy || !w_taps || !dx) return FEAR_TRAIN_ERR_NULL;
     if (!dw_shape_ok(B, H, W, C, k, stride)) return FEAR_TRAIN_ERR_SHAPE;
+    if (!ld_ok(lddy, C) || !ld_ok(lddx, C)) return FEAR_TRAIN_ERR_SHAPE;      // float4 rows
     DwDgradArgs a{};
     a.dY = dy; a.Wt = w_taps; a.dX = dx; a.H = H; a.W = W; a.Ho = H / stride; a.Wo = W / stride; a.C = C; a.lddy = lddy; a.lddx = lddx;
     a.total = (long)B * H * W * (C / 4);
@@ -886,6 +893,7 @@ int fear_dw_backward_weight(const float* dy, int lddy, const float* x, int ldx, 
                             size_t ws_bytes, int B, int H, int W, int C, int k, int stride, void* stream) {
     if (!dy || !x || !dw_taps || !workspace) return FEAR_TRAIN_ERR_NULL;
     if (B < 1 || !dw_shape_ok(B, H, W, C, k, stride)) return FEAR_TRAIN_ERR_SHAPE;
+    if (!ld_ok(lddy, C) || !ld_ok(ldx, C)) return FEAR_TRAIN_ERR_SHAPE;      // float4 rows
     const int Ho = H / stride, Wo = W / stride;
     const long pixels = (long)B * Ho * Wo;
     const int blocks = col_blocks(pixels);
@@ -919,6 +927,7 @@ int fear_bn_train_forward(const float* x, int ldx, const float* gamma, const flo
                           int relu, float* workspace, size_t ws_bytes, void* stream) {
     if (!x || !gamma || !beta || !y || !mean || !rstd || !workspace) return FEAR_TRAIN_ERR_NULL;
     if (M <= 0 || C < 4 || C % 4 || C > 1024) return FEAR_TRAIN_ERR_SHAPE;
+    if (!ld_ok(ldx, C) || !ld_ok(ldy, C)) return FEAR_TRAIN_ERR_SHAPE;      // float4 rows
     const int blocks = col_blocks(M);
     if (ws_bytes < (size_t)blocks * 2 * C * sizeof(double)) return FEAR_TRAIN_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -943,6 +952,7 @@ int fear_bn_train_backward(const float* dy, int lddy, const float* y_act, int ld
                            int C, float* workspace, size_t ws_bytes, void* stream) {
     if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !workspace) return FEAR_TRAIN_ERR_NULL;
     if (M <= 0 || C < 4 || C % 4 || C > 1024) return FEAR_TRAIN_ERR_SHAPE;
+    if (!ld_ok(lddy, C) || !ld_ok(ldx, C) || !ld_ok(lddx, C) || (y_act && !ld_ok(ldy, C))) return FEAR_TRAIN_ERR_SHAPE;      // float4 rows
     const int blocks = col_blocks(M);
     if (ws_bytes < (size_t)blocks * 2 * C * sizeof(double)) return FEAR_TRAIN_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -967,6 +977,7 @@ int fear_bn_train_backward(const float* dy, int lddy, const float* y_act, int ld
 int fear_bn_reduce(const float* x, int ldx, double* sums, long M, int C, float* workspace, size_t ws_bytes, void* stream) {
     if (!x || !sums || !workspace) return FEAR_TRAIN_ERR_NULL;
     if (M <= 0 || C < 4 || C % 4 || C > 1024) return FEAR_TRAIN_ERR_SHAPE;
+    if (!ld_ok(ldx, C)) return FEAR_TRAIN_ERR_SHAPE;      // float4 rows
     const int blocks = col_blocks(M);
     if (ws_bytes < (size_t)blocks * 2 * C * sizeof(double)) return FEAR_TRAIN_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -986,6 +997,7 @@ int fear_bn_forward_from_sums(const float* x, int ldx, const double* sums, doubl
                               double momentum, double eps, long M, int C, int relu, void* stream) {
     if (!x || !sums || !gamma || !beta || !y || !mean || !rstd) return FEAR_TRAIN_ERR_NULL;
     if (M <= 0 || C < 4 || C % 4 || C > 1024 || !(count >= (double)M)) return FEAR_TRAIN_ERR_SHAPE;
+    if (!ld_ok(ldx, C) || !ld_ok(ldy, C)) return FEAR_TRAIN_ERR_SHAPE;      // float4 rows
     hipStream_t s = static_cast<hipStream_t>(stream);
     BnFromSumsArgs f{};
     f.sums = sums; f.mean = mean; f.rstd = rstd; f.running_mean = running_mean; f.running_var = running_var; f.C = C;
@@ -1004,6 +1016,7 @@ int fear_bn_backward_reduce(const float* dy, int lddy, const float* y_act, int l
                             const float* rstd, double* sums, long M, int C, float* workspace, size_t ws_bytes, void* stream) {
     if (!dy || !x || !mean || !rstd || !sums || !workspace) return FEAR_TRAIN_ERR_NULL;
     if (M <= 0 || C < 4 || C % 4 || C > 1024) return FEAR_TRAIN_ERR_SHAPE;
+    if (!ld_ok(lddy, C) || !ld_ok(ldx, C) || (y_act && !ld_ok(ldy, C))) return FEAR_TRAIN_ERR_SHAPE;      // float4 rows
     const int blocks = col_blocks(M);
     if (ws_bytes < (size_t)blocks * 2 * C * sizeof(double)) return FEAR_TRAIN_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1026,6 +1039,7 @@ int fear_bn_backward_from_sums(const float* dy, int lddy, const float* y_act, in
     if (!dy || !x || !mean || !rstd || !gamma || !sums_all || !sums_local || !dx || !dgamma || !dbeta || !workspace)
         return FEAR_TRAIN_ERR_NULL;
     if (M <= 0 || C < 4 || C % 4 || C > 1024 || !(count >= (double)M)) return FEAR_TRAIN_ERR_SHAPE;
+    if (!ld_ok(lddy, C) || !ld_ok(ldx, C) || !ld_ok(lddx, C) || (y_act && !ld_ok(ldy, C))) return FEAR_TRAIN_ERR_SHAPE;      // float4 rows
     if (ws_bytes < (size_t)2 * C * sizeof(float)) return FEAR_TRAIN_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     // the parameter gradients are this rank's sums (data-parallel averaging happens with all the other gradients); the input

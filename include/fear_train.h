@@ -35,6 +35,9 @@ extern "C" {
 
 size_t fear_train_workspace_bytes(long rows, int max_channels);
 
+/* Layout rules for every operator below: activations are row-major [rows][ld] fp32 with 16-byte-aligned bases; channel
+ * counts and leading dimensions are multiples of 4 floats (rows are read and written as float4s), ld >= the row's width;
+ * violations return FEAR_TRAIN_ERR_SHAPE. */
 /* nn.Conv2d(K, N, 1): y[m][n] = sum_k x[m][k] w[n][k] (+ bias[n]); K, N multiples of 4 (v_mfma_f32_16x16x4_f32) */
 int fear_pw_forward(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, long M, int K, int N,
                     void* stream);

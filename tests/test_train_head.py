@@ -31,6 +31,15 @@ def test_training_operators_are_exported():
     assert lib.fear_pw_forward(None, 0, None, None, None, 0, 16, 8, 8, None) == -1
     assert lib.fear_pw_backward_weight(None, 0, None, 0, None, None, 0, 16, 8, 8, None) == -1
     assert lib.fear_bn_train_forward(None, 0, None, None, None, 0, None, None, None, None, 0.1, 1e-5, 16, 8, 1, None, 0, None) == -1
+    # layout rules are checked before anything touches the device: leading dimensions are multiples of 4 floats and cover the row
+    import ctypes
+    fake = ctypes.c_void_p(4096)
+    assert lib.fear_pw_forward(fake, 10, fake, None, fake, 8, 16, 8, 8, None) == -2            # ldx % 4
+    assert lib.fear_pw_forward(fake, 4, fake, None, fake, 8, 16, 8, 8, None) == -2             # ldx < K
+    assert lib.fear_pw_backward_weight(fake, 8, fake, 6, fake, fake, 1 << 20, 16, 8, 8, None) == -2
+    assert lib.fear_bn_train_forward(fake, 8, fake, fake, fake, 6, fake, fake, None, None, 0.1, 1e-5, 16, 8, 1, fake, 1 << 20, None) == -2
+    assert lib.fear_dw_forward(fake, 8, fake, None, fake, 7, 1, 4, 4, 8, 3, 1, None) == -2
+    assert lib.fear_bn_reduce(fake, 9, fake, 16, 8, fake, 1 << 20, None) == -2
 
 
 def test_fixture_is_self_consistent(golden_dir):
