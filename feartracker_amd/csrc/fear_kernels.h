@@ -561,8 +561,9 @@ __global__ __launch_bounds__(256) void normalize_kernel(NormArgs a) {
 // get_extended_crop + normalise on device: context box -> constant border with the (saturate-
 // cast) mean colour -> cv2.INTER_LINEAR uint8 resize (11-bit fixed point, half-pixel centres) -> ImageNet
 // normalisation -> fp32 NCHW.  Reference: model_training/utils/utils.py:215-253 (cv2.copyMakeBorder + A.Resize)
-// and tracker/base_tracker.py:70-103.  Bit-exact against the host restatement feartracker_amd/geometry.py
-// (crop parity against real cv2 is unpinned in this image).  One thread per output pixel.
+// and tracker/base_tracker.py:70-103.  Bit-exact against the host restatement feartracker_amd/geometry.py and against the
+// independent table-driven restatement of resize.cpp the tests carry, cv_ref.c (crop parity against real cv2 is unpinned in this image, see
+// DESIGN.md).  One thread per output pixel.
 struct CropArgs {
     const uint8_t* frame;   // [H][W][3] RGB
     const int* ctx;         // [n][4] context box x, y, w, h (frame coordinates, may leave the frame)
@@ -572,17 +573,25 @@ struct CropArgs {
     float mean[3], inv_std[3];
 };
 
+// One axis of OpenCV's 8u INTER_LINEAR coefficient table (resize.cpp), in its order of operations: scale = 1 / (dst / src) in
+// double, the position rounded to float FIRST, floored, the fraction = the float difference; weights = cvRound(w * 2048).
+// Columns (CLAMP) pin positions outside [0, src - 1] to the edge pixel with weights 2048 | 0; rows keep the table's weights and
+// clip the two row INDICES (an edge row blended with itself — not the same number after the >> 16 truncations).  The
+// double products are rounded separately (__dmul_rn / __dadd_rn: hipcc would otherwise contract them into one fma).
+template <bool CLAMP>
 __device__ __forceinline__ void linear_tap(int d, int dst, int src, int& i0, int& i1, int& w0, int& w1) {
-    const double scale = (double)src / (double)dst;
-    const double pos = ((double)d + 0.5) * scale - 0.5;
-    int idx = (int)floor(pos);
-    float frac = (float)(pos - (double)idx);
-    if (idx < 0) { frac = 0.f; idx = 0; }
-    if (idx >= src - 1) { frac = 0.f; idx = src - 1; }
-    w1 = (int)rint((double)frac * 2048.0);
-    w0 = (int)rint((double)(1.0f - frac) * 2048.0);
-    i0 = idx;
-    i1 = min(idx + 1, src - 1);
+    const double scale = 1.0 / ((double)dst / (double)src);
+    float f = (float)__dadd_rn(__dmul_rn((double)d + 0.5, scale), -0.5);
+    int idx = (int)floorf(f);
+    f = __fsub_rn(f, (float)idx);
+    if (CLAMP) {
+        if (idx < 0) { f = 0.f; idx = 0; }
+        if (idx >= src - 1) { f = 0.f; idx = src - 1; }
+    }
+    w0 = (int)rintf(__fmul_rn(__fsub_rn(1.0f, f), 2048.0f));
+    w1 = (int)rintf(__fmul_rn(f, 2048.0f));
+    i0 = min(max(idx, 0), src - 1);
+    i1 = min(max(idx + 1, 0), src - 1);
 }
 
 __global__ __launch_bounds__(256) void crop_resize_normalize_kernel(CropArgs a) {
@@ -593,9 +602,10 @@ __global__ __launch_bounds__(256) void crop_resize_normalize_kernel(CropArgs a) 
     const int dy = px / a.S, dx = px % a.S;
     const int cx = a.ctx[crop * 4], cy = a.ctx[crop * 4 + 1], cw = a.ctx[crop * 4 + 2], ch = a.ctx[crop * 4 + 3];
     int x0, x1, ax0, ax1, y0, y1, ay0, ay1;
-    linear_tap(dx, a.S, cw, x0, x1, ax0, ax1);
-    linear_tap(dy, a.S, ch, y0, y1, ay0, ay1);
+    linear_tap<true>(dx, a.S, cw, x0, x1, ax0, ax1);
+    linear_tap<false>(dy, a.S, ch, y0, y1, ay0, ay1);
     const bool same = (cw == a.S) && (ch == a.S);      // the reference's resize is the identity then
+    const bool half = (cw == 2 * a.S) && (ch == 2 * a.S);   // cv::resize runs an exact 2x2 decimation as the 2x2 box mean
     auto sample = [&](int sx, int sy, int c) -> int {
         const int fx = cx + sx, fy = cy + sy;
         if (fx < 0 || fx >= a.W || fy < 0 || fy >= a.H) return a.pad[crop * 3 + c];
@@ -606,6 +616,9 @@ __global__ __launch_bounds__(256) void crop_resize_normalize_kernel(CropArgs a) 
         int v;
         if (same) {
             v = sample(dx, dy, c);
+        } else if (half) {
+            v = (sample(2 * dx, 2 * dy, c) + sample(2 * dx + 1, 2 * dy, c) + sample(2 * dx, 2 * dy + 1, c) +
+                 sample(2 * dx + 1, 2 * dy + 1, c) + 2) >> 2;
         } else {
             const int r0 = sample(x0, y0, c) * ax0 + sample(x1, y0, c) * ax1;
             const int r1 = sample(x0, y1, c) * ax0 + sample(x1, y1, c) * ax1;

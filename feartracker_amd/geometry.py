@@ -14,7 +14,8 @@ The reference delegates padding to `cv2.copyMakeBorder` and resizing to albument
 `A.Resize` (= `cv2.resize(..., INTER_LINEAR)`); neither library exists in this image, so
 `copy_make_border` / `resize_bilinear_u8` below restate OpenCV's uint8 behaviour
 (saturate-cast of the border value; 11-bit fixed-point bilinear with half-pixel centres).
-Crop parity against real cv2 is UNPINNED here.
+Crop parity against real cv2 is UNPINNED here; what pins these functions is the
+independent, table-driven C restatement of resize.cpp that the tests carry (cv_ref.c), bit for bit.
 """
 from __future__ import annotations
 
@@ -91,20 +92,27 @@ def copy_make_border(img: np.ndarray, top: int, bottom: int, left: int, right: i
     return out
 
 
-def _linear_taps(dst: int, src: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
-    """Source index and the two int16 fixed-point weights per destination coordinate."""
-    scale = float(src) / float(dst)
-    pos = (np.arange(dst, dtype=np.float64) + 0.5) * scale - 0.5
-    idx = np.floor(pos).astype(np.int64)
-    frac = (pos - idx).astype(np.float32)
-    low = idx < 0
-    frac[low] = 0.0
-    idx[low] = 0
-    high = idx >= src - 1
-    frac[high] = 0.0
-    idx[high] = src - 1
-    w1 = np.rint(frac.astype(np.float64) * _COEF_ONE).astype(np.int64)
-    w0 = np.rint((1.0 - frac).astype(np.float64) * _COEF_ONE).astype(np.int64)
+def _linear_taps(dst: int, src: int, clamp: bool) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Source index and the two int16 fixed-point weights per destination coordinate, in OpenCV's order of operations:
+    the position is rounded to float32 FIRST, floored, and the fraction is the float32 difference (resize.cpp: `fx =
+    (float)((dx+0.5)*scale_x - 0.5); sx = cvFloor(fx); fx -= sx`), scale = 1 / (dst / src) in double.  Columns
+    (`clamp=True`) pin positions left of pixel 0 / right of the last pixel to that pixel with weight 2048 | 0; rows
+    (`clamp=False`) keep their raw index and weights — the caller clips the two ROW INDICES instead, so an edge row is
+    blended with itself at the table's weights, which is not the same number after the >> 16 truncations."""
+    scale = 1.0 / (float(dst) / float(src))
+    pos = ((np.arange(dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+    idx_f = np.floor(pos)
+    frac = pos - idx_f                                   # float32 - float32
+    idx = idx_f.astype(np.int64)
+    if clamp:
+        low = idx < 0
+        frac[low] = 0.0
+        idx[low] = 0
+        high = idx >= src - 1
+        frac[high] = 0.0
+        idx[high] = src - 1
+    w0 = np.rint((np.float32(1.0) - frac) * np.float32(_COEF_ONE)).astype(np.int64)     # cvRound: half to even
+    w1 = np.rint(frac * np.float32(_COEF_ONE)).astype(np.int64)
     return idx, w0, w1
 
 
@@ -112,20 +120,25 @@ def resize_bilinear_u8(img: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
     """cv2.resize(img, (out_w, out_h), interpolation=cv2.INTER_LINEAR) for uint8 HxWxC.
 
     Horizontal pass in 11-bit fixed point to int32, vertical pass
-    `(((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2` as in OpenCV's 8u linear resizer.
+    `(((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2` as in OpenCV's 8u linear resizer; an exact 2x2 decimation is
+    the 2x2 box mean `(a+b+c+d+2)>>2` (cv::resize runs INTER_LINEAR as the fast INTER_AREA there).  Compared bit for bit
+    with the independent table-driven restatement cv_ref.c in tests/test_cv_parity.py.
     """
     if img.dtype != np.uint8:
         raise TypeError("resize_bilinear_u8 expects uint8 input")
     src_h, src_w = img.shape[:2]
     if (src_h, src_w) == (out_h, out_w):
         return img.copy()
-    ix, ax0, ax1 = _linear_taps(out_w, src_w)
-    iy, ay0, ay1 = _linear_taps(out_h, src_h)
-    ix1 = np.minimum(ix + 1, src_w - 1)
-    iy1 = np.minimum(iy + 1, src_h - 1)
     src = img.astype(np.int64)
+    if src_h == 2 * out_h and src_w == 2 * out_w:
+        return ((src[0::2, 0::2] + src[0::2, 1::2] + src[1::2, 0::2] + src[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    ix, ax0, ax1 = _linear_taps(out_w, src_w, clamp=True)
+    iy, ay0, ay1 = _linear_taps(out_h, src_h, clamp=False)
+    ix1 = np.minimum(ix + 1, src_w - 1)
+    iy0 = np.clip(iy, 0, src_h - 1)
+    iy1 = np.clip(iy + 1, 0, src_h - 1)
     rows = src[:, ix] * ax0[None, :, None] + src[:, ix1] * ax1[None, :, None]      # (src_h, out_w, C)
-    s0 = rows[iy] >> 4
+    s0 = rows[iy0] >> 4
     s1 = rows[iy1] >> 4
     out = (((ay0[:, None, None] * s0) >> 16) + ((ay1[:, None, None] * s1) >> 16) + 2) >> 2
     return np.clip(out, 0, 255).astype(np.uint8)
@@ -140,9 +153,17 @@ def crop_geometry(image_shape: Tuple[int, ...], bbox: Sequence[float], crop_size
     cx, cy, cw, ch = (int(v) for v in ctx)
     box_in_pad = ensure_bbox_boundaries(
         np.array([bbox[0] - ctx[0], bbox[1] - ctx[1], bbox[2], bbox[3]]), img_shape=(ch, cw))
-    sx, sy = crop_size / float(cw), crop_size / float(ch)
-    box_in_crop = np.array([box_in_pad[0] * sx, box_in_pad[1] * sy, box_in_pad[2] * sx, box_in_pad[3] * sy])
-    return ctx, box_in_crop
+    return ctx, _resized_coco_box(box_in_pad, ch, cw, crop_size)
+
+
+def _resized_coco_box(box: Sequence[float], rows: int, cols: int, size: int) -> np.ndarray:
+    """An xywh box of a rows x cols image after A.Compose([A.Resize(size, size)], bbox_params=coco) — albumentations'
+    own float64 sequence (bbox_utils: corners / (cols, rows), clip to [0, 1], * size, width = x_max - x_min)."""
+    x_min, y_min = box[0] / cols, box[1] / rows
+    x_max, y_max = (box[0] + box[2]) / cols, (box[1] + box[3]) / rows
+    x_min, y_min, x_max, y_max = (min(max(float(v), 0.0), 1.0) for v in (x_min, y_min, x_max, y_max))
+    x_min, x_max, y_min, y_max = x_min * size, x_max * size, y_min * size, y_max * size
+    return np.array([x_min, y_min, x_max - x_min, y_max - y_min])
 
 
 def border_color_u8(padding_value: Sequence[float]) -> np.ndarray:
@@ -169,11 +190,8 @@ def get_extended_crop(image: np.ndarray, bbox: Sequence[float], crop_size: int, 
     box_in_pad = ensure_bbox_boundaries(
         np.array([bbox[0] - ctx[0], bbox[1] - ctx[1], bbox[2], bbox[3]]), img_shape=padded.shape[:2])
     crop = resize_bilinear_u8(padded, crop_size, crop_size)
-    # albumentations rescales coco boxes through normalised coordinates
     ph, pw = padded.shape[:2]
-    sx, sy = crop_size / float(pw), crop_size / float(ph)
-    box_in_crop = np.array([box_in_pad[0] * sx, box_in_pad[1] * sy, box_in_pad[2] * sx, box_in_pad[3] * sy])
-    return crop, box_in_crop, ctx
+    return crop, _resized_coco_box(box_in_pad, ph, pw, crop_size), ctx
 
 
 _MEAN = np.array([0.485, 0.456, 0.406], dtype=np.float32) * np.float32(255.0)
