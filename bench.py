@@ -46,6 +46,7 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 = fp32 vector rate
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (no sparsity)
 FLOPS_PER_CROP = 922_787_840    # 2 x 461 393 920 MAC
 BYTES_PER_CROP = 857_088        # compulsory fp32 bytes per crop
 
@@ -77,10 +78,77 @@ def _lscpu_model() -> str:
     return "unknown"
 
 
+def _cpu_node_worker(idx, cpus, threads, weights, seconds, q):
+    """One of the node-level baseline's processes: the CPU oracle on `threads` threads pinned to `cpus`, batches of 8 of the
+    same seeded synthetic crops, for ~`seconds`; reports (crops, elapsed)."""
+    try:
+        os.sched_setaffinity(0, cpus)
+    except Exception:      # noqa: BLE001 — affinity is an optimisation, not a requirement
+        pass
+    torch.set_num_threads(threads)
+    from oracle.fear_oracle import OracleNet  # checker/baseline only
+    net = OracleNet(weights)
+    g = torch.Generator().manual_seed(idx)
+    x = norm_u8(torch.randint(0, 256, (8, 3, 256, 256), dtype=torch.uint8, generator=g))
+    z = net.get_features(norm_u8(torch.randint(0, 256, (8, 3, 128, 128), dtype=torch.uint8, generator=g)))
+    net.track(x, z)
+    q.put(("ready", idx))
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        net.track(x, z)
+        n += 8
+    q.put(("done", idx, n, time.perf_counter() - t0))
+
+
+def cpu_node_baseline(weights, threads_per_proc: int = 16, seconds: float = 8.0):
+    """The NODE's CPU throughput on this path (north_star: "timed on the node's host cores (count stated)"): one oracle
+    process per `threads_per_proc` logical CPUs (the per-process optimum, tools/cpu_sweep.py), each pinned to its own block,
+    all running the same bounded sample at once; value = the sum.  Bounded: ~`seconds` of wall clock plus process start-up."""
+    import multiprocessing as mp
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except Exception:      # noqa: BLE001
+        cpus = list(range(os.cpu_count() or 1))
+    nproc = max(1, len(cpus) // threads_per_proc)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cpu_node_worker, args=(i, set(cpus[i * threads_per_proc:(i + 1) * threads_per_proc]),
+                                                         threads_per_proc, weights, seconds, q)) for i in range(nproc)]
+    t_start = time.perf_counter()
+    for p in procs:
+        p.start()
+    done = []
+    try:
+        import queue as _queue
+        deadline = time.perf_counter() + 300
+        while len(done) < nproc:
+            try:
+                msg = q.get(timeout=2)
+            except _queue.Empty:
+                dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+                if dead or time.perf_counter() > deadline:
+                    raise RuntimeError(f"cpu baseline workers failed (exit codes {dead})")
+                continue
+            if msg[0] == "done":
+                done.append(msg)
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.terminate()
+    rates = [n / dt for _, _, n, dt in done]
+    return {"value": float(sum(rates)), "unit": "crops/s", "processes": nproc, "threads_per_process": threads_per_proc,
+            "cores": nproc * threads_per_proc, "host_cpus": os.cpu_count(), "per_process_min_max": [min(rates), max(rates)],
+            "sample": f"{sum(n for _, _, n, _ in done)} crops: {nproc} oracle processes x batches of 8 of the same synthetic 256x256 "
+                      f"workload, {seconds:.0f} s each, all at once (wall {time.perf_counter() - t_start:.0f} s incl. start-up)"}
+
+
 def cpu_baseline(search_u8, tmpl_u8, weights, budget_s: float = 10.0):
-    """Oracle (kind='port') on the host cores, bounded sample: batches of 8 crops for ~budget_s (the headline CPU number),
-    plus the two legs BASELINE.md §3.2 names — B=1 (20 warm-up + up to 100 timed calls) and B=32 — each bounded to a few
-    seconds so that the default bench run stays within minutes."""
+    """Oracle (kind='port') on the host cores, bounded sample.  `value` / `cores` = the whole NODE (one 16-thread oracle process
+    per 16 logical CPUs, all at once: cpu_node_baseline); `single_process` = one process on its best thread count (batches of 8
+    crops for ~budget_s) plus the two legs BASELINE.md §3.2 names — B=1 (20 warm-up + up to 100 timed calls) and B=32 — each
+    bounded to a few seconds so that the default bench run stays within minutes."""
     from oracle.fear_oracle import OracleNet  # checker/baseline only, never on the product path
     # torch/oneDNN fp32 conv throughput on this graph peaks at ~16 threads on the 2x64-core EPYC host
     # (tools/cpu_sweep.py: 16 thr 93 crops/s, 32 thr 85, 64 thr 42, 128 thr 15); use the best setting.
@@ -105,12 +173,22 @@ def cpu_baseline(search_u8, tmpl_u8, weights, budget_s: float = 10.0):
     v8, it8, dt8 = leg(8, 1, 512, budget_s)
     v1, it1, dt1 = leg(1, 20, 100, 5.0)
     v32, it32, dt32 = leg(32, 1, 20, 6.0)
-    return {"value": v8, "unit": "crops/s", "cores": torch.get_num_threads(), "kind": "port",
-            "host_cpus": os.cpu_count(), "cpu_model": _lscpu_model(),
-            "sample": f"{it8 * 8} crops (batches of 8) of the same synthetic 256x256 workload, torch fp32 oracle, {dt8:.1f}s",
-            "batch1": {"value": v1, "unit": "crops/s", "ms_per_crop": 1e3 / v1, "iters": it1,
-                       "protocol": "20 warm-up + <=100 timed calls (README.md:43, Benchmark.swift:55-77)"},
-            "batch32": {"value": v32, "unit": "crops/s", "iters": it32, "seconds": dt32}}
+    single = {"value": v8, "unit": "crops/s", "cores": torch.get_num_threads(),
+              "sample": f"{it8 * 8} crops (batches of 8) of the same synthetic 256x256 workload, torch fp32 oracle, {dt8:.1f}s",
+              "batch1": {"value": v1, "unit": "crops/s", "ms_per_crop": 1e3 / v1, "iters": it1,
+                         "protocol": "20 warm-up + <=100 timed calls (README.md:43, Benchmark.swift:55-77)"},
+              "batch32": {"value": v32, "unit": "crops/s", "iters": it32, "seconds": dt32}}
+    del net
+    try:
+        node = cpu_node_baseline(weights)
+    except Exception as exc:      # noqa: BLE001 — the single-process number still stands
+        node = {"error": f"{type(exc).__name__}: {exc}"}
+    if "value" in node:
+        return {"value": node["value"], "unit": "crops/s", "cores": node["cores"], "kind": "port", "host_cpus": os.cpu_count(),
+                "cpu_model": _lscpu_model(), "sample": node["sample"], "processes": node["processes"],
+                "threads_per_process": node["threads_per_process"], "per_process_min_max": node["per_process_min_max"],
+                "single_process": single}
+    return dict(single, kind="port", host_cpus=os.cpu_count(), cpu_model=_lscpu_model(), node=node)
 
 
 def config4_fear_m(dev, steps: int = 20, warmup: int = 5, batch: int = 512):
@@ -139,6 +217,40 @@ def config4_fear_m(dev, steps: int = 20, warmup: int = 5, batch: int = 512):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         res[tag] = {"value": batch / dt, "unit": "crops/s", "ms_per_step": 1e3 * dt}
+        if mode == 2:
+            # roofline of this configuration's dominant kernel: every launch bracketed with HIP events on the launch stream
+            plan = net.plan(256, True)
+            net.set_profile(True, op=-1)
+            net.profile_reset()
+            for _ in range(3):
+                net.track_maps(search, z, out=(bbox, cls))
+            torch.cuda.synchronize()
+            prof = net.profile_read(256, True)
+            net.set_profile(False)
+            per_launch = [ms / max(cnt, 1) for ms, cnt in prof]
+            per_step = [ms / 3 for ms, _ in prof]
+            groups = {}
+            for i, (nm, _, _) in enumerate(plan):
+                groups[nm] = groups.get(nm, 0.0) + per_step[i]
+            dom_name = max(groups, key=groups.get)
+            di = [i for i, (nm, _, _) in enumerate(plan) if nm == dom_name][0]
+            _, fl, by = plan[di]
+            crops_per_launch = batch / max(prof[di][1] / 3, 1)
+            t = per_launch[di] * 1e-3
+            tf, gbs = fl * crops_per_launch / t / 1e12, by * crops_per_launch / t / 1e9
+            ridge = PEAK_BF16_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+            if fl / by >= ridge:
+                roof = {"bound": "mfma", "achieved": tf, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_BF16_MFMA_TFLOPS}
+            else:
+                roof = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS}
+            tr, tr_file = pmc_traffic(dom_name, "fear_m")
+            roof.update({"traffic": tr, "traffic_source": tr_file, "kernel": dom_name, "avg_launch_ms": per_launch[di],
+                         "share_of_step": groups[dom_name] / max(sum(per_step), 1e-12),
+                         "arithmetic_intensity_flop_per_byte": fl / by, "tflops_of_that_kernel": tf,
+                         "sum_of_kernels_ms_per_step": sum(per_step),
+                         "note": "bf16 operands on the matrix pipe (dense peak ~2.5 PFLOP/s): at this kernel's algorithmic intensity "
+                                 "the bounding roofline is the one named in `bound`"})
+            res["roofline"] = roof
         if ref is None:
             ref = (bbox[:32].clone(), cls[:32].clone())
             flops = sum(f for _, f, _ in net.plan(256, True))
@@ -153,7 +265,8 @@ def config4_fear_m(dev, steps: int = 20, warmup: int = 5, batch: int = 512):
             "metric": "search-region crops/sec", "dtype": "bf16 operands on v_mfma_f32_16x16x32_bf16, fp32 accumulate (FEAR_OPT_MATH=2); "
                                                          "depthwise / bias / residuals fp32",
             "value": res["bf16"]["value"], "unit": "crops/s", "steps": steps, "warmup": warmup,
-            "tflops_bf16_path": res["bf16"]["value"] * flops / 1e12, "bf16": res["bf16"], "fp32_same_model": res["fp32"]}
+            "tflops_bf16_path": res["bf16"]["value"] * flops / 1e12, "bf16": res["bf16"], "fp32_same_model": res["fp32"],
+            "roofline": res.get("roofline")}
 
 
 def config5_train_step(dev, batch: int = 128, steps: int = 5, warmup: int = 2):
@@ -332,15 +445,18 @@ def latency_batch1(weights, frames_cap: int = 120):
             "boxes_identical_to_cpu_oracle": bool(np.array_equal(host_boxes[:ncpu - 1], cpu_boxes))}
 
 
-def pmc_traffic(op_name: str):
+def pmc_traffic(op_name: str, tag: str = ""):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
     command (profiles/rNN_traffic.json via tools/pmc_to_traffic.py; op -> kernel symbol via rNN_per_op.csv).
     PMC counters cannot be collected from inside the timed run, so this is the offline measurement or null."""
     import csv
     import glob
     try:
-        per_op = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_per_op.csv")))[-1]
-        traffic = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]
+        suf = f"_{tag}" if tag else ""
+        pick = lambda pat: sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", pat))
+                                  if tag or not any(t in os.path.basename(f) for t in ("_fear_m_", "_train_")))[-1]
+        per_op = pick(f"r*{suf}_per_op.csv")
+        traffic = pick(f"r*{suf}_traffic.json")
         sym = None
         with open(per_op) as fh:
             for r in csv.DictReader(fh):
@@ -427,10 +543,17 @@ def main() -> None:
         # RCCL prints a version banner through C stdio on STDOUT when the first communicator comes up; stdout must carry
         # exactly one JSON line, so fd 1 points at stderr while the communicator is created (and libc's buffer is flushed
         # there before fd 1 is restored)
+        # RCCL's own account of the communicator (its INIT lines carry "rank r nranks N") goes to STDERR, next to ours below,
+        # so that a driver log shows N ranks the day a multi-GPU node runs this
+        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT")
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
         with _c_stdout_to_stderr():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
             dist.barrier()
             torch.cuda.synchronize()
+        print(f"[bench] rank {dist.get_rank()} of {dist.get_world_size()} (torch.distributed, backend {dist.get_backend()}) on "
+              f"cuda:{local_rank} = {torch.cuda.get_device_name(local_rank)}", file=sys.stderr, flush=True)
 
     from feartracker_amd import FEARNetHIP, DEFAULT_WEIGHTS
     from feartracker_amd.sharding import OverlappedGather, gather_packed
@@ -657,7 +780,7 @@ def main() -> None:
         if ddp_train is not None:
             out["config5_train_step_data_parallel"] = ddp_train
         if use_dist:
-            out["collective"] = {"backend": "nccl (RCCL)", "ranks": world, "op": "all_gather_into_tensor",
+            out["collective"] = {"backend": "nccl (RCCL)", "ranks": dist.get_world_size(), "op": "all_gather_into_tensor",
                                  "bytes_per_rank": B * 5 * 16 * 16 * 4, "ms_alone": gather_ms,
                                  "overlapped_with_next_batch": overlap is not None}
         if not args.no_cpu_baseline and world == 1:

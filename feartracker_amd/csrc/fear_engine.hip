@@ -175,7 +175,7 @@ struct fear_handle {
                                           // measured 104.3 k vs 104.8 k crops/s single-stream — the 16x16 kernels are ALU-bound, a second
                                           // resident workgroup per CU buys nothing: kbench 512 vs 2 x 256 crops, +2 %)
     int plan_crops = 0;                   // FEAR_OPT_PLAN_CROPS: crop count whose plan the introspection calls describe (0: max_batch)
-    hipStream_t last_stream = nullptr;    // the caller stream of the previous call: a call on another stream first waits for it
+    hipStream_t last_stream = nullptr;    // the caller stream of the previous call (compared only): a call on another stream first waits for `stream_switch`
     bool last_stream_valid = false;       // (the workspace and the branch stream are shared by all calls on a handle)
     hipEvent_t stream_switch = nullptr;
     std::vector<hipEvent_t> event_pool;   // recycled profiling events (creation is slow enough to perturb timing)
@@ -1212,11 +1212,10 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
         h->fused_attr_set = true;
     }
     // one workspace per handle: a call on another stream than the previous one must not overtake it
-    if (h->last_stream_valid && h->last_stream != s_main) {
-        if (!h->stream_switch) HIP_TRY(h, hipEventCreateWithFlags(&h->stream_switch, hipEventDisableTiming));
-        HIP_TRY(h, hipEventRecord(h->stream_switch, h->last_stream));
-        HIP_TRY(h, hipStreamWaitEvent(s_main, h->stream_switch, 0));
-    }
+    // (the event was recorded on the previous call's stream at the END of that call, below: the old stream handle is only
+    // compared here, never used — the caller may have destroyed that stream since)
+    if (!h->stream_switch) HIP_TRY(h, hipEventCreateWithFlags(&h->stream_switch, hipEventDisableTiming));
+    if (h->last_stream_valid && h->last_stream != s_main) HIP_TRY(h, hipStreamWaitEvent(s_main, h->stream_switch, 0));
     h->last_stream = s_main;
     h->last_stream_valid = true;
     const size_t slab = p.buf_floats_per_crop * pass_cap(h, p);
@@ -1416,6 +1415,7 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
         HIP_TRY(h, hipEventRecord(h->branch_join, h->branch_stream));
         HIP_TRY(h, hipStreamWaitEvent(s_main, h->branch_join, 0));
     }
+    HIP_TRY(h, hipEventRecord(h->stream_switch, s_main));      // what a later call on ANOTHER stream waits for (see above)
     HIP_TRY(h, hipGetLastError());
     return FEAR_OK;
 }

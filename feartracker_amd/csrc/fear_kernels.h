@@ -1433,7 +1433,11 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
     float* const WS = lds + EBUF;       // [2][AP + BP]
 
     const long long tk_start = (FEAR_ABL & 4096) ? wall_clock64() : 0;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // the wave index in an SGPR: the per-m-tile trip counts and every wave-dependent address stay on the scalar unit (a VGPR
+    // copy made each `(wave + 8 * i) * 16 >= NPIX` test an exec-mask update with two VALU instructions, 5.8 cycles each on the
+    // ALU the MFMAs share: profiles/r03_issue_probe.txt)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lk = lane >> 4;
     const int tiles = t.tiles_x * t.tiles_y;
     const unsigned tix = xcd_tile_index(blockIdx.x, gridDim.x);

@@ -608,9 +608,11 @@ __global__ void loss_finalize_kernel(LossArgs a) {
     double s[6] = {0, 0, 0, 0, 0, 0};
     for (int b = 0; b < a.blocks; ++b)
         for (int j = 0; j < 6; ++j) s[j] += (double)a.partial[(long)b * 8 + j];
-    // _weighted_cls_loss: mean over the selected cells (nn.BCEWithLogitsLoss of an empty selection is NaN in torch; the
-    // reference's batches always hold both kinds, and so must the caller's)
-    const double lp = s[0] > 0 ? s[3] / s[0] : 0.0, ln = s[1] > 0 ? s[4] / s[1] : 0.0;
+    // _weighted_cls_loss (loss.py:68-73): mean over the selected cells.  A selection of exactly ONE cell is a 0-dim index
+    // after the reference's `.nonzero().squeeze()` and `_weighted_cls_loss` then returns a constant 0 — no loss and no
+    // gradient from that half; mirrored here (loss_grad_kernel too).  An EMPTY selection is NaN in torch
+    // (BCEWithLogitsLoss over nothing); here that half is 0 — the one stated deviation (fear_train.h).
+    const double lp = s[0] > 1 ? s[3] / s[0] : 0.0, ln = s[1] > 1 ? s[4] / s[1] : 0.0;
     const double lr = s[2] > 0 ? s[5] / s[2] : 0.0;
     a.totals[0] = (float)s[0]; a.totals[1] = (float)s[1]; a.totals[2] = (float)s[2];
     a.totals[3] = (float)((0.5 * lp + 0.5 * ln) * a.coef_cls);
@@ -624,8 +626,8 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(LossArgs a) {
     const float x = a.cls[m], y = a.gt_cls[m];
     const float sg = 1.f / (1.f + expf(-x));
     float dc = 0.f;
-    if (y == 1.f) dc = 0.5f * a.coef_cls * (sg - 1.f) / n_pos;
-    else if (y == 0.f) dc = 0.5f * a.coef_cls * sg / n_neg;
+    if (y == 1.f) dc = n_pos > 1.f ? 0.5f * a.coef_cls * (sg - 1.f) / n_pos : 0.f;      // one selected cell: no gradient (see
+    else if (y == 0.f) dc = n_neg > 1.f ? 0.5f * a.coef_cls * sg / n_neg : 0.f;           // loss_finalize_kernel)
     a.dcls[m] = dc;
     f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (a.gt_w[m] > 0.f) {
@@ -695,6 +697,7 @@ struct AdamArgs {
     float* v;
     long n;
     float lr_over_bc1, beta1, beta2, eps, weight_decay, bc2_sqrt;
+    float one_minus_beta1, one_minus_beta2;      // computed in double on the host like torch's scalar arguments (1.f - 0.999f is 1.3e-5 off 0.001f)
 };
 
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
@@ -703,8 +706,8 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     float g = a.g[i];
     const float p = a.p[i];
     if (a.weight_decay != 0.f) g += a.weight_decay * p;
-    const float m = a.m[i] + (g - a.m[i]) * (1.f - a.beta1);          // exp_avg.lerp_(grad, 1 - beta1)
-    const float v = a.v[i] * a.beta2 + (1.f - a.beta2) * g * g;       // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    const float m = a.m[i] + (g - a.m[i]) * a.one_minus_beta1;          // exp_avg.lerp_(grad, 1 - beta1)
+    const float v = a.v[i] * a.beta2 + a.one_minus_beta2 * g * g;      // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
     const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
     a.m[i] = m;
     a.v[i] = v;
@@ -1062,7 +1065,8 @@ int fear_xcorr_forward(const float* x, int ldx, const float* z_nchw, float* s_ou
     // s[b][p][j] = sum_c x[b][p][c] z[b][c][j]   (MobileCorrelation, blocks.py:121-123); z is the caller's NCHW (C, J) block
     if (B == 0) return FEAR_TRAIN_OK;
     if (!x || !z_nchw || !s_out) return FEAR_TRAIN_ERR_NULL;
-    if (B < 0 || P < 1 || C % 4 || J % 4) return FEAR_TRAIN_ERR_SHAPE;
+    // a wave of pw_mfma_kernel owns 32 rows and picks its crop's weight matrix once: rows of two crops must not share a wave
+    if (B < 0 || P < 1 || P % 32 || C < 4 || J < 4 || C % 4 || J % 4 || !ld_ok(ldx, C) || !ld_ok(lds, J)) return FEAR_TRAIN_ERR_SHAPE;
     PwArgs a{};
     a.X = x; a.ldx = ldx; a.W = z_nchw; a.Y = s_out; a.ldy = lds; a.M = B * P; a.K = C; a.N = J;
     a.rows_per_crop = P; a.w_crop_stride = (long)C * J;
@@ -1194,6 +1198,7 @@ int fear_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
     AdamArgs a{};
     a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.n = n;
     a.beta1 = (float)beta1; a.beta2 = (float)beta2; a.eps = (float)eps; a.weight_decay = (float)weight_decay;
+    a.one_minus_beta1 = (float)(1.0 - beta1); a.one_minus_beta2 = (float)(1.0 - beta2);
     a.lr_over_bc1 = (float)(lr / (1.0 - pow(beta1, step)));           // step_size = lr / bias_correction1
     a.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, step));
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), a);

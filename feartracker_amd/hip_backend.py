@@ -17,6 +17,7 @@ import ctypes
 import os
 from typing import Dict, Optional, Tuple
 
+import numpy as np
 import torch  # must be imported before the library so that both share one libamdhip64
 
 from .constants import TARGET_CLASSIFICATION_KEY, TARGET_REGRESSION_LABEL_KEY
@@ -339,24 +340,54 @@ class FEARNetHIP:
         return out
 
     @torch.no_grad()
-    def crop_normalize(self, frame_u8: torch.Tensor, ctx_xywh, pad_rgb_u8, out_hw: int) -> torch.Tensor:
-        """Device get_extended_crop + normalise (utils.py:215-253 + base_tracker.py:97-103): frame (H,W,3) uint8 on
-        the GPU, ctx_xywh (n,4) int context boxes, pad_rgb_u8 (n,3) uint8 border colours -> (n,3,out_hw,out_hw) fp32."""
+    def crop_normalize(self, frame_u8, ctx_xywh, pad_rgb_u8, out_hw: int) -> torch.Tensor:
+        """Device get_extended_crop + normalise (utils.py:215-253 + base_tracker.py:97-103): frame (H,W,3) uint8 — a numpy
+        array / CPU tensor (uploaded here) or a tensor already on the GPU —, ctx_xywh (n,4) int context boxes, pad_rgb_u8
+        (n,3) uint8 border colours -> (n,3,out_hw,out_hw) fp32.
+
+        Of a HOST frame only the rectangle the context boxes can sample travels over PCIe (their union clipped to the frame:
+        a 225x870 context in a 1080p frame is 0.3 MB of the frame's 6.2 MB; the boxes are shifted to that rectangle's
+        origin, everything outside it is border colour for the kernel exactly as the rest of the frame's outside is), and
+        the context boxes and border colours go up in ONE small transfer."""
+        if isinstance(frame_u8, np.ndarray):
+            frame_u8 = torch.from_numpy(frame_u8)
         if frame_u8.dtype != torch.uint8 or frame_u8.dim() != 3 or frame_u8.shape[2] != 3:
             raise ValueError("frame must be uint8 (H,W,3)")
-        # (a host frame goes up with one plain .to(): a reused pinned staging buffer was tried — ADVICE r1 — and measured
-        # 10x SLOWER per frame on the 256-core host, torch's CPU->pinned copy_ costs milliseconds there)
-        frame_u8 = frame_u8.to(self.device).contiguous()
-        ctx = torch.as_tensor(ctx_xywh, dtype=torch.int32).reshape(-1, 4).to(self.device).contiguous()
-        pad = torch.as_tensor(pad_rgb_u8, dtype=torch.uint8).reshape(-1, 3).to(self.device).contiguous()
-        n = ctx.shape[0]
-        if pad.shape[0] != n:
+        ctx_np = np.ascontiguousarray(np.asarray(ctx_xywh, dtype=np.int32).reshape(-1, 4))
+        pad_np = np.ascontiguousarray(np.asarray(pad_rgb_u8, dtype=np.uint8).reshape(-1, 3))
+        n = ctx_np.shape[0]
+        if pad_np.shape[0] != n:
             raise ValueError("one border colour per context box")
+        if not frame_u8.is_cuda:
+            fh, fw = int(frame_u8.shape[0]), int(frame_u8.shape[1])
+            x0 = y0 = x1 = y1 = 0
+            if n:
+                x0 = int(np.clip(ctx_np[:, 0].min(), 0, fw))
+                y0 = int(np.clip(ctx_np[:, 1].min(), 0, fh))
+                x1 = int(np.clip((ctx_np[:, 0].astype(np.int64) + ctx_np[:, 2]).max(), x0, fw))
+                y1 = int(np.clip((ctx_np[:, 1].astype(np.int64) + ctx_np[:, 3]).max(), y0, fh))
+            if x1 <= x0 or y1 <= y0:                      # nothing of the frame is visible: one pixel keeps the shapes legal
+                x0, y0 = min(x0, fw - 1), min(y0, fh - 1)
+                x1, y1 = x0 + 1, y0 + 1
+            if (x1 - x0, y1 - y0) != (fw, fh):
+                frame_u8 = frame_u8[y0:y1, x0:x1]
+                ctx_np = ctx_np.copy()
+                ctx_np[:, 0] -= x0
+                ctx_np[:, 1] -= y0
+            # (one plain .to(): a reused pinned staging buffer was tried — ADVICE r1 — and measured 10x SLOWER per frame on
+            # the 256-core host, torch's CPU->pinned copy_ costs milliseconds there)
+            frame_u8 = frame_u8.contiguous().to(self.device)
+        else:
+            frame_u8 = frame_u8.to(self.device).contiguous()
+        meta = np.zeros(n * 16 + (n * 3 + 3) // 4 * 4, dtype=np.uint8)      # [n x 4 int32 boxes | n x 3 uint8 colours]
+        meta[: n * 16] = ctx_np.view(np.uint8).reshape(-1)
+        meta[n * 16: n * 16 + n * 3] = pad_np.reshape(-1)
+        meta_d = torch.from_numpy(meta).to(self.device)
         out = torch.empty((n, 3, out_hw, out_hw), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             self._check(self._lib.fear_crop_normalize(self._h, frame_u8.data_ptr(), frame_u8.shape[0], frame_u8.shape[1],
-                                                      ctx.data_ptr(), pad.data_ptr(), n, int(out_hw), out.data_ptr(),
-                                                      self._stream()))
+                                                      meta_d.data_ptr(), meta_d.data_ptr() + n * 16, n, int(out_hw),
+                                                      out.data_ptr(), self._stream()))
         return out
 
     # ------------------------------------------------------------------ measurement

@@ -96,38 +96,56 @@ class OverlappedGather:
         return None if self.last is None else self.gathered[self.last]
 
 
-def track_sharded(net, search: torch.Tensor, template_features: torch.Tensor, group=None):
-    """Run `net.track` on this rank's contiguous shard of a replicated global batch and all-gather.
-
-    search (N,3,256,256) / template_features (N,256,8,8) are the GLOBAL batch (same on every rank, any
-    device); returns (bbox (N,4,S,S), cls (N,1,S,S)) for the whole batch on every rank.  Ragged splits
-    (N % world != 0) are padded to the largest shard for the collective and trimmed afterwards.
-    """
+def track_local_shard(net, search_shard: torch.Tensor, template_shard: torch.Tensor, n_global: int, group=None):
+    """Every rank hands in ONLY its own contiguous shard — crops [lo, hi) = shard_range(n_global, world, rank) of a global batch
+    of n_global crops that no rank ever holds as a whole (at B = 2048 the fp32 search crops are 1.6 GB) — runs `net.track`
+    on it and all-gathers the packed maps: returns (bbox (n_global,4,S,S), cls (n_global,1,S,S)) on every rank.  Ragged
+    splits (n_global % world != 0) are padded to the largest shard for the collective and trimmed afterwards; a rank whose
+    shard is empty still takes part in the collective."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    n = search.shape[0]
-    lo, hi = shard_range(n, world, rank)
+    lo, hi = shard_range(n_global, world, rank)
+    if search_shard.shape[0] != hi - lo or template_shard.shape[0] != hi - lo:
+        raise ValueError(f"rank {rank} of {world} owns crops [{lo}, {hi}) of {n_global}: expected {hi - lo} crops, got "
+                         f"{search_shard.shape[0]} search / {template_shard.shape[0]} template")
     from .constants import TARGET_CLASSIFICATION_KEY, TARGET_REGRESSION_LABEL_KEY
-    cap = (n + world - 1) // world
+    cap = (n_global + world - 1) // world
+    s_hw = int(getattr(net, "map_size", 16))                  # score-map side (16 for the 256-pixel search crop)
+    dev = getattr(net, "device", search_shard.device)
     if world > 1 and hasattr(net, "track_packed"):
         # the engine writes this rank's maps straight into the head of the (padded) send buffer
-        s_hw = 16
-        packed = torch.zeros((cap, 5, s_hw, s_hw), dtype=torch.float32, device=net.device)
+        packed = torch.zeros((cap, 5, s_hw, s_hw), dtype=torch.float32, device=dev)
         if hi > lo:
-            net.track_packed(search[lo:hi], template_features[lo:hi], out=packed[: hi - lo])
-    else:
-        out = net.track(search[lo:hi], template_features[lo:hi])
+            net.track_packed(search_shard, template_shard, out=packed[: hi - lo])
+    elif hi > lo or world == 1:
+        out = net.track(search_shard, template_shard)
         bbox, cls = out[TARGET_REGRESSION_LABEL_KEY], out[TARGET_CLASSIFICATION_KEY]
         if world == 1:
             return bbox, cls
         packed = torch.zeros((cap, 5) + tuple(bbox.shape[2:]), dtype=bbox.dtype, device=bbox.device)
-        if hi > lo:
-            pack_maps(bbox, cls, packed[: hi - lo])
+        pack_maps(bbox, cls, packed[: hi - lo])
+    else:                                                     # an empty shard still takes part in the collective
+        packed = torch.zeros((cap, 5, s_hw, s_hw), dtype=torch.float32, device=dev)
     gathered = torch.empty((world * cap,) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
     dist.all_gather_into_tensor(gathered, packed, group=group)
-    parts = []
-    for r in range(world):
-        rlo, rhi = shard_range(n, world, r)
-        parts.append(gathered[r * cap: r * cap + (rhi - rlo)])
-    full = torch.cat(parts, dim=0)
+    if n_global % world == 0:
+        full = gathered
+    else:
+        parts = []
+        for r in range(world):
+            rlo, rhi = shard_range(n_global, world, r)
+            parts.append(gathered[r * cap: r * cap + (rhi - rlo)])
+        full = torch.cat(parts, dim=0)
     return full[:, :4].contiguous(), full[:, 4:].contiguous()
+
+
+def track_sharded(net, search: torch.Tensor, template_features: torch.Tensor, group=None):
+    """Convenience form for a batch that IS replicated (same tensors on every rank, any device): slices this rank's
+    contiguous shard out of it and calls `track_local_shard`.  Returns (bbox (N,4,S,S), cls (N,1,S,S)) for the whole batch on
+    every rank.  Production callers that shard their inputs at the source (bench.py, a data loader per rank) use
+    `track_local_shard` and never materialise the global batch."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n = search.shape[0]
+    lo, hi = shard_range(n, world, rank)
+    return track_local_shard(net, search[lo:hi], template_features[lo:hi], n, group=group)

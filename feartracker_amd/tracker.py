@@ -199,19 +199,22 @@ class FEARTracker(Tracker):
         st.mean_color = np.mean(image, axis=(0, 1))
         self._template_features = self.get_template_features(image, rect)
 
-    def _device_crop(self) -> bool:
+    def _device_crop(self, image: np.ndarray) -> bool:
         """Crop + border + resize + normalise on the GPU (`fear_crop_normalize`) whenever the model offers
-        it — bit-identical to the host path (tests/test_gpu_parity.py: same floats, same boxes on both clips) and 7x faster
-        per frame (bench.py `latency_batch1`: 0.7 vs 4.8 ms) — unless the tracking config says `device_crop=False` (not a key
-        of the reference config; the reference always crops on the host with cv2, utils.py:215-253)."""
-        return bool(self.tracking_config.get("device_crop", True)) and hasattr(self.net, "crop_normalize")
+        it and the frame is what that kernel reads — uint8, H x W x >= 3 — : bit-identical to the host path
+        (tests/test_gpu_parity.py, tests/test_cv_parity.py: same floats, same boxes on both clips) and 7x faster per frame
+        (bench.py `latency_batch1`).  Any other frame (float, uint16, grey) takes the reference-style host path, as does
+        `device_crop=False` in the tracking config (not a key of the reference config; the reference always crops on the
+        host with cv2, utils.py:215-253)."""
+        return bool(self.tracking_config.get("device_crop", True)) and hasattr(self.net, "crop_normalize") and \
+            isinstance(image, np.ndarray) and image.dtype == np.uint8 and image.ndim == 3 and image.shape[2] >= 3
 
     def get_template_features(self, image: np.ndarray, rect: np.ndarray):
         cfg = self.tracking_config
-        if self._device_crop():
+        if self._device_crop(image):
             ctx, _ = crop_geometry(image.shape, rect, cfg["template_size"], cfg["template_bbox_offset"])
             pad = border_color_u8(np.mean(image, axis=(0, 1)))
-            x = self.net.crop_normalize(torch.from_numpy(np.ascontiguousarray(image[:, :, :3])), ctx, pad, cfg["template_size"])
+            x = self.net.crop_normalize(image[:, :, :3], ctx, pad, cfg["template_size"])
             return self.net.get_features(x)
         crop, _, _ = get_extended_crop(image=image, bbox=rect, offset=cfg["template_bbox_offset"],
                                        crop_size=cfg["template_size"])
@@ -219,12 +222,11 @@ class FEARTracker(Tracker):
 
     def update(self, image: np.ndarray, *kw) -> Dict[str, Any]:
         cfg, st = self.tracking_config, self.tracking_state
-        if self._device_crop():
+        if self._device_crop(image):
             context, box_in_crop = crop_geometry(image.shape, st.bbox, cfg["instance_size"], cfg["search_context"])
             st.mapping = context
             st.prev_size = box_in_crop[2:]
-            search = self.net.crop_normalize(torch.from_numpy(np.ascontiguousarray(image[:, :, :3])), context,
-                                             border_color_u8(st.mean_color), cfg["instance_size"])
+            search = self.net.crop_normalize(image[:, :, :3], context, border_color_u8(st.mean_color), cfg["instance_size"])
             pred, _ = self._postprocess(track_result=self.net.track(search, self._template_features))
             pred = clamp_bbox(self._rescale_bbox(pred, st.mapping), image.shape)
             st.bbox = pred

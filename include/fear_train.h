@@ -105,7 +105,11 @@ int fear_exp_head_backward(const float* p, const float* adjust, const float* bbo
                            float* dbias4, float* workspace, size_t ws_bytes, long M, void* stream);
 
 /* FEARLoss forward + gradient (train/loss.py:45-96): bbox / gt_reg rows of 4 (ltrb), cls / gt_cls / gt_weight one value per row.
- * losses2 = {classification, regression} (each times its coefficient); dbbox / dcls = d(sum of both) / d(bbox, cls).       */
+ * losses2 = {classification, regression} (each times its coefficient); dbbox / dcls = d(sum of both) / d(bbox, cls).
+ * Selections of one or no cell: the reference indexes with `label.eq(1).nonzero().squeeze()` (loss.py:77-78), so exactly ONE
+ * positive (or one negative) cell makes `_weighted_cls_loss` return a constant 0 for that half — mirrored: no loss, no gradient.
+ * With NO positive / negative / weighted cell torch yields NaN (mean over nothing); this operator yields 0 for that term — the
+ * one deliberate deviation (a NaN would poison the all-reduced gradient buffer of every rank).                                */
 int fear_head_loss(const float* bbox, const float* cls, const float* gt_reg, const float* gt_cls, const float* gt_weight,
                    float coef_cls, float coef_reg, float* losses2, float* dbbox, float* dcls, float* workspace, size_t ws_bytes,
                    long M, void* stream);

@@ -170,9 +170,17 @@ def fear_loss(bbox, cls, gt_reg, gt_cls, gt_weight, coef_cls=1.0, coef_reg=1.0):
     sel = torch.nonzero(gt_weight.reshape(-1) > 0).squeeze(1)
     reg = (1 - calc_iou(t[sel], p[sel])).mean()
     pred, label = cls.reshape(-1), gt_cls.reshape(-1)
-    pos, neg = label.eq(1).nonzero().squeeze(1), label.eq(0).nonzero().squeeze(1)
+    # loss.py:77-78 indexes with `.nonzero().squeeze()`: a selection of exactly one cell becomes a 0-dim index and
+    # `_weighted_cls_loss` (loss.py:68-73) then returns the constant 0 for that half
+    pos, neg = label.eq(1).nonzero().squeeze(), label.eq(0).nonzero().squeeze()
     bce = nn.BCEWithLogitsLoss()
-    lc = 0.5 * bce(pred[pos], label[pos]) + 0.5 * bce(pred[neg], label[neg])
+
+    def half(sel):
+        if sel.dim() == 0:
+            return pred.new_zeros(())
+        return bce(pred[sel], label[sel])
+
+    lc = 0.5 * half(pos) + 0.5 * half(neg)
     return lc * coef_cls, reg * coef_reg
 
 

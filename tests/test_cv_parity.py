@@ -138,7 +138,9 @@ def test_device_crop_matches_the_table_driven_restatement_on_a_size_sweep():
     rng = np.random.RandomState(21)
     for i in range(60):
         w, h = rng.randint(3, 420), rng.randint(3, 300)
-        box = np.array([rng.randint(-60, 470), rng.randint(-60, 250), w, h], dtype=np.float64)
+        # what the tracker can hold: initialize()/update() clamp the box to the frame (fear_tracker.py:24,62), so a context
+        # always overlaps it (a context wholly outside makes the reference's own slice `image[a:-b]` wrap around)
+        box = geo.clamp_bbox(np.array([rng.randint(-60, 470), rng.randint(-60, 250), w, h]), frame.shape).astype(np.float64)
         size, off = ((256, 2.0), (128, 0.2), (256, 0.1))[i % 3]
         crop, ctx = cv_ref.get_extended_crop(frame, box, size, off, padding_value=mean)
         want = np.transpose(geo.normalize_image(crop), (2, 0, 1))

@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from feartracker_amd.sharding import gather_maps, shard_range, track_sharded
+from feartracker_amd.sharding import gather_maps, gather_packed, shard_range, track_local_shard, track_sharded
 
 
 class FakeNet:
@@ -71,6 +71,51 @@ def test_sharded_track_equals_single_process(n):
         if n % world == 0:
             assert torch.equal(g2[:, :4], ref["TARGET_REGRESSION_LABEL_KEY"])
             assert torch.equal(g2[:, 4:], ref["TARGET_CLASSIFICATION_KEY"])
+
+
+def _local_shard_worker(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_range(n, world, rank)
+    # every rank builds ONLY its own crops (the global batch never exists in one place): crop i is seeded by i
+    search = torch.stack([torch.randn(3, 256, 256, generator=torch.Generator().manual_seed(i)) for i in range(lo, hi)]) \
+        if hi > lo else torch.empty(0, 3, 256, 256)
+    z = torch.stack([torch.randn(256, 8, 8, generator=torch.Generator().manual_seed(1000 + i)) for i in range(lo, hi)]) \
+        if hi > lo else torch.empty(0, 256, 8, 8)
+    bbox, cls = track_local_shard(FakeNet(), search, z, n)
+    wrong = None
+    try:
+        track_local_shard(FakeNet(), search[:0], z[:0], n + world)          # a shard of the wrong size is refused, not padded
+    except ValueError as e:
+        wrong = str(e)
+    q.put((rank, bbox.numpy(), cls.numpy(), wrong))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [5, 1])
+def test_local_shards_never_materialise_the_global_batch(n):
+    """sharding.track_local_shard: each rank hands in only its own crops (even, ragged, and an EMPTY shard on rank 1 for
+    n = 1) and every rank gets the whole result, bit for bit what one process computes."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_local_shard_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    search = torch.stack([torch.randn(3, 256, 256, generator=torch.Generator().manual_seed(i)) for i in range(n)])
+    z = torch.stack([torch.randn(256, 8, 8, generator=torch.Generator().manual_seed(1000 + i)) for i in range(n)])
+    ref = FakeNet().track(search, z)
+    for rank, bbox, cls, wrong in results:
+        assert torch.equal(torch.from_numpy(bbox), ref["TARGET_REGRESSION_LABEL_KEY"])
+        assert torch.equal(torch.from_numpy(cls), ref["TARGET_CLASSIFICATION_KEY"])
+        assert wrong is not None and "expected" in wrong
 
 
 def _overlap_worker(rank, world, port, q):
@@ -148,6 +193,46 @@ def test_rccl_gather_of_hip_maps_single_rank():
         assert full.shape == (5, 5, 16, 16)
         assert torch.equal(full[:, :4], bbox) and torch.equal(full[:, 4:], cls)
         b2, c2 = track_sharded(net, search, z)
+        assert torch.equal(b2, bbox) and torch.equal(c2, cls)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_ragged_shards_through_track_packed_and_rccl():
+    """The N > 1 data path with the real engine on the one GPU a box has: a 7-crop global batch cut into the ragged shards of
+    2, 3 and 4 ranks (shard_range), each shard written by fear_track_packed into the head of a zero-padded send buffer of the
+    largest shard's size — what `track_local_shard` hands to the collective —, every send buffer through a real RCCL
+    all_gather_into_tensor (1-rank group), the receive buffers trimmed and joined the way `track_local_shard` does: the result
+    must be bit for bit the single-call maps, whatever the cut (so must an empty shard: 1 crop over 2 ranks)."""
+    from conftest import WEIGHTS
+    from feartracker_amd import FEARNetHIP
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        net = FEARNetHIP(WEIGHTS, device=0, max_batch=8)
+        g = torch.Generator().manual_seed(9)
+        search = torch.randn(7, 3, 256, 256, generator=g).to(dev)
+        z = net.get_features(torch.randn(7, 3, 128, 128, generator=g).to(dev))
+        bbox, cls = net.track_maps(search, z)
+        torch.cuda.synchronize()
+        for n, world in ((7, 2), (7, 3), (7, 4), (1, 2)):
+            cap = (n + world - 1) // world
+            parts = []
+            for rank in range(world):
+                lo, hi = shard_range(n, world, rank)
+                packed = torch.zeros((cap, 5, 16, 16), dtype=torch.float32, device=dev)
+                if hi > lo:
+                    net.track_packed(search[lo:hi], z[lo:hi], out=packed[: hi - lo])
+                got = gather_packed(packed)                       # RCCL, this rank's slice of the receive buffer
+                assert got.shape == (cap, 5, 16, 16)
+                parts.append(got[: hi - lo])
+                assert torch.count_nonzero(got[hi - lo:]) == 0    # the padding stays padding
+            full = torch.cat(parts, dim=0)
+            assert torch.equal(full[:, :4], bbox[:n]) and torch.equal(full[:, 4:], cls[:n]), (n, world)
+        b2, c2 = track_local_shard(net, search, z, 7)             # world 1: the whole batch is this rank's shard
         assert torch.equal(b2, bbox) and torch.equal(c2, cls)
     finally:
         dist.destroy_process_group()

@@ -305,3 +305,59 @@ def test_whole_network_training_step_matches_autograd():
             continue
         worst[n] = _close(out["grads"][n], gr, "grad " + n)
     print("worst relative gradient errors:", sorted(worst.items(), key=lambda kv: -kv[1])[:4])
+
+
+def _loss_edge_cases(golden_dir):
+    d = np.load(f"{golden_dir}/loss_edge.npz")
+    for tag in ("one_pos", "two_pos", "one_neg"):
+        yield tag, {k[len(tag) + 1:]: d[k] for k in d.files if k.startswith(tag + "_")}
+
+
+def test_training_oracle_loss_on_single_cell_selections(golden_dir):
+    """The reference's FEARLoss indexes with `.nonzero().squeeze()` (loss.py:77-78): exactly one positive (or negative) cell
+    makes that half of the classification loss a constant 0.  Fixture = the reference's own FEARLoss + autograd
+    (tools/make_golden.py section 11b); the oracle restatement must reproduce value and gradient."""
+    from oracle.fear_train_oracle import fear_loss
+    for tag, c in _loss_edge_cases(golden_dir):
+        bbox = torch.from_numpy(c["bbox"]).requires_grad_(True)
+        cls = torch.from_numpy(c["cls"]).requires_grad_(True)
+        lc, lr = fear_loss(bbox, cls, torch.from_numpy(c["gt_reg"]), torch.from_numpy(c["gt_cls"]), torch.from_numpy(c["gt_weight"]))
+        (lc + lr).backward()
+        assert abs(float(lc) - float(c["loss_cls"])) < 1e-6 and abs(float(lr) - float(c["loss_reg"])) < 1e-6, tag
+        np.testing.assert_allclose(cls.grad.numpy(), c["dcls"], rtol=1e-5, atol=1e-8, err_msg=tag)
+        np.testing.assert_allclose(bbox.grad.numpy(), c["dbbox"], rtol=1e-5, atol=1e-8, err_msg=tag)
+    one = dict(_loss_edge_cases(golden_dir))["one_pos"]
+    assert np.count_nonzero(one["dcls"].reshape(-1)[one["gt_cls"].reshape(-1) == 1]) == 0      # the lone positive gets no gradient
+
+
+@pytest.mark.gpu
+def test_head_loss_operator_on_single_cell_selections(golden_dir):
+    """fear_head_loss through the C ABI on the same fixture: one positive / two positives / one negative cell, values and both
+    gradients; and the stated deviation — no positive cell at all gives 0 for that half (torch: NaN), finite gradients."""
+    from feartracker_amd.train_head import _p, load_train_library
+    lib = load_train_library()
+    dev = torch.device("cuda:0")
+    ws = torch.empty(lib.fear_train_workspace_bytes(4096, 320) // 4 + 1024, device=dev)
+
+    def run(bbox, cls, gt_reg, gt_cls, gt_w):
+        M = 256
+        rows = lambda a, c: torch.from_numpy(np.ascontiguousarray(np.asarray(a, np.float32).reshape(c, M).T)).to(dev).contiguous()
+        b, c_, gr = rows(bbox, 4), rows(cls, 1).reshape(M), rows(gt_reg, 4)
+        gc = torch.from_numpy(np.asarray(gt_cls, np.float32).reshape(M)).to(dev)
+        gw = torch.from_numpy(np.asarray(gt_w, np.float32).reshape(M)).to(dev)
+        losses, db, dc = torch.zeros(2, device=dev), torch.empty(M, 4, device=dev), torch.empty(M, device=dev)
+        assert lib.fear_head_loss(_p(b), _p(c_), _p(gr), _p(gc), _p(gw), 1.0, 1.0, _p(losses), _p(db), _p(dc), _p(ws),
+                                  ws.numel() * 4, M, None) == 0
+        torch.cuda.synchronize()
+        return losses.cpu().numpy(), db.cpu().numpy().T.reshape(1, 4, 16, 16), dc.cpu().numpy().reshape(1, 1, 16, 16)
+
+    for tag, c in _loss_edge_cases(golden_dir):
+        losses, db, dc = run(c["bbox"], c["cls"], c["gt_reg"], c["gt_cls"], c["gt_weight"])
+        np.testing.assert_allclose(losses, [c["loss_cls"], c["loss_reg"]], rtol=2e-6, err_msg=tag)
+        np.testing.assert_allclose(dc, c["dcls"], rtol=2e-5, atol=1e-8, err_msg=tag)
+        np.testing.assert_allclose(db, c["dbbox"], rtol=2e-5, atol=1e-8, err_msg=tag)
+    c = dict(_loss_edge_cases(golden_dir))["two_pos"]
+    losses, db, dc = run(c["bbox"], c["cls"], c["gt_reg"], np.zeros_like(c["gt_cls"]), np.zeros_like(c["gt_weight"]))
+    assert np.isfinite(losses).all() and np.isfinite(dc).all() and np.isfinite(db).all() and losses[1] == 0.0
+    x = c["cls"].reshape(-1).astype(np.float64)
+    np.testing.assert_allclose(losses[0], 0.5 * np.mean(np.maximum(x, 0) + np.log1p(np.exp(-np.abs(x)))), rtol=2e-6)

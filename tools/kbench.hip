@@ -7,7 +7,10 @@
 #include <cstdlib>
 #include <vector>
 
-#include "../feartracker_amd/csrc/fear_kernels.h"
+#ifndef KHDR
+#define KHDR "../feartracker_amd/csrc/fear_kernels.h"     // -DKHDR='"/path/to/variant.h"' benches a saved variant of the header
+#endif
+#include KHDR
 
 using namespace fear;
 
