@@ -82,7 +82,8 @@ def _cpu_node_worker(idx, cpus, threads, weights, seconds, q):
     """One of the node-level baseline's processes: the CPU oracle on `threads` threads pinned to `cpus`, batches of 8 of the
     same seeded synthetic crops, for ~`seconds`; reports (crops, elapsed)."""
     try:
-        os.sched_setaffinity(0, cpus)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
     except Exception:      # noqa: BLE001 — affinity is an optimisation, not a requirement
         pass
     torch.set_num_threads(threads)
@@ -101,6 +102,23 @@ def _cpu_node_worker(idx, cpus, threads, weights, seconds, q):
     q.put(("done", idx, n, time.perf_counter() - t0))
 
 
+def cpu_quota_cpus():
+    """CPUs' worth of CPU time the container may use (cgroup v2 cpu.max / v1 cfs quota), None when unlimited.  The GPU boxes of
+    this pool show 256 logical CPUs of a shared 2x64-core host but cap the job at 16 (`cpu.max = 1600000 100000`,
+    profiles/r03_box_cpu_probe.txt): more than 16 busy threads are throttled, which is why the oracle peaks at 16 threads."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:      # noqa: BLE001
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except Exception:      # noqa: BLE001
+        return None
+
+
 def cpu_node_baseline(weights, threads_per_proc: int = 16, seconds: float = 8.0):
     """The NODE's CPU throughput on this path (north_star: "timed on the node's host cores (count stated)"): one oracle
     process per `threads_per_proc` logical CPUs (the per-process optimum, tools/cpu_sweep.py), each pinned to its own block,
@@ -110,10 +128,14 @@ def cpu_node_baseline(weights, threads_per_proc: int = 16, seconds: float = 8.0)
         cpus = sorted(os.sched_getaffinity(0))
     except Exception:      # noqa: BLE001
         cpus = list(range(os.cpu_count() or 1))
-    nproc = max(1, len(cpus) // threads_per_proc)
+    quota = cpu_quota_cpus()
+    usable = len(cpus) if quota is None else max(1, min(len(cpus), int(quota)))
+    nproc = max(1, usable // threads_per_proc)
+    if quota is not None and quota < len(cpus):
+        cpus = None                 # under a CPU-time quota pinning to fixed blocks only hurts: let the scheduler place the threads
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_cpu_node_worker, args=(i, set(cpus[i * threads_per_proc:(i + 1) * threads_per_proc]),
+    procs = [ctx.Process(target=_cpu_node_worker, args=(i, set(cpus[i * threads_per_proc:(i + 1) * threads_per_proc]) if cpus else None,
                                                          threads_per_proc, weights, seconds, q)) for i in range(nproc)]
     t_start = time.perf_counter()
     for p in procs:
@@ -139,7 +161,8 @@ def cpu_node_baseline(weights, threads_per_proc: int = 16, seconds: float = 8.0)
                 p.terminate()
     rates = [n / dt for _, _, n, dt in done]
     return {"value": float(sum(rates)), "unit": "crops/s", "processes": nproc, "threads_per_process": threads_per_proc,
-            "cores": nproc * threads_per_proc, "host_cpus": os.cpu_count(), "per_process_min_max": [min(rates), max(rates)],
+            "cores": nproc * threads_per_proc, "host_cpus": os.cpu_count(), "cpu_quota_cpus": quota,
+            "per_process_min_max": [min(rates), max(rates)],
             "sample": f"{sum(n for _, _, n, _ in done)} crops: {nproc} oracle processes x batches of 8 of the same synthetic 256x256 "
                       f"workload, {seconds:.0f} s each, all at once (wall {time.perf_counter() - t_start:.0f} s incl. start-up)"}
 
@@ -185,6 +208,9 @@ def cpu_baseline(search_u8, tmpl_u8, weights, budget_s: float = 10.0):
         node = {"error": f"{type(exc).__name__}: {exc}"}
     if "value" in node:
         return {"value": node["value"], "unit": "crops/s", "cores": node["cores"], "kind": "port", "host_cpus": os.cpu_count(),
+                "cpu_quota_cpus": node.get("cpu_quota_cpus"),
+                "cores_note": "cores = every CPU the job may use: the container's cgroup CPU quota when there is one (the host's "
+                              "other logical CPUs belong to other tenants), else all logical CPUs, 16 oracle threads per process",
                 "cpu_model": _lscpu_model(), "sample": node["sample"], "processes": node["processes"],
                 "threads_per_process": node["threads_per_process"], "per_process_min_max": node["per_process_min_max"],
                 "single_process": single}
@@ -247,6 +273,7 @@ def config4_fear_m(dev, steps: int = 20, warmup: int = 5, batch: int = 512):
             roof.update({"traffic": tr, "traffic_source": tr_file, "kernel": dom_name, "avg_launch_ms": per_launch[di],
                          "share_of_step": groups[dom_name] / max(sum(per_step), 1e-12),
                          "arithmetic_intensity_flop_per_byte": fl / by, "tflops_of_that_kernel": tf,
+                         "frac_of_bf16_mfma_peak": tf / PEAK_BF16_MFMA_TFLOPS, "frac_of_hbm_peak": gbs / PEAK_HBM_GBS,
                          "sum_of_kernels_ms_per_step": sum(per_step),
                          "note": "bf16 operands on the matrix pipe (dense peak ~2.5 PFLOP/s): at this kernel's algorithmic intensity "
                                  "the bounding roofline is the one named in `bound`"})
@@ -545,15 +572,25 @@ def main() -> None:
         # there before fd 1 is restored)
         # RCCL's own account of the communicator (its INIT lines carry "rank r nranks N") goes to STDERR, next to ours below,
         # so that a driver log shows N ranks the day a multi-GPU node runs this
+        # (RCCL logs to a per-process FILE: at INFO level it writes to stdout from its own threads at times of its choosing, and
+        # stdout must carry exactly one JSON line; the lines that name the communicator are relayed to stderr below)
+        rccl_log = f"/tmp/fear_bench_rccl.{os.getpid()}.log"
         os.environ.setdefault("NCCL_DEBUG", "INFO")
         os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT")
-        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
+        os.environ.setdefault("NCCL_DEBUG_FILE", rccl_log)
         with _c_stdout_to_stderr():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
             dist.barrier()
             torch.cuda.synchronize()
         print(f"[bench] rank {dist.get_rank()} of {dist.get_world_size()} (torch.distributed, backend {dist.get_backend()}) on "
               f"cuda:{local_rank} = {torch.cuda.get_device_name(local_rank)}", file=sys.stderr, flush=True)
+        try:
+            with open(os.environ["NCCL_DEBUG_FILE"]) as fh:
+                for line in fh:
+                    if "nranks" in line or "Init COMPLETE" in line or "RCCL version" in line:
+                        print(f"[bench] RCCL: {line.strip()}", file=sys.stderr, flush=True)
+        except OSError:
+            pass
 
     from feartracker_amd import FEARNetHIP, DEFAULT_WEIGHTS
     from feartracker_amd.sharding import OverlappedGather, gather_packed

@@ -178,8 +178,10 @@ def test_tracker_clip_through_drop_in_api(hip_net, golden_dir):
     from feartracker_amd import DEFAULT_TRACKING_CONFIG, FEARTracker
     d = np.load(f"{golden_dir}/clip_synth.npz")
     trk = FEARTracker(hip_net, cuda_id=0, **DEFAULT_TRACKING_CONFIG)      # default: device crop + device post-processing
-    assert trk._device_crop()
     frames = d["frames"]
+    assert trk._device_crop(frames[0])
+    # frames the device kernel does not read (float, uint16, grey) take the reference-style host path instead of failing
+    assert not trk._device_crop(frames[0].astype(np.float32)) and not trk._device_crop(frames[0][:, :, 0])
     trk.initialize(frames[0], d["init_bbox"])
     assert trk._template_features.is_cuda
     assert rel_err(trk._template_features, torch.from_numpy(d["template_features"])) < REL
