@@ -29,6 +29,19 @@ using namespace fear;
         if (hipGetLastError() != hipSuccess) return FEAR_TRAIN_ERR_HIP; \
     } while (0)
 
+// Activation applied to a producer's raw output as it is loaded (fused training step, see "Fused conv + BatchNorm operators" below)
+struct ActIn {
+    const float* a;      // [C] or nullptr: x is used as it is
+    const float* b;
+    int relu;
+};
+
+__device__ __forceinline__ f32x4 act4(const f32x4& x, const f32x4& a, const f32x4& b, bool relu) {
+    f32x4 y = (f32x4){__builtin_fmaf(x.x, a.x, b.x), __builtin_fmaf(x.y, a.y, b.y), __builtin_fmaf(x.z, a.z, b.z), __builtin_fmaf(x.w, a.w, b.w)};
+    if (relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+    return y;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Column reductions over rows: per-channel sums.  Block = 256 threads = (C/4 channel quads) x (R row lanes); a block reduces
 // `rpb` rows (col_rows_per_block: 64, doubled until there are at most 1024 blocks) into partial[block][2][C];
@@ -46,6 +59,8 @@ struct ColArgs {
     double* partial;     // [blocks][2][C] float64
     long M;
     int C, lda, ldy, ldx, rpb;
+    const float* act_a;  // mode 1, fused step: the ReLU mask is recomputed from x, active where fma(x, act_a, act_b) > 0
+    const float* act_b;  // (Yact is nullptr then)
 };
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -67,9 +82,11 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(ColArgs a) {
     const long r1 = r0 + a.rpb < a.M ? r0 + a.rpb : a.M;
     if (rl < R) {
         f32x4 mu = (f32x4){0.f, 0.f, 0.f, 0.f}, rs = mu;
+        f32x4 ma = mu, mb = mu;
         if (MODE == 1) {
             mu = *reinterpret_cast<const f32x4*>(a.mean + cq * 4);
             rs = *reinterpret_cast<const f32x4*>(a.rstd + cq * 4);
+            if (a.act_a) { ma = *reinterpret_cast<const f32x4*>(a.act_a + cq * 4); mb = *reinterpret_cast<const f32x4*>(a.act_b + cq * 4); }
         }
         for (long r = r0 + rl; r < r1; r += R) {
             f32x4 v = *reinterpret_cast<const f32x4*>(a.A + r * a.lda + cq * 4);
@@ -82,7 +99,12 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(ColArgs a) {
                     const f32x4 y = *reinterpret_cast<const f32x4*>(a.Yact + r * a.ldy + cq * 4);
                     v.x = y.x > 0.f ? v.x : 0.f; v.y = y.y > 0.f ? v.y : 0.f; v.z = y.z > 0.f ? v.z : 0.f; v.w = y.w > 0.f ? v.w : 0.f;
                 }
-                const f32x4 xh = (*reinterpret_cast<const f32x4*>(a.X + r * a.ldx + cq * 4) - mu) * rs;
+                const f32x4 xin = *reinterpret_cast<const f32x4*>(a.X + r * a.ldx + cq * 4);
+                if (a.act_a) {
+                    v.x = __builtin_fmaf(xin.x, ma.x, mb.x) > 0.f ? v.x : 0.f; v.y = __builtin_fmaf(xin.y, ma.y, mb.y) > 0.f ? v.y : 0.f;
+                    v.z = __builtin_fmaf(xin.z, ma.z, mb.z) > 0.f ? v.z : 0.f; v.w = __builtin_fmaf(xin.w, ma.w, mb.w) > 0.f ? v.w : 0.f;
+                }
+                const f32x4 xh = (xin - mu) * rs;
                 s1 += to_f64(v);
                 s2 += to_f64(v) * to_f64(xh);
             } else {
@@ -232,6 +254,8 @@ struct BnBwdArgs {
     long M;
     int C, lddy, ldy, ldx, lddx;
     double count;            // rows the sums were taken over (0 = M; SyncBatchNorm: all ranks' rows)
+    const float* act_a;      // fused step: ReLU mask recomputed from X (active where fma(x, act_a, act_b) > 0), Yact = nullptr
+    const float* act_b;
 };
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
@@ -246,7 +270,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
         g.x = y.x > 0.f ? g.x : 0.f; g.y = y.y > 0.f ? g.y : 0.f; g.z = y.z > 0.f ? g.z : 0.f; g.w = y.w > 0.f ? g.w : 0.f;
     }
     const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + c), rs = *reinterpret_cast<const f32x4*>(a.rstd + c);
-    const f32x4 xh = (*reinterpret_cast<const f32x4*>(a.X + r * a.ldx + c) - mu) * rs;
+    const f32x4 xin = *reinterpret_cast<const f32x4*>(a.X + r * a.ldx + c);
+    if (a.act_a) {
+        const f32x4 ma = *reinterpret_cast<const f32x4*>(a.act_a + c), mb = *reinterpret_cast<const f32x4*>(a.act_b + c);
+        g.x = __builtin_fmaf(xin.x, ma.x, mb.x) > 0.f ? g.x : 0.f; g.y = __builtin_fmaf(xin.y, ma.y, mb.y) > 0.f ? g.y : 0.f;
+        g.z = __builtin_fmaf(xin.z, ma.z, mb.z) > 0.f ? g.z : 0.f; g.w = __builtin_fmaf(xin.w, ma.w, mb.w) > 0.f ? g.w : 0.f;
+    }
+    const f32x4 xh = (xin - mu) * rs;
     const float inv_m = (float)(1.0 / (a.count > 0.0 ? a.count : (double)a.M));
     const f32x4 sg = *reinterpret_cast<const f32x4*>(a.sum_g + c) * inv_m;
     const f32x4 sgx = *reinterpret_cast<const f32x4*>(a.sum_gx + c) * inv_m;
@@ -271,6 +301,9 @@ struct WgradArgs {
     long rows_per_slice, M;      // M = rows per crop when batched
     long dy_crop_stride, x_crop_stride;
     int N, K, lddy, ldx, n_tiles, k_tiles, crops;      // N and K multiples of 4
+    const float* act_a;  // fused step: X holds a producer's raw output, the operand is max(fma(x, act_a, act_b), 0) / fma(...)
+    const float* act_b;
+    int act_relu;
 };
 
 __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs a) {
@@ -290,6 +323,9 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs a) {
     const long m0 = (long)slice * a.rows_per_slice;
     const long m1 = m0 + a.rows_per_slice < a.M ? m0 + a.rows_per_slice : a.M;
     const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool act = a.act_a != nullptr;
+    f32x4 ia = zero, ib = zero;
+    if (act && kv) { ia = *reinterpret_cast<const f32x4*>(a.act_a + k4); ib = *reinterpret_cast<const f32x4*>(a.act_b + k4); }
     for (long m = m0 + wave * 16; m < m1; m += 64) {
         f32x4 dv[4], xv[4];
 #pragma unroll
@@ -298,6 +334,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs a) {
             const bool rv = r < m1;
             dv[u] = rv && nv ? *reinterpret_cast<const f32x4*>(dy + r * a.lddy) : zero;
             xv[u] = rv && kv ? *reinterpret_cast<const f32x4*>(x + r * a.ldx) : zero;
+            if (act && rv && kv) xv[u] = act4(xv[u], ia, ib, a.act_relu != 0);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -374,6 +411,9 @@ struct DwWgradArgs {
     float* partial;
     long pixels;          // B*Ho*Wo
     int H, W, Ho, Wo, C, lddy, ldx, rpb;
+    const float* act_a;   // fused step: X is a producer's raw output, the operand is its activation (see WgradArgs)
+    const float* act_b;
+    int act_relu;
 };
 
 template <int KS, int S>
@@ -389,6 +429,9 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgradArgs a) {
     const long p0 = (long)blockIdx.x * a.rpb;
     const long p1 = p0 + a.rpb < a.pixels ? p0 + a.rpb : a.pixels;
     constexpr int T = S == 1 ? 8 : 4, WIN = S * (T - 1) + KS;
+    const bool act = a.act_a != nullptr;
+    f32x4 ia = (f32x4){0.f, 0.f, 0.f, 0.f}, ib = ia;
+    if (act && rl < R) { ia = *reinterpret_cast<const f32x4*>(a.act_a + cq * 4); ib = *reinterpret_cast<const f32x4*>(a.act_b + cq * 4); }
     if (a.Wo % T == 0) {
         // runs of T output pixels of one row: the KS input rows are walked once as a WIN-wide register window instead of KS*KS
         // loads per pixel (the loads, not the FMAs, bound this kernel: 25 of them per pixel and channel quad)
@@ -412,6 +455,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgradArgs a) {
                         const int xx = ox0 * S + i - P;
                         xr[i] = (xx >= 0 && xx < a.W) ? *reinterpret_cast<const f32x4*>(xb + ((long)yy * a.W + xx) * a.ldx)
                                                       : (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (act && xx >= 0 && xx < a.W) xr[i] = act4(xr[i], ia, ib, a.act_relu != 0);      // padding stays zero
                     }
 #pragma unroll
                     for (int kx = 0; kx < KS; ++kx)
@@ -434,7 +478,9 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(DwWgradArgs a) {
                 for (int kx = 0; kx < KS; ++kx) {
                     const int xx = ox * S + kx - P;
                     if (xx < 0 || xx >= a.W) continue;
-                    acc[ky * KS + kx] += g * *reinterpret_cast<const f32x4*>(xb + ((long)yy * a.W + xx) * a.ldx);
+                    f32x4 xv = *reinterpret_cast<const f32x4*>(xb + ((long)yy * a.W + xx) * a.ldx);
+                    if (act) xv = act4(xv, ia, ib, a.act_relu != 0);
+                    acc[ky * KS + kx] += g * xv;
                 }
             }
         }
@@ -752,6 +798,282 @@ long wgrad_rows_per_slice(long M) {
 }
 int wgrad_slices(long M) { const long r = wgrad_rows_per_slice(M); return (int)((M + r - 1) / r); }
 
+// ================================================================================================
+// Fused conv + BatchNorm operators of the trunk's training step.
+//
+// The unfused step wrote, for every conv + BN + ReLU, the raw conv output, read it for the statistics, read it again and wrote
+// the activation, and read THAT in the consumer — five passes over tensors of up to 0.8 GB — and eleven more in the backward;
+// rocprofv3 (profiles/r03_train_kernel_stats.csv): 38 % of the 31.6 ms step in BatchNorm passes at 2.6-6 TB/s, i.e.
+// the kernels stream well and the traffic itself is the cost.  Here an activation is never written:
+//   producer   raw conv output `pre` + its column sums (sum x, sum x^2) from the accumulators, same pass
+//   finalize   sums -> mean, rstd, running statistics and the affine  a = gamma * rstd,  b = beta - mean * a
+//   consumer   act(x) = max(fma(x, a, b), 0) (or without the max) applied to x = pre as it is loaded — forward conv, weight
+//              gradient (its x operand) and the ReLU mask of the backward all use this ONE expression, so they agree bit for
+//              bit on which elements are active
+// Block outputs (the projection's BatchNorm, no ReLU, + residual) are the only activations materialised (fear_bn_act).
+// Pointwise conv forward Y = act(X) W^T with the column sums of Y: pw_mfma_kernel's tiling (4 waves x 32 rows per workgroup,
+// NT column tiles per pass), the input affine applied to the B-operand fragments, and per pass the accumulators' sum / sum of
+// squares reduced over the wave's 32 rows in fp32 (two values per lane, then a 16-lane butterfly), over the four waves in
+// float64 through LDS, and written as this workgroup's partial [2][N] (col_finalize_kernel adds the workgroups in float64).
+struct PwStatArgs {
+    const float* X;
+    const float* W;      // [N][K]
+    float* Y;
+    ActIn in;
+    double* partial;     // [gridDim.x][2][N]
+    int ldx, ldy, M, K, N;
+};
+
+__device__ __forceinline__ float row16_sum(float v) {      // sum over the 16 lanes that share lane >> 4
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void pw_stat_kernel(PwStatArgs a) {
+    constexpr int MT = 2;
+    __shared__ double red[4][2][NT * 16];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int m_wave = (blockIdx.x * 4 + wave) * (MT * 16);
+    const float* xrow[MT];
+    bool mvalid[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int m = m_wave + mt * 16 + li;
+        mvalid[mt] = m < a.M;
+        if (m >= a.M) m = a.M - 1;
+        xrow[mt] = a.X + (long)m * a.ldx;
+    }
+    const bool affine = a.in.a != nullptr;
+    const int n_tiles = (a.N + 15) >> 4;
+    for (int nc = 0; nc < n_tiles; nc += NT) {
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        int nrow[NT];
+        bool nvalid[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = (nc + nt) * 16 + li;
+            nvalid[nt] = n < a.N;
+            nrow[nt] = nvalid[nt] ? n : (a.N - 1);
+        }
+        for (int kg = 0; kg < a.K; kg += 16) {
+            const int k = kg + lk * 4;
+            const bool kvalid = k < a.K;
+            f32x4 xf[MT], wf[NT];
+            f32x4 ia = (f32x4){1.f, 1.f, 1.f, 1.f}, ib = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (affine && kvalid) {
+                ia = *reinterpret_cast<const f32x4*>(a.in.a + k);
+                ib = *reinterpret_cast<const f32x4*>(a.in.b + k);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                xf[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (kvalid) {
+                    xf[mt] = *reinterpret_cast<const f32x4*>(xrow[mt] + k);
+                    if (affine) xf[mt] = act4(xf[mt], ia, ib, a.in.relu != 0);
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                wf[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (kvalid && nvalid[nt]) wf[nt] = *reinterpret_cast<const f32x4*>(a.W + (long)nrow[nt] * a.K + k);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][i], xf[mt][i], acc[mt][nt], 0, 0, 0);
+        }
+        // store + statistics: lane holds channels n0 + 4*lk + {0..3} of pixels m_wave + mt*16 + li
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = (nc + nt) * 16 + lk * 4;
+            f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f}, s2 = s1;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if (!mvalid[mt]) continue;
+                const f32x4 v = acc[mt][nt];
+                s1 += v;
+                s2 += v * v;
+                if (n < a.N) *reinterpret_cast<f32x4*>(a.Y + (long)(m_wave + mt * 16 + li) * a.ldy + n) = v;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float t1 = row16_sum(s1[c]), t2 = row16_sum(s2[c]);
+                if (li == 0) {
+                    red[wave][0][nt * 16 + lk * 4 + c] = (double)t1;
+                    red[wave][1][nt * 16 + lk * 4 + c] = (double)t2;
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * NT * 16; i += 256) {
+            const int which = i / (NT * 16), col = i % (NT * 16);
+            const int n = nc * 16 + col;
+            if (n < a.N)
+                a.partial[((long)blockIdx.x * 2 + which) * a.N + n] =
+                    ((red[0][which][col] + red[1][which][col]) + red[2][which][col]) + red[3][which][col];      // fixed order
+        }
+        __syncthreads();
+    }
+}
+
+// Depthwise conv forward with the input affine (zero padding stays zero: it pads the ACTIVATION) and the column sums of the
+// output: dw_conv_kernel's mapping (a thread = 4 channels of a vertical strip of RO output pixels; consecutive threads walk
+// channel quads, then x), the workgroup's per-channel sums through LDS in float64, fixed order.
+struct DwStatArgs {
+    const float* X;
+    const float* Wt;     // [KS*KS][C]
+    float* Y;
+    ActIn in;
+    double* partial;     // [gridDim.x][2][C]
+    int ldx, ldy, B, H, W, C, Ho, Wo;
+};
+
+template <int KS, int S, int RO>
+__global__ __launch_bounds__(256) void dw_stat_kernel(DwStatArgs a) {
+    constexpr int P = KS / 2;
+    constexpr int IR = (RO - 1) * S + KS;
+    __shared__ f64x4 red[2][256];
+    const int cgs = a.C >> 2;
+    const int strips = (a.Ho + RO - 1) / RO;
+    const long idx0 = (long)blockIdx.x * blockDim.x;
+    long idx = idx0 + threadIdx.x;
+    const long total = (long)a.B * strips * a.Wo * cgs;
+    const bool live = idx < total;
+    const f64x4 zero = (f64x4){0.0, 0.0, 0.0, 0.0};
+    f64x4 t1 = zero, t2 = zero;
+    if (live) {
+        const int cg = idx % cgs; idx /= cgs;
+        const int ox = idx % a.Wo; idx /= a.Wo;
+        const int st = idx % strips;
+        const int b = idx / strips;
+        const int c = cg * 4;
+        const int oy0 = st * RO;
+        f32x4 w[KS * KS];
+#pragma unroll
+        for (int t = 0; t < KS * KS; ++t) w[t] = *reinterpret_cast<const f32x4*>(a.Wt + (long)t * a.C + c);
+        f32x4 acc[RO];
+#pragma unroll
+        for (int r = 0; r < RO; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const bool affine = a.in.a != nullptr;
+        f32x4 ia = (f32x4){1.f, 1.f, 1.f, 1.f}, ib = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (affine) { ia = *reinterpret_cast<const f32x4*>(a.in.a + c); ib = *reinterpret_cast<const f32x4*>(a.in.b + c); }
+        const float* xb = a.X + (long)b * a.H * a.W * a.ldx + c;
+        const int iy0 = oy0 * S - P;
+        const int ix0 = ox * S - P;
+#pragma unroll
+        for (int iy = 0; iy < IR; ++iy) {
+            const int y = iy0 + iy;
+            if (y < 0 || y >= a.H) continue;
+            const float* xr = xb + (long)y * a.W * a.ldx;
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+                const int x = ix0 + kx;
+                if (x < 0 || x >= a.W) continue;
+                f32x4 v = *reinterpret_cast<const f32x4*>(xr + (long)x * a.ldx);
+                if (affine) v = act4(v, ia, ib, a.in.relu != 0);
+#pragma unroll
+                for (int r = 0; r < RO; ++r) {
+                    const int ky = iy - r * S;
+                    if (ky >= 0 && ky < KS) acc[r] += v * w[ky * KS + kx];
+                }
+            }
+        }
+        f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f}, s2 = s1;
+#pragma unroll
+        for (int r = 0; r < RO; ++r) {
+            const int oy = oy0 + r;
+            if (oy >= a.Ho) break;
+            s1 += acc[r];
+            s2 += acc[r] * acc[r];
+            *reinterpret_cast<f32x4*>(a.Y + (((long)b * a.Ho + oy) * a.Wo + ox) * a.ldy + c) = acc[r];
+        }
+        t1 = to_f64(s1);
+        t2 = to_f64(s2);
+    }
+    red[0][threadIdx.x] = t1;
+    red[1][threadIdx.x] = t2;
+    __syncthreads();
+    // thread t < cgs owns the channel quad (idx0 + t) % cgs and adds the entries t, t + cgs, ... of this workgroup (256 >= cgs:
+    // every quad occurs at least once per workgroup)
+    if ((int)threadIdx.x < cgs) {
+        f64x4 s1 = zero, s2 = zero;
+        for (int j = threadIdx.x; j < 256; j += cgs) { s1 += red[0][j]; s2 += red[1][j]; }
+        const int cg = (int)((idx0 + threadIdx.x) % cgs);
+        double* p = a.partial + (long)blockIdx.x * 2 * a.C;
+        *reinterpret_cast<f64x4*>(p + cg * 4) = s1;
+        *reinterpret_cast<f64x4*>(p + a.C + cg * 4) = s2;
+    }
+}
+
+// sums [2][C] (float64, all ranks' when SyncBatchNorm) -> mean, rstd, running statistics, a = gamma * rstd, b = beta - mean * a
+struct BnFinArgs {
+    const double* sums;
+    const float* gamma;
+    const float* beta;
+    float* mean;
+    float* rstd;
+    float* oa;
+    float* ob;
+    float* running_mean;
+    float* running_var;
+    int C;
+    double count, eps, momentum;
+};
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(BnFinArgs a) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.C) return;
+    const double mean = a.sums[c] / a.count;
+    double var = (a.sums[a.C + c] - a.sums[c] * mean) / a.count;
+    if (var < 0.0) var = 0.0;
+    const float mf = (float)mean, rf = (float)(1.0 / sqrt(var + a.eps));
+    a.mean[c] = mf;
+    a.rstd[c] = rf;
+    const float av = a.gamma[c] * rf;
+    a.oa[c] = av;
+    a.ob[c] = __builtin_fmaf(-mf, av, a.beta[c]);
+    if (a.running_mean) {
+        a.running_mean[c] = (float)((1.0 - a.momentum) * (double)a.running_mean[c] + a.momentum * mean);
+        const double unbiased = a.count > 1.0 ? var * a.count / (a.count - 1.0) : var;
+        a.running_var[c] = (float)((1.0 - a.momentum) * (double)a.running_var[c] + a.momentum * unbiased);
+    }
+}
+
+// y = act(x) [+ residual]: the one activation the fused step materialises (block outputs)
+struct BnActArgs {
+    const float* X;
+    const float* R;      // residual or nullptr
+    float* Y;
+    ActIn in;
+    long M;
+    int C, ldx, ldr, ldy;
+};
+
+__global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a) {
+    const int c4n = a.C >> 2;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.M * c4n) return;
+    const long r = i / c4n;
+    const int c = (int)(i % c4n) * 4;
+    f32x4 y = act4(*reinterpret_cast<const f32x4*>(a.X + r * a.ldx + c), *reinterpret_cast<const f32x4*>(a.in.a + c),
+                   *reinterpret_cast<const f32x4*>(a.in.b + c), a.in.relu != 0);
+    if (a.R) y += *reinterpret_cast<const f32x4*>(a.R + r * a.ldr + c);
+    *reinterpret_cast<f32x4*>(a.Y + r * a.ldy + c) = y;
+}
+
 }  // namespace
 
 extern "C" {
@@ -796,9 +1118,11 @@ int fear_pw_backward_data(const float* dy, int lddy, const float* w, const float
 }
 
 static int wgrad_impl(const float* dy, int lddy, long dy_crop_stride, const float* x, int ldx, long x_crop_stride, float* dw,
-                      float* workspace, size_t ws_bytes, long M, int K, int N, int crops, hipStream_t s) {
+                      float* workspace, size_t ws_bytes, long M, int K, int N, int crops, hipStream_t s, const float* act_a = nullptr,
+                      const float* act_b = nullptr, int act_relu = 0) {
     WgradArgs a{};
     a.dY = dy; a.X = x; a.lddy = lddy; a.ldx = ldx; a.N = N; a.K = K; a.M = M; a.crops = crops;
+    a.act_a = act_a; a.act_b = act_b; a.act_relu = act_relu;
     a.dy_crop_stride = dy_crop_stride; a.x_crop_stride = x_crop_stride;
     a.n_tiles = (N + 63) / 64; a.k_tiles = (K + 63) / 64;
     a.rows_per_slice = crops > 1 ? M : wgrad_rows_per_slice(M);
@@ -892,19 +1216,16 @@ int fear_dw_backward_data(const float* dy, int lddy, const float* w_taps, float*
     return FEAR_TRAIN_OK;
 }
 
-int fear_dw_backward_weight(const float* dy, int lddy, const float* x, int ldx, float* dw_taps, float* workspace,
-                            size_t ws_bytes, int B, int H, int W, int C, int k, int stride, void* stream) {
-    if (!dy || !x || !dw_taps || !workspace) return FEAR_TRAIN_ERR_NULL;
-    if (B < 1 || !dw_shape_ok(B, H, W, C, k, stride)) return FEAR_TRAIN_ERR_SHAPE;
-    if (!ld_ok(lddy, C) || !ld_ok(ldx, C)) return FEAR_TRAIN_ERR_SHAPE;      // float4 rows
+static int dw_wgrad_impl(const float* dy, int lddy, const float* x, int ldx, float* dw_taps, float* workspace, size_t ws_bytes, int B,
+                         int H, int W, int C, int k, int stride, hipStream_t s, const float* act_a, const float* act_b, int act_relu) {
     const int Ho = H / stride, Wo = W / stride;
     const long pixels = (long)B * Ho * Wo;
     const int blocks = col_blocks(pixels);
     const long count = (long)k * k * C;
     if (ws_bytes < (size_t)blocks * count * sizeof(float)) return FEAR_TRAIN_ERR_WORKSPACE;
-    hipStream_t s = static_cast<hipStream_t>(stream);
     DwWgradArgs a{};
     a.dY = dy; a.X = x; a.partial = workspace; a.pixels = pixels; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.C = C; a.lddy = lddy; a.ldx = ldx; a.rpb = col_rows_per_block(pixels);
+    a.act_a = act_a; a.act_b = act_b; a.act_relu = act_relu;
     if (k == 3 && stride == 1) hipLaunchKernelGGL((dw_wgrad_kernel<3, 1>), dim3(blocks), dim3(256), 0, s, a);
     else if (k == 3) hipLaunchKernelGGL((dw_wgrad_kernel<3, 2>), dim3(blocks), dim3(256), 0, s, a);
     else if (stride == 1) hipLaunchKernelGGL((dw_wgrad_kernel<5, 1>), dim3(blocks), dim3(256), 0, s, a);
@@ -912,6 +1233,15 @@ int fear_dw_backward_weight(const float* dy, int lddy, const float* x, int ldx, 
     launch_slice_sum(workspace, dw_taps, count, blocks, s);
     LAUNCH_CHECK();
     return FEAR_TRAIN_OK;
+}
+
+int fear_dw_backward_weight(const float* dy, int lddy, const float* x, int ldx, float* dw_taps, float* workspace,
+                            size_t ws_bytes, int B, int H, int W, int C, int k, int stride, void* stream) {
+    if (!dy || !x || !dw_taps || !workspace) return FEAR_TRAIN_ERR_NULL;
+    if (B < 1 || !dw_shape_ok(B, H, W, C, k, stride)) return FEAR_TRAIN_ERR_SHAPE;
+    if (!ld_ok(lddy, C) || !ld_ok(ldx, C)) return FEAR_TRAIN_ERR_SHAPE;      // float4 rows
+    return dw_wgrad_impl(dy, lddy, x, ldx, dw_taps, workspace, ws_bytes, B, H, W, C, k, stride, static_cast<hipStream_t>(stream), nullptr,
+                         nullptr, 0);
 }
 
 int fear_stem_im2col(const float* x_nchw, float* rows28, long n, int H, int W, void* stream) {
@@ -973,6 +1303,157 @@ int fear_bn_train_backward(const float* dy, int lddy, const float* y_act, int ld
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, b);
     LAUNCH_CHECK();
     return FEAR_TRAIN_OK;
+}
+
+// ---- fused conv + BatchNorm operators (see "Fused conv + BatchNorm operators" above) ----------------------------------------
+static int finalize_sums(const double* partial, int blocks, int C, double* sums, hipStream_t s) {
+    ColFinArgs f{};
+    f.partial = partial; f.dsum = sums; f.blocks = blocks; f.C = C; f.mode = 3;
+    hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, s, f);
+    return 0;
+}
+
+int fear_pw_forward_stats(const float* x, int ldx, const float* in_a, const float* in_b, int in_relu, const float* w, float* y,
+                          int ldy, long M, int K, int N, double* sums, float* workspace, size_t ws_bytes, void* stream) {
+    if (!x || !w || !y || !sums || !workspace || (in_a && !in_b)) return FEAR_TRAIN_ERR_NULL;
+    if (M <= 0 || K < 4 || K % 4 || N < 4 || N % 4 || N > 1024 || M > 0x7fffffffL || !ld_ok(ldx, K) || !ld_ok(ldy, N)) return FEAR_TRAIN_ERR_SHAPE;
+    const int blocks = (int)((M + 127) / 128);
+    if (ws_bytes < (size_t)blocks * 2 * N * sizeof(double)) return FEAR_TRAIN_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    PwStatArgs a{};
+    a.X = x; a.ldx = ldx; a.W = w; a.Y = y; a.ldy = ldy; a.M = (int)M; a.K = K; a.N = N;
+    a.in.a = in_a; a.in.b = in_b; a.in.relu = in_relu;
+    a.partial = reinterpret_cast<double*>(workspace);
+    dim3 grid((unsigned)blocks);
+    switch (train_pick_nt((N + 15) / 16)) {
+        case 1: hipLaunchKernelGGL((pw_stat_kernel<1>), grid, dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((pw_stat_kernel<2>), grid, dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL((pw_stat_kernel<3>), grid, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((pw_stat_kernel<4>), grid, dim3(256), 0, s, a); break;
+        case 6: hipLaunchKernelGGL((pw_stat_kernel<6>), grid, dim3(256), 0, s, a); break;
+        case 7: hipLaunchKernelGGL((pw_stat_kernel<7>), grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((pw_stat_kernel<8>), grid, dim3(256), 0, s, a); break;
+    }
+    finalize_sums(a.partial, blocks, N, sums, s);
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+int fear_dw_forward_stats(const float* x, int ldx, const float* in_a, const float* in_b, int in_relu, const float* w_taps, float* y,
+                          int ldy, int B, int H, int W, int C, int k, int stride, double* sums, float* workspace, size_t ws_bytes,
+                          void* stream) {
+    if (!x || !w_taps || !y || !sums || !workspace || (in_a && !in_b)) return FEAR_TRAIN_ERR_NULL;
+    if (B < 1 || !dw_shape_ok(B, H, W, C, k, stride) || !ld_ok(ldx, C) || !ld_ok(ldy, C)) return FEAR_TRAIN_ERR_SHAPE;
+    DwStatArgs a{};
+    a.X = x; a.ldx = ldx; a.Wt = w_taps; a.Y = y; a.ldy = ldy; a.B = B; a.H = H; a.W = W; a.C = C; a.Ho = H / stride; a.Wo = W / stride;
+    a.in.a = in_a; a.in.b = in_b; a.in.relu = in_relu;
+    const long strips = (a.Ho + 3) / 4;
+    const long total = (long)B * strips * a.Wo * (C / 4);
+    const long blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffL) return FEAR_TRAIN_ERR_SHAPE;
+    if (ws_bytes < (size_t)blocks * 2 * C * sizeof(double)) return FEAR_TRAIN_ERR_WORKSPACE;
+    a.partial = reinterpret_cast<double*>(workspace);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    dim3 grid((unsigned)blocks);
+    if (k == 3 && stride == 1) hipLaunchKernelGGL((dw_stat_kernel<3, 1, 4>), grid, dim3(256), 0, s, a);
+    else if (k == 3) hipLaunchKernelGGL((dw_stat_kernel<3, 2, 4>), grid, dim3(256), 0, s, a);
+    else if (stride == 1) hipLaunchKernelGGL((dw_stat_kernel<5, 1, 4>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((dw_stat_kernel<5, 2, 4>), grid, dim3(256), 0, s, a);
+    finalize_sums(a.partial, (int)blocks, C, sums, s);
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+size_t fear_train_stats_workspace_bytes(long rows, int channels) {
+    // partial [workgroups][2][C] float64.  Pointwise producer: one workgroup per 128 rows.  Depthwise producer: one per 256 threads,
+    // a thread = 4 channels x 4 output rows of one column -> rows * C / 4096 workgroups (+ ragged strips / the last one).
+    const size_t pw = (size_t)((rows + 127) / 128 + 1);
+    const size_t dw = (size_t)(rows * (long)((channels + 3) / 4) / 512 + 64);      // strips round up: allow 2x rows * C / 4096
+    return (pw > dw ? pw : dw) * 2 * (size_t)channels * sizeof(double);
+}
+
+int fear_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float* mean, float* rstd, float* a_out,
+                     float* b_out, float* running_mean, float* running_var, double momentum, double eps, int C, void* stream) {
+    if (!sums || !gamma || !beta || !mean || !rstd || !a_out || !b_out) return FEAR_TRAIN_ERR_NULL;
+    if (C < 1 || !(count >= 1.0)) return FEAR_TRAIN_ERR_SHAPE;
+    BnFinArgs f{};
+    f.sums = sums; f.gamma = gamma; f.beta = beta; f.mean = mean; f.rstd = rstd; f.oa = a_out; f.ob = b_out;
+    f.running_mean = running_mean; f.running_var = running_var; f.C = C; f.count = count; f.eps = eps; f.momentum = momentum;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), f);
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+int fear_bn_act(const float* x, int ldx, const float* a, const float* b, int relu, const float* residual, int ldr, float* y, int ldy,
+                long M, int C, void* stream) {
+    if (M == 0) return FEAR_TRAIN_OK;
+    if (!x || !a || !b || !y) return FEAR_TRAIN_ERR_NULL;
+    if (M < 0 || C < 4 || C % 4 || !ld_ok(ldx, C) || !ld_ok(ldy, C) || (residual && !ld_ok(ldr, C))) return FEAR_TRAIN_ERR_SHAPE;
+    BnActArgs k{};
+    k.X = x; k.R = residual; k.Y = y; k.in.a = a; k.in.b = b; k.in.relu = relu; k.M = M; k.C = C; k.ldx = ldx; k.ldr = ldr; k.ldy = ldy;
+    const long n4 = M * (C / 4);
+    hipLaunchKernelGGL(bn_act_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), k);
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+int fear_bn_backward_reduce_x(const float* dy, int lddy, const float* x, int ldx, const float* act_a, const float* act_b, int relu,
+                              const float* mean, const float* rstd, double* sums, long M, int C, float* workspace, size_t ws_bytes,
+                              void* stream) {
+    if (!dy || !x || !mean || !rstd || !sums || !workspace || (relu && (!act_a || !act_b))) return FEAR_TRAIN_ERR_NULL;
+    if (M <= 0 || C < 4 || C % 4 || C > 1024 || !ld_ok(lddy, C) || !ld_ok(ldx, C)) return FEAR_TRAIN_ERR_SHAPE;
+    const int blocks = col_blocks(M);
+    if (ws_bytes < (size_t)blocks * 2 * C * sizeof(double)) return FEAR_TRAIN_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ColArgs a{};
+    a.A = dy; a.lda = lddy; a.X = x; a.ldx = ldx; a.mean = mean; a.rstd = rstd;
+    a.act_a = relu ? act_a : nullptr; a.act_b = relu ? act_b : nullptr;
+    a.partial = reinterpret_cast<double*>(workspace); a.M = M; a.C = C; a.rpb = col_rows_per_block(M);
+    hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(blocks), dim3(256), 0, s, a);
+    finalize_sums(a.partial, blocks, C, sums, s);
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+int fear_bn_backward_apply_x(const float* dy, int lddy, const float* x, int ldx, const float* act_a, const float* act_b, int relu,
+                             const float* mean, const float* rstd, const float* gamma, const double* sums_all, double count,
+                             const double* sums_local, float* dx, int lddx, float* dgamma, float* dbeta, float* workspace,
+                             size_t ws_bytes, long M, int C, void* stream) {
+    if (!dy || !x || !mean || !rstd || !gamma || !sums_all || !sums_local || !dx || !dgamma || !dbeta || !workspace ||
+        (relu && (!act_a || !act_b)))
+        return FEAR_TRAIN_ERR_NULL;
+    if (M <= 0 || C < 4 || C % 4 || C > 1024 || !(count >= (double)M) || !ld_ok(lddy, C) || !ld_ok(ldx, C) || !ld_ok(lddx, C))
+        return FEAR_TRAIN_ERR_SHAPE;
+    if (ws_bytes < (size_t)2 * C * sizeof(float)) return FEAR_TRAIN_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(sums_to_float_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums_local, dbeta, dgamma, C);
+    float* g1 = workspace;
+    float* g2 = workspace + C;
+    hipLaunchKernelGGL(sums_to_float_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sums_all, g1, g2, C);
+    BnBwdArgs b{};
+    b.dY = dy; b.X = x; b.mean = mean; b.rstd = rstd; b.gamma = gamma; b.sum_g = g1; b.sum_gx = g2;
+    b.dX = dx; b.M = M; b.C = C; b.lddy = lddy; b.ldx = ldx; b.lddx = lddx; b.count = count;
+    b.act_a = relu ? act_a : nullptr; b.act_b = relu ? act_b : nullptr;
+    const long n4 = M * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, b);
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+int fear_pw_backward_weight_act(const float* dy, int lddy, const float* x, int ldx, const float* in_a, const float* in_b, int in_relu,
+                                float* dw, float* workspace, size_t ws_bytes, long M, int K, int N, void* stream) {
+    if (!dy || !x || !dw || (in_a && !in_b)) return FEAR_TRAIN_ERR_NULL;
+    if (M <= 0 || K < 4 || K % 4 || N < 4 || N % 4 || !ld_ok(lddy, N) || !ld_ok(ldx, K)) return FEAR_TRAIN_ERR_SHAPE;
+    return wgrad_impl(dy, lddy, 0, x, ldx, 0, dw, workspace, ws_bytes, M, K, N, 1, static_cast<hipStream_t>(stream), in_a, in_b, in_relu);
+}
+
+int fear_dw_backward_weight_act(const float* dy, int lddy, const float* x, int ldx, const float* in_a, const float* in_b, int in_relu,
+                                float* dw_taps, float* workspace, size_t ws_bytes, int B, int H, int W, int C, int k, int stride,
+                                void* stream) {
+    if (!dy || !x || !dw_taps || !workspace || (in_a && !in_b)) return FEAR_TRAIN_ERR_NULL;
+    if (B < 1 || !dw_shape_ok(B, H, W, C, k, stride) || !ld_ok(lddy, C) || !ld_ok(ldx, C)) return FEAR_TRAIN_ERR_SHAPE;
+    return dw_wgrad_impl(dy, lddy, x, ldx, dw_taps, workspace, ws_bytes, B, H, W, C, k, stride, static_cast<hipStream_t>(stream), in_a,
+                         in_b, in_relu);
 }
 
 // ---- SyncBatchNorm (the reference's multi-GPU backends set sync_bn: True, config/backend/*.yaml): the two reductions of a

@@ -10,8 +10,8 @@ only sequences them and keeps the parameters, like the reference's Python does a
 stream provider and — for several ranks — the RCCL all-reduce of the flat gradient buffer (`allreduce_gradients`; the
 reference uses Lightning DDP, train/trainer.py:50-52).  Parameter and gradient names are the reference's `state_dict` keys.
 
-Not in this slice: the trunk's backward (the FBNet blocks need the unfolded, un-recoverable `mobile_cv` BatchNorm
-parameters), SyncBatchNorm across ranks, the optimiser.
+The trunk, SyncBatchNorm over the data-parallel group and the optimiser build on this module: `train_net.FEARNetTrainHIP`
+(whole network, fused conv + BatchNorm operators), `SyncBN` below, `optim.AdamHIP`.
 """
 from __future__ import annotations
 
@@ -42,6 +42,15 @@ TRAIN_SYMBOLS = {
     "fear_bn_forward_from_sums": ([_P, _i, _P, _d, _P, _P, _P, _i, _P, _P, _P, _P, _d, _d, _l, _i, _i, _P], _i),
     "fear_bn_backward_reduce": ([_P, _i, _P, _i, _P, _i, _P, _P, _P, _l, _i, _P, _sz, _P], _i),
     "fear_bn_backward_from_sums": ([_P, _i, _P, _i, _P, _i, _P, _P, _P, _P, _d, _P, _P, _i, _P, _P, _P, _sz, _l, _i, _P], _i),
+    "fear_pw_forward_stats": ([_P, _i, _P, _P, _i, _P, _P, _i, _l, _i, _i, _P, _P, _sz, _P], _i),
+    "fear_dw_forward_stats": ([_P, _i, _P, _P, _i, _P, _P, _i, _i, _i, _i, _i, _i, _i, _P, _P, _sz, _P], _i),
+    "fear_train_stats_workspace_bytes": ([_l, _i], _sz),
+    "fear_bn_finalize": ([_P, _d, _P, _P, _P, _P, _P, _P, _P, _P, _d, _d, _i, _P], _i),
+    "fear_bn_act": ([_P, _i, _P, _P, _i, _P, _i, _P, _i, _l, _i, _P], _i),
+    "fear_bn_backward_reduce_x": ([_P, _i, _P, _i, _P, _P, _i, _P, _P, _P, _l, _i, _P, _sz, _P], _i),
+    "fear_bn_backward_apply_x": ([_P, _i, _P, _i, _P, _P, _i, _P, _P, _P, _P, _d, _P, _P, _i, _P, _P, _P, _sz, _l, _i, _P], _i),
+    "fear_pw_backward_weight_act": ([_P, _i, _P, _i, _P, _P, _i, _P, _P, _sz, _l, _i, _i, _P], _i),
+    "fear_dw_backward_weight_act": ([_P, _i, _P, _i, _P, _P, _i, _P, _P, _sz, _i, _i, _i, _i, _i, _i, _P], _i),
     "fear_xcorr_forward": ([_P, _i, _P, _P, _i, _i, _i, _i, _i, _P], _i),
     "fear_xcorr_backward": ([_P, _i, _P, _i, _P, _P, _i, _P, _i, _P, _i, _i, _i, _i, _P], _i),
     "fear_exp_head_forward": ([_P, _P, _P, _P, _l, _P], _i),

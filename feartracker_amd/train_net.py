@@ -112,12 +112,21 @@ class _ConvBN:
 
 class FEARNetTrainHIP:
     def __init__(self, state_dict: Dict[str, "np.ndarray | torch.Tensor"], device: int = 0, momentum: float = 0.1, eps: float = 1e-5,
-                 coef_cls: float = 1.0, coef_reg: float = 1.0, sync_bn: bool = False, group=None):
+                 coef_cls: float = 1.0, coef_reg: float = 1.0, sync_bn: bool = False, group=None, fused: bool = False):
         if not torch.cuda.is_available():
             raise RuntimeError("FEARNetTrainHIP needs a ROCm GPU; there is no CPU fallback")
         self.lib = load_train_library()
         self.device = torch.device(f"cuda:{int(device)}")
         self.momentum, self.eps = momentum, eps
+        # fused=True: the trunk runs on the fused conv + BatchNorm operators of include/fear_train.h — a BatchNorm'd activation
+        # is never written, consumers apply it on load: 11 instead of 16 passes over every saved tensor and 13.7 instead of
+        # 21.7 GB at 128 pairs, the same gradients (tests/test_train_head.py) — and, measured, NOT faster: 33.8 vs 31.6 ms of
+        # kernel time per 128-pair step (profiles/r03_train_kernel_stats{,_fused}.csv).  The step's kernels are not bound by
+        # the bytes the fusion removes: at 25 us per launch on average they are latency- and issue-bound, the activation
+        # arithmetic added to the weight-gradient loads costs more (+1.9 ms) than the two removed passes save, and the
+        # producers' per-workgroup partial sums add finalisation work.  So the default stays one kernel per layer and
+        # direction; fused is the memory-saving mode (larger per-rank batches).
+        self.fused = bool(fused)
         sd = {k: torch.as_tensor(np.asarray(v)) if not isinstance(v, torch.Tensor) else v.detach().cpu() for k, v in state_dict.items()}
         dev = self.device
         self.stem = _ConvBN("stem", "stem", sd, dev, k=3, stride=2)
@@ -224,6 +233,123 @@ class FEARNetTrainHIP:
         self._check(self.lib.fear_add(_p(a), _p(b), _p(out), a.numel(), self._stream()))
         return out
 
+    # ------------------------------------------------------------------ fused conv + BN units
+    def _workspace_stats(self, rows: int, channels: int):
+        need = max(int(self.lib.fear_train_stats_workspace_bytes(rows, channels)), int(self.lib.fear_train_workspace_bytes(rows, 672)))
+        if self._ws is None or self._ws.numel() * 4 < need:
+            self._ws = None
+            self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
+        return _p(self._ws), self._ws.numel() * 4
+
+    def _fwd_f(self, L: _ConvBN, x: torch.Tensor, x_act, B: int, H: int, saved: list):
+        """One conv + BatchNorm unit on the fused operators.  x: rows [B*H*H][cin] — a previous unit's RAW conv output when
+        `x_act` = (a, b, relu) names the activation to apply on load, else a plain tensor.  Writes this unit's raw output and
+        returns (raw, (a, b, relu)): whoever consumes it applies the BatchNorm [+ ReLU] itself."""
+        lib, st = self.lib, self._stream()
+        Ho = H // L.stride if L.kind == "dw" else H
+        M = B * Ho * Ho
+        ws, wsb = self._workspace_stats(max(M, B * H * H), L.cout)
+        pre = self._new(M, L.cout)
+        sums = torch.empty(2 * L.cout, dtype=torch.float64, device=self.device)
+        ia, ib, irelu = (_p(x_act[0]), _p(x_act[1]), int(x_act[2])) if x_act is not None else (None, None, 0)
+        if L.kind == "dw":
+            self._check(lib.fear_dw_forward_stats(_p(x), L.cin, ia, ib, irelu, _p(L.w), _p(pre), L.cout, B, H, H, L.cin, L.k, L.stride,
+                                                  _p(sums), ws, wsb, st))
+        else:
+            self._check(lib.fear_pw_forward_stats(_p(x), L.cin, ia, ib, irelu, _p(L.w), _p(pre), L.cout, M, L.cin, L.cout, _p(sums),
+                                                  ws, wsb, st))
+        count = float(M)
+        if self.sync is not None:
+            self.sync.all_reduce(sums)
+            count *= self.sync.world
+        mean, rstd, a, b = self._new(L.cout), self._new(L.cout), self._new(L.cout), self._new(L.cout)
+        self._check(lib.fear_bn_finalize(_p(sums), count, _p(L.gamma), _p(L.beta), _p(mean), _p(rstd), _p(a), _p(b), _p(L.running_mean),
+                                         _p(L.running_var), self.momentum, self.eps, L.cout, st))
+        act = (a, b, 1 if L.relu else 0)
+        saved.append(dict(L=L, x=x, x_act=x_act, pre=pre, mean=mean, rstd=rstd, act=act, B=B, H=H))
+        return pre, act
+
+    def _materialise(self, pre: torch.Tensor, act, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        out = self._new(*pre.shape)
+        C = pre.shape[1]
+        self._check(self.lib.fear_bn_act(_p(pre), C, _p(act[0]), _p(act[1]), int(act[2]), _p(residual), C, _p(out), C, pre.shape[0], C,
+                                         self._stream()))
+        return out
+
+    def _bwd_f(self, rec: dict, dy: torch.Tensor, gbuf: torch.Tensor, need_dx: bool = True,
+               add: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+        """Backward of one fused unit given dy = gradient of its ACTIVATION; parameter gradients go to their slots of `gbuf`.
+        `add` (pointwise units): a tensor added to the input gradient in the same kernel (the residual branch's gradient)."""
+        L, x, x_act, pre, mean, rstd, act, B, H = (rec[k] for k in ("L", "x", "x_act", "pre", "mean", "rstd", "act", "B", "H"))
+        lib, st = self.lib, self._stream()
+        Ho = H // L.stride if L.kind == "dw" else H
+        M = B * Ho * Ho
+        ws, wsb = self._workspace_stats(max(M, B * H * H), max(L.cout, L.cin))
+        sums = torch.empty(2 * L.cout, dtype=torch.float64, device=self.device)
+        a, b, relu = act
+        self._check(lib.fear_bn_backward_reduce_x(_p(dy), L.cout, _p(pre), L.cout, _p(a), _p(b), relu, _p(mean), _p(rstd), _p(sums), M,
+                                                  L.cout, ws, wsb, st))
+        local, count = sums, float(M)
+        if self.sync is not None:
+            local = sums.clone()
+            self.sync.all_reduce(sums)
+            count *= self.sync.world
+        dpre = self._new(M, L.cout)
+        dgamma, dbeta = self._gslot(gbuf, L.bn_key + ".weight", L.cout), self._gslot(gbuf, L.bn_key + ".bias", L.cout)
+        self._check(lib.fear_bn_backward_apply_x(_p(dy), L.cout, _p(pre), L.cout, _p(a), _p(b), relu, _p(mean), _p(rstd), _p(L.gamma),
+                                                 _p(sums), count, _p(local), _p(dpre), L.cout, _p(dgamma), _p(dbeta), ws, wsb, M, L.cout, st))
+        ia, ib, irelu = (_p(x_act[0]), _p(x_act[1]), int(x_act[2])) if x_act is not None else (None, None, 0)
+        dx = None
+        if L.kind == "dw":
+            dtaps = self._gslot(gbuf, L.conv_key, L.k * L.k, L.cout)
+            self._check(lib.fear_dw_backward_weight_act(_p(dpre), L.cout, _p(x), L.cin, ia, ib, irelu, _p(dtaps), ws, wsb, B, H, H, L.cin,
+                                                        L.k, L.stride, st))
+            if need_dx:
+                dx = self._new(B * H * H, L.cin)
+                self._check(lib.fear_dw_backward_data(_p(dpre), L.cout, _p(L.w), _p(dx), L.cin, B, H, H, L.cin, L.k, L.stride, st))
+                if add is not None:
+                    self._check(lib.fear_add(_p(dx), _p(add), _p(dx), dx.numel(), st))
+        else:
+            dw = self._gslot(gbuf, L.conv_key, L.cout, L.cin)
+            self._check(lib.fear_pw_backward_weight_act(_p(dpre), L.cout, _p(x), L.cin, ia, ib, irelu, _p(dw), ws, wsb, M, L.cin, L.cout, st))
+            if L.kind != "stem" and need_dx:
+                dx = self._new(M, L.cin)
+                self._check(lib.fear_pw_backward_data(_p(dpre), L.cout, _p(L.w), _p(add), L.cin if add is not None else 0, _p(dx), L.cin,
+                                                      M, L.cin, L.cout, st))
+        return dx
+
+    def _features_forward_f(self, img: torch.Tensor):
+        """Fused form of `_features_forward`: img (B,3,H,H) NCHW -> (feature rows [B*(H/16)^2][256], context for the backward)."""
+        B, H = img.shape[0], img.shape[2]
+        saved: list = []
+        h = H // 2
+        col = self._new(B * h * h, 28)
+        self._check(self.lib.fear_stem_im2col(_p(img), _p(col), B, H, H, self._stream()))
+        pre, act = self._fwd_f(self.stem, col, None, B, h, saved)
+        x = self._materialise(pre, act)                              # block 1 adds it back as its residual: a real tensor
+        block_recs = []
+        for blk in self.blocks:
+            start = len(saved)
+            y, yact = x, None
+            if blk["pw"] is not None:
+                y, yact = self._fwd_f(blk["pw"], y, yact, B, h, saved)
+            y, yact = self._fwd_f(blk["dw"], y, yact, B, h, saved)
+            h = h // blk["dw"].stride
+            y, yact = self._fwd_f(blk["pwl"], y, yact, B, h, saved)
+            x = self._materialise(y, yact, x if blk["residual"] else None)     # BN of the projection (+ residual): the block output
+            block_recs.append((start, len(saved), blk["residual"]))
+        pre, act = self._fwd_f(self.neck, x, None, B, h, saved)
+        return self._materialise(pre, act), (saved, block_recs, B, h)
+
+    def _features_backward_f(self, ctx, dfeat: torch.Tensor, gbuf: torch.Tensor) -> None:
+        saved, block_recs, B, h = ctx
+        d = self._bwd_f(saved[-1], dfeat, gbuf)                      # neck
+        for start, end, residual in reversed(block_recs):
+            dres = d if residual else None
+            for i in range(end - 1, start - 1, -1):
+                d = self._bwd_f(saved[i], d, gbuf, add=dres if i == start else None)     # the block's first unit also takes the skip's gradient
+        self._bwd_f(saved[0], d, gbuf, need_dx=False)                # stem: the image needs no gradient
+
     # ------------------------------------------------------------------ trunk + neck
     def _features_forward(self, img: torch.Tensor):
         """img (B,3,H,H) NCHW -> (feature rows [B*(H/16)^2][256], saved records for the backward)."""
@@ -274,8 +400,10 @@ class FEARNetTrainHIP:
             raise ValueError("expected template (B,3,128,128) and search (B,3,256,256)")
         with torch.cuda.device(dev):
             st = self._stream()
-            zrows, zctx = self._features_forward(t)                  # template first, like FEARNet.forward
-            xrows, xctx = self._features_forward(s)
+            ffwd = self._features_forward_f if self.fused else self._features_forward
+            fbwd = self._features_backward_f if self.fused else self._features_backward
+            zrows, zctx = ffwd(t)                                    # template first, like FEARNet.forward
+            xrows, xctx = ffwd(s)
             z = self._new(B, 256, 8, 8)
             x = self._new(B, 256, 16, 16)
             self._check(self.lib.fear_nhwc_to_nchw(_p(zrows), _p(z), B, 256, 64, 256, 0, st))
@@ -287,8 +415,8 @@ class FEARNetTrainHIP:
             self._check(self.lib.fear_nchw_to_nhwc(_p(out["grad_search"]), _p(dx), B, 256, 256, 256, 0, st))
             self._check(self.lib.fear_nchw_to_nhwc(_p(out["grad_template"].contiguous()), _p(dz), B, 256, 64, 256, 0, st))
             gflat = torch.empty(2, self._gtotal, dtype=torch.float32, device=dev)      # fresh per step: the caller keeps `grads`
-            self._features_backward(xctx, dx, gflat[0])
-            self._features_backward(zctx, dz, gflat[1])
+            fbwd(xctx, dx, gflat[0])
+            fbwd(zctx, dz, gflat[1])
             self._check(self.lib.fear_add(_p(gflat[0]), _p(gflat[1]), _p(gflat[0]), self._gtotal, st))   # shared parameters: the two passes add up
             for L in self._trunk_layers():
                 gw = self._gslot(gflat[0], L.conv_key, *L.w.shape)
@@ -354,11 +482,22 @@ class FEARNetTrainHIP:
         out: Dict[str, List[torch.Tensor]] = {}
         for ctx in self.last_contexts:
             saved = ctx[0]
-            for (L, x, pre, act, mean, rstd, B, H) in saved:
-                if not L.relu:
-                    continue
+            for rec in saved:
+                if isinstance(rec, dict):                # fused unit: the mask is what every consumer recomputes, fma(pre, a, b) > 0
+                    L, B, H = rec["L"], rec["B"], rec["H"]
+                    if not L.relu:
+                        continue
+                    a, b, _ = rec["act"]
+                    y = torch.from_numpy(np.float32(rec["pre"].cpu().numpy().astype(np.float64) * a.cpu().numpy().astype(np.float64)
+                                                    + b.cpu().numpy().astype(np.float64)))      # fp32 fma: exact product, one rounding
+                    act = y
+                else:
+                    L, x, pre, act, mean, rstd, B, H = rec
+                    if not L.relu:
+                        continue
+                    act = act.cpu()
                 Ho = H // L.stride if L.kind == "dw" else H
-                out.setdefault(L.name, []).append((act > 0).reshape(B, Ho, Ho, L.cout).permute(0, 3, 1, 2).cpu())
+                out.setdefault(L.name, []).append((act > 0).reshape(B, Ho, Ho, L.cout).permute(0, 3, 1, 2))
         for bname, br in self.head.branches.items():
             for L in [br["enc"], br["corr"]] + br["tower"]:
                 m = (L.y.reshape(-1, L.ldy)[:, : L.cout] > 0)

@@ -92,6 +92,43 @@ int fear_bn_backward_from_sums(const float* dy, int lddy, const float* y_act, in
                                const double* sums_local, float* dx, int lddx, float* dgamma, float* dbeta, float* workspace,
                                size_t ws_bytes, long M, int C, void* stream);
 
+/* ---- fused conv + BatchNorm training operators (the trunk's step; model/blocks.py:27-35 over mobile_cv's conv-BN-ReLU units) ----
+ * A BatchNorm'd activation is never written out.  A PRODUCER writes the convolution's raw output y and, from the same pass, the
+ * float64 column sums of it (sums = [2][C]: sum y | sum y^2 — exactly what SyncBatchNorm all-reduces); fear_bn_finalize turns the
+ * (possibly all-reduced) sums into mean / rstd / running statistics and the affine a = gamma * rstd, b = beta - mean * a; every
+ * CONSUMER applies act(x) = fma(x, a, b) [then max(., 0)] to the raw tensor as it loads it: in_a / in_b / in_relu below (in_a = NULL:
+ * the input is used as it is).  The ReLU mask of the backward is recomputed from the raw tensor with the same expression, so the
+ * forward and the backward agree bit for bit on which elements are active.  Zero padding of a depthwise conv pads the
+ * ACTIVATION (stays zero).  fear_bn_act materialises act(x) [+ residual] where a tensor is needed (block outputs).
+ * Against the unfused operators above: 11 instead of 16 passes over every saved tensor, half the saved memory. */
+int fear_pw_forward_stats(const float* x, int ldx, const float* in_a, const float* in_b, int in_relu, const float* w, float* y,
+                          int ldy, long M, int K, int N, double* sums, float* workspace, size_t ws_bytes, void* stream);
+int fear_dw_forward_stats(const float* x, int ldx, const float* in_a, const float* in_b, int in_relu, const float* w_taps, float* y,
+                          int ldy, int B, int H, int W, int C, int k, int stride, double* sums, float* workspace, size_t ws_bytes,
+                          void* stream);
+/* bytes of workspace the two producers need for `rows` output rows of `channels` channels (partial sums per workgroup) */
+size_t fear_train_stats_workspace_bytes(long rows, int channels);
+int fear_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float* mean, float* rstd, float* a_out,
+                     float* b_out, float* running_mean, float* running_var, double momentum, double eps, int C, void* stream);
+int fear_bn_act(const float* x, int ldx, const float* a, const float* b, int relu, const float* residual, int ldr, float* y, int ldy,
+                long M, int C, void* stream);
+/* backward through (ReLU? o BatchNorm) of a raw tensor x: sums = [2][C] float64 (sum g | sum g * xhat, g = dy where act(x) > 0 when
+ * relu); then dx from the (all ranks') sums and row count, d gamma / d beta from the local sums — the split of
+ * fear_bn_backward_reduce / _from_sums above, with the mask taken from x instead of a stored activation */
+int fear_bn_backward_reduce_x(const float* dy, int lddy, const float* x, int ldx, const float* act_a, const float* act_b, int relu,
+                              const float* mean, const float* rstd, double* sums, long M, int C, float* workspace, size_t ws_bytes,
+                              void* stream);
+int fear_bn_backward_apply_x(const float* dy, int lddy, const float* x, int ldx, const float* act_a, const float* act_b, int relu,
+                             const float* mean, const float* rstd, const float* gamma, const double* sums_all, double count,
+                             const double* sums_local, float* dx, int lddx, float* dgamma, float* dbeta, float* workspace,
+                             size_t ws_bytes, long M, int C, void* stream);
+/* weight gradients whose x operand is act(raw x) applied on load */
+int fear_pw_backward_weight_act(const float* dy, int lddy, const float* x, int ldx, const float* in_a, const float* in_b, int in_relu,
+                                float* dw, float* workspace, size_t ws_bytes, long M, int K, int N, void* stream);
+int fear_dw_backward_weight_act(const float* dy, int lddy, const float* x, int ldx, const float* in_a, const float* in_b, int in_relu,
+                                float* dw_taps, float* workspace, size_t ws_bytes, int B, int H, int W, int C, int k, int stride,
+                                void* stream);
+
 /* MobileCorrelation (blocks.py:121-123): s[b][p][j] = sum_c x[b][p][c] z[b][c][j]; z_nchw = (B, C, J) as the reference holds it */
 int fear_xcorr_forward(const float* x, int ldx, const float* z_nchw, float* s_out, int lds, int B, int P, int C, int J,
                        void* stream);
