@@ -458,6 +458,27 @@ def latency_batch1(weights, frames_cap: int = 120):
                                            **dict(DEFAULT_TRACKING_CONFIG, device_crop=False, device_postprocess=False)), sync, True)
     dev_ms, dev_boxes = loop(FEARTracker(net, cuda_id=torch.cuda.current_device(),
                                          **dict(DEFAULT_TRACKING_CONFIG, device_crop=True, device_postprocess=True)), sync, False)
+    # a 1920x1080 leg: the same tracker on full-HD frames (the demo clip tiled 4 x 4.2 to 1080p, the init box moved with it):
+    # the per-frame cost of a LARGE frame — host mean colour at initialize, context geometry, the upload of the context
+    # rectangle only (hip_backend.crop_normalize), crop + net + decode on the device
+    reps = (-(-1080 // frames.shape[1]), -(-1920 // frames.shape[2]))
+    big = np.ascontiguousarray(np.tile(frames[:31], (1, reps[0], reps[1], 1))[:, :1080, :1920])
+    big_init = init.copy()
+    trk_hd = FEARTracker(net, cuda_id=torch.cuda.current_device(), **dict(DEFAULT_TRACKING_CONFIG, device_crop=True, device_postprocess=True))
+    hd = {}
+    for rep in range(2):
+        trk_hd.initialize(big[0], big_init.copy())
+        sync()
+        t0 = time.perf_counter()
+        ctx_px = 0
+        for f in big[1:]:
+            trk_hd.update(f)
+            ctx_px += int(trk_hd.tracking_state.mapping[2]) * int(trk_hd.tracking_state.mapping[3])
+        sync()
+        hd = {"total": 1e3 * (time.perf_counter() - t0) / (len(big) - 1), "frames": len(big) - 1, "frame_shape": list(big[0].shape),
+              "frame_bytes": int(big[0].nbytes), "mean_context_pixels": ctx_px // (len(big) - 1),
+              "uploaded": "frame ∩ context rectangle per update (not the 6.2 MB frame)"}
+    del big
     from oracle.fear_oracle import OracleNet  # CPU baseline leg only
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     ncpu = min(len(frames), 41)
@@ -466,7 +487,7 @@ def latency_batch1(weights, frames_cap: int = 120):
     frames = frames_all
     return {"unit": "ms/frame", "frames": len(frames) - 1, "frame_shape": list(frames[0].shape), "clip": "tests/clipgen.demo_clip "
             "(480x256, init box [163,53,45,174]; assets/test.mp4 not decodable here: no H.264 decoder)",
-            "host_crop_path": host_ms, "device_crop_and_postprocess": dev_ms,
+            "host_crop_path": host_ms, "device_crop_and_postprocess": dev_ms, "device_path_1920x1080": hd,
             "device_boxes_identical_to_host_path": bool(np.array_equal(dev_boxes, host_boxes)),
             "cpu_oracle_tracker": dict(cpu_ms, frames=ncpu - 1, threads=torch.get_num_threads()),
             "boxes_identical_to_cpu_oracle": bool(np.array_equal(host_boxes[:ncpu - 1], cpu_boxes))}
@@ -524,6 +545,8 @@ def main() -> None:
     ap.add_argument("--math", type=int, default=int(os.environ.get("FEAR_MATH", "0")), choices=[0, 1],
                     help="0: fp32 MFMA (exact fp32, default); 1: fp16 hi+lo split operands on the matrix pipe, fp32 accumulate")
     ap.add_argument("--dual-head", action="store_true", help="A/B: the head's two branches on two streams (FEAR_OPT_DUAL_HEAD)")
+    ap.add_argument("--head-stagger", type=int, default=int(os.environ.get("FEAR_HEAD_STAGGER", "-1")),
+                    help="A/B: microseconds the head's second branch is held back behind the first (two streams); -1 = the engine's default")
     ap.add_argument("--no-chain", action="store_true", help="A/B: one fused kernel per stride-16 block instead of the chain kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-math", action="store_true",
@@ -602,6 +625,8 @@ def main() -> None:
         net.set_chain(False)
     if args.dual_head:
         net.set_dual_head(True)
+    if args.head_stagger >= 0:
+        net.set_head_stagger(args.head_stagger)
     search_u8, tmpl_u8 = synth_batch(B, rank)
     search = norm_u8(search_u8.to(dev)).contiguous()
     tmpl_feats = net.get_features(norm_u8(tmpl_u8.to(dev)).contiguous())

@@ -171,6 +171,7 @@ struct fear_handle {
     std::vector<float*> weight_allocs;    // per-conv weights: live as long as the handle
     std::vector<float*> plan_allocs;      // weights packed for the fused kernels of the cached plans: freed with the plans
     bool building_plan = false;           // upload() books into plan_allocs while a plan is being built
+    int head_stagger_us = 0;              // FEAR_OPT_HEAD_STAGGER: the second branch starts this many microseconds after the first
     int dual_head = 0;                    // FEAR_OPT_DUAL_HEAD: throughput plan runs the head's two branches on two streams (A/B option:
                                           // measured 104.3 k vs 104.8 k crops/s single-stream — the 16x16 kernels are ALU-bound, a second
                                           // resident workgroup per CU buys nothing: kbench 512 vs 2 x 256 crops, +2 %)
@@ -1168,6 +1169,14 @@ struct Ext {
     long bbox_stride = 4 * 256, cls_stride = 256;   // floats between consecutive crops' maps (fear_track_packed: 5 * 256 both)
 };
 
+// One wavefront that does nothing for `ticks` x 10 ns (wall_clock64 runs at 100 MHz) and at most ~1 ms: put in front of the
+// head's second branch (FEAR_OPT_HEAD_STAGGER) so that the two branches' kernels — co-resident, one workgroup of each per CU —
+// run half a kernel out of phase: one branch's prologue / output burst then falls into the other's MFMA stretch.
+__global__ void delay_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    for (int i = 0; i < 100000 && wall_clock64() - t0 < ticks; ++i) __builtin_amdgcn_s_sleep(16);
+}
+
 int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main) {
     if (!h->fused_attr_set) {
         for (const Fused16& f : kFused16) {
@@ -1236,6 +1245,8 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
         if (dual && op_index == p.head_first) {
             HIP_TRY(h, hipEventRecord(h->branch_fork, s_main));            // the trunk's output is ready after this point
             HIP_TRY(h, hipStreamWaitEvent(h->branch_stream, h->branch_fork, 0));
+            if (h->head_stagger_us > 0)
+                hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, h->branch_stream, (long long)h->head_stagger_us * 100);
             forked = true;
         }
         const hipStream_t s = (dual && op.lane == 1) ? h->branch_stream : s_main;
@@ -1544,6 +1555,10 @@ int fear_set_option(fear_handle* h, int option, int64_t value) {
             if (value != 0 && value != 1) return FEAR_ERR_SHAPE;
             if (h->dual_head != (int)value) { h->dual_head = (int)value; return drop_plans(h); }
             return FEAR_OK;
+        case FEAR_OPT_HEAD_STAGGER:
+            if (value < 0 || value > 1000) return FEAR_ERR_SHAPE;
+            h->head_stagger_us = (int)value;
+            return FEAR_OK;
         default: return FEAR_ERR_SHAPE;
     }
 }
@@ -1560,6 +1575,7 @@ int64_t fear_get_option(fear_handle* h, int option) {
         case FEAR_OPT_SMALL_PASS: return h->small_pass;
         case FEAR_OPT_PLAN_CROPS: return h->plan_crops;
         case FEAR_OPT_DUAL_HEAD: return h->dual_head;
+        case FEAR_OPT_HEAD_STAGGER: return h->head_stagger_us;
         default: return FEAR_ERR_SHAPE;
     }
 }

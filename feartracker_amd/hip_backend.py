@@ -36,6 +36,7 @@ FEAR_OPT_CHAIN = 6
 FEAR_OPT_SMALL_PASS = 7
 FEAR_OPT_PLAN_CROPS = 8
 FEAR_OPT_DUAL_HEAD = 9
+FEAR_OPT_HEAD_STAGGER = 10
 
 _lib = None
 
@@ -183,6 +184,10 @@ class FEARNetHIP:
     def set_dual_head(self, on: bool) -> None:
         """Throughput plan: the head's two branches on two streams (default) vs one."""
         self._check(self._lib.fear_set_option(self._h, FEAR_OPT_DUAL_HEAD, 1 if on else 0))
+
+    def set_head_stagger(self, microseconds: int) -> None:
+        """Two head streams: hold the second branch back by this many microseconds (FEAR_OPT_HEAD_STAGGER)."""
+        self._check(self._lib.fear_set_option(self._h, FEAR_OPT_HEAD_STAGGER, int(microseconds)))
 
     def set_plan_crops(self, crops: int) -> None:
         """Crop count whose launch plan `plan()` / `profile_read()` describe (0 = a full pass of max_batch crops)."""

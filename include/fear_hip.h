@@ -127,6 +127,9 @@ int fear_crop_normalize(fear_handle* h, const uint8_t* frame_u8, int frame_h, in
                                /*   FEAR_OPT_MAX_BATCH, i.e. the plan of a full pass                                           */
 #define FEAR_OPT_DUAL_HEAD 9   /* 1: the throughput plan runs the head's cls and bbox branches on two streams (one workgroup   */
                                /*   of each fits on a CU); 0 (default): one stream — measured equal, the kernels are ALU-bound */
+#define FEAR_OPT_HEAD_STAGGER 10 /* with two head streams (FEAR_OPT_DUAL_HEAD, or a small pass): microseconds (0..1000, default 0) the  */
+                               /*   second branch's first kernel is held back, so that the co-resident kernels of the two branches  */
+                               /*   run out of phase and one's prologue / output burst overlaps the other's MFMA stretch            */
 int fear_set_option(fear_handle* h, int option, int64_t value);
 int64_t fear_get_option(fear_handle* h, int option);
 
