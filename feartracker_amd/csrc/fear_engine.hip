@@ -159,6 +159,7 @@ struct fear_handle {
     int profile = 0;
     int profile_op = -1;   // -1: every op, else only this op index of each plan
     int fuse = 1;          // 1: use the fused block kernels where an instantiation exists
+    int tile_v4 = 1;       // FEAR_OPT_TILE_V4: 1 = phase-overlapped tile kernel for the blocks of kFusedTileV4 (throughput plan)
     int chain = 1;         // 1: run the stride-16 trunk stage as one register-resident chain kernel (fp32 mode)
     int small_pass = 96;   // passes of at most this many crops run the small-batch plan (FEAR_OPT_SMALL_PASS; 0: never);
                            // measured crossover with the throughput plan: ~110 crops (1.70 vs 1.93 ms at 96, 2.14 vs 2.01 at 128)
@@ -424,7 +425,22 @@ const TileKSplit* find_tile_ksplit(int id) {
         if (t.id == id) return &t;
     return nullptr;
 }
+// Throughput-plan blocks that run the phase-overlapped kernel (ir_tile_v4_kernel: same tile, packed weights, LDS bytes and
+// arguments as their kFusedTile entry) — the tiles whose E tile leaves room for ONE workgroup per CU, where nobody else fills
+// the LDS round trips of the depthwise; kernel = nullptr: the block stays on ir_tile_v2.  tools/kbench A/B, 256 crops
+// (profiles/r03_tile_v4_kbench.txt): stage 6 +5.5 %; stages 7-10 and 2 lose 3-25 % (the overlap costs ~90 more VGPRs: stages
+// 7 / 8 drop from 2-4 workgroups per CU to 1-2, stage 9's 8 rows per wave spill) and keep v2.
+#define FTILE4(CIN, CEXP, COUT, KS, ST, TW, TH, MINW, HW)                                                        \
+    {CIN, CEXP, COUT, KS, ST, 1, HW, TW, TH, ir_tile_v4_kernel<CIN, CEXP, COUT, KS, ST, TW, TH, MINW>,           \
+     IrT4Geom<CIN, CEXP, COUT, KS, ST, TW, TH>::LDS_BYTES, 8}
+const FusedTile kFusedTileV4[] = {
+    {}, {}, {},
+    FTILE4(24, 144, 32, 5, 2, 16, 16, 2, 64),          // stage 6
+    {}, {}, {}, {},
+};
+static_assert(sizeof(kFusedTileV4) == sizeof(kFusedTile), "same blocks, same order");
 const FusedTile& fp32_tile(int small_tiles, int id) {
+    if (small_tiles == 3) return kFusedTileV4[id];
     return small_tiles == 2 ? kFusedTileTiny[id] : small_tiles ? kFusedTileSmall[id] : kFusedTile[id];
 }
 
@@ -791,7 +807,8 @@ int build_plan_uncached(fear_handle* h, int hw, bool with_head, int mode, Plan**
         const int id = find_fused_tile(cin, d.cout, p.cout, d.k, d.stride, ce >= 0 ? 1 : 0, in.H);
         if (id < 0) return false;
         const int use_h = ce >= 0 ? h->math : 0;   // e1 blocks (no expand GEMM) stay on the fp32 kernel
-        const int small_tiles = small && !use_h ? (mode == 2 ? 2 : 1) : 0;
+        // 1 / 2: the small-batch / tiny plans' tiles; 3: the throughput plan's phase-overlapped kernel where the table has one
+        const int small_tiles = small && !use_h ? (mode == 2 ? 2 : 1) : (!small && !use_h && h->tile_v4 && kFusedTileV4[id].kernel ? 3 : 0);
         const FusedTile& f = use_h == 2 ? kFusedTileB[id] : use_h ? kFusedTileH[id] : fp32_tile(small_tiles, id);
         const int ho = in.H / d.stride;
         if (ho % f.th != 0 || ho % f.tw != 0) return false;
@@ -1189,6 +1206,9 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
         for (const Fused16& f : kFused16H)
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(f.kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, f.lds_bytes));
+        for (const FusedTile& f : kFusedTileV4)
+            if (f.kernel)
+                HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(f.kernel), hipFuncAttributeMaxDynamicSharedMemorySize, f.lds_bytes));
         for (const FusedTile& f : kFusedTile)
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(f.kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, f.lds_bytes));
@@ -1555,6 +1575,10 @@ int fear_set_option(fear_handle* h, int option, int64_t value) {
             if (value != 0 && value != 1) return FEAR_ERR_SHAPE;
             if (h->dual_head != (int)value) { h->dual_head = (int)value; return drop_plans(h); }
             return FEAR_OK;
+        case FEAR_OPT_TILE_V4:
+            if (value != 0 && value != 1) return FEAR_ERR_SHAPE;
+            if (h->tile_v4 != (int)value) { h->tile_v4 = (int)value; return drop_plans(h); }
+            return FEAR_OK;
         case FEAR_OPT_HEAD_STAGGER:
             if (value < 0 || value > 1000) return FEAR_ERR_SHAPE;
             h->head_stagger_us = (int)value;
@@ -1576,6 +1600,7 @@ int64_t fear_get_option(fear_handle* h, int option) {
         case FEAR_OPT_PLAN_CROPS: return h->plan_crops;
         case FEAR_OPT_DUAL_HEAD: return h->dual_head;
         case FEAR_OPT_HEAD_STAGGER: return h->head_stagger_us;
+        case FEAR_OPT_TILE_V4: return h->tile_v4;
         default: return FEAR_ERR_SHAPE;
     }
 }

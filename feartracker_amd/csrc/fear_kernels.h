@@ -22,6 +22,12 @@
 #ifndef IR16_D
 #define IR16_D 4       // LDS read-ahead of ir16_interval, in tap steps
 #endif
+#ifndef FEAR_V4_GS
+#define FEAR_V4_GS 2      // tap steps per scheduling group of ir_tile_v4_kernel
+#endif
+#ifndef FEAR_V4_GUARD
+#define FEAR_V4_GUARD 0   // 1: skip the expansion MFMAs of m-tiles beyond the clipped region (a scalar branch per MFMA)
+#endif
 #ifndef FEAR_ABL
 #define FEAR_ABL 0      // timing ablations for tools/kbench only (bit mask); the product always builds with 0
 #endif
@@ -1448,7 +1454,7 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
     const int cx_lo = max(ix0, 0), cy_lo = max(iy0, 0);
     const int CW = min(ix0 + IWR, t.W) - cx_lo, CH = min(iy0 + IHR, t.H) - cy_lo;
     const int NPIX = CW * CH;
-    const float inv_cw = 1.0f / (float)CW;
+    const float inv_cw = __builtin_amdgcn_rcpf((float)CW);      // 1 ulp is plenty: (q + 0.5) / CW stays 0.5 / CW away from every integer
     const int Wo = t.W / ST, Ho = t.H / ST;
     const float* Xc = STEM ? a.X + crop * 3 * (2 * t.H) * (2 * t.W) : a.X + crop * t.H * t.W * a.ldx;
 
@@ -1489,24 +1495,48 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
     if (STEM) {
         // patch row r <-> image row 2*iy0 - 1 + r; patch col c <-> image col 2*ix0 - 2 + c (2*ix0 - 2 is a multiple of 4:
         // tiles start at multiples of 32 and the halo is one stem pixel)
+        // Integer VALU instructions cost 5.8 cycles of the ALU the MFMAs run on (profiles/r03_issue_probe.txt) and this kernel was
+        // 63 % non-MFMA vector instructions, so the index arithmetic is kept off the vector ALU: a thread owns ONE patch column
+        // (f) and a row slot (one division by a constant per thread, not two per float4), walks the three planes and its rows with
+        // adds, and the im2col tap offsets come from a compile-time table instead of eight k / 9, k % 9 / 3, k % 3 chains.
         const int img_h = 2 * t.H, img_w = 2 * t.W;
         const int row0 = 2 * iy0 - 1, col0 = 2 * ix0 - 2;
-        for (int it = tid; it < 3 * PR * PF4; it += 512) {
-            const int row = it / PF4, f = it - row * PF4;
-            const int ci = row / PR, pr = row - ci * PR;
-            const int iy = row0 + pr, ix = col0 + 4 * f;
-            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (iy >= 0 && iy < img_h && ix >= 0 && ix < img_w && !(FEAR_ABL & 512))
-                v = *reinterpret_cast<const f32x4*>(Xc + ((long)ci * img_h + iy) * img_w + ix);
-            *reinterpret_cast<f32x4*>(E + row * PWID + 4 * f) = v;
-        }
+        constexpr int RS = 512 / PF4;                          // row slots: RS * PF4 <= 512 threads stage, the rest idle here
+        const int rs = tid / PF4, f = tid - rs * PF4;
+        if (rs < RS && !(FEAR_ABL & 512)) {
+            const int ix = col0 + 4 * f;
+            const bool xin = ix >= 0 && ix < img_w;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = (j >> 2) * 16 + lk * 4 + (j & 3);
-            const int kk = k < 27 ? k : 0;             // K padding: its weights are zero, any finite patch value will do
-            const int ci = kk / 9, ky = (kk % 9) / 3, kx = kk % 3;
-            s_off[j] = (ci * PR + ky) * PWID + kx + 1;  // stem pixel (gy, gx) reads image col 2*gx - 1 + kx = col0 + 2*(gx-ix0) + 1 + kx
+            for (int ci = 0; ci < 3; ++ci) {
+                const float* plane = Xc + (long)ci * img_h * img_w + ix;
+#pragma unroll
+                for (int pr0 = 0; pr0 < PR; pr0 += RS) {
+                    const int pr = pr0 + rs;
+                    const int iy = row0 + pr;
+                    if (pr < PR) {
+                        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (xin && iy >= 0 && iy < img_h) v = *reinterpret_cast<const f32x4*>(plane + (long)iy * img_w);
+                        *reinterpret_cast<f32x4*>(E + (ci * PR + pr) * PWID + 4 * f) = v;
+                    }
+                }
+            }
         }
+        // tap j of lane group lk is k = (j >> 2) * 16 + lk * 4 + (j & 3) = (ci * 3 + ky) * 3 + kx; stem pixel (gy, gx) reads image
+        // col 2*gx - 1 + kx = col0 + 2*(gx - ix0) + 1 + kx.  K padding (k >= 27): its weights are zero, any finite value will do
+        struct Tab {
+            int v[4][8];
+            constexpr Tab() : v{} {
+                for (int g = 0; g < 4; ++g)
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = (j >> 2) * 16 + g * 4 + (j & 3);
+                        const int kk = k < 27 ? k : 0;
+                        v[g][j] = ((kk / 9) * PR + (kk % 9) / 3) * PWID + kk % 3 + 1;
+                    }
+            }
+        };
+        static constexpr Tab tab{};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s_off[j] = tab.v[lk][j];
         __syncthreads();                               // patch complete
     }
 #pragma unroll
@@ -1701,6 +1731,257 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
         for (int q = 0; q < 6; ++q) dbg[q] = (float)tm[q];
         dbg[6] = (float)(tk_begin - tk_start);
         dbg[7] = (float)(wall_clock64() - tk_loop_end);
+    }
+}
+
+// ================================================================================================
+// ir_tile_v4: ir_tile_v2's tile, weights and LDS footprint with the three phases of a chunk OVERLAPPED inside each wave.
+//
+// v2 runs expansion (MFMA), depthwise (LDS reads + packed FMAs) and projection (MFMA) of a 16-channel chunk one after the
+// other with a barrier in between; every wave of the workgroup is in the same phase, so the LDS pipe idles during the MFMA
+// phases and the ALU during the depthwise's LDS round trips.  With two or three workgroups on a CU the other workgroups fill
+// part of that; the tiles whose E tile takes half the LDS (stages 6, 9, 10: one workgroup per CU, 2 waves per SIMD) have
+// nobody to fill it: 59-75 % ALU-busy (profiles/r02_sq_counters.txt) against 85 % for the small tiles.
+// Here the depthwise of chunk c is a chain of tap steps whose ds_read_b128s run D steps ahead of the FMAs that use them, and
+// the expansion MFMAs of chunk c + 1 are dealt out between the steps — ir16_interval's pipeline — but the expanded chunk
+// c + 1 stays in REGISTERS (one float4 per m-tile) until the barrier that ends the reads of chunk c, so the E tile is not
+// double buffered and the LDS footprint is v2's (the double-buffered variant measured in round 1 lost its occupancy):
+//     interval 1   taps(c) from E  ||  expansion MFMAs (c + 1) -> registers          barrier
+//     interval 2   registers -> E (chunk c + 1)  ||  projection MFMAs (c)             barrier
+// ds_read issue is free beside MFMAs, a ds_write_b128 costs ~20 cycles of the SIMD's ALU time, an MFMA <-> VALU switch ~8
+// (profiles/r03_issue_probe.txt): the E writes sit next to the projection MFMAs, the FMAs of a step are issued together.
+// Weights: A-part (expansion) and BC-part (depthwise + projection) of the packed per-chunk blocks are double buffered
+// separately and arrive by asynchronous global -> LDS copies issued one interval ahead.
+// compile-time loop: f(std::integral_constant<int, B>{}), ..., f(std::integral_constant<int, E - 1>{}) — every index a constant
+// expression whatever the unroller's size heuristics decide (a partially unrolled tap loop turns the register arrays it indexes
+// into scratch memory)
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+template <int CIN, int CEXPP, int COUT, int KS, int ST, int TW, int TH>
+struct IrT4Geom : IrT2Geom<CIN, CEXPP, COUT, KS, ST, TW, TH, true> {
+    using B = IrT2Geom<CIN, CEXPP, COUT, KS, ST, TW, TH, true>;
+    static constexpr int IR = (B::MTC - 1) * ST + KS;          // input rows under a wave's MTC output rows
+    static constexpr int NS = KS * IR;                         // tap steps per chunk: kx outer, input row inner
+    static constexpr int D = IR < 4 ? IR : 4;                  // LDS read-ahead in tap steps (never more than one column ahead)
+    static constexpr int MPT = B::KHALF ? (B::KG - 1) * 4 + 2 : B::KG * 4;      // expansion MFMAs per m-tile
+    static constexpr int NU = B::MTA * MPT;
+    static constexpr int LDS_BYTES = (B::EBUF + 2 * B::AP + 2 * B::BP + B::DUMMY) * 4;
+};
+
+template <int CIN, int CEXPP, int COUT, int KS, int ST, int TW, int TH, int MINW>
+__global__ __launch_bounds__(512, MINW) void ir_tile_v4_kernel(IrT2Args t) {
+    using G = IrT4Geom<CIN, CEXPP, COUT, KS, ST, TW, TH>;
+    const Ir2Args& a = t.b;
+    constexpr int P = G::P, IWR = G::IWR, IHR = G::IHR, SEG = G::SEG, MTC = G::MTC, MTA = G::MTA;
+    constexpr int NCHUNK = G::NCHUNK, NTP = G::NTP, KG = G::KG, AP = G::AP, BP = G::BP, EBUF = G::EBUF, EPX = G::EPX;
+    constexpr bool KHALF = G::KHALF;
+    constexpr int CST = AP + BP, IR = G::IR, NS = G::NS, D = G::D, MPT = G::MPT, NU = G::NU;
+    static_assert(G::NMT_OUT % 8 == 0 && (SEG == 1 || SEG == 2) && NCHUNK >= 2 && KG >= 1, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const E = lds;                       // [EBUF]
+    float* const WA = lds + EBUF;               // [2][AP]
+    float* const WB = WA + 2 * AP;              // [2][BP]
+    float* const DUMMYP = WB + 2 * BP;          // where lanes beyond the clipped region park their E stores
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int tiles = t.tiles_x * t.tiles_y;
+    const unsigned tix = xcd_tile_index(blockIdx.x, gridDim.x);
+    const long crop = tix / tiles;
+    const int tile = tix % tiles;
+    const int ox0 = (tile % t.tiles_x) * TW, oy0 = (tile / t.tiles_x) * TH;
+    const int ix0 = ox0 * ST - P, iy0 = oy0 * ST - P;
+    const int cx_lo = max(ix0, 0), cy_lo = max(iy0, 0);
+    const int CW = min(ix0 + IWR, t.W) - cx_lo, CH = min(iy0 + IHR, t.H) - cy_lo;
+    const int NPIX = CW * CH;
+    const float inv_cw = __builtin_amdgcn_rcpf((float)CW);
+    const int Wo = t.W / ST, Ho = t.H / ST;
+    const float* Xc = a.X + crop * t.H * t.W * a.ldx;
+    // m-tiles of the clipped input region this wave expands: wave, wave + 8, ... < ceil(NPIX / 16)
+    const int n_mt = (NPIX + 15) >> 4;
+    const int cnt = wave < n_mt ? (n_mt - wave + 7) >> 3 : 0;
+
+    for (int i = tid * 4; i < EBUF; i += 512 * 4) *reinterpret_cast<f32x4*>(E + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto stage_a = [&](int c) { lds_copy_async<AP>(a.Wpk + (long)c * CST, WA + (c & 1) * AP, wave, lane); };
+    auto stage_b = [&](int c) { lds_copy_async<BP>(a.Wpk + (long)c * CST + AP, WB + (c & 1) * BP, wave, lane); };
+    stage_a(0);
+    stage_b(0);
+    stage_a(1);
+
+    int eoff[MTA];
+    f32x4 xf[MTA][KG];
+    static_for<0, MTA>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const int q = (wave + 8 * i) * 16 + li;
+        const bool valid = q < NPIX;
+        const int qq = valid ? q : 0;
+        const int cy = (int)(((float)qq + 0.5f) * inv_cw), cx = qq - cy * CW;
+        const int gy = cy_lo + cy, gx = cx_lo + cx;
+        eoff[i] = valid ? G::eo((gy - iy0) * IWR + (gx - ix0), lk) : (int)(DUMMYP - E) + lane * 4;
+        const long xoff = ((long)gy * t.W + gx) * a.ldx;
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) {
+            xf[i][kg] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (KHALF && kg == KG - 1) {       // 8 channels: lane group lk holds channels 2*lk, 2*lk+1 (k-step q = .x / .y)
+                const float2 h2 = *reinterpret_cast<const float2*>(Xc + xoff + kg * 16 + lk * 2);
+                xf[i][kg].x = h2.x; xf[i][kg].y = h2.y;
+            } else if (kg * 16 + lk * 4 < CIN) xf[i][kg] = *reinterpret_cast<const f32x4*>(Xc + xoff + kg * 16 + lk * 4);
+        }
+    });
+
+    auto relu4 = [](f32x4& v) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); };
+
+    __syncthreads();                           // zero fill done, A(0) / BC(0) / A(1) landed
+    {   // chunk 0's expansion, not overlapped with anything
+        const float* wa = WA;
+        f32x4 wf[KG];
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) wf[kg] = *reinterpret_cast<const f32x4*>(wa + kg * 256 + lane * 4);
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(wa + KG * 256 + lk * 4);
+        static_for<0, MTA>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            if (i < cnt) {                     // wave-uniform
+                f32x4 acc = bias;
+#pragma unroll
+                for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
+                    for (int q = 0; q < ((KHALF && kg == KG - 1) ? 2 : 4); ++q)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kg][q], xf[i][kg][q], acc, 0, 0, 0);
+                relu4(acc);
+                *reinterpret_cast<f32x4*>(E + eoff[i]) = acc;
+            }
+        });
+    }
+    __syncthreads();
+
+    const int seg = SEG == 1 ? 0 : (wave & 1);
+    const int r0 = (SEG == 1 ? wave : (wave >> 1)) * MTC;
+    f32x4 accp[MTC][NTP];
+#pragma unroll
+    for (int r = 0; r < MTC; ++r)
+#pragma unroll
+        for (int nt = 0; nt < NTP; ++nt) accp[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* const Ebase = E + G::eo((r0 * ST) * IWR + (seg * 16 + li) * ST, lk);
+
+    for (int c = 0; c < NCHUNK; ++c) {
+        const bool more = c + 1 < NCHUNK;
+        if (c + 2 < NCHUNK) stage_a(c + 2);
+        if (more) stage_b(c + 1);
+        const float* wa = WA + ((c + 1) & 1) * AP;         // expansion weights of chunk c + 1
+        const float* wb = WB + (c & 1) * BP;               // depthwise + projection weights of chunk c
+        const float* wd = wb + NTP * 256 + lk * 4;
+        // ---- interval 1: taps of chunk c, expansion MFMAs of chunk c + 1 dealt between them
+        f32x4 wf[KG];
+        f32x4 eacc[MTA];
+        if (more) {
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg) wf[kg] = *reinterpret_cast<const f32x4*>(wa + kg * 256 + lane * 4);
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(wa + KG * 256 + lk * 4);
+#pragma unroll
+            for (int i = 0; i < MTA; ++i) eacc[i] = bias;
+        }
+        f32x4 d[MTC];
+        {
+            const f32x4 bd = *reinterpret_cast<const f32x4*>(wd + KS * KS * 16);
+#pragma unroll
+            for (int r = 0; r < MTC; ++r) d[r] = bd;
+        }
+        f32x4 ev[D], wv[2][KS];
+#pragma unroll
+        for (int s = 0; s < D; ++s) {                      // prime the read-ahead window (D <= IR: all in column 0)
+            ev[s] = *reinterpret_cast<const f32x4*>(Ebase + (s * IWR) * EPX);
+            if (s < KS) wv[0][s] = *reinterpret_cast<const f32x4*>(wd + (s * KS) * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // GS tap steps form one scheduling group: [the group's LDS reads, D steps ahead][its share of the expansion MFMAs][its
+        // packed FMAs] — an MFMA <-> VALU switch costs ~8 cycles, so FMAs and MFMAs are issued in runs
+        constexpr int GS = FEAR_V4_GS;
+        static_for<0, (NS + GS - 1) / GS>([&](auto Gi) {
+            constexpr int g0 = decltype(Gi)::value * GS, g1 = (g0 + GS < NS) ? g0 + GS : NS;
+            f32x4 eg[GS];
+            static_for<g0, g1>([&](auto S) {
+                constexpr int s = decltype(S)::value;
+                eg[s - g0] = ev[s % D];
+                if constexpr (s + D < NS) {
+                    constexpr int kx2 = (s + D) / IR, iy2 = (s + D) % IR;
+                    ev[s % D] = *reinterpret_cast<const f32x4*>(Ebase + (iy2 * IWR + kx2) * EPX);
+                    if constexpr (iy2 < KS) wv[kx2 & 1][iy2] = *reinterpret_cast<const f32x4*>(wd + (iy2 * KS + kx2) * 16);
+                }
+            });
+            if (more) {
+                static_for<g0 * NU / NS, g1 * NU / NS>([&](auto U) {
+                    // units in m-tile pairs: (i0, k0), (i1, k0), (i0, k1), (i1, k1), ... so consecutive MFMAs never share an accumulator
+                    constexpr int u = decltype(U)::value;
+                    constexpr int pair = u / (2 * MPT), w = u % (2 * MPT);
+                    constexpr bool single = 2 * pair + 1 >= MTA;               // the last m-tile of an odd MTA stands alone
+                    constexpr int i = single ? 2 * pair : 2 * pair + (w & 1);
+                    constexpr int k = single ? w : w >> 1;                      // k-step index within the m-tile, 0 .. MPT - 1
+                    if constexpr (!(single && w >= MPT)) {
+                        constexpr int kg = k / 4, q = k % 4;
+                        if (!FEAR_V4_GUARD || i < cnt) eacc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kg][q], xf[i][kg][q], eacc[i], 0, 0, 0);
+                    }
+                });
+            }
+            static_for<g0, g1>([&](auto S) {
+                constexpr int s = decltype(S)::value;
+                constexpr int kx = s / IR, iy = s % IR;
+                static_for<0, MTC>([&](auto R) {
+                    constexpr int r = decltype(R)::value;
+                    constexpr int ky = iy - r * ST;
+                    if constexpr (ky >= 0 && ky < KS) pk_fma4(d[r], eg[s - g0], wv[kx & 1][ky]);
+                });
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (a.relu_dw) {
+#pragma unroll
+            for (int r = 0; r < MTC; ++r) relu4(d[r]);
+        }
+        asm volatile("s_nop 7");                // the inline-asm FMA results feed MFMAs below (hipcc's hazard recognizer does not see them)
+        __syncthreads();                       // every wave has read chunk c out of E
+        // ---- interval 2: chunk c + 1 into E, projection of chunk c
+        if (more) {
+            static_for<0, MTA>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                if (i < cnt) {
+                    relu4(eacc[i]);
+                    *reinterpret_cast<f32x4*>(E + eoff[i]) = eacc[i];
+                }
+            });
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTP; ++nt) {
+            const f32x4 wp = *reinterpret_cast<const f32x4*>(wb + nt * 256 + lane * 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < MTC; ++r) accp[r][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[q], d[r][q], accp[r][nt], 0, 0, 0);
+        }
+        __syncthreads();                       // E holds chunk c + 1; the staged weights have landed
+    }
+
+#pragma unroll
+    for (int nt = 0; nt < NTP; ++nt) {
+        const int n = nt * 16 + lk * 4;
+        if (n >= COUT) continue;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(a.bp + n);
+#pragma unroll
+        for (int r = 0; r < MTC; ++r) {
+            const int oy = oy0 + r0 + r, ox = ox0 + seg * 16 + li;
+            const long m = (crop * Ho + oy) * Wo + ox;
+            f32x4 v = accp[r][nt] + b;
+            if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
+            if (a.relu_out) relu4(v);
+            *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = v;
+        }
     }
 }
 
@@ -2065,7 +2346,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ir_tile_h_kernel(IrT2Args t) {
     const int cx_lo = max(ix0, 0), cy_lo = max(iy0, 0);
     const int CW = min(ix0 + IWR, t.W) - cx_lo, CH = min(iy0 + IHR, t.H) - cy_lo;
     const int NPIX = CW * CH;
-    const float inv_cw = 1.0f / (float)CW;
+    const float inv_cw = __builtin_amdgcn_rcpf((float)CW);      // 1 ulp is plenty: (q + 0.5) / CW stays 0.5 / CW away from every integer
     const int Wo = t.W / ST, Ho = t.H / ST;
     const float* Xc = a.X + crop * t.H * t.W * a.ldx;
 

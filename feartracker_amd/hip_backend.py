@@ -37,6 +37,7 @@ FEAR_OPT_SMALL_PASS = 7
 FEAR_OPT_PLAN_CROPS = 8
 FEAR_OPT_DUAL_HEAD = 9
 FEAR_OPT_HEAD_STAGGER = 10
+FEAR_OPT_TILE_V4 = 11
 
 _lib = None
 
@@ -184,6 +185,10 @@ class FEARNetHIP:
     def set_dual_head(self, on: bool) -> None:
         """Throughput plan: the head's two branches on two streams (default) vs one."""
         self._check(self._lib.fear_set_option(self._h, FEAR_OPT_DUAL_HEAD, 1 if on else 0))
+
+    def set_tile_v4(self, on: bool) -> None:
+        """Throughput plan: the phase-overlapped tile kernel for the blocks that have one (default on) vs ir_tile_v2 everywhere."""
+        self._check(self._lib.fear_set_option(self._h, FEAR_OPT_TILE_V4, 1 if on else 0))
 
     def set_head_stagger(self, microseconds: int) -> None:
         """Two head streams: hold the second branch back by this many microseconds (FEAR_OPT_HEAD_STAGGER)."""

@@ -130,6 +130,9 @@ int fear_crop_normalize(fear_handle* h, const uint8_t* frame_u8, int frame_h, in
 #define FEAR_OPT_HEAD_STAGGER 10 /* with two head streams (FEAR_OPT_DUAL_HEAD, or a small pass): microseconds (0..1000, default 0) the  */
                                /*   second branch's first kernel is held back, so that the co-resident kernels of the two branches  */
                                /*   run out of phase and one's prologue / output burst overlaps the other's MFMA stretch            */
+#define FEAR_OPT_TILE_V4 11    /* 1 (default): the throughput plan runs the blocks listed in the engine's kFusedTileV4 (stage 6) on the   */
+                               /*   phase-overlapped tile kernel (depthwise taps of chunk c interleaved with the expansion MFMAs of      */
+                               /*   chunk c + 1); 0: every tiled block on ir_tile_v2 (A/B)                                              */
 int fear_set_option(fear_handle* h, int option, int64_t value);
 int64_t fear_get_option(fear_handle* h, int option);
 

@@ -346,6 +346,27 @@ def test_other_sizes_and_second_weight_set(oracle_net):
     assert rel_err(b, other["TARGET_REGRESSION_LABEL_KEY"]) > 1e-2     # different trained weights, different maps
 
 
+def test_phase_overlapped_tile_kernel_matches_the_phased_one(hip_net, oracle_net):
+    """FEAR_OPT_TILE_V4: stage 6 (24 -> 144 -> 32, k5 s2 at 64x64) on ir_tile_v4_kernel — depthwise taps of chunk c interleaved
+    with the expansion MFMAs of chunk c + 1, the expanded chunk parked in registers — against ir_tile_v2_kernel (three phases,
+    barrier between them): the same arithmetic per output, maps equal to fp32 summation-order noise, both equal to the oracle."""
+    from feartracker_amd import FEARNetHIP
+    from conftest import WEIGHTS
+    nets = {}
+    for on in (True, False):
+        nets[on] = FEARNetHIP(WEIGHTS, device=0, max_batch=64)
+        nets[on].set_small_pass(0)                      # throughput plan whatever the batch
+        nets[on].set_tile_v4(on)
+    g = torch.Generator().manual_seed(77)
+    x = norm_u8(torch.randint(0, 256, (5, 3, 256, 256), dtype=torch.uint8, generator=g))
+    z = hip_net.get_features(norm_u8(torch.randint(0, 256, (5, 3, 128, 128), dtype=torch.uint8, generator=g)).cuda())
+    b1, c1 = nets[True].track_maps(x.cuda(), z)
+    b0, c0 = nets[False].track_maps(x.cuda(), z)
+    assert rel_err(b1, b0) < 1e-5 and rel_err(c1, c0) < 1e-5
+    ref = oracle_net.track(x, z.cpu())
+    assert rel_err(b1, ref["TARGET_REGRESSION_LABEL_KEY"]) < REL and rel_err(c1, ref["TARGET_CLASSIFICATION_KEY"]) < REL
+
+
 def test_chain_kernel_matches_per_block_kernels(hip_net):
     """FEAR_OPT_CHAIN: the stride-16 trunk stage + neck as one register-resident chain kernel vs one fused kernel per
     block (same arithmetic, activations kept in registers between blocks)."""

@@ -3,6 +3,7 @@
 // Run on the GPU box: tools/kbench [crops=256] [iters=20]   (weights are random: timing only)
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -100,6 +101,74 @@ static void bench_tile(const char* tag, int crops, int iters, int hw) {
     }
 }
 
+// v2 against v4 (phase-overlapped) on the same tile: same inputs and packed weights, outputs compared, both timed
+template <int CIN, int CEXP, int COUT, int KS, int ST, int TW, int TH, int MINW2, int MINW4>
+static void bench_tile_v4(const char* tag, int crops, int iters, int hw) {
+#ifdef FEAR_HAVE_V4
+    using G = IrT2Geom<CIN, CEXP, COUT, KS, ST, TW, TH, true>;
+    using G4 = IrT4Geom<CIN, CEXP, COUT, KS, ST, TW, TH>;
+    if (G4::LDS_BYTES > 160 * 1024) { printf("%-24s skipped: LDS %d B\n", tag, G4::LDS_BYTES); return; }
+    const int ho = hw / ST;
+    const double flops = 2.0 * ((double)CIN * CEXP * hw * hw + ((double)CEXP * KS * KS + (double)CEXP * COUT) * ho * ho) * crops;
+    IrT2Args t{};
+    Ir2Args& a = t.b;
+    a.ldx = CIN; a.ldr = COUT; a.ldy = COUT;
+    a.X = dev_rand((size_t)crops * hw * hw * CIN, 2.f);
+    a.Wpk = dev_rand((size_t)G::NCHUNK * (G::AP + G::BP), 0.3f);
+    a.bp = dev_rand(64, 0.2f);
+    const size_t ny = (size_t)crops * ho * ho * COUT;
+    float *y2, *y4;
+    CK(hipMalloc(&y2, ny * sizeof(float)));
+    CK(hipMalloc(&y4, ny * sizeof(float)));
+    CK(hipMemset(y2, 0, ny * sizeof(float)));
+    CK(hipMemset(y4, 0xff, ny * sizeof(float)));
+    a.relu_dw = 1; a.relu_out = 0;
+    t.H = hw; t.W = hw; t.tiles_x = ho / TW; t.tiles_y = ho / TH;
+    auto k2 = ir_tile_v2_kernel<CIN, CEXP, COUT, KS, ST, TW, TH, true, MINW2>;
+    auto k4 = ir_tile_v4_kernel<CIN, CEXP, COUT, KS, ST, TW, TH, MINW4>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, G4::LDS_BYTES));
+    const dim3 grid((unsigned)crops * t.tiles_x * t.tiles_y);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    double us[2];
+    for (int v = 0; v < 2; ++v) {
+        a.Y = v ? y4 : y2;
+        for (int i = 0; i < 3; ++i) {
+            if (v) hipLaunchKernelGGL(k4, grid, dim3(512), G4::LDS_BYTES, 0, t);
+            else hipLaunchKernelGGL(k2, grid, dim3(512), G::LDS_BYTES, 0, t);
+        }
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < iters; ++i) {
+            if (v) hipLaunchKernelGGL(k4, grid, dim3(512), G4::LDS_BYTES, 0, t);
+            else hipLaunchKernelGGL(k2, grid, dim3(512), G::LDS_BYTES, 0, t);
+        }
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        us[v] = 1e3 * ms / iters;
+    }
+    std::vector<float> h2(ny), h4(ny);
+    CK(hipMemcpy(h2.data(), y2, ny * sizeof(float), hipMemcpyDeviceToHost));
+    CK(hipMemcpy(h4.data(), y4, ny * sizeof(float), hipMemcpyDeviceToHost));
+    double maxd = 0, maxv = 0;
+    size_t bad = 0;
+    for (size_t i = 0; i < ny; ++i) {
+        const double dd = fabs((double)h2[i] - (double)h4[i]);
+        if (!(dd <= 1e30)) { ++bad; continue; }
+        if (dd > maxd) maxd = dd;
+        if (fabs(h2[i]) > maxv) maxv = fabs(h2[i]);
+    }
+    printf("%-30s v2 %8.1f us %6.1f TF/s | v4 %8.1f us %6.1f TF/s (%+.1f%%) | max|v2-v4| %.3g of max|y| %.3g, non-finite %zu  (LDS %d B)\n", tag,
+           us[0], flops / us[0] * 1e-6, us[1], flops / us[1] * 1e-6, 100.0 * (us[0] / us[1] - 1.0), maxd, maxv, bad, G4::LDS_BYTES);
+    CK(hipFree(y2)); CK(hipFree(y4));
+#else
+    (void)tag; (void)crops; (void)iters; (void)hw;
+#endif
+}
+
 static void bench_stem(int crops, int iters) {
     using G = IrT2Geom<27, 16, 16, 3, 1, 32, 16, true>;
     const int hw = 128;
@@ -171,6 +240,14 @@ int main(int argc, char** argv) {
     bench_tile<32, 192, 32, 5, 1, 16, 32, true, 2>("s8  irt_32x192x32_k5 16x32", crops, iters, 32);
     bench_tile<32, 192, 32, 3, 1, 32, 32, true, 2>("s9  irt_32x192x32_k3 32x32", crops, iters, 32);
     bench_tile<32, 192, 64, 5, 2, 16, 16, true, 2>("s10 irt_32x192x64_k5s2 16x16", crops, iters, 32);
+#ifdef FEAR_HAVE_V4
+    bench_tile_v4<24, 144, 32, 5, 2, 16, 16, 2, 2>("s6  v4 24x144x32_k5s2 16x16", crops, iters, 64);
+    bench_tile_v4<32, 192, 32, 3, 1, 32, 32, 2, 2>("s9  v4 32x192x32_k3 32x32", crops, iters, 32);
+    bench_tile_v4<32, 192, 64, 5, 2, 16, 16, 2, 2>("s10 v4 32x192x64_k5s2 16x16", crops, iters, 32);
+    bench_tile_v4<32, 192, 32, 5, 1, 16, 32, 2, 2>("s8  v4 32x192x32_k5 16x32", crops, iters, 32);
+    bench_tile_v4<32, 96, 32, 5, 1, 16, 16, 2, 2>("s7  v4 32x96x32_k5 16x16", crops, iters, 32);
+    bench_tile_v4<16, 96, 24, 3, 2, 16, 8, 4, 2>("s2  v4 16x96x24_k3s2 16x8", crops, iters, 128);
+#endif
     if (!all) return 0;
     bench<112, 672, 112, 5, true>("ir16_112x672x112_k5", crops, iters);
     bench<64, 384, 64, 5, true>("ir16_64x384x64_k5", crops, iters);

@@ -5,6 +5,7 @@
 #   1. python bench.py                       -> gpurun_out/round/bench.json (+ cpu_baseline)
 #   2. rocprofv3 --kernel-trace --stats       (math 0 and math 1, --dump-ops: per-op table on stderr)
 #   3. rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes (no other trace domains)
+#   4. the same for configs[3] (tools/fear_m_prof.py) and a kernel-stats trace of configs[4] (tools/train_prof.py)
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/round
@@ -19,6 +20,13 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c -d "$O/pmc_$c" -o p --output-format csv -- \
     python "$R/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-other-math --no-pipelined --no-latency --no-fear-m --no-train > "$O/pmc_$c.json" 2> "$O/pmc_$c.err"
 done
+# BASELINE configs[3] (synthetic FEAR-M, bf16, B=512): kernel trace + the two PMC passes of the same script
+rocprofv3 --kernel-trace --stats -d "$O/fear_m_trace" -o p --output-format csv -- python "$R/tools/fear_m_prof.py" 10 > "$O/fear_m_trace.out" 2> "$O/fear_m_trace.err"
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c -d "$O/fear_m_pmc_$c" -o p --output-format csv -- python "$R/tools/fear_m_prof.py" 3 > "$O/fear_m_pmc_$c.out" 2> "$O/fear_m_pmc_$c.err"
+done
+# BASELINE configs[4] (one rank's 128 pairs of the training step): kernel stats
+rocprofv3 --kernel-trace --stats -d "$O/train_trace" -o p --output-format csv -- python "$R/tools/train_prof.py" 128 5 0 > "$O/train_trace.out" 2> "$O/train_trace.err"
 python "$R/bench_latency.py" > "$O/latency.json" 2> "$O/latency.err"
 # the distributed code path (RCCL process group, barriers, fear_track_packed + all-gather) with the one rank a 1-GPU box has
 FEAR_BENCH_FORCE_DIST=1 python "$R/bench.py" --no-cpu-baseline --no-other-math > "$O/bench_force_dist.json" 2> "$O/bench_force_dist.err"
