@@ -112,7 +112,8 @@ class _ConvBN:
 
 class FEARNetTrainHIP:
     def __init__(self, state_dict: Dict[str, "np.ndarray | torch.Tensor"], device: int = 0, momentum: float = 0.1, eps: float = 1e-5,
-                 coef_cls: float = 1.0, coef_reg: float = 1.0, sync_bn: bool = False, group=None, fused: bool = False):
+                 coef_cls: float = 1.0, coef_reg: float = 1.0, sync_bn: bool = False, group=None, fused: bool = False,
+                 two_streams: bool = True):
         if not torch.cuda.is_available():
             raise RuntimeError("FEARNetTrainHIP needs a ROCm GPU; there is no CPU fallback")
         self.lib = load_train_library()
@@ -127,6 +128,14 @@ class FEARNetTrainHIP:
         # producers' per-workgroup partial sums add finalisation work.  So the default stays one kernel per layer and
         # direction; fused is the memory-saving mode (larger per-rank batches).
         self.fused = bool(fused)
+        # two_streams: the BACKWARD of the template pass (a quarter of the search pass's work, the same launches) runs on a second
+        # HIP stream next to the search pass's — the two are independent between the head and the final add of the shared
+        # parameters' gradients, and their small kernels fill each other's tails.  Each lane has its own workspace; SyncBatchNorm
+        # keeps one stream (its collectives must be issued in the same order on every rank).
+        self.two_streams = bool(two_streams) and not sync_bn
+        self._side = None
+        self._lane = 0
+        self._ws_lanes = {}
         sd = {k: torch.as_tensor(np.asarray(v)) if not isinstance(v, torch.Tensor) else v.detach().cpu() for k, v in state_dict.items()}
         dev = self.device
         self.stem = _ConvBN("stem", "stem", sd, dev, k=3, stride=2)
@@ -141,7 +150,6 @@ class FEARNetTrainHIP:
                                      device=device, momentum=momentum, eps=eps, coef_cls=coef_cls, coef_reg=coef_reg,
                                      sync_bn=sync_bn, group=group)
         self.sync = self.head.sync                 # SyncBatchNorm over the data-parallel group (config/backend/*.yaml: sync_bn)
-        self._ws = None
         self.last_contexts = None
         # the trunk runs twice per step (template, search): each pass writes its parameter gradients into one flat buffer
         # (kernel layouts, offsets below) and ONE add joins the two — not one add launch per parameter
@@ -172,11 +180,14 @@ class FEARNetTrainHIP:
         return torch.empty(shape, dtype=torch.float32, device=self.device)
 
     def _workspace(self, rows: int):
-        need = int(self.lib.fear_train_workspace_bytes(rows, 672))
-        if self._ws is None or self._ws.numel() * 4 < need:
-            self._ws = None
-            self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
-        return _p(self._ws), self._ws.numel() * 4
+        return self._lane_workspace(int(self.lib.fear_train_workspace_bytes(rows, 672)))
+
+    def _lane_workspace(self, need: int):
+        ws = self._ws_lanes.get(self._lane)
+        if ws is None or ws.numel() * 4 < need:
+            self._ws_lanes[self._lane] = None
+            ws = self._ws_lanes[self._lane] = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
+        return _p(ws), ws.numel() * 4
 
     # ------------------------------------------------------------------ one conv + BN [+ ReLU]
     def _fwd(self, L: _ConvBN, x: torch.Tensor, B: int, H: int, saved: list) -> torch.Tensor:
@@ -235,11 +246,8 @@ class FEARNetTrainHIP:
 
     # ------------------------------------------------------------------ fused conv + BN units
     def _workspace_stats(self, rows: int, channels: int):
-        need = max(int(self.lib.fear_train_stats_workspace_bytes(rows, channels)), int(self.lib.fear_train_workspace_bytes(rows, 672)))
-        if self._ws is None or self._ws.numel() * 4 < need:
-            self._ws = None
-            self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
-        return _p(self._ws), self._ws.numel() * 4
+        return self._lane_workspace(max(int(self.lib.fear_train_stats_workspace_bytes(rows, channels)),
+                                        int(self.lib.fear_train_workspace_bytes(rows, 672))))
 
     def _fwd_f(self, L: _ConvBN, x: torch.Tensor, x_act, B: int, H: int, saved: list):
         """One conv + BatchNorm unit on the fused operators.  x: rows [B*H*H][cin] — a previous unit's RAW conv output when
@@ -402,6 +410,12 @@ class FEARNetTrainHIP:
             st = self._stream()
             ffwd = self._features_forward_f if self.fused else self._features_forward
             fbwd = self._features_backward_f if self.fused else self._features_backward
+            main = torch.cuda.current_stream(dev)
+            if self.two_streams and self._side is None:
+                self._side = torch.cuda.Stream(device=dev)
+            side = self._side if self.two_streams else None
+            # (the FORWARD passes stay in order on one stream: both update the shared trunk's BatchNorm running statistics,
+            # template first — torch's two forward calls — and that read-modify-write must not race)
             zrows, zctx = ffwd(t)                                    # template first, like FEARNet.forward
             xrows, xctx = ffwd(s)
             z = self._new(B, 256, 8, 8)
@@ -415,8 +429,19 @@ class FEARNetTrainHIP:
             self._check(self.lib.fear_nchw_to_nhwc(_p(out["grad_search"]), _p(dx), B, 256, 256, 256, 0, st))
             self._check(self.lib.fear_nchw_to_nhwc(_p(out["grad_template"].contiguous()), _p(dz), B, 256, 64, 256, 0, st))
             gflat = torch.empty(2, self._gtotal, dtype=torch.float32, device=dev)      # fresh per step: the caller keeps `grads`
-            fbwd(xctx, dx, gflat[0])
-            fbwd(zctx, dz, gflat[1])
+            if side is not None:
+                side.wait_stream(main)                               # dz and the gradient buffer exist
+                dz.record_stream(side)
+                gflat.record_stream(side)
+                with torch.cuda.stream(side):
+                    self._lane = 1
+                    fbwd(zctx, dz, gflat[1])
+                    self._lane = 0
+                fbwd(xctx, dx, gflat[0])
+                main.wait_stream(side)
+            else:
+                fbwd(xctx, dx, gflat[0])
+                fbwd(zctx, dz, gflat[1])
             self._check(self.lib.fear_add(_p(gflat[0]), _p(gflat[1]), _p(gflat[0]), self._gtotal, st))   # shared parameters: the two passes add up
             for L in self._trunk_layers():
                 gw = self._gslot(gflat[0], L.conv_key, *L.w.shape)
