@@ -169,8 +169,9 @@ static void bench_tile_v4(const char* tag, int crops, int iters, int hw) {
 #endif
 }
 
-static void bench_stem(int crops, int iters) {
-    using G = IrT2Geom<27, 16, 16, 3, 1, 32, 16, true>;
+template <int TW, int TH, int MINW>
+static void bench_stem_shape(int crops, int iters) {
+    using G = IrT2Geom<27, 16, 16, 3, 1, TW, TH, true>;
     const int hw = 128;
     const double flops = 2.0 * (27.0 * 16 + 16.0 * 9 + 16.0 * 16) * hw * hw * crops;
     IrT2Args t{};
@@ -182,8 +183,8 @@ static void bench_stem(int crops, int iters) {
     float* y;
     CK(hipMalloc(&y, (size_t)crops * hw * hw * 16 * sizeof(float)));
     a.Y = y; a.relu_dw = 1; a.relu_out = 0;
-    t.H = hw; t.W = hw; t.tiles_x = hw / 32; t.tiles_y = hw / 16;
-    auto k = ir_tile_v2_kernel<27, 16, 16, 3, 1, 32, 16, true, 4, true>;
+    t.H = hw; t.W = hw; t.tiles_x = hw / TW; t.tiles_y = hw / TH;
+    auto k = ir_tile_v2_kernel<27, 16, 16, 3, 1, TW, TH, true, MINW, true>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -197,7 +198,18 @@ static void bench_stem(int crops, int iters) {
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = 1e3 * ms / iters;
-    printf("%-24s fp32-stem  %8.1f us  %6.1f TF/s  (LDS %d B)\n", "stem_irt_3x16x16_hw256", us, flops / us * 1e-6, G::LDS_BYTES);
+    printf("stem_irt_3x16x16_hw256 %dx%d w%d fp32-stem  %8.1f us  %6.1f TF/s  (LDS %d B)\n", TW, TH, MINW, us, flops / us * 1e-6, G::LDS_BYTES);
+    CK(hipFree(y));
+}
+
+static void bench_stem(int crops, int iters) {
+    bench_stem_shape<32, 16, 4>(crops, iters);
+#ifdef FEAR_STEM_SHAPES
+    bench_stem_shape<32, 8, 4>(crops, iters);
+    bench_stem_shape<32, 8, 6>(crops, iters);
+    bench_stem_shape<32, 16, 6>(crops, iters);
+    bench_stem_shape<32, 16, 4>(crops, iters);
+#endif
 }
 
 template <int CIN, int COUT, int KS>
