@@ -768,3 +768,48 @@ def test_dual_stream_head_in_the_throughput_plan(hip_net):
     for _ in range(10):
         b2, c2 = two.track_maps(x, z)
         assert torch.equal(b1, b2) and torch.equal(c1, c2)
+
+
+def test_fear_m_at_the_config_size_512_crops():
+    """BASELINE configs[3] at ITS size — synthetic FEAR-M, B = 512, bf16 matrix-pipe mode (what bench.py times) — through
+    size-independent properties: finite maps; batch invariance (crop i alone = crop i inside the batch, bit for bit, in the
+    bf16 mode too: every crop is an independent unit) and permutation equivariance; the fp32 mode of the same model against the
+    CPU oracle on 32 of the 512 crops at the path's 1e-3; the bf16 maps inside their stated tolerance of the fp32 ones on the
+    whole batch, arg-max cell kept wherever the fp32 top-2 margin exceeds twice the observed logit deviation."""
+    from feartracker_amd import FEARNetHIP
+    from feartracker_amd.hip_backend import WEIGHTS_FEAR_M
+    from oracle.fear_oracle import OracleNet
+    B = 512
+    net = FEARNetHIP(WEIGHTS_FEAR_M, device=0, max_batch=B)
+    net.set_small_pass(0)
+    g = torch.Generator().manual_seed(512)
+    x = norm_u8(torch.randint(0, 256, (B, 3, 256, 256), dtype=torch.uint8, generator=g)).cuda()
+    t = norm_u8(torch.randint(0, 256, (B, 3, 128, 128), dtype=torch.uint8, generator=g)).cuda()
+    maps = {}
+    for mode in (0, 2):
+        net.set_math(mode)
+        z = net.get_features(t)
+        bbox, cls = net.track_maps(x, z)
+        assert torch.isfinite(bbox).all() and torch.isfinite(cls).all() and (bbox > 0).all()
+        for i in (0, 301, B - 1):
+            bi, ci = net.track_maps(x[i:i + 1], z[i:i + 1])
+            assert torch.equal(bi[0], bbox[i]) and torch.equal(ci[0], cls[i]), (mode, i)
+        perm = torch.randperm(B, generator=g).cuda()
+        bp, cp = net.track_maps(x[perm].contiguous(), z[perm].contiguous())
+        assert torch.equal(bp, bbox[perm]) and torch.equal(cp, cls[perm]), mode
+        maps[mode] = (bbox.clone(), cls.clone(), z.clone())
+    b0, c0, z0 = maps[0]
+    sample = list(range(5, B, 16))                     # 32 of the 512 crops through the oracle (fp32 mode)
+    ora = OracleNet(WEIGHTS_FEAR_M)
+    ref = ora.track(x[sample].cpu(), z0[sample].cpu())
+    assert_maps_close(b0[sample], c0[sample], ref["TARGET_REGRESSION_LABEL_KEY"], ref["TARGET_CLASSIFICATION_KEY"])
+    b2, c2, _ = maps[2]
+    dev_b = float(((b2 - b0).abs() / b0.abs()).max())
+    dev_c = float((c2 - c0).abs().max())
+    print(f"FEAR-M B=512, bf16 vs fp32: bbox {dev_b:.2e} rel, cls {dev_c:.2e} abs")
+    assert 1e-4 < dev_b < 8e-2 and 1e-4 < dev_c < 0.15
+    flat = c0.reshape(B, -1)
+    top2 = torch.topk(flat, 2, dim=1).values
+    need = (top2[:, 0] - top2[:, 1]) > 2 * dev_c
+    assert int(need.sum()) >= B // 4
+    assert torch.equal(c2.reshape(B, -1).argmax(dim=1)[need], flat.argmax(dim=1)[need])
