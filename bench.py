@@ -330,6 +330,23 @@ def config5_train_step(dev, batch: int = 128, steps: int = 5, warmup: int = 2):
         opt.step(out["grads"])
     torch.cuda.synchronize()
     adam_ms = 1e3 * (time.perf_counter() - ta) / steps
+    # roofline of the step's dominant kernel symbol (pw_wgrad_kernel: 12.6 % of the kernel time, profiles/r03_train_kernel_stats.csv):
+    # every launch of it bracketed with events on the stream it runs on, in extra steps after the timed ones
+    net.timing = []
+    for _ in range(2):
+        net.step(tmpl, srch, gt_reg, gt_cls, gt_w)
+    torch.cuda.synchronize()
+    wg_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in net.timing)
+    wg_bytes = sum(b for _, _, b, _ in net.timing)
+    wg_flops = sum(f for _, _, _, f in net.timing)
+    n_wg = len(net.timing)
+    net.timing = None
+    gbs = wg_bytes / (wg_ms * 1e-3) / 1e9
+    train_roof = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+                  "kernel": "pw_wgrad_kernel (pointwise-conv weight gradients of the trunk, both passes)", "launches": n_wg,
+                  "avg_launch_ms": wg_ms / max(n_wg, 1), "share_of_step": (wg_ms / 2) / (1e3 * dt),
+                  "arithmetic_intensity_flop_per_byte": wg_flops / wg_bytes, "tflops_of_that_kernel": wg_flops / (wg_ms * 1e-3) / 1e12,
+                  "note": "dW[n][k] = sum over millions of rows of dY[m][n] X[m][k] with N, K <= 672: a few FLOP per byte, HBM-side"}
     fwd_macs = 461_393_920 + 75_970_000           # search path + template path, forward MACs per pair
     nparams = sum(v.numel() for v in out["grads"].values())
     return {"workload": f"FEARNet training step (trunk + neck on both crops, correlation head, FEARLoss; forward in train mode + "
@@ -337,7 +354,8 @@ def config5_train_step(dev, batch: int = 128, steps: int = 5, warmup: int = 2):
             "value": batch / dt, "unit": "pairs/s per GPU", "ms_per_step": 1e3 * dt, "steps": steps, "warmup": warmup,
             "approx_tflops": 3 * 2 * fwd_macs * batch / dt / 1e12,
             "loss": [float(out["loss_cls"]), float(out["loss_reg"])], "dtype": "f32",
-            "parameter_tensors_with_gradients": len(out["grads"]), "parameters": nparams, "adam_update_ms": adam_ms,
+            "parameter_tensors_with_gradients": len(out["grads"]), "parameters": nparams, "adam_update_ms": adam_ms, "roofline": train_roof,
+            "template_backward_on_second_stream": bool(net.two_streams),
             "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
 
 

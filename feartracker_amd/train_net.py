@@ -136,6 +136,7 @@ class FEARNetTrainHIP:
         self._side = None
         self._lane = 0
         self._ws_lanes = {}
+        self.timing = None        # a list: every pointwise weight-gradient launch is bracketed with events and appended (bench.py's roofline)
         sd = {k: torch.as_tensor(np.asarray(v)) if not isinstance(v, torch.Tensor) else v.detach().cpu() for k, v in state_dict.items()}
         dev = self.device
         self.stem = _ConvBN("stem", "stem", sd, dev, k=3, stride=2)
@@ -232,7 +233,14 @@ class FEARNetTrainHIP:
                 self._check(lib.fear_dw_backward_data(_p(dpre), L.cout, _p(L.w), _p(dx), L.cin, B, H, H, L.cin, L.k, L.stride, st))
         else:
             dw = self._gslot(gbuf, L.conv_key, L.cout, L.cin)
+            if self.timing is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             self._check(lib.fear_pw_backward_weight(_p(dpre), L.cout, _p(x), L.cin, _p(dw), ws, wsb, M, L.cin, L.cout, st))
+            if self.timing is not None:
+                e1.record()
+                # algorithmic bytes of dW[n][k] = sum_m dY[m][n] X[m][k]: both operands read once, dW written once
+                self.timing.append((e0, e1, 4.0 * (M * L.cout + M * L.cin + L.cout * L.cin), 2.0 * M * L.cout * L.cin))
             if L.kind != "stem":
                 if need_dx:
                     dx = self._new(M, L.cin)
