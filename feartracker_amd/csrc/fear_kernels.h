@@ -1336,7 +1336,7 @@ __global__ __launch_bounds__(512) void sep16_kernel(Ir2Args a) {
             f32x4 v = accp[mt][nt] + b;
             if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
             if (a.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = v;
+            if (!(FEAR_ABL & 2048) || v.x == 1234.5f) *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = v;      // (ablation: no output stores)
             if (CORR) accp[mt][nt] = v;          // the finished feature fragment = B operand of the correlation
         }
     }

@@ -260,6 +260,11 @@ int main(int argc, char** argv) {
     bench_tile_v4<32, 96, 32, 5, 1, 16, 16, 2, 2>("s7  v4 32x96x32_k5 16x16", crops, iters, 32);
     bench_tile_v4<16, 96, 24, 3, 2, 16, 8, 4, 2>("s2  v4 16x96x24_k3s2 16x8", crops, iters, 128);
 #endif
+#ifdef FEAR_SEP_ONLY
+    bench_sep<256, 256, 3>("sep16_256x256_k3", crops, iters);
+    bench_sep<320, 256, 3>("sep16_320x256_k3", crops, iters);
+    return 0;
+#endif
     if (!all) return 0;
     bench<112, 672, 112, 5, true>("ir16_112x672x112_k5", crops, iters);
     bench<64, 384, 64, 5, true>("ir16_64x384x64_k5", crops, iters);
