@@ -359,16 +359,18 @@ class FEARNetHIP:
         a 225x870 context in a 1080p frame is 0.3 MB of the frame's 6.2 MB; the boxes are shifted to that rectangle's
         origin, everything outside it is border colour for the kernel exactly as the rest of the frame's outside is), and
         the context boxes and border colours go up in ONE small transfer."""
-        if isinstance(frame_u8, np.ndarray):
-            frame_u8 = torch.from_numpy(frame_u8)
-        if frame_u8.dtype != torch.uint8 or frame_u8.dim() != 3 or frame_u8.shape[2] != 3:
+        is_np = isinstance(frame_u8, np.ndarray)          # (kept as numpy until the rectangle is cut: views with negative strides —
+        if is_np:                                         #  a BGR -> RGB flip `img[:, :, ::-1]` — are fine for numpy, not for from_numpy)
+            if frame_u8.dtype != np.uint8 or frame_u8.ndim != 3 or frame_u8.shape[2] != 3:
+                raise ValueError("frame must be uint8 (H,W,3)")
+        elif frame_u8.dtype != torch.uint8 or frame_u8.dim() != 3 or frame_u8.shape[2] != 3:
             raise ValueError("frame must be uint8 (H,W,3)")
         ctx_np = np.ascontiguousarray(np.asarray(ctx_xywh, dtype=np.int32).reshape(-1, 4))
         pad_np = np.ascontiguousarray(np.asarray(pad_rgb_u8, dtype=np.uint8).reshape(-1, 3))
         n = ctx_np.shape[0]
         if pad_np.shape[0] != n:
             raise ValueError("one border colour per context box")
-        if not frame_u8.is_cuda:
+        if is_np or not frame_u8.is_cuda:
             fh, fw = int(frame_u8.shape[0]), int(frame_u8.shape[1])
             x0 = y0 = x1 = y1 = 0
             if n:
@@ -386,6 +388,8 @@ class FEARNetHIP:
                 ctx_np[:, 1] -= y0
             # (one plain .to(): a reused pinned staging buffer was tried — ADVICE r1 — and measured 10x SLOWER per frame on
             # the 256-core host, torch's CPU->pinned copy_ costs milliseconds there)
+            if is_np:
+                frame_u8 = torch.from_numpy(np.ascontiguousarray(frame_u8))
             frame_u8 = frame_u8.contiguous().to(self.device)
         else:
             frame_u8 = frame_u8.to(self.device).contiguous()

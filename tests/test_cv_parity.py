@@ -122,6 +122,12 @@ def test_device_crop_reproduces_the_reference_crops(golden_dir):
         want = np.transpose(geo.normalize_image(d[f"crop_{name}"]), (2, 0, 1))
         got = net.crop_normalize(torch.from_numpy(frame).cuda(), d[f"ctx_{name}"], geo.border_color_u8(mean), size)[0].cpu().numpy()
         np.testing.assert_array_equal(got, want, err_msg=name)
+        # the same crop from a HOST frame (only the context rectangle is uploaded, boxes shifted to it), given as a numpy view
+        # with a negative stride (a BGR frame flipped to RGB) and as a CPU tensor
+        bgr = np.ascontiguousarray(frame[:, :, ::-1])
+        for host in (bgr[:, :, ::-1], torch.from_numpy(frame)):
+            got = net.crop_normalize(host, d[f"ctx_{name}"], geo.border_color_u8(mean), size)[0].cpu().numpy()
+            np.testing.assert_array_equal(got, want, err_msg=name + " (host frame)")
 
 
 @pytest.mark.gpu
