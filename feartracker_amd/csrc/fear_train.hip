@@ -791,8 +791,11 @@ int col_blocks(long M) { const int r = col_rows_per_block(M); return (int)((M + 
 
 // row slices of the pointwise weight gradient: 1024 rows each, but never more than 256 slices (the partials are
 // [slices][N][K] floats; at the trunk's 128x128 maps a batch has millions of rows)
+#ifndef FEAR_WGRAD_ROWS
+#define FEAR_WGRAD_ROWS 1024
+#endif
 long wgrad_rows_per_slice(long M) {
-    long r = 1024;
+    long r = FEAR_WGRAD_ROWS;
     while ((M + r - 1) / r > 256) r *= 2;
     return r;
 }
