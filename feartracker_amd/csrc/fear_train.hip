@@ -135,6 +135,10 @@ struct ColFinArgs {
     float* running_mean;   // mode 0, optional
     float* running_var;
     double* dsum;          // mode 3: the two sums as float64 [2][C] (what several ranks all-reduce for SyncBatchNorm)
+    const float* gamma;    // mode 0, optional: also write the affine a = gamma * rstd, b = beta - mean * a (bn_finalize_kernel's)
+    const float* beta;
+    float* out_a;
+    float* out_b;
     int blocks, C, mode, rpb;
     double M, eps, momentum;
 };
@@ -164,8 +168,14 @@ __global__ __launch_bounds__(1024) void col_finalize_kernel(ColFinArgs a) {
         const double m2 = s2 - s1 * mean;
         double var = m2 / a.M;
         if (var < 0.0) var = 0.0;
-        a.out1[c] = (float)mean;
-        a.out2[c] = (float)(1.0 / sqrt(var + a.eps));
+        const float mf = (float)mean, rf = (float)(1.0 / sqrt(var + a.eps));
+        a.out1[c] = mf;
+        a.out2[c] = rf;
+        if (a.out_a) {
+            const float av = a.gamma[c] * rf;
+            a.out_a[c] = av;
+            a.out_b[c] = __builtin_fmaf(-mf, av, a.beta[c]);
+        }
         if (a.running_mean) {
             a.running_mean[c] = (float)((1.0 - a.momentum) * (double)a.running_mean[c] + a.momentum * mean);
             const double unbiased = a.M > 1.0 ? var * a.M / (a.M - 1.0) : var;
@@ -1457,6 +1467,62 @@ int fear_dw_backward_weight_act(const float* dy, int lddy, const float* x, int l
     if (B < 1 || !dw_shape_ok(B, H, W, C, k, stride) || !ld_ok(lddy, C) || !ld_ok(ldx, C)) return FEAR_TRAIN_ERR_SHAPE;
     return dw_wgrad_impl(dy, lddy, x, ldx, dw_taps, workspace, ws_bytes, B, H, W, C, k, stride, static_cast<hipStream_t>(stream), in_a,
                          in_b, in_relu);
+}
+
+// BatchNorm (train mode) of a raw conv output in the affine form of the fused operators, WITH the activation written out:
+// column sums -> mean / rstd / running statistics and a = gamma * rstd, b = beta - mean * a -> y = fma(x, a, b) [max 0] [+ residual].
+// Same three launches as fear_bn_train_forward; its backward (fear_bn_train_backward_x) recomputes the ReLU mask from x with the
+// same fma, so the stored activation is never read again on the way back (2 of the 7 passes over a ReLU layer's tensors).
+int fear_bn_train_forward_ab(const float* x, int ldx, const float* gamma, const float* beta, int relu, const float* residual, int ldr,
+                             float* y, int ldy, float* mean, float* rstd, float* a_out, float* b_out, float* running_mean,
+                             float* running_var, double momentum, double eps, long M, int C, float* workspace, size_t ws_bytes,
+                             void* stream) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd || !a_out || !b_out || !workspace) return FEAR_TRAIN_ERR_NULL;
+    if (M <= 0 || C < 4 || C % 4 || C > 1024 || !ld_ok(ldx, C) || !ld_ok(ldy, C) || (residual && !ld_ok(ldr, C))) return FEAR_TRAIN_ERR_SHAPE;
+    const int blocks = col_blocks(M);
+    if (ws_bytes < (size_t)blocks * 2 * C * sizeof(double)) return FEAR_TRAIN_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ColArgs a{};
+    a.A = x; a.lda = ldx; a.partial = reinterpret_cast<double*>(workspace); a.M = M; a.C = C; a.rpb = col_rows_per_block(M);
+    hipLaunchKernelGGL(col_reduce_kernel<0>, dim3(blocks), dim3(256), 0, s, a);
+    ColFinArgs f{};
+    f.partial = reinterpret_cast<const double*>(workspace); f.out1 = mean; f.out2 = rstd; f.running_mean = running_mean; f.running_var = running_var;
+    f.gamma = gamma; f.beta = beta; f.out_a = a_out; f.out_b = b_out;
+    f.blocks = blocks; f.C = C; f.mode = 0; f.M = (double)M; f.rpb = a.rpb; f.eps = eps; f.momentum = momentum;
+    hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, s, f);
+    BnActArgs k{};
+    k.X = x; k.R = residual; k.Y = y; k.in.a = a_out; k.in.b = b_out; k.in.relu = relu; k.M = M; k.C = C; k.ldx = ldx; k.ldr = ldr; k.ldy = ldy;
+    const long n4 = M * (C / 4);
+    hipLaunchKernelGGL(bn_act_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, k);
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+int fear_bn_train_backward_x(const float* dy, int lddy, const float* x, int ldx, const float* act_a, const float* act_b, int relu,
+                             const float* mean, const float* rstd, const float* gamma, float* dx, int lddx, float* dgamma, float* dbeta,
+                             long M, int C, float* workspace, size_t ws_bytes, void* stream) {
+    if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !workspace || (relu && (!act_a || !act_b)))
+        return FEAR_TRAIN_ERR_NULL;
+    if (M <= 0 || C < 4 || C % 4 || C > 1024 || !ld_ok(lddy, C) || !ld_ok(ldx, C) || !ld_ok(lddx, C)) return FEAR_TRAIN_ERR_SHAPE;
+    const int blocks = col_blocks(M);
+    if (ws_bytes < (size_t)blocks * 2 * C * sizeof(double)) return FEAR_TRAIN_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ColArgs a{};
+    a.A = dy; a.lda = lddy; a.X = x; a.ldx = ldx; a.mean = mean; a.rstd = rstd;
+    a.act_a = relu ? act_a : nullptr; a.act_b = relu ? act_b : nullptr;
+    a.partial = reinterpret_cast<double*>(workspace); a.M = M; a.C = C; a.rpb = col_rows_per_block(M);
+    hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(blocks), dim3(256), 0, s, a);
+    ColFinArgs f{};
+    f.partial = reinterpret_cast<const double*>(workspace); f.out1 = dbeta; f.out2 = dgamma; f.blocks = blocks; f.C = C; f.mode = 1; f.M = (double)M; f.rpb = a.rpb;
+    hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, s, f);
+    BnBwdArgs b{};
+    b.dY = dy; b.X = x; b.mean = mean; b.rstd = rstd; b.gamma = gamma; b.sum_g = dbeta; b.sum_gx = dgamma;
+    b.dX = dx; b.M = M; b.C = C; b.lddy = lddy; b.ldx = ldx; b.lddx = lddx;
+    b.act_a = a.act_a; b.act_b = a.act_b;
+    const long n4 = M * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, b);
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
 }
 
 // ---- SyncBatchNorm (the reference's multi-GPU backends set sync_bn: True, config/backend/*.yaml): the two reductions of a

@@ -49,6 +49,8 @@ TRAIN_SYMBOLS = {
     "fear_bn_act": ([_P, _i, _P, _P, _i, _P, _i, _P, _i, _l, _i, _P], _i),
     "fear_bn_backward_reduce_x": ([_P, _i, _P, _i, _P, _P, _i, _P, _P, _P, _l, _i, _P, _sz, _P], _i),
     "fear_bn_backward_apply_x": ([_P, _i, _P, _i, _P, _P, _i, _P, _P, _P, _P, _d, _P, _P, _i, _P, _P, _P, _sz, _l, _i, _P], _i),
+    "fear_bn_train_forward_ab": ([_P, _i, _P, _P, _i, _P, _i, _P, _i, _P, _P, _P, _P, _P, _P, _d, _d, _l, _i, _P, _sz, _P], _i),
+    "fear_bn_train_backward_x": ([_P, _i, _P, _i, _P, _P, _i, _P, _P, _P, _P, _i, _P, _P, _l, _i, _P, _sz, _P], _i),
     "fear_pw_backward_weight_act": ([_P, _i, _P, _i, _P, _P, _i, _P, _P, _sz, _l, _i, _i, _P], _i),
     "fear_dw_backward_weight_act": ([_P, _i, _P, _i, _P, _P, _i, _P, _P, _sz, _i, _i, _i, _i, _i, _i, _P], _i),
     "fear_xcorr_forward": ([_P, _i, _P, _P, _i, _i, _i, _i, _i, _P], _i),

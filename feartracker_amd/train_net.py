@@ -29,7 +29,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
-from .train_head import BoxTowerTrainHIP, SyncBN, TrainError, _p, bn_backward, bn_forward, load_train_library
+from .train_head import BoxTowerTrainHIP, SyncBN, TrainError, _p, load_train_library
 
 # (cin, cexp, cout, k, stride, expand, residual): fbnet_c stages[1:18]
 TRUNK_BLOCKS = [
@@ -191,8 +191,9 @@ class FEARNetTrainHIP:
         return _p(ws), ws.numel() * 4
 
     # ------------------------------------------------------------------ one conv + BN [+ ReLU]
-    def _fwd(self, L: _ConvBN, x: torch.Tensor, B: int, H: int, saved: list) -> torch.Tensor:
-        """x: NHWC rows [B*H*H][cin] (stem: the im2col rows of the output grid).  Returns the activation rows."""
+    def _fwd(self, L: _ConvBN, x: torch.Tensor, B: int, H: int, saved: list, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x: NHWC rows [B*H*H][cin] (stem: the im2col rows of the output grid).  Returns the activation rows (+ `residual`, the
+        block input, when given: the skip connection is added by the BatchNorm's own apply kernel)."""
         lib, st = self.lib, self._stream()
         Ho = H // L.stride if L.kind == "dw" else H
         M = B * Ho * Ho
@@ -203,9 +204,25 @@ class FEARNetTrainHIP:
         else:
             self._check(lib.fear_pw_forward(_p(x), L.cin, _p(L.w), None, _p(pre), L.cout, M, L.cin, L.cout, st))
         out, mean, rstd = self._new(M, L.cout), self._new(L.cout), self._new(L.cout)
-        self._check(bn_forward(lib, st, ws, wsb, self.sync, pre, L.cout, L.gamma, L.beta, out, L.cout, mean, rstd, L.running_mean,
-                               L.running_var, self.momentum, self.eps, M, L.cout, 1 if L.relu else 0))
-        saved.append((L, x, pre, out, mean, rstd, B, H))
+        ab = None
+        if self.sync is None:
+            # the affine form a = gamma * rstd, b = beta - mean * a: y = fma(pre, a, b) — the backward recomputes the ReLU mask from
+            # `pre` with the same fma and never reads `out` again (2 of the 7 passes over a ReLU layer's tensors on the way back)
+            ab = (self._new(L.cout), self._new(L.cout))
+            self._check(lib.fear_bn_train_forward_ab(_p(pre), L.cout, _p(L.gamma), _p(L.beta), 1 if L.relu else 0, _p(residual), L.cout,
+                                                     _p(out), L.cout, _p(mean), _p(rstd), _p(ab[0]), _p(ab[1]), _p(L.running_mean),
+                                                     _p(L.running_var), self.momentum, self.eps, M, L.cout, ws, wsb, st))
+        else:
+            # SyncBatchNorm: the same arithmetic with the float64 sums added over the ranks between the two halves
+            sums = torch.empty(2 * L.cout, dtype=torch.float64, device=self.device)
+            self._check(lib.fear_bn_reduce(_p(pre), L.cout, _p(sums), M, L.cout, ws, wsb, st))
+            self.sync.all_reduce(sums)
+            ab = (self._new(L.cout), self._new(L.cout))
+            self._check(lib.fear_bn_finalize(_p(sums), float(M) * self.sync.world, _p(L.gamma), _p(L.beta), _p(mean), _p(rstd), _p(ab[0]),
+                                             _p(ab[1]), _p(L.running_mean), _p(L.running_var), self.momentum, self.eps, L.cout, st))
+            self._check(lib.fear_bn_act(_p(pre), L.cout, _p(ab[0]), _p(ab[1]), 1 if L.relu else 0, _p(residual), L.cout, _p(out), L.cout,
+                                        M, L.cout, st))
+        saved.append((L, x, pre, out, mean, rstd, B, H, ab))
         return out
 
     def _gslot(self, gbuf: torch.Tensor, key: str, *shape) -> torch.Tensor:
@@ -213,17 +230,29 @@ class FEARNetTrainHIP:
         off = self._goff[key]
         return gbuf[off: off + n].view(*shape)
 
-    def _bwd(self, rec, dy: torch.Tensor, gbuf: torch.Tensor, need_dx: bool = True) -> Optional[torch.Tensor]:
-        """Backward of one conv + BN [+ ReLU]; the parameter gradients go to their slots of `gbuf` (kernel layouts)."""
-        L, x, pre, out, mean, rstd, B, H = rec
+    def _bwd(self, rec, dy: torch.Tensor, gbuf: torch.Tensor, need_dx: bool = True,
+             add: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+        """Backward of one conv + BN [+ ReLU]; the parameter gradients go to their slots of `gbuf` (kernel layouts).  `add`: a
+        tensor added to the input gradient (the skip connection's gradient) — inside the dgrad GEMM for pointwise units."""
+        L, x, pre, out, mean, rstd, B, H, ab = rec
         lib, st = self.lib, self._stream()
         Ho = H // L.stride if L.kind == "dw" else H
         M = B * Ho * Ho
         ws, wsb = self._workspace(max(M, B * H * H))
         dpre = self._new(M, L.cout)
         dgamma, dbeta = self._gslot(gbuf, L.bn_key + ".weight", L.cout), self._gslot(gbuf, L.bn_key + ".bias", L.cout)
-        self._check(bn_backward(lib, st, ws, wsb, self.sync, dy, L.cout, out if L.relu else None, L.cout, pre, L.cout, mean, rstd,
-                                L.gamma, dpre, L.cout, dgamma, dbeta, M, L.cout))
+        if self.sync is None:
+            self._check(lib.fear_bn_train_backward_x(_p(dy), L.cout, _p(pre), L.cout, _p(ab[0]), _p(ab[1]), 1 if L.relu else 0, _p(mean),
+                                                     _p(rstd), _p(L.gamma), _p(dpre), L.cout, _p(dgamma), _p(dbeta), M, L.cout, ws, wsb, st))
+        else:
+            sums = torch.empty(2 * L.cout, dtype=torch.float64, device=self.device)
+            self._check(lib.fear_bn_backward_reduce_x(_p(dy), L.cout, _p(pre), L.cout, _p(ab[0]), _p(ab[1]), 1 if L.relu else 0, _p(mean),
+                                                      _p(rstd), _p(sums), M, L.cout, ws, wsb, st))
+            local = sums.clone()
+            self.sync.all_reduce(sums)
+            self._check(lib.fear_bn_backward_apply_x(_p(dy), L.cout, _p(pre), L.cout, _p(ab[0]), _p(ab[1]), 1 if L.relu else 0, _p(mean),
+                                                     _p(rstd), _p(L.gamma), _p(sums), float(M) * self.sync.world, _p(local), _p(dpre), L.cout,
+                                                     _p(dgamma), _p(dbeta), ws, wsb, M, L.cout, st))
         dx = None
         if L.kind == "dw":
             dtaps = self._gslot(gbuf, L.conv_key, L.k * L.k, L.cout)
@@ -231,6 +260,8 @@ class FEARNetTrainHIP:
             if need_dx:
                 dx = self._new(B * H * H, L.cin)
                 self._check(lib.fear_dw_backward_data(_p(dpre), L.cout, _p(L.w), _p(dx), L.cin, B, H, H, L.cin, L.k, L.stride, st))
+                if add is not None:
+                    self._check(lib.fear_add(_p(dx), _p(add), _p(dx), dx.numel(), st))
         else:
             dw = self._gslot(gbuf, L.conv_key, L.cout, L.cin)
             if self.timing is not None:
@@ -244,7 +275,8 @@ class FEARNetTrainHIP:
             if L.kind != "stem":
                 if need_dx:
                     dx = self._new(M, L.cin)
-                    self._check(lib.fear_pw_backward_data(_p(dpre), L.cout, _p(L.w), None, 0, _p(dx), L.cin, M, L.cin, L.cout, st))
+                    self._check(lib.fear_pw_backward_data(_p(dpre), L.cout, _p(L.w), _p(add), L.cin if add is not None else 0, _p(dx),
+                                                          L.cin, M, L.cin, L.cout, st))
         return dx
 
     def _add(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
@@ -383,9 +415,7 @@ class FEARNetTrainHIP:
                 y = self._fwd(blk["pw"], y, B, h, saved)
             y = self._fwd(blk["dw"], y, B, h, saved)
             h = h // blk["dw"].stride
-            y = self._fwd(blk["pwl"], y, B, h, saved)
-            if blk["residual"]:
-                y = self._add(x, y)
+            y = self._fwd(blk["pwl"], y, B, h, saved, residual=x if blk["residual"] else None)
             block_recs.append((start, len(saved), blk["residual"]))
             x = y
         feats = self._fwd(self.neck, x, B, h, saved)
@@ -395,11 +425,9 @@ class FEARNetTrainHIP:
         saved, block_recs, B, h = ctx
         d = self._bwd(saved[-1], dfeat, gbuf)                        # neck
         for start, end, residual in reversed(block_recs):
-            dres = d
+            dres = d if residual else None
             for i in range(end - 1, start - 1, -1):
-                d = self._bwd(saved[i], d, gbuf)
-            if residual:
-                d = self._add(d, dres)
+                d = self._bwd(saved[i], d, gbuf, add=dres if i == start else None)     # the block's first unit also takes the skip's gradient
         self._bwd(saved[0], d, gbuf, need_dx=False)                  # stem: the image needs no gradient
 
     # ------------------------------------------------------------------ the step
@@ -525,7 +553,7 @@ class FEARNetTrainHIP:
                                                     + b.cpu().numpy().astype(np.float64)))      # fp32 fma: exact product, one rounding
                     act = y
                 else:
-                    L, x, pre, act, mean, rstd, B, H = rec
+                    L, x, pre, act, mean, rstd, B, H = rec[:8]
                     if not L.relu:
                         continue
                     act = act.cpu()

@@ -122,6 +122,15 @@ int fear_bn_backward_apply_x(const float* dy, int lddy, const float* x, int ldx,
                              const float* mean, const float* rstd, const float* gamma, const double* sums_all, double count,
                              const double* sums_local, float* dx, int lddx, float* dgamma, float* dbeta, float* workspace,
                              size_t ws_bytes, long M, int C, void* stream);
+/* the layer-wise step's BatchNorm in the same affine form, activation written out (y = act(x) [+ residual]), and its backward with
+ * the ReLU mask recomputed from x — the stored activation is not read on the way back; three launches each, one rank */
+int fear_bn_train_forward_ab(const float* x, int ldx, const float* gamma, const float* beta, int relu, const float* residual, int ldr,
+                             float* y, int ldy, float* mean, float* rstd, float* a_out, float* b_out, float* running_mean,
+                             float* running_var, double momentum, double eps, long M, int C, float* workspace, size_t ws_bytes,
+                             void* stream);
+int fear_bn_train_backward_x(const float* dy, int lddy, const float* x, int ldx, const float* act_a, const float* act_b, int relu,
+                             const float* mean, const float* rstd, const float* gamma, float* dx, int lddx, float* dgamma, float* dbeta,
+                             long M, int C, float* workspace, size_t ws_bytes, void* stream);
 /* weight gradients whose x operand is act(raw x) applied on load */
 int fear_pw_backward_weight_act(const float* dy, int lddy, const float* x, int ldx, const float* in_a, const float* in_b, int in_relu,
                                 float* dw, float* workspace, size_t ws_bytes, long M, int K, int N, void* stream);
