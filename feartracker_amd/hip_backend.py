@@ -109,6 +109,22 @@ class FearError(RuntimeError):
     pass
 
 
+def context_rectangle(frame_h: int, frame_w: int, ctx_xywh: np.ndarray) -> Tuple[int, int, int, int]:
+    """(x0, y0, x1, y1): the part of an H x W frame that context boxes (n, 4) int xywh can sample — their union clipped to the
+    frame; when nothing of the frame is visible one pixel keeps the shapes legal (every sample is border colour then anyway)."""
+    ctx = np.asarray(ctx_xywh, dtype=np.int64).reshape(-1, 4)
+    x0 = y0 = x1 = y1 = 0
+    if ctx.shape[0]:
+        x0 = int(np.clip(ctx[:, 0].min(), 0, frame_w))
+        y0 = int(np.clip(ctx[:, 1].min(), 0, frame_h))
+        x1 = int(np.clip((ctx[:, 0] + ctx[:, 2]).max(), x0, frame_w))
+        y1 = int(np.clip((ctx[:, 1] + ctx[:, 3]).max(), y0, frame_h))
+    if x1 <= x0 or y1 <= y0:
+        x0, y0 = min(x0, frame_w - 1), min(y0, frame_h - 1)
+        x1, y1 = x0 + 1, y0 + 1
+    return x0, y0, x1, y1
+
+
 class FEARNetHIP:
     """FEAR network running on one MI355X through libfear_hip.so.
 
@@ -372,15 +388,7 @@ class FEARNetHIP:
             raise ValueError("one border colour per context box")
         if is_np or not frame_u8.is_cuda:
             fh, fw = int(frame_u8.shape[0]), int(frame_u8.shape[1])
-            x0 = y0 = x1 = y1 = 0
-            if n:
-                x0 = int(np.clip(ctx_np[:, 0].min(), 0, fw))
-                y0 = int(np.clip(ctx_np[:, 1].min(), 0, fh))
-                x1 = int(np.clip((ctx_np[:, 0].astype(np.int64) + ctx_np[:, 2]).max(), x0, fw))
-                y1 = int(np.clip((ctx_np[:, 1].astype(np.int64) + ctx_np[:, 3]).max(), y0, fh))
-            if x1 <= x0 or y1 <= y0:                      # nothing of the frame is visible: one pixel keeps the shapes legal
-                x0, y0 = min(x0, fw - 1), min(y0, fh - 1)
-                x1, y1 = x0 + 1, y0 + 1
+            x0, y0, x1, y1 = context_rectangle(fh, fw, ctx_np)
             if (x1 - x0, y1 - y0) != (fw, fh):
                 frame_u8 = frame_u8[y0:y1, x0:x1]
                 ctx_np = ctx_np.copy()
