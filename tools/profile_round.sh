@@ -27,7 +27,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 # BASELINE configs[4] (one rank's 128 pairs of the training step): kernel stats
 rocprofv3 --kernel-trace --stats -d "$O/train_trace" -o p --output-format csv -- python "$R/tools/train_prof.py" 128 5 0 > "$O/train_trace.out" 2> "$O/train_trace.err"
-python "$R/bench_latency.py" > "$O/latency.json" 2> "$O/latency.err"
 # the distributed code path (RCCL process group, barriers, fear_track_packed + all-gather) with the one rank a 1-GPU box has
 FEAR_BENCH_FORCE_DIST=1 python "$R/bench.py" --no-cpu-baseline --no-other-math > "$O/bench_force_dist.json" 2> "$O/bench_force_dist.err"
 tail -c 600 "$O/bench.json"
