@@ -113,6 +113,7 @@ struct Op {
     int small_tiles = 0;      // OP_IRTILE: 1 = kFusedTileSmall (small-batch plan), 2 = kFusedTileTiny (a handful of crops)
     int pw_split = 0;         // OP_PW / OP_CORR: spread the output-channel passes over gridDim.y workgroups (small-batch plan)
     int splitk = 0;           // OP_IR16: > 0 = workgroups per crop (split over expansion chunks) + a reduce launch
+    int tiny = 0;             // OP_IR16 (sep16, 16 output channels per workgroup): sep16_tiny_kernel (Fused16::kernel_tiny)
     int nsplit = 0;           // OP_IR16 (sep16): > 0 = 16-channel output slices, one workgroup each (Ir2Args::nsplit_wstride)
     int part_buf = -1;        //          scratch buffer of the partial projections
     int lane = 0;             // 1: bbox branch of the head, may run on the handle's second stream (small batches)
@@ -159,6 +160,7 @@ struct fear_handle {
     int profile = 0;
     int profile_op = -1;   // -1: every op, else only this op index of each plan
     int fuse = 1;          // 1: use the fused block kernels where an instantiation exists
+    int tiny_sep = 1;      // FEAR_OPT_TINY_SEP: 1 = the tiny plan's 16-channel SepConv slices run sep16_tiny_kernel
     int tile_v4 = 1;       // FEAR_OPT_TILE_V4: 1 = phase-overlapped tile kernel for the blocks of kFusedTileV4 (throughput plan)
     int chain = 1;         // 1: run the stride-16 trunk stage as one register-resident chain kernel (fp32 mode)
     int small_pass = 96;   // passes of at most this many crops run the small-batch plan (FEAR_OPT_SMALL_PASS; 0: never);
@@ -307,18 +309,32 @@ struct Fused16 {
     int lds_bytes;
     void (*kernel_splitk)(Ir2Args);     // small-batch variant: several workgroups per crop, one chunk range each (or nullptr)
     int splitk_kc;                      // chunks per workgroup compiled into that variant (0: run-time, Ir2Args::kc_count)
+    void (*kernel_tiny)(Ir2Args);       // 16-channel output slice of kTinyRows map rows per workgroup (sep16_tiny_kernel), a handful of crops
+    int lds_tiny;
 };
 #define FUSED16(CIN, CEXP, COUT, KS, EXP) \
     {CIN, CEXP, COUT, KS, EXP, ir16v2_fused_kernel<CIN, CEXP, COUT, KS, (EXP) != 0>, Ir2Geom<CIN, CEXP, COUT, KS, (EXP) != 0>::LDS_BYTES, \
      ir16v2_fused_kernel<CIN, CEXP, COUT, KS, (EXP) != 0, true>, 0}
 #define SEP16(CIN, COUT, KS, KC) \
     {CIN, CIN, COUT, KS, 0, sep16_kernel<CIN, COUT, KS>, Sep16Geom<CIN, COUT, KS>::LDS_BYTES, sep16_kernel<CIN, COUT, KS, false, false, KC>, KC}
+#ifndef FEAR_TINY_ROWS
+#define FEAR_TINY_ROWS 2
+#endif
+#ifndef FEAR_TINY_KSPLIT
+#define FEAR_TINY_KSPLIT 4
+#endif
+// (batch-1 track call, ms, rows x wave groups: 8x1 0.375 | 4x1 0.357 | 4x2 0.352 | 2x2 0.344 | 2x4 0.342; sep16_kernel<CIN, 16, 3> 0.383)
+constexpr int kTinyRows = FEAR_TINY_ROWS;       // map rows per workgroup of sep16_tiny_kernel (one wave each)
+constexpr int kTinyKSplit = FEAR_TINY_KSPLIT;   // wave groups per workgroup, each over its share of the input chunks
+#define SEP16T(CIN, KS, KC) \
+    {CIN, CIN, 16, KS, 0, sep16_kernel<CIN, 16, KS>, Sep16Geom<CIN, 16, KS>::LDS_BYTES, sep16_kernel<CIN, 16, KS, false, false, KC>, KC, \
+     sep16_tiny_kernel<CIN, KS, kTinyRows, kTinyKSplit>, Sep16TinyGeom<CIN, KS, kTinyRows, kTinyKSplit>::LDS_BYTES}
 const Fused16 kFused16[] = {
     FUSED16(64, 192, 64, 5, 1),   FUSED16(64, 384, 64, 5, 1),  FUSED16(64, 384, 112, 5, 1),
     FUSED16(112, 672, 112, 5, 1), FUSED16(112, 336, 112, 5, 1),
     SEP16(256, 256, 3, 4), SEP16(320, 256, 3, 4),
-    SEP16(256, 16, 3, 2),              // bbox_pred / cls_pred: 4 / 1 output channels padded to one 16-channel tile
-    SEP16(320, 16, 3, 2),              // N-split slices of the 320 -> 256 SepConv (very small batches)
+    SEP16T(256, 3, 2),                 // bbox_pred / cls_pred: 4 / 1 output channels padded to one 16-channel tile
+    SEP16T(320, 3, 2),                 // N-split slices of the 320 -> 256 SepConv (very small batches)
 };
 
 // Spatially tiled fused block kernels (ir_tile_fused_kernel) for the high-resolution trunk stages.
@@ -740,6 +756,7 @@ int build_plan_uncached(fear_handle* h, int hw, bool with_head, int mode, Plan**
         if (id16 >= 0) {
             op.nsplit = p.cout / 16;
             op.fused_id = id16;
+            op.tiny = h->tiny_sep && kFused16[id16].kernel_tiny ? 1 : 0;
             if (pack_sep16_nsplit(h, cd, cp, &op.d_packed) != FEAR_OK) return false;
         } else if ((h->math ? pack_fused_h(h, ce, cd, cp, &op.d_packed, h->math == 2) : pack_fused16(h, ce, cd, cp, &op.d_packed)) != FEAR_OK)
             return false;
@@ -792,6 +809,7 @@ int build_plan_uncached(fear_handle* h, int hw, bool with_head, int mode, Plan**
         op.in_buf = in.buf; op.in_ld = in.ld; op.in_off = in.off;
         op.H = 16; op.W = 16; op.Ho = 16; op.Wo = 16; op.C = d.cout; op.N = p.cout;
         op.pred_cout = p.cout; op.act = act; op.out_external = ext;
+        op.tiny = mode == 2 && !h->math && h->tiny_sep && kFused16[id].kernel_tiny ? 1 : 0;
         snprintf(op.name, sizeof(op.name), "%s_%dx%d_k%d", ext == 3 ? "cls_pred16" : "bbox_pred16", d.cout, p.cout, d.k);
         op.flops = 2.0 * 256 * ((double)d.cout * d.k * d.k + (double)d.cout * p.cout);
         op.bytes = 4.0 * 256 * (d.cout + p.cout);
@@ -1202,6 +1220,9 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
             if (f.kernel_splitk)
                 HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(f.kernel_splitk),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, f.lds_bytes));
+            if (f.kernel_tiny)
+                HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(f.kernel_tiny),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, f.lds_tiny));
         }
         for (const Fused16& f : kFused16H)
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(f.kernel),
@@ -1307,7 +1328,11 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
                 int nt = pick_nt(n_tiles);
                 const int rows_per_block = 4 * 2 * 16;
                 dim3 grid((a.M + rows_per_block - 1) / rows_per_block);
-                if (op.pw_split && n_tiles % 2 == 0) { nt = 2; grid.y = n_tiles / 2; }
+                if (op.pw_split && n_tiles % 2 == 0) {
+                    grid.y = n_tiles / 2;
+                    hipLaunchKernelGGL((pw_mfma_kernel<2, 2, false, 8>), grid, dim3(256), 0, s, a);
+                    break;
+                }
                 launch_pw_nt<2, false>(nt, grid, s, a);
                 break;
             }
@@ -1322,7 +1347,11 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
                 const int rows_per_block = 4 * 2 * 16;
                 dim3 grid((a.M + rows_per_block - 1) / rows_per_block);
                 int nt = pick_nt(op.N / 16);
-                if (op.pw_split) { nt = 1; grid.y = op.N / 16; }
+                if (op.pw_split) {
+                    grid.y = op.N / 16;
+                    hipLaunchKernelGGL((pw_mfma_kernel<2, 1, true, 8>), grid, dim3(256), 0, s, a);
+                    break;
+                }
                 launch_pw_nt<2, true>(nt, grid, s, a);
                 break;
             }
@@ -1362,7 +1391,10 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
                 if (op.nsplit) {
                     const Conv& dconv = h->convs[op.conv_d];
                     a.nsplit_wstride = (long)(dconv.cout / 16) * (256 + dconv.k * dconv.k * 16 + 16);
-                    hipLaunchKernelGGL(f.kernel, dim3(n, op.nsplit), dim3(512), f.lds_bytes, s, a);
+                    if (op.tiny) hipLaunchKernelGGL(f.kernel_tiny, dim3(n, op.nsplit, 16 / kTinyRows), dim3(64 * kTinyRows * kTinyKSplit), f.lds_tiny, s, a);
+                    else hipLaunchKernelGGL(f.kernel, dim3(n, op.nsplit), dim3(512), f.lds_bytes, s, a);
+                } else if (op.tiny) {
+                    hipLaunchKernelGGL(f.kernel_tiny, dim3(n, 1, 16 / kTinyRows), dim3(64 * kTinyRows * kTinyKSplit), f.lds_tiny, s, a);
                 } else if (op.splitk) {
                     // several workgroups per crop, each over its own chunk range -> partial projections -> reduce
                     Ir2Args pa = a;
@@ -1579,6 +1611,10 @@ int fear_set_option(fear_handle* h, int option, int64_t value) {
             if (value != 0 && value != 1) return FEAR_ERR_SHAPE;
             if (h->tile_v4 != (int)value) { h->tile_v4 = (int)value; return drop_plans(h); }
             return FEAR_OK;
+        case FEAR_OPT_TINY_SEP:
+            if (value != 0 && value != 1) return FEAR_ERR_SHAPE;
+            if (h->tiny_sep != (int)value) { h->tiny_sep = (int)value; return drop_plans(h); }
+            return FEAR_OK;
         case FEAR_OPT_HEAD_STAGGER:
             if (value < 0 || value > 1000) return FEAR_ERR_SHAPE;
             h->head_stagger_us = (int)value;
@@ -1601,6 +1637,7 @@ int64_t fear_get_option(fear_handle* h, int option) {
         case FEAR_OPT_DUAL_HEAD: return h->dual_head;
         case FEAR_OPT_HEAD_STAGGER: return h->head_stagger_us;
         case FEAR_OPT_TILE_V4: return h->tile_v4;
+        case FEAR_OPT_TINY_SEP: return h->tiny_sep;
         default: return FEAR_ERR_SHAPE;
     }
 }

@@ -67,7 +67,11 @@ struct PwArgs {
     long w_crop_stride;  // ... this many floats after the previous one (the correlation and its gradients); 0: shared weights
 };
 
-template <int MT, int NT, bool WKN>
+// KU = k-groups (16 input channels each) whose operands are loaded together before their MFMAs are issued.  1 for the
+// throughput launches (the other workgroups of a CU hide the loads); 8 for the small-batch plans, where a launch is a
+// handful of workgroups alone on their CUs and every trip of the k loop otherwise costs one L2 / HBM round trip (the 256-channel
+// correlation at one crop: 16 trips, 14.7 us).  Same MFMAs in the same order: bit-identical results.
+template <int MT, int NT, bool WKN, int KU = 1>
 __global__ __launch_bounds__(256) void pw_mfma_kernel(PwArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -107,34 +111,41 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(PwArgs a) {
             nrow[nt] = nvalid[nt] ? n : (a.N - 1);
         }
 
-        for (int kg = 0; kg < a.K; kg += 16) {
-            const int k = kg + lk * 4;
-            const bool kvalid = k < a.K;   // K is a multiple of 4 (asserted on the host)
-            f32x4 xf[MT], wf[NT];
+        for (int kg0 = 0; kg0 < a.K; kg0 += 16 * KU) {
+            f32x4 xf[KU][MT], wf[KU][NT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                xf[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (kvalid) xf[mt] = *reinterpret_cast<const f32x4*>(xrow[mt] + k);
-            }
+            for (int u = 0; u < KU; ++u) {
+                const int k = kg0 + u * 16 + lk * 4;
+                const bool kvalid = k < a.K;   // K is a multiple of 4 (asserted on the host)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                wf[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (kvalid && nvalid[nt]) {
-                    if (WKN) {
-                        const float* p = Wp + (long)k * a.N + nrow[nt];
-                        wf[nt] = (f32x4){p[0], p[a.N], p[2 * a.N], p[3 * a.N]};
-                    } else {
-                        wf[nt] = *reinterpret_cast<const f32x4*>(Wp + (long)nrow[nt] * a.K + k);
+                for (int mt = 0; mt < MT; ++mt) {
+                    xf[u][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (kvalid) xf[u][mt] = *reinterpret_cast<const f32x4*>(xrow[mt] + k);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    wf[u][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (kvalid && nvalid[nt]) {
+                        if (WKN) {
+                            const float* p = Wp + (long)k * a.N + nrow[nt];
+                            wf[u][nt] = (f32x4){p[0], p[a.N], p[2 * a.N], p[3 * a.N]};
+                        } else {
+                            wf[u][nt] = *reinterpret_cast<const f32x4*>(Wp + (long)nrow[nt] * a.K + k);
+                        }
                     }
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int u = 0; u < KU; ++u) {
+                if (KU > 1 && kg0 + u * 16 >= a.K) break;      // (zero operands: nothing to add)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][i], xf[mt][i], acc[mt][nt], 0, 0, 0);
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u][nt][i], xf[u][mt][i], acc[mt][nt], 0, 0, 0);
+            }
         }
 
         // epilogue: lane holds channels n0 + 4*lk + {0..3} of pixel m0 + li
@@ -454,7 +465,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(SplitKReduceArgs a) 
     const long m = idx / q;
     const int n = (int)(idx - m * q) * 4;
     f32x4 v = *reinterpret_cast<const f32x4*>(a.bias + n);
-    for (int w = 0; w < a.W; ++w) v += *reinterpret_cast<const f32x4*>(a.P + w * a.part_stride + m * a.ldp + n);
+    // the partials are loaded a dozen at a time and added in order: a launch is a few thousand threads on an otherwise idle GPU,
+    // and one load per trip made every one of the 12-24 partials a full memory round trip (7-9 us per launch at one crop)
+    constexpr int UB = 12;
+    const float* p0 = a.P + m * a.ldp + n;
+    for (int w0 = 0; w0 < a.W; w0 += UB) {
+        f32x4 pv[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+            if (w0 + u < a.W) pv[u] = *reinterpret_cast<const f32x4*>(p0 + (long)(w0 + u) * a.part_stride);
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+            if (w0 + u < a.W) v += pv[u];
+    }
     if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
     if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = v;
@@ -1761,6 +1784,180 @@ __device__ __forceinline__ void static_for(F&& f) {
         f(std::integral_constant<int, B>{});
         static_for<B + 1, E>(f);
     }
+}
+
+// ================================================================================================
+// sep16 for a handful of crops (the batch-1 tracker): one 16-channel output slice of ROWS map rows per workgroup — the N-split
+// launch of sep16_kernel<CIN, 16, KS> cut once more, over rows — with one row per wave and nothing fetched inside the chunk loop.
+// At one crop a sep16_kernel<CIN, 16, KS> workgroup is ALONE on its CU and still does the whole depthwise of the crop
+// (CIN x 256 pixels, recomputed by each of the COUT/16 slices): 2 waves per SIMD x 2 rows x CIN/16 chunks of
+// [18 packed FMAs + 8 MFMAs + LDS round trip] = 10 us of instruction issue behind a 5 us launch, six launches in a row per
+// tower (profiles/r02_batch1_timeline.txt).  (Prefetching everything into registers / LDS first does not help — measured
+// 22.6 vs 18.6 us: the loop is issue-bound, not latency-bound.)  Cutting the map into 16 / ROWS row groups puts one row on a
+// SIMD: a fraction of the issue time per workgroup, 16 / ROWS times the workgroups (128 per layer and crop at ROWS = 2);
+// the ROWS + 2P input rows of a group are loaded once, before the loop (a 0.2 us interval cannot hide a global load), the
+// slice's packed weight set (CIN/16 x [1 fragment | Wd | bd], 26-33 KB) likewise.
+// Same arithmetic as sep16_kernel (bias, then taps kx outer / ky inner; projection chunk by chunk): with KSPLIT = 1 the outputs
+// are bit-identical to it; with KSPLIT wave groups the projection is summed per group and the groups added in order
+// (deterministic, 1e-6 from the single-group sum).
+template <int CIN, int KS, int ROWS, int KSPLIT = 1>
+struct Sep16TinyGeom {
+    static constexpr int S = 16, P = KS / 2, PW = S + 2 * P, PH = ROWS + 2 * P, NCHUNK = CIN / 16;
+    static constexpr int WPF = 256, WDF = KS * KS * 16 + 16, CST = WPF + WDF;
+    static constexpr int EP = 4, EQ = (PH * PW * 4 + 63) / 64 * 64;      // four planes (one per channel quad) of [pixel][4]
+    static constexpr int EBUF = 4 * EQ;
+    static constexpr int LDS_BYTES = (KSPLIT * 2 * EBUF + NCHUNK * CST) * 4;
+};
+
+// KSPLIT > 1: KSPLIT wave groups per workgroup, group kh running the input chunks [kh, kh + 1) * NCHUNK / KSPLIT on its own pair
+// of LDS tiles; the groups' projections are added in group order at the end (through LDS).
+template <int CIN, int KS, int ROWS, int KSPLIT = 1>
+__global__ __launch_bounds__(64 * ROWS * KSPLIT) void sep16_tiny_kernel(Ir2Args a) {
+    using G = Sep16TinyGeom<CIN, KS, ROWS, KSPLIT>;
+    constexpr int S = G::S, P = G::P, PW = G::PW, EP = G::EP, EQ = G::EQ, NCHUNK = G::NCHUNK / KSPLIT, NCHUNK_ALL = G::NCHUNK;
+    constexpr int WPF = G::WPF, CST = G::CST, EBUF = G::EBUF, NT = 64 * ROWS * KSPLIT;
+    static_assert(G::NCHUNK % KSPLIT == 0, "chunks per wave group");
+    constexpr int NS = KS * KS, D = 4, NU = 4;
+    constexpr int W4 = NCHUNK_ALL * CST / 4, NRW = (W4 + NT - 1) / NT;
+    static_assert(CIN % 16 == 0 && NCHUNK >= 2 && NS >= D && 16 % ROWS == 0 && 2 * P <= ROWS, "shape");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const WALL = lds + KSPLIT * 2 * EBUF;   // [NCHUNK_ALL][CST]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_all % ROWS, kh = wave_all / ROWS;
+    float* const Ebuf = lds + kh * 2 * EBUF;       // [2][EBUF] of this wave group
+    const int cg0 = kh * NCHUNK;                   // first input chunk of this wave group
+    const int li = lane & 15, lk = lane >> 4;
+    const long crop = blockIdx.x;
+    const float* Xc = a.X + crop * 256 * a.ldx;
+    const int r0 = blockIdx.z * ROWS;           // first output row of this workgroup; wave w computes row r0 + w
+    if (a.nsplit_wstride) {                     // N-split: this workgroup's 16-channel output slice
+        a.Wpk += (long)blockIdx.y * a.nsplit_wstride;
+        a.bp += blockIdx.y * 16;
+        a.Y += blockIdx.y * 16;
+        if (a.R) a.R += blockIdx.y * 16;
+    }
+    // the slice's weights: global -> registers -> LDS, all chunks at once
+    f32x4 rw[NRW];
+#pragma unroll
+    for (int r = 0; r < NRW; ++r) {
+        const int idx = tid + r * NT;
+        if (idx < W4) rw[r] = *reinterpret_cast<const f32x4*>(a.Wpk + (long)idx * 4);
+    }
+    // the tile rows this wave stages: slot = wave (input row r0 - P + wave) and, for the first 2P waves, slot = ROWS + wave
+    const int ya = r0 - P + wave, yb = r0 - P + ROWS + wave;
+    const bool has_a = ya >= 0 && ya < S, has_b = wave < 2 * P && yb < S;
+    f32x4 rx[NCHUNK][2];
+    static_for<0, NCHUNK>([&](auto C) {
+        constexpr int c = decltype(C)::value;
+        if (has_a) rx[c][0] = *reinterpret_cast<const f32x4*>(Xc + (long)(ya * S + li) * a.ldx + (cg0 + c) * 16 + lk * 4);
+        if (has_b) rx[c][1] = *reinterpret_cast<const f32x4*>(Xc + (long)(yb * S + li) * a.ldx + (cg0 + c) * 16 + lk * 4);
+    });
+    for (int i = tid * 4; i < KSPLIT * 2 * EBUF; i += NT * 4) *reinterpret_cast<f32x4*>(lds + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < NRW; ++r) {
+        const int idx = tid + r * NT;
+        if (idx < W4) *reinterpret_cast<f32x4*>(WALL + idx * 4) = rw[r];
+    }
+    __syncthreads();                            // zero fill and weights in place (rows outside the map are never written: zero)
+
+    auto store_x = [&](auto C) {
+        constexpr int c = decltype(C)::value;
+        float* E = Ebuf + (c & 1) * EBUF;
+        if (has_a) *reinterpret_cast<f32x4*>(E + (wave * PW + li + P) * EP + lk * EQ) = rx[c][0];
+        if (has_b) *reinterpret_cast<f32x4*>(E + ((ROWS + wave) * PW + li + P) * EP + lk * EQ) = rx[c][1];
+    };
+
+    f32x4 accp = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 d0;                           // depthwise result of the chunk being projected
+    // projection of chunk c (PROJ) dealt between the tap steps of the depthwise of chunk c + 1 (DW)
+    auto interval = [&](int c, auto proj_tag, auto dw_tag) {
+        constexpr bool PROJ = decltype(proj_tag)::value, DW = decltype(dw_tag)::value;
+        const int cd = PROJ ? c + 1 : c;
+        const float* wd = WALL + (cg0 + cd) * CST + WPF + lk * 4;
+        const float* e0 = Ebuf + (cd & 1) * EBUF + (wave * PW + li) * EP + lk * EQ;
+        f32x4 n0, ev[D], wv[D], wpq = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (PROJ) wpq = *reinterpret_cast<const f32x4*>(WALL + (cg0 + c) * CST + lane * 4);
+        if (DW) {
+            n0 = *reinterpret_cast<const f32x4*>(wd + KS * KS * 16);
+#pragma unroll
+            for (int t = 0; t < D; ++t) {
+                const int kx = t / KS, ky = t % KS;
+                ev[t] = *reinterpret_cast<const f32x4*>(e0 + (ky * PW + kx) * EP);
+                wv[t] = *reinterpret_cast<const f32x4*>(wd + (ky * KS + kx) * 16);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            f32x4 e, w;
+            if (DW) {
+                e = ev[t % D]; w = wv[t % D];
+                if (t + D < NS) {
+                    const int kx2 = (t + D) / KS, ky2 = (t + D) % KS;
+                    ev[t % D] = *reinterpret_cast<const f32x4*>(e0 + (ky2 * PW + kx2) * EP);
+                    wv[t % D] = *reinterpret_cast<const f32x4*>(wd + (ky2 * KS + kx2) * 16);
+                }
+            }
+            if (PROJ) {
+#pragma unroll
+                for (int u = t * NU / NS; u < (t + 1) * NU / NS; ++u)
+                    accp = __builtin_amdgcn_mfma_f32_16x16x4f32(wpq[u], d0[u], accp, 0, 0, 0);
+            }
+            if (DW) pk_fma4(n0, e, w);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (DW) {
+            f32x4 dummy = n0;
+            pk_fma_settle(n0, dummy);
+            if (a.relu_dw) { n0.x = fmaxf(n0.x, 0.f); n0.y = fmaxf(n0.y, 0.f); n0.z = fmaxf(n0.z, 0.f); n0.w = fmaxf(n0.w, 0.f); }
+            d0 = n0;
+        }
+    };
+
+    store_x(std::integral_constant<int, 0>{});
+    store_x(std::integral_constant<int, 1>{});
+    __syncthreads();
+    interval(0, std::false_type{}, std::true_type{});
+    __syncthreads();                            // E[0] is overwritten at the end of interval 0
+    static_for<0, NCHUNK>([&](auto C) {
+        constexpr int c = decltype(C)::value;
+        if constexpr (c + 1 < NCHUNK) interval(c, std::true_type{}, std::true_type{});
+        else interval(c, std::true_type{}, std::false_type{});
+        if constexpr (c + 2 < NCHUNK) store_x(std::integral_constant<int, c + 2>{});      // E[c & 1]: last read before the previous barrier
+        if constexpr (c + 1 < NCHUNK) __syncthreads();
+    });
+
+    if (KSPLIT > 1) {               // add the wave groups' projections up, in group order
+        __syncthreads();            // every tile has been read for the last time
+        f32x4* red = reinterpret_cast<f32x4*>(lds);
+        if (kh > 0) red[((kh - 1) * ROWS + wave) * 64 + lane] = accp;
+        __syncthreads();
+        if (kh > 0) return;
+#pragma unroll
+        for (int k = 1; k < KSPLIT; ++k) accp += red[((k - 1) * ROWS + wave) * 64 + lane];
+    }
+    const int px = (r0 + wave) * S + li;
+    if (a.pred_cout > 0) {          // prediction head: lanes lk == 0 hold channels 0..3 of their pixel
+        if (lk == 0) {
+            const float vals[4] = {accp.x, accp.y, accp.z, accp.w};
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                if (n < a.pred_cout) {
+                    float o = vals[n] + a.bp[n];
+                    if (a.pred_act == 2) o = expf(o);
+                    a.Y[crop * a.pred_stride + n * 256 + px] = o;
+                }
+            }
+        }
+        return;
+    }
+    const int n = lk * 4;
+    const long m = crop * 256 + px;
+    f32x4 v = accp + *reinterpret_cast<const f32x4*>(a.bp + n);
+    if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
+    if (a.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = v;
 }
 
 template <int CIN, int CEXPP, int COUT, int KS, int ST, int TW, int TH>

@@ -38,6 +38,7 @@ FEAR_OPT_PLAN_CROPS = 8
 FEAR_OPT_DUAL_HEAD = 9
 FEAR_OPT_HEAD_STAGGER = 10
 FEAR_OPT_TILE_V4 = 11
+FEAR_OPT_TINY_SEP = 12
 
 _lib = None
 
@@ -206,6 +207,10 @@ class FEARNetHIP:
         """Throughput plan: the phase-overlapped tile kernel for the blocks that have one (default on) vs ir_tile_v2 everywhere."""
         self._check(self._lib.fear_set_option(self._h, FEAR_OPT_TILE_V4, 1 if on else 0))
 
+
+    def set_tiny_sep(self, on: bool) -> None:
+        """A/B switch for the tiny plan's row-split SepConv slice kernel (FEAR_OPT_TINY_SEP, default on)."""
+        self._check(self._lib.fear_set_option(self._h, FEAR_OPT_TINY_SEP, 1 if on else 0))
     def set_head_stagger(self, microseconds: int) -> None:
         """Two head streams: hold the second branch back by this many microseconds (FEAR_OPT_HEAD_STAGGER)."""
         self._check(self._lib.fear_set_option(self._h, FEAR_OPT_HEAD_STAGGER, int(microseconds)))

@@ -367,6 +367,38 @@ def test_phase_overlapped_tile_kernel_matches_the_phased_one(hip_net, oracle_net
     assert rel_err(b1, ref["TARGET_REGRESSION_LABEL_KEY"]) < REL and rel_err(c1, ref["TARGET_CLASSIFICATION_KEY"]) < REL
 
 
+def test_tiny_plan_row_split_sepconv_slices(hip_net, oracle_net):
+    """FEAR_OPT_TINY_SEP: in the plan of <= 8 crops the head's 16-channel SepConv slices and the two prediction convs run
+    sep16_tiny_kernel (2 map rows per workgroup, one per wave, 4 wave groups over the input chunks; input rows and the slice's
+    weights loaded once) instead of sep16_kernel<CIN, 16, 3> (the whole map per workgroup): the same products, summed per wave
+    group — maps equal to fp32 summation-order noise for 1, 3 and 8 crops, bit-identical from call to call, equal to the oracle."""
+    from feartracker_amd import FEARNetHIP
+    from conftest import WEIGHTS
+    nets = {}
+    for on in (True, False):
+        nets[on] = FEARNetHIP(WEIGHTS, device=0, max_batch=8)
+        nets[on].set_tiny_sep(on)
+    nets[True].set_plan_crops(1)
+    nets[False].set_plan_crops(1)
+    names_on = [n for n, _, _ in nets[True].plan(256, True)]
+    assert names_on == [n for n, _, _ in nets[False].plan(256, True)]          # same ops, another kernel behind some of them
+    assert any("nsplit" in n for n in names_on) and any("pred16" in n for n in names_on)
+    g = torch.Generator().manual_seed(79)
+    x = norm_u8(torch.randint(0, 256, (8, 3, 256, 256), dtype=torch.uint8, generator=g))
+    z = hip_net.get_features(norm_u8(torch.randint(0, 256, (8, 3, 128, 128), dtype=torch.uint8, generator=g)).cuda())
+    for n in (1, 3, 8):
+        b1, c1 = nets[True].track_maps(x[:n].cuda(), z[:n])
+        b0, c0 = nets[False].track_maps(x[:n].cuda(), z[:n])
+        assert rel_err(b1, b0) < 1e-5 and rel_err(c1, c0) < 1e-5, n
+        b2, c2 = nets[True].track_maps(x[:n].cuda(), z[:n])
+        assert torch.equal(b1, b2) and torch.equal(c1, c2), n
+        # crop i of a pass of n == crop i alone (no cross-crop state in the row / chunk split)
+        bs, cs = nets[True].track_maps(x[n - 1:n].cuda(), z[n - 1:n])
+        assert torch.equal(bs[0], b1[n - 1]) and torch.equal(cs[0], c1[n - 1]), n
+    ref = oracle_net.track(x, z.cpu())
+    assert rel_err(b1, ref["TARGET_REGRESSION_LABEL_KEY"]) < REL and rel_err(c1, ref["TARGET_CLASSIFICATION_KEY"]) < REL
+
+
 def test_chain_kernel_matches_per_block_kernels(hip_net):
     """FEAR_OPT_CHAIN: the stride-16 trunk stage + neck as one register-resident chain kernel vs one fused kernel per
     block (same arithmetic, activations kept in registers between blocks)."""
