@@ -1348,8 +1348,11 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
                 dim3 grid((a.M + rows_per_block - 1) / rows_per_block);
                 int nt = pick_nt(op.N / 16);
                 if (op.pw_split) {
+                    // 16 rows per wave and the whole K = 256 in one batch of loads: 16 workgroups per crop, one memory round trip
+                    grid.x = (a.M + 63) / 64;
                     grid.y = op.N / 16;
-                    hipLaunchKernelGGL((pw_mfma_kernel<2, 1, true, 8>), grid, dim3(256), 0, s, a);
+                    if (a.K <= 256) hipLaunchKernelGGL((pw_mfma_kernel<1, 1, true, 16>), grid, dim3(256), 0, s, a);
+                    else hipLaunchKernelGGL((pw_mfma_kernel<1, 1, true, 8>), grid, dim3(256), 0, s, a);
                     break;
                 }
                 launch_pw_nt<2, true>(nt, grid, s, a);

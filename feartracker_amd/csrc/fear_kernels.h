@@ -989,14 +989,29 @@ __global__ __launch_bounds__(512) void ir16v2_fused_kernel(Ir2Args a) {
 #pragma unroll
         for (int nt = 0; nt < NTP; ++nt) accp[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // ---- prologue: stage A(0), A(1), BC(0); produce E[0]
+    // ---- prologue: stage A(0), A(1), BC(0); produce E[0].  A(1) is fetched together with A(0) into registers of its own: one
+    //      memory round trip before the first MFMA instead of two (a split-K workgroup at one crop runs 1-2 chunks in all)
+    f32x4 ra1[EXPAND ? NRA : 1];
     load_a(0);
     load_b(0);
+    if (EXPAND && NCHUNK > 1) {
+#pragma unroll
+        for (int r = 0; r < NRA; ++r) {
+            const int idx = tid + r * 512;
+            if (idx < AP4) ra1[r] = *reinterpret_cast<const f32x4*>(Wpk + (long)CST + idx * 4);
+        }
+    }
     __syncthreads();                       // zero fill done before the first E / stage writes
     store_a(0);
     store_b(0);
     if (EXPAND) {
-        if (NCHUNK > 1) { load_a(1); store_a(1); }
+        if (NCHUNK > 1) {
+#pragma unroll
+            for (int r = 0; r < NRA; ++r) {
+                const int idx = tid + r * 512;
+                if (idx < AP4) *reinterpret_cast<f32x4*>(WA + AP + idx * 4) = ra1[r];
+            }
+        }
         __syncthreads();
         phase_a(0);
     }
