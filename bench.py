@@ -497,6 +497,17 @@ def latency_batch1(weights, frames_cap: int = 120):
               "frame_bytes": int(big[0].nbytes), "mean_context_pixels": ctx_px // (len(big) - 1),
               "uploaded": "frame ∩ context rectangle per update (not the 6.2 MB frame)"}
     del big
+    # the network alone: one search crop + resident template features per fear_track call, calls back to back on one stream
+    xs = torch.randn(1, 3, 256, 256, device="cuda")
+    zs = net.get_features(torch.randn(1, 3, 128, 128, device="cuda"))
+    for _ in range(50):
+        net.track_maps(xs, zs)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(500):
+        net.track_maps(xs, zs)
+    sync()
+    track_call_ms = 1e3 * (time.perf_counter() - t0) / 500
     from oracle.fear_oracle import OracleNet  # CPU baseline leg only
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     ncpu = min(len(frames), 41)
@@ -506,6 +517,7 @@ def latency_batch1(weights, frames_cap: int = 120):
     return {"unit": "ms/frame", "frames": len(frames) - 1, "frame_shape": list(frames[0].shape), "clip": "tests/clipgen.demo_clip "
             "(480x256, init box [163,53,45,174]; assets/test.mp4 not decodable here: no H.264 decoder)",
             "host_crop_path": host_ms, "device_crop_and_postprocess": dev_ms, "device_path_1920x1080": hd,
+            "track_call_batch1_ms": track_call_ms, "track_call_plan_ops": len(net.plan(256, True)),
             "device_boxes_identical_to_host_path": bool(np.array_equal(dev_boxes, host_boxes)),
             "cpu_oracle_tracker": dict(cpu_ms, frames=ncpu - 1, threads=torch.get_num_threads()),
             "boxes_identical_to_cpu_oracle": bool(np.array_equal(host_boxes[:ncpu - 1], cpu_boxes))}

@@ -1172,13 +1172,13 @@ int ensure_workspace(fear_handle* h, const Plan& p) {
 template <int MT, bool WKN>
 void launch_pw_nt(int nt, dim3 grid, hipStream_t s, const PwArgs& a) {
     switch (nt) {
-        case 1: hipLaunchKernelGGL((pw_mfma_kernel<MT, 1, WKN>), grid, dim3(256), 0, s, a); break;
-        case 2: hipLaunchKernelGGL((pw_mfma_kernel<MT, 2, WKN>), grid, dim3(256), 0, s, a); break;
-        case 3: hipLaunchKernelGGL((pw_mfma_kernel<MT, 3, WKN>), grid, dim3(256), 0, s, a); break;
-        case 4: hipLaunchKernelGGL((pw_mfma_kernel<MT, 4, WKN>), grid, dim3(256), 0, s, a); break;
-        case 6: hipLaunchKernelGGL((pw_mfma_kernel<MT, 6, WKN>), grid, dim3(256), 0, s, a); break;
-        case 7: hipLaunchKernelGGL((pw_mfma_kernel<MT, 7, WKN>), grid, dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL((pw_mfma_kernel<MT, 8, WKN>), grid, dim3(256), 0, s, a); break;
+        case 1: hipLaunchKernelGGL((pw_mfma_kernel<MT, 1, WKN, FEAR_PW_KU(1)>), grid, dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((pw_mfma_kernel<MT, 2, WKN, FEAR_PW_KU(2)>), grid, dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL((pw_mfma_kernel<MT, 3, WKN, FEAR_PW_KU(3)>), grid, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((pw_mfma_kernel<MT, 4, WKN, FEAR_PW_KU(4)>), grid, dim3(256), 0, s, a); break;
+        case 6: hipLaunchKernelGGL((pw_mfma_kernel<MT, 6, WKN, FEAR_PW_KU(6)>), grid, dim3(256), 0, s, a); break;
+        case 7: hipLaunchKernelGGL((pw_mfma_kernel<MT, 7, WKN, FEAR_PW_KU(7)>), grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((pw_mfma_kernel<MT, 8, WKN, FEAR_PW_KU(8)>), grid, dim3(256), 0, s, a); break;
     }
 }
 

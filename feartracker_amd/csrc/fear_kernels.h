@@ -67,6 +67,12 @@ struct PwArgs {
     long w_crop_stride;  // ... this many floats after the previous one (the correlation and its gradients); 0: shared weights
 };
 
+#ifndef FEAR_PW_KU
+#define FEAR_PW_KU(NT) ((NT) <= FEAR_PW_KU_NT ? 2 : 1)   // KU of the throughput / training launches of pw_mfma_kernel<MT, NT, ..>
+#endif
+#ifndef FEAR_PW_KU_NT
+#define FEAR_PW_KU_NT 4
+#endif
 // KU = k-groups (16 input channels each) whose operands are loaded together before their MFMAs are issued.  1 for the
 // throughput launches (the other workgroups of a CU hide the loads); 8 for the small-batch plans, where a launch is a
 // handful of workgroups alone on their CUs and every trip of the k loop otherwise costs one L2 / HBM round trip (the 256-channel

@@ -779,13 +779,13 @@ int train_pick_nt(int n_tiles) {
 template <bool WKN>
 void launch_pw(int nt, dim3 grid, hipStream_t s, const PwArgs& a) {
     switch (nt) {
-        case 1: hipLaunchKernelGGL((pw_mfma_kernel<2, 1, WKN>), grid, dim3(256), 0, s, a); break;
-        case 2: hipLaunchKernelGGL((pw_mfma_kernel<2, 2, WKN>), grid, dim3(256), 0, s, a); break;
-        case 3: hipLaunchKernelGGL((pw_mfma_kernel<2, 3, WKN>), grid, dim3(256), 0, s, a); break;
-        case 4: hipLaunchKernelGGL((pw_mfma_kernel<2, 4, WKN>), grid, dim3(256), 0, s, a); break;
-        case 6: hipLaunchKernelGGL((pw_mfma_kernel<2, 6, WKN>), grid, dim3(256), 0, s, a); break;
-        case 7: hipLaunchKernelGGL((pw_mfma_kernel<2, 7, WKN>), grid, dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL((pw_mfma_kernel<2, 8, WKN>), grid, dim3(256), 0, s, a); break;
+        case 1: hipLaunchKernelGGL((pw_mfma_kernel<2, 1, WKN, FEAR_PW_KU(1)>), grid, dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((pw_mfma_kernel<2, 2, WKN, FEAR_PW_KU(2)>), grid, dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL((pw_mfma_kernel<2, 3, WKN, FEAR_PW_KU(3)>), grid, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((pw_mfma_kernel<2, 4, WKN, FEAR_PW_KU(4)>), grid, dim3(256), 0, s, a); break;
+        case 6: hipLaunchKernelGGL((pw_mfma_kernel<2, 6, WKN, FEAR_PW_KU(6)>), grid, dim3(256), 0, s, a); break;
+        case 7: hipLaunchKernelGGL((pw_mfma_kernel<2, 7, WKN, FEAR_PW_KU(7)>), grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((pw_mfma_kernel<2, 8, WKN, FEAR_PW_KU(8)>), grid, dim3(256), 0, s, a); break;
     }
 }
 
