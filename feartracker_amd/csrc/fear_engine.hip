@@ -1646,7 +1646,12 @@ int64_t fear_get_option(fear_handle* h, int option) {
 }
 
 // the plan a pass of nb crops runs on (build_plan's mode)
-constexpr int kTinyPass = 8;
+// ms per track call (profiles/r03_plan_sweep.txt), crops: tiny plan 1: 0.30  4: 0.34  8: 0.40  12: 0.50  16: 0.59  24: 0.78  32: 0.95
+//                                                          small plan 1: 0.53  4: 0.54  8: 0.56  12: 0.59  16: 0.61  24: 0.68  32: 0.75
+#ifndef FEAR_TINY_PASS
+#define FEAR_TINY_PASS 16
+#endif
+constexpr int kTinyPass = FEAR_TINY_PASS;
 static int small_pass(const fear_handle* h, int nb) { return h->fuse && nb <= h->small_pass ? (nb <= kTinyPass ? 2 : 1) : 0; }
 
 // the plan fear_plan_* / fear_profile_read describe: that of a pass of FEAR_OPT_PLAN_CROPS crops (default: a full pass)

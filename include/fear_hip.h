@@ -119,7 +119,7 @@ int fear_crop_normalize(fear_handle* h, const uint8_t* frame_u8, int frame_h, in
                                /*   (fp32 mode); 0: one fused kernel per block                                 */
 #define FEAR_OPT_SMALL_PASS 7  /* passes of at most this many crops (default 96; 0 = never) run the small-batch plan:      */
                                /*   several workgroups per crop in the 16x16 kernels (split over channel chunks, partial   */
-                               /*   sums reduced afterwards), the head's two branches on two streams; passes of <= 8 crops  */
+                               /*   sums reduced afterwards), the head's two branches on two streams; passes of <= 16 crops */
                                /*   run a third plan (one chunk per workgroup, the head's SepConvs as 16-channel output     */
                                /*   slices without partial sums, 16x8 tiles split over their expansion chunks)             */
 #define FEAR_OPT_PLAN_CROPS 8  /* crop count whose launch plan fear_plan_size / fear_plan_op / fear_profile_read describe (a    */
@@ -133,7 +133,7 @@ int fear_crop_normalize(fear_handle* h, const uint8_t* frame_u8, int frame_h, in
 #define FEAR_OPT_TILE_V4 11    /* 1 (default): the throughput plan runs the blocks listed in the engine's kFusedTileV4 (stage 6) on the   */
                                /*   phase-overlapped tile kernel (depthwise taps of chunk c interleaved with the expansion MFMAs of      */
                                /*   chunk c + 1); 0: every tiled block on ir_tile_v2 (A/B)                                              */
-#define FEAR_OPT_TINY_SEP 12   /* 1 (default): in the plan of a handful of crops (<= 8) the head's 16-channel SepConv slices and the      */
+#define FEAR_OPT_TINY_SEP 12   /* 1 (default): in the plan of a handful of crops (<= 16) the head's 16-channel SepConv slices and the      */
                                /*   prediction convs run sep16_tiny_kernel (the map cut into row groups as well, one row per wave: 4x the */
                                /*   workgroups, a quarter of the instruction issue per workgroup); 0: sep16_kernel<CIN, 16, KS> (A/B)     */
 int fear_set_option(fear_handle* h, int option, int64_t value);

@@ -368,7 +368,7 @@ def test_phase_overlapped_tile_kernel_matches_the_phased_one(hip_net, oracle_net
 
 
 def test_tiny_plan_row_split_sepconv_slices(hip_net, oracle_net):
-    """FEAR_OPT_TINY_SEP: in the plan of <= 8 crops the head's 16-channel SepConv slices and the two prediction convs run
+    """FEAR_OPT_TINY_SEP: in the plan of <= 16 crops the head's 16-channel SepConv slices and the two prediction convs run
     sep16_tiny_kernel (2 map rows per workgroup, one per wave, 4 wave groups over the input chunks; input rows and the slice's
     weights loaded once) instead of sep16_kernel<CIN, 16, 3> (the whole map per workgroup): the same products, summed per wave
     group — maps equal to fp32 summation-order noise for 1, 3 and 8 crops, bit-identical from call to call, equal to the oracle."""
@@ -511,14 +511,14 @@ def test_small_batch_plan_vs_oracle_and_clip(oracle_net, golden_dir):
     for _ in range(20):                      # the two streams and the partial-sum scratch must not race
         b2, c2 = net.track_maps(x.cuda(), net.get_features(t.cuda()))
         assert torch.equal(b, b2) and torch.equal(c, c2)
-    # 9..96 crops: the small-batch plan proper (split-K head, 16x16 / 16x8 tiles); the <= 8-crop pass above ran the tiny plan
+    # 17..96 crops: the small-batch plan proper (split-K head, 16x16 / 16x8 tiles); the <= 16-crop pass above ran the tiny plan
     # (N-split head slices, 16x8 tiles everywhere)
-    net12 = FEARNetHIP(WEIGHTS, device=0, max_batch=12)
+    net12 = FEARNetHIP(WEIGHTS, device=0, max_batch=20)
     names12 = [n for n, _, _ in net12.plan(256, True)]
     assert any("sep16_splitk" in n for n in names12) and not any("nsplit" in n for n in names12)
     assert any("sep16_nsplit" in n for n, _, _ in net.plan(256, True))
-    x12 = norm_u8(torch.randint(0, 256, (12, 3, 256, 256), dtype=torch.uint8, generator=g))
-    t12 = norm_u8(torch.randint(0, 256, (12, 3, 128, 128), dtype=torch.uint8, generator=g))
+    x12 = norm_u8(torch.randint(0, 256, (20, 3, 256, 256), dtype=torch.uint8, generator=g))
+    t12 = norm_u8(torch.randint(0, 256, (20, 3, 128, 128), dtype=torch.uint8, generator=g))
     ref12 = oracle_net.track(x12, oracle_net.get_features(t12))
     b12, c12 = net12.track_maps(x12.cuda(), net12.get_features(t12.cuda()))
     assert_maps_close(b12, c12, ref12["TARGET_REGRESSION_LABEL_KEY"], ref12["TARGET_CLASSIFICATION_KEY"])
