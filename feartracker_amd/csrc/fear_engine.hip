@@ -1182,6 +1182,21 @@ void launch_pw_nt(int nt, dim3 grid, hipStream_t s, const PwArgs& a) {
     }
 }
 
+// FEAR_OPT_MATH = 1 / 2: the same GEMM on the matrix pipe (pw_h_kernel); 4, 2 or 1 channel tiles per pass
+template <bool WKN>
+void launch_pw_h(int math, int n_tiles, dim3 grid, hipStream_t s, const PwArgs& a) {
+    const int nt = n_tiles % 4 == 0 ? 4 : n_tiles % 2 == 0 ? 2 : 1;
+    if (math == 2) {
+        if (nt == 4) hipLaunchKernelGGL((pw_h_kernel<2, 4, WKN, 2>), grid, dim3(256), 0, s, a);
+        else if (nt == 2) hipLaunchKernelGGL((pw_h_kernel<2, 2, WKN, 2>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((pw_h_kernel<2, 1, WKN, 2>), grid, dim3(256), 0, s, a);
+    } else {
+        if (nt == 4) hipLaunchKernelGGL((pw_h_kernel<2, 4, WKN, 1>), grid, dim3(256), 0, s, a);
+        else if (nt == 2) hipLaunchKernelGGL((pw_h_kernel<2, 2, WKN, 1>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((pw_h_kernel<2, 1, WKN, 1>), grid, dim3(256), 0, s, a);
+    }
+}
+
 // channel tiles per pass: the largest of {8,7,6,4,3,2,1} that divides the tile count
 int pick_nt(int n_tiles) {
     for (int nt : {8, 7, 6, 4, 3, 2, 1})
@@ -1333,7 +1348,8 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
                     hipLaunchKernelGGL((pw_mfma_kernel<2, 2, false, 8>), grid, dim3(256), 0, s, a);
                     break;
                 }
-                launch_pw_nt<2, false>(nt, grid, s, a);
+                if (h->math && p.with_head) launch_pw_h<false>(h->math, n_tiles, grid, s, a);   // (the template branch's features stay fp32)
+                else launch_pw_nt<2, false>(nt, grid, s, a);
                 break;
             }
             case OP_CORR: {
@@ -1355,7 +1371,8 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
                     else hipLaunchKernelGGL((pw_mfma_kernel<1, 1, true, 8>), grid, dim3(256), 0, s, a);
                     break;
                 }
-                launch_pw_nt<2, true>(nt, grid, s, a);
+                if (h->math) launch_pw_h<true>(h->math, op.N / 16, grid, s, a);
+                else launch_pw_nt<2, true>(nt, grid, s, a);
                 break;
             }
             case OP_DW: {

@@ -2263,6 +2263,12 @@ template <> struct MatOps<1> {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, hi, acc, 0, 0, 0);
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(w, lo, acc, 0, 0, 0);
     }
+    // both operands are activations (the correlation): (whi + wlo)(xhi + xlo) without the lo x lo term (2^-22 relative)
+    static __device__ __forceinline__ f32x4 mma2(const V& whi, const V& wlo, const V& hi, const V& lo, f32x4 acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, hi, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, lo, acc, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, hi, acc, 0, 0, 0);
+    }
 };
 template <> struct MatOps<2> {
     using V = bf8;
@@ -2273,7 +2279,112 @@ template <> struct MatOps<2> {
     static __device__ __forceinline__ f32x4 mma(const V& w, const V& hi, const V&, f32x4 acc) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, hi, acc, 0, 0, 0);
     }
+    static __device__ __forceinline__ f32x4 mma2(const V& whi, const V&, const V& hi, const V&, f32x4 acc) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, hi, acc, 0, 0, 0);
+    }
 };
+
+// ------------------------------------------------------------------------------------------------
+// pw_mfma_kernel's GEMM (the neck, the pixel-wise correlation, any pointwise conv without a fused block) on the matrix pipe
+// for FEAR_OPT_MATH = 1 / 2: same workgroup tiling and epilogue, k in groups of 32 (lane (li, lk) holds 8 consecutive input
+// channels of its pixel / output channel), MatOps arithmetic — MM = 1: activations as fp16 hi + lo against the exact-fp16
+// weights (two MFMAs), and for the correlation (WKN: the "weights" are the crop's template features, activations too) both
+// operands split, three MFMAs; MM = 2: both operands rounded to bf16, one MFMA.  fp32 accumulate, fp32 epilogue.
+// In those modes the fp32 kernel was 9 % of the fp16-split step and 6 % of the bf16 FEAR-M step for 1.2 % of the FLOPs.
+template <int MT, int NT, bool WKN, int MM>
+__global__ __launch_bounds__(256) void pw_h_kernel(PwArgs a) {
+    using MX = MatOps<MM>;
+    using V8 = typename MX::V;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int li = lane & 15;
+    const int lk = lane >> 4;
+    const int m_wave = (blockIdx.x * 4 + wave) * (MT * 16);
+    if (m_wave >= a.M) return;
+    const float* Wp = a.W;
+    if (a.rows_per_crop > 0) Wp += (long)(m_wave / a.rows_per_crop) * a.w_crop_stride;   // per-crop weight matrices
+    const float* xrow[MT];
+    bool mvalid[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int m = m_wave + mt * 16 + li;
+        mvalid[mt] = m < a.M;
+        if (m >= a.M) m = a.M - 1;
+        xrow[mt] = a.X + (long)m * a.ldx;
+    }
+    const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int n_tiles = (a.N + 15) >> 4;
+    for (int nc = blockIdx.y * NT; nc < n_tiles; nc += NT * gridDim.y) {
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = zero;
+        int nrow[NT];
+        bool nvalid[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = (nc + nt) * 16 + li;
+            nvalid[nt] = n < a.N;
+            nrow[nt] = nvalid[nt] ? n : (a.N - 1);
+        }
+#pragma unroll 2
+        for (int kg = 0; kg < a.K; kg += 32) {
+            const int k = kg + lk * 8;
+            const bool k0v = k < a.K, k1v = k + 4 < a.K;           // K is a multiple of 4
+            V8 xhi[MT], xlo[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const f32x4 v0 = k0v ? *reinterpret_cast<const f32x4*>(xrow[mt] + k) : zero;
+                const f32x4 v1 = k1v ? *reinterpret_cast<const f32x4*>(xrow[mt] + k + 4) : zero;
+                MX::split(v0, v1, xhi[mt], xlo[mt]);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 w0 = zero, w1 = zero;
+                if (nvalid[nt]) {
+                    if (WKN) {
+                        const float* p = Wp + (long)k * a.N + nrow[nt];
+                        if (k0v) w0 = (f32x4){p[0], p[a.N], p[2 * a.N], p[3 * a.N]};
+                        if (k1v) w1 = (f32x4){p[4 * (long)a.N], p[5 * (long)a.N], p[6 * (long)a.N], p[7 * (long)a.N]};
+                    } else {
+                        const float* p = Wp + (long)nrow[nt] * a.K + k;
+                        if (k0v) w0 = *reinterpret_cast<const f32x4*>(p);
+                        if (k1v) w1 = *reinterpret_cast<const f32x4*>(p + 4);
+                    }
+                }
+                V8 whi, wlo;
+                MX::split(w0, w1, whi, wlo);      // conv weights are exact fp16 numbers: their lo half is zero (MM = 1) / unused (MM = 2)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt][nt] = WKN ? MX::mma2(whi, wlo, xhi[mt], xlo[mt], acc[mt][nt]) : MX::mma(whi, xhi[mt], xlo[mt], acc[mt][nt]);
+            }
+        }
+        // epilogue: lane holds channels n0 + 4*lk + {0..3} of pixel m0 + li
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = (nc + nt) * 16 + lk * 4;
+            if (n >= a.N) continue;   // N is a multiple of 4
+            f32x4 b = zero;
+            if (a.bias) b = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if (!mvalid[mt]) continue;
+                const long m = m_wave + mt * 16 + li;
+                f32x4 v = acc[mt][nt] + b;
+                if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
+                if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (a.nchw_hw > 0) {
+                    const long crop = m / a.nchw_hw, px = m % a.nchw_hw;
+                    float* y = a.Y + (crop * a.N + n) * a.nchw_hw + px;
+                    y[0] = v.x; y[a.nchw_hw] = v.y; y[2 * (long)a.nchw_hw] = v.z; y[3 * (long)a.nchw_hw] = v.w;
+                } else {
+                    *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = v;
+                }
+            }
+        }
+    }
+}
 
 template <int CIN, int CEXP, int COUT, int KS, bool EXPAND, int MM = 1>
 __global__ __launch_bounds__(512) void ir16h_fused_kernel(Ir2Args a) {

@@ -748,7 +748,7 @@ def test_fear_m_synthetic_deeper_trunk_all_math_modes():
     engine is weight-file driven: every block must land on a fused kernel; fp32 and the fp16-split mode must match the
     oracle on the same file at the path's 1e-3; the bf16 mode (FEAR_OPT_MATH=2: operands rounded to 8 mantissa bits, fp32
     accumulate) is reduced precision by construction — its stated tolerance against the fp32 path is 8e-2 relative on the
-    ltrb maps and 0.15 absolute on the logits (measured 2.7e-2 / 5.4e-2), and it must keep the arg-max cell wherever the
+    ltrb maps and 0.15 absolute on the logits (measured 2.5e-2 / 7.2e-2), and it must keep the arg-max cell wherever the
     fp32 top-2 logit margin exceeds twice the observed logit deviation."""
     from feartracker_amd import FEARNetHIP
     from feartracker_amd.hip_backend import WEIGHTS_FEAR_M
