@@ -387,6 +387,101 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs a) {
         }
 }
 
+// pw_wgrad_kernel for K <= 32 input channels (the stem and every expansion / e1 projection of the 128x128 and 64x64 maps: the
+// layers with the MOST rows).  The 64 x 64 tile pads K = 16 four times over on the matrix instructions — those launches ran at
+// the MFMA rate of their padding, not at the HBM rate of their bytes (0.13 of it in the bench line's roofline).  Here the tile is
+// 64 (n) x 16 KB (k): the B operand of MFMA (p, b) is ONE float per lane, X[m + lk][16 b + li], so a launch issues
+// 4 KB instead of 16 MFMAs per four rows.  Rows are dealt to the waves and the partial tiles added exactly as in
+// pw_wgrad_kernel — every dW element sees the same products in the same order: the results are bit-identical.
+template <int KB>
+__global__ __launch_bounds__(256) void pw_wgrad_smallk_kernel(WgradArgs a) {
+    __shared__ f32x4 red[2][4 * KB * 64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int nt = blockIdx.x, slice = blockIdx.y, crop = blockIdx.z;
+    const int n4 = nt * 64 + li * 4;
+    const bool nv = n4 < a.N;
+    const float* dy = a.dY + (long)crop * a.dy_crop_stride + (nv ? n4 : 0);
+    bool kv[KB];
+    const float* x[KB];
+#pragma unroll
+    for (int b = 0; b < KB; ++b) {
+        kv[b] = b * 16 + li < a.K;
+        x[b] = a.X + (long)crop * a.x_crop_stride + (kv[b] ? b * 16 + li : 0);
+    }
+    f32x4 acc[4][KB];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int b = 0; b < KB; ++b) acc[p][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const long m0 = (long)slice * a.rows_per_slice;
+    const long m1 = m0 + a.rows_per_slice < a.M ? m0 + a.rows_per_slice : a.M;
+    const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool act = a.act_a != nullptr;
+    float ia[KB], ib[KB];
+#pragma unroll
+    for (int b = 0; b < KB; ++b) {
+        ia[b] = act && kv[b] ? a.act_a[b * 16 + li] : 0.f;
+        ib[b] = act && kv[b] ? a.act_b[b * 16 + li] : 0.f;
+    }
+    for (long m = m0 + wave * 16; m < m1; m += 64) {
+        f32x4 dv[4];
+        float xs[4][KB];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long r = m + u * 4 + lk;
+            const bool rv = r < m1;
+            dv[u] = rv && nv ? *reinterpret_cast<const f32x4*>(dy + r * a.lddy) : zero;
+#pragma unroll
+            for (int b = 0; b < KB; ++b) {
+                float v = rv && kv[b] ? x[b][r * a.ldx] : 0.f;
+                if (act && rv && kv[b]) {
+                    v = __builtin_fmaf(v, ia[b], ib[b]);
+                    if (a.act_relu) v = fmaxf(v, 0.f);
+                }
+                xs[u][b] = v;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int b = 0; b < KB; ++b) acc[p][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[u][p], xs[u][b], acc[p][b], 0, 0, 0);
+    }
+    // (w0 + w2) + (w1 + w3), fixed order
+    if (wave >= 2) {
+#pragma unroll
+        for (int i = 0; i < 4 * KB; ++i) red[wave - 2][i * 64 + lane] = acc[i / KB][i % KB];
+    }
+    __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+        for (int i = 0; i < 4 * KB; ++i) acc[i / KB][i % KB] += red[wave][i * 64 + lane];
+    }
+    __syncthreads();
+    if (wave == 1) {
+#pragma unroll
+        for (int i = 0; i < 4 * KB; ++i) red[0][i * 64 + lane] = acc[i / KB][i % KB];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int i = 0; i < 4 * KB; ++i) acc[i / KB][i % KB] += red[0][i * 64 + lane];
+    // acc[p][b] lane (li, lk), component r  =  dW[nt*64 + 16 lk + 4 r + p][16 b + li]
+    float* P = a.P + (((long)slice * a.crops + crop) * a.N) * a.K;
+#pragma unroll
+    for (int b = 0; b < KB; ++b) {
+        if (!kv[b]) continue;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int nn = nt * 64 + lk * 16 + r * 4 + p;
+                if (nn < a.N) P[(long)nn * a.K + b * 16 + li] = acc[p][b][r];
+            }
+    }
+}
+
 // out[i] = sum over slices of P[s][i], fixed order (i over crops*N*K): `lanes` threads per float4 (lane l adds slices l, l+lanes,
 // ... in order, then the lane sums are added in lane order); lanes = 1 for a handful of slices, 16 for the long reductions
 __global__ __launch_bounds__(256) void slice_sum_kernel(const float* P, float* out, long count, int slices, int lanes) {
@@ -804,6 +899,9 @@ int col_blocks(long M) { const int r = col_rows_per_block(M); return (int)((M + 
 #ifndef FEAR_WGRAD_ROWS
 #define FEAR_WGRAD_ROWS 1024
 #endif
+#ifndef FEAR_WGRAD_SMALLK
+#define FEAR_WGRAD_SMALLK 1   // 0: every weight gradient on the 64 x 64 tile kernel (A/B)
+#endif
 long wgrad_rows_per_slice(long M) {
     long r = FEAR_WGRAD_ROWS;
     while ((M + r - 1) / r > 256) r *= 2;
@@ -1147,7 +1245,9 @@ static int wgrad_impl(const float* dy, int lddy, long dy_crop_stride, const floa
         if (!workspace || ws_bytes < need) return FEAR_TRAIN_ERR_WORKSPACE;
         a.P = workspace;
     }
-    hipLaunchKernelGGL(pw_wgrad_kernel, dim3(a.n_tiles * a.k_tiles, slices, crops), dim3(256), 0, s, a);
+    if (FEAR_WGRAD_SMALLK && K <= 16) hipLaunchKernelGGL(pw_wgrad_smallk_kernel<1>, dim3(a.n_tiles, slices, crops), dim3(256), 0, s, a);
+    else if (FEAR_WGRAD_SMALLK && K <= 32) hipLaunchKernelGGL(pw_wgrad_smallk_kernel<2>, dim3(a.n_tiles, slices, crops), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(pw_wgrad_kernel, dim3(a.n_tiles * a.k_tiles, slices, crops), dim3(256), 0, s, a);
     if (slices > 1) {
         const long count = (long)crops * N * K;
         launch_slice_sum(workspace, dw, count, slices, s);

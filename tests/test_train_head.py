@@ -130,7 +130,9 @@ def test_training_operators_individually_vs_torch():
     g = torch.Generator().manual_seed(3)
     ws = torch.empty(lib.fear_train_workspace_bytes(4096, 320) // 4 + 1024, device=dev)
     wsb = ws.numel() * 4
-    for M, K, N in ((1000, 320, 256), (2304, 256, 4), (130, 64, 112)):
+    # (K <= 32 takes pw_wgrad_smallk_kernel: 16 / 28 / 24 / 32 input channels, ragged row counts, several row slices)
+    for M, K, N in ((1000, 320, 256), (2304, 256, 4), (130, 64, 112), (5000, 16, 96), (3001, 28, 16), (70000, 16, 16), (2050, 24, 144),
+                    (1111, 32, 192), (9, 4, 8)):
         x, w, dy = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.1, torch.randn(M, N, generator=g)
         b = torch.randn(N, generator=g)
         xd, wd, dyd, bd = x.to(dev), w.to(dev), dy.to(dev), b.to(dev)
@@ -453,6 +455,12 @@ def test_fused_conv_bn_operators_individually_vs_torch():
     dw = torch.empty(N, K, device=dev)
     assert lib.fear_pw_backward_weight_act(_p(D(dy)), N, _p(D(x)), K, _p(D(a)), _p(D(b)), 1, _p(dw), _p(ws), wsb, M, K, N, None) == 0
     _close(dw, dy.t() @ act(x, a, b, 1), "pw wgrad act", 2e-5)
+    for M, K, N, relu in ((4100, 16, 96, 1), (3000, 24, 144, 0), (2500, 32, 64, 1)):      # the K <= 32 kernel applies it per scalar
+        x, dy = torch.randn(M, K, generator=g), torch.randn(M, N, generator=g)
+        a, b = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.3
+        dw = torch.empty(N, K, device=dev)
+        assert lib.fear_pw_backward_weight_act(_p(D(dy)), N, _p(D(x)), K, _p(D(a)), _p(D(b)), relu, _p(dw), _p(ws), wsb, M, K, N, None) == 0
+        _close(dw, dy.t() @ act(x, a, b, relu), f"pw wgrad act K={K}", 2e-5)
     for B, H, C, k, st_ in ((2, 16, 96, 3, 2), (2, 8, 64, 5, 1), (3, 12, 32, 3, 1)):
         x = torch.randn(B, C, H, H, generator=g)
         a, b = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
