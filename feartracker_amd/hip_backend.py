@@ -113,9 +113,14 @@ class FearError(RuntimeError):
 def context_rectangle(frame_h: int, frame_w: int, ctx_xywh: np.ndarray) -> Tuple[int, int, int, int]:
     """(x0, y0, x1, y1): the part of an H x W frame that context boxes (n, 4) int xywh can sample — their union clipped to the
     frame; when nothing of the frame is visible one pixel keeps the shapes legal (every sample is border colour then anyway)."""
-    ctx = np.asarray(ctx_xywh, dtype=np.int64).reshape(-1, 4)
+    ctx = np.asarray(ctx_xywh).reshape(-1, 4)
     x0 = y0 = x1 = y1 = 0
-    if ctx.shape[0]:
+    if ctx.shape[0] == 1:                                   # the tracker's case: plain integers
+        cx, cy, cw, ch = (int(v) for v in ctx[0])
+        x0, y0 = min(max(cx, 0), frame_w), min(max(cy, 0), frame_h)
+        x1, y1 = min(max(cx + cw, x0), frame_w), min(max(cy + ch, y0), frame_h)
+    elif ctx.shape[0]:
+        ctx = ctx.astype(np.int64)
         x0 = int(np.clip(ctx[:, 0].min(), 0, frame_w))
         y0 = int(np.clip(ctx[:, 1].min(), 0, frame_h))
         x1 = int(np.clip((ctx[:, 0] + ctx[:, 2]).max(), x0, frame_w))
@@ -317,6 +322,24 @@ class FEARNetHIP:
     __call__ = forward
 
     # ------------------------------------------------------------------ device-side helpers
+    def _decode_outputs(self, n: int):
+        """The three outputs of the decode kernels as views of ONE device buffer [xywh f64 (n,4) | rc i32 (n,2) | score f32 (n)],
+        so that a caller who wants them on the host fetches 44 bytes per crop in one transfer (`decoded_to_host`)."""
+        buf = torch.empty(n * 44 + 4, dtype=torch.uint8, device=self.device)
+        xywh = buf[: n * 32].view(torch.float64).view(n, 4)
+        rc = buf[n * 32: n * 40].view(torch.int32).view(n, 2)
+        score = buf[n * 40: n * 44].view(torch.float32)
+        return buf, rc, xywh, score
+
+    @staticmethod
+    def decoded_to_host(rc: torch.Tensor, xywh: torch.Tensor, score: torch.Tensor):
+        """(rc, xywh, score) of `decode` / `decode_smooth` as numpy arrays with ONE device-to-host copy (they are views of one
+        buffer; three `.cpu()` calls would be three synchronising transfers)."""
+        n = xywh.shape[0]
+        host = torch.empty(0, dtype=torch.uint8, device=xywh.device).set_(xywh.untyped_storage(), xywh.storage_offset() * 8, (n * 44,)).cpu().numpy()
+        return (host[n * 32: n * 40].view(np.int32).reshape(n, 2), host[: n * 32].view(np.float64).reshape(n, 4),
+                host[n * 40: n * 44].view(np.float32))
+
     @torch.no_grad()
     def decode(self, cls: torch.Tensor, bbox: torch.Tensor, score_size: int = 16, total_stride: int = 16,
                instance_size: int = 256):
@@ -325,9 +348,7 @@ class FEARNetHIP:
         cls = self._prep(cls, "cls")
         bbox = self._prep(bbox, "bbox")
         n = cls.shape[0]
-        rc = torch.empty((n, 2), dtype=torch.int32, device=self.device)
-        xywh = torch.empty((n, 4), dtype=torch.float64, device=self.device)
-        score = torch.empty((n,), dtype=torch.float32, device=self.device)
+        _, rc, xywh, score = self._decode_outputs(n)
         with torch.cuda.device(self.device):
             self._check(self._lib.fear_decode(self._h, cls.data_ptr(), bbox.data_ptr(), n, score_size, total_stride,
                                               instance_size, rc.data_ptr(), xywh.data_ptr(), score.data_ptr(),
@@ -347,9 +368,7 @@ class FEARNetHIP:
         win = torch.as_tensor(window, dtype=torch.float64).reshape(-1).to(self.device).contiguous()
         if prev.shape[0] != n or win.numel() != score_size * score_size:
             raise ValueError("prev_size must be (N,2) and window (score_size, score_size)")
-        rc = torch.empty((n, 2), dtype=torch.int32, device=self.device)
-        xywh = torch.empty((n, 4), dtype=torch.float64, device=self.device)
-        score = torch.empty((n,), dtype=torch.float32, device=self.device)
+        _, rc, xywh, score = self._decode_outputs(n)
         with torch.cuda.device(self.device):
             self._check(self._lib.fear_decode_smooth(self._h, cls.data_ptr(), bbox.data_ptr(), n, score_size, total_stride,
                                                      instance_size, prev.data_ptr(), win.data_ptr(), float(penalty_k),
@@ -391,29 +410,36 @@ class FEARNetHIP:
         n = ctx_np.shape[0]
         if pad_np.shape[0] != n:
             raise ValueError("one border colour per context box")
+        meta_bytes = (n * 16 + n * 3 + 15) // 16 * 16                       # [n x 4 int32 boxes | n x 3 uint8 colours], 16-byte padded
         if is_np or not frame_u8.is_cuda:
+            # ONE transfer: [meta | the context rectangle of the frame] assembled in one host buffer (a reused pinned staging
+            # buffer was tried — ADVICE r1 — and measured 10x SLOWER per frame on the 256-core host: torch's CPU->pinned copy_
+            # costs milliseconds there; a plain pageable .to() of a fresh small array does not)
             fh, fw = int(frame_u8.shape[0]), int(frame_u8.shape[1])
             x0, y0, x1, y1 = context_rectangle(fh, fw, ctx_np)
             if (x1 - x0, y1 - y0) != (fw, fh):
-                frame_u8 = frame_u8[y0:y1, x0:x1]
                 ctx_np = ctx_np.copy()
                 ctx_np[:, 0] -= x0
                 ctx_np[:, 1] -= y0
-            # (one plain .to(): a reused pinned staging buffer was tried — ADVICE r1 — and measured 10x SLOWER per frame on
-            # the 256-core host, torch's CPU->pinned copy_ costs milliseconds there)
-            if is_np:
-                frame_u8 = torch.from_numpy(np.ascontiguousarray(frame_u8))
-            frame_u8 = frame_u8.contiguous().to(self.device)
+            rh, rw = y1 - y0, x1 - x0
+            host = np.empty(meta_bytes + rh * rw * 3, dtype=np.uint8)
+            host[: n * 16] = ctx_np.view(np.uint8).reshape(-1)
+            host[n * 16: n * 16 + n * 3] = pad_np.reshape(-1)
+            roi = frame_u8[y0:y1, x0:x1]
+            host[meta_bytes:].reshape(rh, rw, 3)[...] = roi if is_np else roi.numpy()    # (numpy copies any strides, also negative ones)
+            dev = torch.from_numpy(host).to(self.device)
+            meta_ptr, frame_ptr = dev.data_ptr(), dev.data_ptr() + meta_bytes
         else:
             frame_u8 = frame_u8.to(self.device).contiguous()
-        meta = np.zeros(n * 16 + (n * 3 + 3) // 4 * 4, dtype=np.uint8)      # [n x 4 int32 boxes | n x 3 uint8 colours]
-        meta[: n * 16] = ctx_np.view(np.uint8).reshape(-1)
-        meta[n * 16: n * 16 + n * 3] = pad_np.reshape(-1)
-        meta_d = torch.from_numpy(meta).to(self.device)
+            rh, rw = int(frame_u8.shape[0]), int(frame_u8.shape[1])
+            meta = np.zeros(meta_bytes, dtype=np.uint8)
+            meta[: n * 16] = ctx_np.view(np.uint8).reshape(-1)
+            meta[n * 16: n * 16 + n * 3] = pad_np.reshape(-1)
+            dev = torch.from_numpy(meta).to(self.device)
+            meta_ptr, frame_ptr = dev.data_ptr(), frame_u8.data_ptr()
         out = torch.empty((n, 3, out_hw, out_hw), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            self._check(self._lib.fear_crop_normalize(self._h, frame_u8.data_ptr(), frame_u8.shape[0], frame_u8.shape[1],
-                                                      meta_d.data_ptr(), meta_d.data_ptr() + n * 16, n, int(out_hw),
+            self._check(self._lib.fear_crop_normalize(self._h, frame_ptr, rh, rw, meta_ptr, meta_ptr + n * 16, n, int(out_hw),
                                                       out.data_ptr(), self._stream()))
         return out
 
