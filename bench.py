@@ -578,6 +578,7 @@ def main() -> None:
     ap.add_argument("--head-stagger", type=int, default=int(os.environ.get("FEAR_HEAD_STAGGER", "-1")),
                     help="A/B: microseconds the head's second branch is held back behind the first (two streams); -1 = the engine's default")
     ap.add_argument("--no-tile-v4", action="store_true", help="A/B: every tiled block on ir_tile_v2 (no phase-overlapped kernel)")
+    ap.add_argument("--no-head-chain", action="store_true", help="A/B: the BoxTower as eight sep16 launches instead of one headchain launch")
     ap.add_argument("--no-chain", action="store_true", help="A/B: one fused kernel per stride-16 block instead of the chain kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-math", action="store_true",
@@ -660,6 +661,8 @@ def main() -> None:
         net.set_head_stagger(args.head_stagger)
     if args.no_tile_v4:
         net.set_tile_v4(False)
+    if args.no_head_chain:
+        net.set_head_chain(False)
     search_u8, tmpl_u8 = synth_batch(B, rank)
     search = norm_u8(search_u8.to(dev)).contiguous()
     tmpl_feats = net.get_features(norm_u8(tmpl_u8.to(dev)).contiguous())

@@ -20,6 +20,7 @@
 #include "../../include/fear_hip.h"
 #include "../../include/fearw_format.h"
 #include "fear_kernels.h"
+#include "fear_headchain.h"
 
 namespace {
 
@@ -92,7 +93,7 @@ struct Conv {
     bool is_pw() const { return groups == 1 && k == 1; }
 };
 
-enum OpType { OP_STEM, OP_PW, OP_DW, OP_CORR, OP_PW_SMALL, OP_IR16, OP_IRTILE, OP_CHAIN16 };
+enum OpType { OP_STEM, OP_PW, OP_DW, OP_CORR, OP_PW_SMALL, OP_IR16, OP_IRTILE, OP_CHAIN16, OP_HEADCHAIN };
 
 struct Op {
     OpType type;
@@ -130,6 +131,14 @@ struct Op {
     int chain_cp[8] = {0};
     float* neck_pk = nullptr;
     int neck_conv = -1;
+    // OP_HEADCHAIN (headchain_kernel): per branch (0 = classification, 1 = regression) the pass-major weights of its four SepConvs,
+    // the depthwise weights of the first layer and of the correlation chunks, the packed prediction SepConv and its pointwise conv
+    float* hc_w[2][4] = {{nullptr}};
+    float* hc_wd0[2] = {nullptr};
+    float* hc_wdc[2] = {nullptr};
+    float* hc_pred[2] = {nullptr};
+    int hc_pred_conv[2] = {-1, -1};
+    int hc_pred_act[2] = {0, 0};
     char name[64];
     double flops = 0, bytes = 0;  // per crop: algorithmic FLOPs, compulsory bytes (in + out + weights excluded)
     // profiling
@@ -163,6 +172,7 @@ struct fear_handle {
     int tiny_sep = 1;      // FEAR_OPT_TINY_SEP: 1 = the tiny plan's 16-channel SepConv slices run sep16_tiny_kernel
     int tile_v4 = 1;       // FEAR_OPT_TILE_V4: 1 = phase-overlapped tile kernel for the blocks of kFusedTileV4 (throughput plan)
     int chain = 1;         // 1: run the stride-16 trunk stage as one register-resident chain kernel (fp32 mode)
+    int head_chain = 1;    // FEAR_OPT_HEAD_CHAIN: 1 = the whole BoxTower as one launch (headchain_kernel; fp32 mode, throughput plan)
     int small_pass = 96;   // passes of at most this many crops run the small-batch plan (FEAR_OPT_SMALL_PASS; 0: never);
                            // measured crossover with the throughput plan: ~110 crops (1.70 vs 1.93 ms at 96, 2.14 vs 2.01 at 128)
     int math = 0;          // 0: fp32 MFMA everywhere; 1: fp16-split operands on the matrix pipe in the fused 16x16 blocks
@@ -516,7 +526,7 @@ int find_fused16(int cin, int cexp, int cout, int ks, int expand) {
 // Pack the weights of one fused 16x16 block per 16-channel chunk in the order ir16v2_fused_kernel stages them:
 //   [A-part: KG fragments x 256 | be[16]] [BC-part: NTP fragments x 256 | Wd[k*k][16] | bd[16]]
 // (fragment lane l holds W[row0 + (l&15)][col0 + 4*(l>>4) + 0..3]).
-int pack_fused16(fear_handle* h, int ce, int cd, int cp, float** out) {
+std::vector<float> pack_fused16_host(const fear_handle* h, int ce, int cd, int cp) {
     const Conv& d = h->convs[cd];
     const Conv& p = h->convs[cp];
     const Conv* e = ce >= 0 ? &h->convs[ce] : nullptr;
@@ -550,8 +560,10 @@ int pack_fused16(fear_handle* h, int ce, int cd, int cp, float** out) {
             for (int ch = 0; ch < 16; ++ch) buf.push_back(c0 + ch < cexp ? d.w[(size_t)(c0 + ch) * kk + t] : 0.f);
         for (int ch = 0; ch < 16; ++ch) buf.push_back(d.has_bias && c0 + ch < cexp ? d.b[c0 + ch] : 0.f);
     }
-    return upload(h, buf, out);
+    return buf;
 }
+
+int pack_fused16(fear_handle* h, int ce, int cd, int cp, float** out) { return upload(h, pack_fused16_host(h, ce, cd, cp), out); }
 
 
 // N-split packing of a SepConv (Ir2Args::nsplit_wstride): one weight set per 16-channel output slice, each in the layout
@@ -626,6 +638,10 @@ auto* const kChainXSKernel =
                    ChainBlk<112, 336, 112, 5, true>, kChainNeckOut>;
 constexpr int kChainXSLds =
     Chain16Lds<5, Ir2Geom<112, 672, 112, 5, true>::AP, Ir2Geom<112, 672, 112, 5, true>::BP>::FLOATS * 4;
+
+// the whole BoxTower as one launch (fear_headchain.h): 3x3 SepConvs, 256 channels, 64 template positions
+auto* const kHeadChainKernel = headchain_kernel<3>;
+using HeadChainG = HeadChainGeom<3>;
 
 // neck weights as MFMA fragments [nt][kg][lane][4] (lane l: W[nt*16 + (l&15)][kg*16 + 4*(l>>4) + 0..3])
 int pack_neck_frags(fear_handle* h, int conv, float** out) {
@@ -1125,6 +1141,71 @@ int build_plan_uncached(fear_handle* h, int hw, bool with_head, int mode, Plan**
         // planned on buffers of its own and run_plan puts it on a second stream next to the cls branch.
         // The throughput plan does the same when FEAR_OPT_DUAL_HEAD is on (off by default): a sep16 workgroup needs 77 KB of LDS and
         // 116 VGPRs, so one workgroup of each branch fits on a CU at the same time — measured: no gain, the kernels are ALU-bound.
+        // ---- the throughput plan in fp32: both branches, all eight SepConvs + correlations + prediction heads in ONE launch
+        auto head_chain = [&]() -> bool {
+            if (!h->head_chain || !h->fuse || h->math || small || S != 16 || feat.C != HeadChainG::C || bbox_tower.size() != 2 ||
+                cls_tower.size() != 2)
+                return false;
+            Op op{};
+            op.type = OP_HEADCHAIN;
+            double fl = 0;
+            for (int br = 0; br < 2; ++br) {
+                const bool is_cls = br == 0;
+                const FearwBlock* seq[4] = {role[is_cls ? FEARW_CLS_ENCODE : FEARW_REG_ENCODE], role[is_cls ? FEARW_CLS_CORR : FEARW_REG_CORR],
+                                            (is_cls ? cls_tower : bbox_tower)[0], (is_cls ? cls_tower : bbox_tower)[1]};
+                const FearwBlock* pred = role[is_cls ? FEARW_CLS_PRED : FEARW_BBOX_PRED];
+                std::vector<float> sep[4];
+                for (int l = 0; l < 4; ++l) {
+                    const Conv& d = h->convs[seq[l]->conv[0]];
+                    const Conv& pw = h->convs[seq[l]->conv[1]];
+                    const int cin = l == 1 ? HeadChainG::CC : HeadChainG::C;
+                    // SepConv + BN + ReLU: depthwise 3x3 s1 without activation, pointwise to 256 with bias and ReLU
+                    if (!d.is_dw() || !pw.is_pw() || d.k != 3 || d.stride != 1 || d.cout != cin || d.relu || pw.cin_g != cin ||
+                        pw.cout != HeadChainG::C || !pw.has_bias || !pw.relu)
+                        return false;
+                    sep[l] = pack_fused16_host(h, -1, seq[l]->conv[0], seq[l]->conv[1]);
+                    fl += 2.0 * 256 * ((double)cin * 9 + (double)cin * HeadChainG::C);
+                }
+                const Conv& pd = h->convs[pred->conv[0]];
+                const Conv& pp = h->convs[pred->conv[1]];
+                if (!pd.is_dw() || !pp.is_pw() || pd.k != 3 || pd.stride != 1 || pd.cout != HeadChainG::C || pd.relu ||
+                    pp.cin_g != HeadChainG::C || pp.cout != (is_cls ? 1 : 4) || !pp.has_bias)
+                    return false;
+                for (int l = 0; l < 4; ++l) {
+                    const Conv& pw = h->convs[seq[l]->conv[1]];
+                    if (upload(h, headchain_pack(sep[l].data(), l == 1 ? HeadChainG::CC : HeadChainG::C, pw.b.data(),
+                                                 l < 3 ? sep[l + 1].data() : nullptr, 3), &op.hc_w[br][l]) != FEAR_OK)
+                        return false;
+                }
+                if (upload(h, headchain_pack_dw(sep[0].data(), 0, HeadChainG::C / 16, 3), &op.hc_wd0[br]) != FEAR_OK ||
+                    upload(h, headchain_pack_dw(sep[1].data(), HeadChainG::C / 16, HeadChainG::TZ / 16, 3), &op.hc_wdc[br]) != FEAR_OK ||
+                    pack_fused16(h, -1, pred->conv[0], pred->conv[1], &op.hc_pred[br]) != FEAR_OK)
+                    return false;
+                op.hc_pred_conv[br] = pred->conv[1];
+                op.hc_pred_act[br] = pred->act;
+                fl += 2.0 * 256 * ((double)HeadChainG::C * HeadChainG::TZ + (double)HeadChainG::C * 9 + (double)HeadChainG::C * pp.cout);
+            }
+            op.in_buf = feat.buf; op.in_ld = feat.ld; op.in_off = feat.off;
+            op.H = S; op.W = S; op.Ho = S; op.Wo = S; op.C = feat.C; op.N = 5;
+            op.relu_dw = 0; op.relu = 1;
+            // scratch of the depthwise results, both branches of a crop side by side
+            op.out_buf = pool.acquire();
+            if ((size_t)2 * HeadChainG::D_FLOATS > max_elems) max_elems = (size_t)2 * HeadChainG::D_FLOATS;
+            snprintf(op.name, sizeof(op.name), "headchain_boxtower_%dx%d", feat.C, tz);
+            op.flops = fl;
+            op.bytes = 4.0 * (S * S * feat.C + 2.0 * feat.C * tz + 5.0 * S * S);
+            ops.push_back(op);
+            pool.release(op.out_buf);
+            return true;
+        };
+        if (head_chain()) {
+            pool.release(feat.buf);
+            plan->n_bufs = pool.count;
+            plan->buf_floats_per_crop = (max_elems + 63) & ~(size_t)63;
+            *out = plan.get();
+            h->plans[key] = std::move(plan);
+            return FEAR_OK;
+        }
         const bool dual = small || (h->dual_head && h->fuse && !h->math);
         const size_t head_first = ops.size();
         pool.hold = dual;
@@ -1272,6 +1353,8 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kSep16CorrLds));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kChainXSKernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kChainXSLds));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kHeadChainKernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, HeadChainG::LDS_BYTES));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kStemTile.kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kStemTile.lds_bytes));
         h->fused_attr_set = true;
@@ -1477,6 +1560,25 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
                 hipLaunchKernelGGL(kChainXSKernel, dim3(n), dim3(512), kChainXSLds, s, a);
                 break;
             }
+            case OP_HEADCHAIN: {
+                HeadChainArgs a{};
+                a.X = buf(op.in_buf) + op.in_off; a.ldx = op.in_ld; a.n_crops = n;
+                a.relu_dw = op.relu_dw; a.relu_out = op.relu;
+                for (int br = 0; br < 2; ++br) {
+                    HeadChainBranch& b = a.br[br];
+                    for (int l = 0; l < 4; ++l) b.W[l] = op.hc_w[br][l];
+                    b.Wd0 = op.hc_wd0[br]; b.WdC = op.hc_wdc[br];
+                    b.Z = (br == 0 && ext.tmpl_cls) ? ext.tmpl_cls : ext.tmpl;
+                    b.z_stride = (long)HeadChainG::C * HeadChainG::TZ;
+                    b.P_Wpk = op.hc_pred[br]; b.P_bp = h->convs[op.hc_pred_conv[br]].d_b;
+                    b.P_Y = br == 0 ? ext.cls_out : ext.bbox_out;
+                    b.pred_stride = br == 0 ? ext.cls_stride : ext.bbox_stride;
+                    b.pred_cout = br == 0 ? 1 : 4; b.pred_act = op.hc_pred_act[br];
+                    b.D = buf(op.out_buf) + (size_t)br * n * HeadChainG::D_FLOATS;
+                }
+                hipLaunchKernelGGL(kHeadChainKernel, dim3(16u * ((unsigned)(n + 7) / 8)), dim3(512), HeadChainG::LDS_BYTES, s, a);
+                break;
+            }
             case OP_PW_SMALL: {
                 PwSmallArgs a{};
                 a.X = buf(op.in_buf); a.ldx = op.in_ld; a.W = c->d_w; a.bias = c->d_b;
@@ -1639,6 +1741,10 @@ int fear_set_option(fear_handle* h, int option, int64_t value) {
             if (value < 0 || value > 1000) return FEAR_ERR_SHAPE;
             h->head_stagger_us = (int)value;
             return FEAR_OK;
+        case FEAR_OPT_HEAD_CHAIN:
+            if (value != 0 && value != 1) return FEAR_ERR_SHAPE;
+            if (h->head_chain != (int)value) { h->head_chain = (int)value; return drop_plans(h); }
+            return FEAR_OK;
         default: return FEAR_ERR_SHAPE;
     }
 }
@@ -1658,6 +1764,7 @@ int64_t fear_get_option(fear_handle* h, int option) {
         case FEAR_OPT_HEAD_STAGGER: return h->head_stagger_us;
         case FEAR_OPT_TILE_V4: return h->tile_v4;
         case FEAR_OPT_TINY_SEP: return h->tiny_sep;
+        case FEAR_OPT_HEAD_CHAIN: return h->head_chain;
         default: return FEAR_ERR_SHAPE;
     }
 }

@@ -39,6 +39,7 @@ FEAR_OPT_DUAL_HEAD = 9
 FEAR_OPT_HEAD_STAGGER = 10
 FEAR_OPT_TILE_V4 = 11
 FEAR_OPT_TINY_SEP = 12
+FEAR_OPT_HEAD_CHAIN = 13
 
 _lib = None
 
@@ -207,6 +208,11 @@ class FEARNetHIP:
     def set_dual_head(self, on: bool) -> None:
         """Throughput plan: the head's two branches on two streams (default) vs one."""
         self._check(self._lib.fear_set_option(self._h, FEAR_OPT_DUAL_HEAD, 1 if on else 0))
+
+    def set_head_chain(self, on: bool) -> None:
+        """A/B switch for the one-launch BoxTower (FEAR_OPT_HEAD_CHAIN, default on; fp32 mode, throughput plan): off = the eight
+        sep16 launches it replaces.  The maps are bit-identical either way."""
+        self._check(self._lib.fear_set_option(self._h, FEAR_OPT_HEAD_CHAIN, 1 if on else 0))
 
     def set_tile_v4(self, on: bool) -> None:
         """Throughput plan: the phase-overlapped tile kernel for the blocks that have one (default on) vs ir_tile_v2 everywhere."""

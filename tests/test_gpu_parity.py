@@ -428,6 +428,44 @@ def test_chain_kernel_matches_per_block_kernels(hip_net):
     assert rel_err(b2, b0) < 1e-5 and rel_err(c2, c0) < 1e-5
 
 
+def test_head_chain_matches_the_eight_sepconv_launches_bit_for_bit(oracle_net):
+    """FEAR_OPT_HEAD_CHAIN: the whole BoxTower (both branches: encode + correlation, correlation SepConv, two tower SepConvs,
+    prediction SepConv — model/blocks.py:129-194) as ONE launch whose activations never leave the CU, vs the eight sep16 launches.
+    Same products in the same order: the maps must be IDENTICAL, for ragged crop counts (the launch deals workgroups in groups of
+    8 crops x 2 branches), with a separate classification template (the `update=` path) and against the oracle."""
+    from feartracker_amd import FEARNetHIP
+    from conftest import WEIGHTS
+    one = FEARNetHIP(WEIGHTS, device=0, max_batch=64)
+    one.set_small_pass(0)
+    eight = FEARNetHIP(WEIGHTS, device=0, max_batch=64)
+    eight.set_small_pass(0)
+    eight.set_head_chain(False)
+    names_one = [n for n, _, _ in one.plan(256, True)]
+    names_eight = [n for n, _, _ in eight.plan(256, True)]
+    assert sum(n.startswith("headchain") for n in names_one) == 1 and not any(n.startswith("sep16") for n in names_one)
+    assert sum(n.startswith("sep16") for n in names_eight) == 8 and len(names_eight) == len(names_one) + 7
+    g = torch.Generator().manual_seed(77)
+    for n in (1, 7, 8, 9, 21, 64, 70):                         # 70 > max_batch: two engine passes
+        x = norm_u8(torch.randint(0, 256, (n, 3, 256, 256), dtype=torch.uint8, generator=g)).cuda()
+        t = norm_u8(torch.randint(0, 256, (n, 3, 128, 128), dtype=torch.uint8, generator=g)).cuda()
+        z = one.get_features(t)
+        b1, c1 = one.track_maps(x, z)
+        b8, c8 = eight.track_maps(x, z)
+        assert torch.equal(b1, b8) and torch.equal(c1, c8), n
+        if n in (7, 21):
+            zc = one.get_features(torch.flip(t, dims=(0,)))    # another classification template per crop
+            b1, c1 = one.track_maps(x, z, update=zc)
+            b8, c8 = eight.track_maps(x, z, update=zc)
+            assert torch.equal(b1, b8) and torch.equal(c1, c8), n
+            assert not torch.equal(c1, one.track_maps(x, z)[1])
+        if n == 9:
+            ref = oracle_net.track(x.cpu(), z.cpu())
+            assert_maps_close(b1, c1, ref["TARGET_REGRESSION_LABEL_KEY"], ref["TARGET_CLASSIFICATION_KEY"])
+    # twice in a row on the same handle (the scratch of the depthwise results is reused): identical
+    b2, c2 = one.track_maps(x, z)
+    assert torch.equal(b2, b1) and torch.equal(c2, c1)
+
+
 def test_device_smooth_postprocess_matches_reference_fixture_and_host(hip_net, golden_dir):
     """fear_decode_smooth vs (a) the reference's own smooth=True result (tests/golden/postprocess.npz, generated by
     importing the reference tracker) and (b) the host restatement on a seeded batch with per-crop previous sizes."""
