@@ -28,7 +28,7 @@
 namespace fear {
 
 struct HeadChainBranch {
-    const float* W[4];       // per layer: pass-major packed weights (headchain_pack): 8 x [NC x 2 fragments | bias 32 | next layer's dw 2 x 160]
+    const float* W[4];       // per layer: pass-major packed weights (headchain_pack): 8 x [NC x 2 fragments | bias 32 | next layer's dw 4 x 160]
     const float* Wd0;        // layer 0's own depthwise weights, 16 chunks x [Wd[k*k][16] | bd[16]]
     const float* WdC;        // layer 1's depthwise weights of the four correlation chunks (16..19)
     const float* Z;          // template features [crop][256][64] (the caller's NCHW (256, 8, 8) tensor)
@@ -60,7 +60,7 @@ struct HeadChainGeom {
     static constexpr int EQ = (PW * PW * 4 + 63) / 64 * 64, EBUF = 4 * EQ;      // the four-plane tile of Sep16Geom, one chunk
     static constexpr int NPASS = 8, NTP = 2;                                    // 8 passes x 2 output tiles
     static constexpr int WDF = KS * KS * 16 + 16;                               // depthwise taps + bias of one chunk
-    static constexpr int wpass(int cin) { return (cin / 16) * NTP * 256 + NTP * 16 + NTP * WDF; }
+    static constexpr int wpass(int cin) { return (cin / 16) * NTP * 256 + NTP * 16 + 2 * NTP * WDF; }
     static constexpr int WMAX = wpass(CC);
     static constexpr int PCH = 256 + WDF;                                       // prediction head, per chunk
     static constexpr int ZS = NTP * 16 * TZ;                                    // template slice of one pass
@@ -81,8 +81,8 @@ inline std::vector<float> headchain_pack(const float* sep_this, int cin, const f
         for (int c = 0; c < nc; ++c)
             for (int nt = 2 * p; nt < 2 * p + 2; ++nt) out.insert(out.end(), sep_this + (size_t)c * cst + nt * 256, sep_this + (size_t)c * cst + nt * 256 + 256);
         out.insert(out.end(), bias256 + 32 * p, bias256 + 32 * p + 32);
-        for (int c = 2 * p; c < 2 * p + 2; ++c) {
-            if (sep_next) out.insert(out.end(), sep_next + (size_t)c * cst + 16 * 256, sep_next + (size_t)c * cst + 16 * 256 + wdf);
+        for (int c = 2 * p - 2; c < 2 * p + 2; ++c) {      // this pass deals with the hand-over of the previous one (and, in the last pass, its own)
+            if (sep_next && c >= 0) out.insert(out.end(), sep_next + (size_t)c * cst + 16 * 256, sep_next + (size_t)c * cst + 16 * 256 + wdf);
             else out.insert(out.end(), wdf, 0.f);
         }
     }
@@ -99,6 +99,7 @@ inline std::vector<float> headchain_pack_dw(const float* sep, int c0, int n, int
 template <int KS>
 __global__ __launch_bounds__(512) void headchain_kernel(HeadChainArgs a) {
     using G = HeadChainGeom<KS>;
+    using std::integral_constant;
     constexpr int C = G::C, TZ = G::TZ, CC = G::CC, S = G::S, P = G::P, PW = G::PW, EP = 4, EQ = G::EQ, EBUF = G::EBUF;
     constexpr int NPASS = G::NPASS, NTP = G::NTP, WDF = G::WDF, WMAX = G::WMAX, PCH = G::PCH, ZS = G::ZS;
     constexpr int NS = KS * (KS + 1), RA = 4;
@@ -230,8 +231,35 @@ __global__ __launch_bounds__(512) void headchain_kernel(HeadChainArgs a) {
             if ((HC_ABL & 128) && MODE == 0 && CIN == C && p >= 2 && p < 5 && crop == 100 && branch == 0 && lane == 0 && fs_i < 21)
                 a.dbg[80 + wave * 21 + fs_i++] = __builtin_amdgcn_s_memtime();
         };
-        auto pass = [&](int p, auto last_tag) {
-            constexpr bool LAST = decltype(last_tag)::value;
+        // The hand-over of pass q (its 32 finished channels = the NEXT layer's input chunks 2q, 2q + 1 are in the tile): the next layer's
+        // depthwise of those chunks -> the scratch (DST < 0) or straight into d[DST], d[DST + 1]; layer 3: the prediction head instead.
+        auto handoff_out = [&](int q, int nt, const f32x4& n0, const f32x4& n1, auto dst_tag) {
+            constexpr int DST = decltype(dst_tag)::value;
+            if (MODE != 2) {
+                if (DST < 0) { *dptr(2 * q + nt, 0) = n0; *dptr(2 * q + nt, 1) = n1; }
+                else { d[DST < 0 ? 0 : DST][0] = n0; d[DST < 0 ? 0 : DST][1] = n1; }
+            } else {
+                // prediction SepConv's 1x1 to <= 4 channels on the depthwise of the finished chunk
+                const f32x4 wq = *reinterpret_cast<const f32x4*>(Zr + (long)(2 * q + nt) * PCH + lane * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    pacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[i], n0[i], pacc[0], 0, 0, 0);
+                    pacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[i], n1[i], pacc[1], 0, 0, 0);
+                }
+            }
+        };
+        // taps + bias of the depthwise that runs on pass q's chunk nt (layer 3: the prediction head's, resident in Zr)
+        auto handoff_wd = [&](int q, int nt, const float* wdw) { return MODE == 2 ? Zr + (long)(2 * q + nt) * PCH + 256 : wdw + nt * WDF; };
+        // One pass.  HAND: the hand-over of the PREVIOUS pass is dealt, one tap step per MFMA group, into this pass's GEMM — on its own
+        // it is LDS-bound (44 tile / tap reads per wave and chunk against 36 packed FMAs) and nothing else can run beside it: a wave
+        // that streams MFMAs keeps the SIMD's ALU to itself, whatever the other wave's priority (measured: s_setprio does not help),
+        // so latencies hide only behind the issuing wave's OWN MFMAs.  Barrier B (every wave has read the tile) therefore sits at
+        // the END of the pass, right in front of the tile's next writes, barrier A (tile complete, next weight block landed) behind them.
+        auto pass = [&](int p, auto last_tag, auto hand_tag) {
+            constexpr bool LAST = decltype(last_tag)::value, HAND = decltype(hand_tag)::value;
+            constexpr int DWOFF = NC * NTP * 256 + NTP * 16;     // block: fragments | bias | dw taps of the next layer's chunks 2p-2 .. 2p+1
+            constexpr int NG = NC * NTP;                         // MFMA groups (8 MFMAs each)
+            static_assert(NG >= 2 * (NS + 2), "the deferred hand-over needs one group per tap step");
             fstamp(p);
             // ---- asynchronous copies for the NEXT pass (their buffers were last read before the previous barrier)
             if (!LAST) lds_copy_async<WP>(Wl + (long)(p + 1) * WP, Wb + ((p + 1) & 1) * WMAX, wave, lane);
@@ -250,19 +278,52 @@ __global__ __launch_bounds__(512) void headchain_kernel(HeadChainArgs a) {
             f32x4 wf[3];
             wf[0] = *reinterpret_cast<const f32x4*>(wb + lane * 4);
             wf[1] = *reinterpret_cast<const f32x4*>(wb + 256 + lane * 4);
-            if (HC_ABL & 128) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); fstamp(p); }
+            // state of the deferred depthwise: tap step t of chunk h is dealt to group h * (NS + 2) + 1 + t; its LDS reads are issued
+            // one group (8 MFMAs, ~260 cycles) ahead
+            // (operands in rotating registers — he[t & 1], hw[t % 3] — so that a step neither copies nor overwrites what the
+            // previous one still multiplies with)
+            f32x4 hn0, hn1, he[2], hw[3];
+            const float* hwd = nullptr;
+            const float* he0 = nullptr;
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
 #pragma unroll
                 for (int nt = 0; nt < NTP; ++nt) {
                     const int u = c * NTP + nt;
-                    if (u + 2 < NC * NTP) wf[(u + 2) % 3] = *reinterpret_cast<const f32x4*>(wb + (u + 2) * 256 + lane * 4);
+                    if (u + 2 < NG) wf[(u + 2) % 3] = *reinterpret_cast<const f32x4*>(wb + (u + 2) * 256 + lane * 4);
                     const f32x4& b0 = c < C / 16 ? d[c < C / 16 ? c : 0][0] : ds[c < C / 16 ? 0 : c - C / 16][0];
                     const f32x4& b1 = c < C / 16 ? d[c < C / 16 ? c : 0][1] : ds[c < C / 16 ? 0 : c - C / 16][1];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u % 3][i], b0[i], acc[0][nt], 0, 0, 0);
                         acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u % 3][i], b1[i], acc[1][nt], 0, 0, 0);
+                    }
+                    if (HAND && u < 2 * (NS + 2)) {
+                        const int h = u / (NS + 2), g = u % (NS + 2);      // chunk of the pair, position in its schedule
+                        if (g == 0) {                                        // begin: bias, first tap's operands
+                            hwd = handoff_wd(p - 1, h, wb + DWOFF) + lk * 4;
+                            he0 = Et + h * EBUF + (y0 * PW + li) * EP + lk * EQ;
+                            hn0 = *reinterpret_cast<const f32x4*>(hwd + KS * KS * 16);
+                            he[0] = *reinterpret_cast<const f32x4*>(he0);
+                            hw[0] = *reinterpret_cast<const f32x4*>(hwd);
+                        } else if (g <= NS) {
+                            const int t = g - 1, iy = t % (KS + 1);
+                            if (t == 0) hn1 = hn0;
+                            if (t + 1 < NS) {
+                                const int kx2 = (t + 1) / (KS + 1), iy2 = (t + 1) % (KS + 1);
+                                he[(t + 1) & 1] = *reinterpret_cast<const f32x4*>(he0 + (iy2 * PW + kx2) * EP);
+                                if (iy2 < KS) hw[(t + 1) % 3] = *reinterpret_cast<const f32x4*>(hwd + (iy2 * KS + kx2) * 16);
+                            }
+                            if (iy < KS) pk_fma4(hn0, he[t & 1], hw[t % 3]);
+                            if (iy >= 1) pk_fma4(hn1, he[t & 1], hw[(t + 2) % 3]);      // the previous step's tap
+                        } else {                                             // end: the chunk's depthwise is complete
+                            pk_fma_settle(hn0, hn1);
+                            if (MODE != 2 && a.relu_dw) {
+                                hn0.x = fmaxf(hn0.x, 0.f); hn0.y = fmaxf(hn0.y, 0.f); hn0.z = fmaxf(hn0.z, 0.f); hn0.w = fmaxf(hn0.w, 0.f);
+                                hn1.x = fmaxf(hn1.x, 0.f); hn1.y = fmaxf(hn1.y, 0.f); hn1.z = fmaxf(hn1.z, 0.f); hn1.w = fmaxf(hn1.w, 0.f);
+                            }
+                            handoff_out(p - 1, h, hn0, hn1, integral_constant<int, -1>{});
+                        }
                     }
                 }
                 if (CIN > C && c >= 4 && c < 4 + (CIN - C) / 16) {
@@ -271,10 +332,10 @@ __global__ __launch_bounds__(512) void headchain_kernel(HeadChainArgs a) {
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) ds[c - 4][mt] = *dptr(C / 16 + c - 4, mt);
                 }
-                if (LAST && MODE != 2 && c < C / 16 - 2) {
+                if (LAST && MODE != 2 && c < C / 16 - NTP) {
                     // the layer is over for chunk c: pull the NEXT layer's depthwise result of chunk c into the freed registers
-                    // (written to the scratch by this lane in the hand-over of pass c / 2; the last two chunks come straight from the
-                    // hand-over below)
+                    // (written to the scratch by this lane in the hand-over of pass c / 2 — the one of pass 6 a few groups ago; the
+                    // last two chunks come straight from the hand-over below)
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) d[c][mt] = *dptr(c, mt);
                 }
@@ -292,7 +353,6 @@ __global__ __launch_bounds__(512) void headchain_kernel(HeadChainArgs a) {
                     if (a.relu_out) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
                     v[mt][nt] = t;
                 }
-                tile_put(nt, v[0][nt], v[1][nt]);
             }
             if (MODE == 1) {
                 // pixel-wise correlation with the template (MobileCorrelation, blocks.py:121-123): the finished fragments are the B
@@ -316,53 +376,33 @@ __global__ __launch_bounds__(512) void headchain_kernel(HeadChainArgs a) {
                 }
             }
             fstamp(p);
-            __syncthreads();                       // tile complete; (also: the next pass's weight block has landed)
+            // B: every wave has read the tile (hand-over of pass p - 1).  (Its scratch stores are wave private and stay in flight.)
+            if (HAND) barrier_lds_only();
             fstamp(p);
-            if (MODE != 2) {
-                // ---- hand-over: the NEXT layer's depthwise of chunks 2p, 2p + 1 (its taps ride at the end of this pass's block)
-                f32x4 n[NTP][2];
 #pragma unroll
-                for (int nt = 0; nt < NTP; ++nt) tile_dw(nt, wb + NC * NTP * 256 + NTP * 16 + nt * WDF, n[nt][0], n[nt][1], a.relu_dw);
-                if (!LAST) {
-#pragma unroll
-                    for (int nt = 0; nt < NTP; ++nt)
-#pragma unroll
-                        for (int mt = 0; mt < 2; ++mt) *dptr(2 * p + nt, mt) = n[nt][mt];
-                } else {
-#pragma unroll
-                    for (int nt = 0; nt < NTP; ++nt)
-#pragma unroll
-                        for (int mt = 0; mt < 2; ++mt) d[C / 16 - NTP + nt][mt] = n[nt][mt];
-                }
-            } else {
-                // ---- prediction SepConv (dw KSxKS + 1x1 to <= 4 channels [+ exp]) on the two finished chunks
+            for (int nt = 0; nt < NTP; ++nt) tile_put(nt, v[0][nt], v[1][nt]);
+            __syncthreads();                       // A: tile complete; the next pass's weight block has landed
+            fstamp(p);
+            if (LAST) {
+                // the layer's last hand-over is not deferred: its results are B fragments of the next layer's first GEMM
 #pragma unroll
                 for (int nt = 0; nt < NTP; ++nt) {
-                    const float* wpk = Zr + (long)(2 * p + nt) * PCH;
                     f32x4 n0, n1;
-                    tile_dw(nt, wpk + 256, n0, n1, false);       // (no activation between the head's depthwise and its 1x1)
-                    const f32x4 wq = *reinterpret_cast<const f32x4*>(wpk + lane * 4);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        pacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[i], n0[i], pacc[0], 0, 0, 0);
-                        pacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[i], n1[i], pacc[1], 0, 0, 0);
-                    }
+                    tile_dw(nt, handoff_wd(p, nt, wb + DWOFF + NTP * WDF), n0, n1, MODE != 2 && a.relu_dw);
+                    if (nt == 0) handoff_out(p, nt, n0, n1, integral_constant<int, MODE == 2 ? -1 : C / 16 - NTP>{});
+                    else handoff_out(p, nt, n0, n1, integral_constant<int, MODE == 2 ? -1 : C / 16 - NTP + 1>{});
                 }
+                barrier_lds_only();
             }
-            fstamp(p);
-            // every wave has read the tile: the next pass may overwrite it.  (The hand-over's scratch stores are wave private and stay
-            // in flight across this barrier; everything else the wave issued was waited for at the barrier above.)
-            if (HC_ABL & 16) __syncthreads();
-            else barrier_lds_only();
-            fstamp(p);
         };
-        for (int p = 0; p < NPASS - 1; ++p) pass(p, std::false_type{});
+        pass(0, std::false_type{}, std::false_type{});
+        for (int p = 1; p < NPASS - 1; ++p) pass(p, std::false_type{}, std::true_type{});
         {
             // (the pass index stays a run-time value in the peeled last pass too: with a constant the LDS addresses of its weight
             // block become literals beyond the 64 KB reach of ds_read's immediate offset, one address register per fragment)
             int p_last = NPASS - 1;
             asm volatile("" : "+s"(p_last));
-            pass(p_last, std::true_type{});
+            pass(p_last, std::true_type{}, std::true_type{});
         }
         if (MODE == 1) {
             // ---- the 64 correlation channels = input chunks 16..19 of layer 1: hand-over, two chunks a round, to the scratch
@@ -399,7 +439,6 @@ __global__ __launch_bounds__(512) void headchain_kernel(HeadChainArgs a) {
         stamp();
     };
 
-    using std::integral_constant;
     layer(integral_constant<int, C>{}, integral_constant<int, 1>{}, b.W[0], b.W[1]);
     layer(integral_constant<int, CC>{}, integral_constant<int, 0>{}, b.W[1], b.W[2]);
     lds_copy_async<16 * PCH>(b.P_Wpk, Zr, wave, lane);      // (Zr: last read in layer 0's correlation hand-over; complete at the next barrier)
