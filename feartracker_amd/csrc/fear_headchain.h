@@ -68,7 +68,7 @@ struct HeadChainGeom {
     static constexpr int LDS_FLOATS = 2 * WMAX + NTP * EBUF + ZREG;
     static constexpr int LDS_BYTES = LDS_FLOATS * 4;
     static constexpr int D_FLOATS = 8 * (CC / 16) * 2 * 256;      // depthwise results of one (crop, branch)
-    static_assert(C / 16 * WDF <= WMAX && 4 * WDF <= ZS, "prologue / correlation depthwise weights are staged in idle buffers");
+    static_assert(2 * ZS + C / 16 * WDF <= ZREG && 4 * WDF <= ZS, "prologue / correlation depthwise weights are staged behind / in the template slices");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
@@ -142,9 +142,14 @@ __global__ __launch_bounds__(512) void headchain_kernel(HeadChainArgs a) {
 
     // the tile's halo is zero for the whole kernel (= the convolutions' padding): only the interior is ever rewritten
     for (int i = tid * 4; i < NTP * EBUF; i += 512 * 4) *reinterpret_cast<f32x4*>(Et + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // the weight blocks stream through Wb two passes ahead of their use (block q of the kernel -> Wb[q & 1], issued when block
+    // q - 2 is dead); likewise the template slices of layer 0 through Zr[0 / 1].  Layer 0's own depthwise taps wait behind them.
+    float* const Wd0s = Zr + 2 * ZS;
     lds_copy_async<G::wpass(C)>(b.W[0], Wb, wave, lane);
-    lds_copy_async<C / 16 * WDF>(b.Wd0, Wb + WMAX, wave, lane);
+    lds_copy_async<G::wpass(C)>(b.W[0] + G::wpass(C), Wb + WMAX, wave, lane);
+    lds_copy_async<C / 16 * WDF>(b.Wd0, Wd0s, wave, lane);
     lds_copy_async<ZS>(b.Z + crop * b.z_stride, Zr, wave, lane);
+    lds_copy_async<ZS>(b.Z + crop * b.z_stride + ZS, Zr + ZS, wave, lane);
 
     f32x4 d[C / 16][2];                 // B fragments of the layer in flight: depthwise result [input chunk][row] of this wave's two rows
 
@@ -202,8 +207,8 @@ __global__ __launch_bounds__(512) void headchain_kernel(HeadChainArgs a) {
             tile_put(0, d[2 * r][0], d[2 * r][1]);
             tile_put(1, d[2 * r + 1][0], d[2 * r + 1][1]);
             __syncthreads();
-            tile_dw(0, Wb + WMAX + (2 * r) * WDF, d[2 * r][0], d[2 * r][1], a.relu_dw);
-            tile_dw(1, Wb + WMAX + (2 * r + 1) * WDF, d[2 * r + 1][0], d[2 * r + 1][1], a.relu_dw);
+            tile_dw(0, Wd0s + (2 * r) * WDF, d[2 * r][0], d[2 * r][1], a.relu_dw);
+            tile_dw(1, Wd0s + (2 * r + 1) * WDF, d[2 * r + 1][0], d[2 * r + 1][1], a.relu_dw);
             __syncthreads();
         }
     }
@@ -212,6 +217,9 @@ __global__ __launch_bounds__(512) void headchain_kernel(HeadChainArgs a) {
     f32x4 cacc[2][TZ / 16];             // layer 0: correlation accumulators
     f32x4 pacc[2];                      // layer 3: prediction accumulators
     f32x4 ds[TZ / 16][2];               // layer 1: the streamed B fragments of the correlation chunks (16..19)
+    f32x4 wf0, wf1;                     // the first two weight fragments of the next pass (read between its two barriers)
+    wf0 = *reinterpret_cast<const f32x4*>(Wb + lane * 4);
+    wf1 = *reinterpret_cast<const f32x4*>(Wb + 256 + lane * 4);
 
     // One SepConv layer = 8 passes.  MODE 0: plain, 1: + correlation (layer 0), 2: prediction head instead of a hand-over (layer 3).
     // On entry d[][] holds the layer's depthwise results (layer 1: chunks 16..19 are streamed from the scratch), Wb[0] its pass-0 block.
@@ -261,13 +269,6 @@ __global__ __launch_bounds__(512) void headchain_kernel(HeadChainArgs a) {
             constexpr int NG = NC * NTP;                         // MFMA groups (8 MFMAs each)
             static_assert(NG >= 2 * (NS + 2), "the deferred hand-over needs one group per tap step");
             fstamp(p);
-            // ---- asynchronous copies for the NEXT pass (their buffers were last read before the previous barrier)
-            if (!LAST) lds_copy_async<WP>(Wl + (long)(p + 1) * WP, Wb + ((p + 1) & 1) * WMAX, wave, lane);
-            else if (Wnext) lds_copy_async<G::wpass(MODE == 1 ? CC : C)>(Wnext, Wb + ((p + 1) & 1) * WMAX, wave, lane);
-            if (MODE == 1) {
-                if (!LAST) lds_copy_async<ZS>(b.Z + crop * b.z_stride + (long)(p + 1) * ZS, Zr + ((p + 1) & 1) * ZS, wave, lane);
-                else lds_copy_async<4 * WDF>(b.WdC, Zr + ((p + 1) & 1) * ZS, wave, lane);     // the correlation chunks' depthwise weights
-            }
             const float* wb = Wb + (p & 1) * WMAX;
             f32x4 acc[2][NTP];
 #pragma unroll
@@ -276,8 +277,8 @@ __global__ __launch_bounds__(512) void headchain_kernel(HeadChainArgs a) {
                 for (int nt = 0; nt < NTP; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             // ---- the pass's GEMM: no barrier inside; fragment reads run two fragments ahead
             f32x4 wf[3];
-            wf[0] = *reinterpret_cast<const f32x4*>(wb + lane * 4);
-            wf[1] = *reinterpret_cast<const f32x4*>(wb + 256 + lane * 4);
+            wf[0] = wf0;
+            wf[1] = wf1;
             // state of the deferred depthwise: tap step t of chunk h is dealt to group h * (NS + 2) + 1 + t; its LDS reads are issued
             // one group (8 MFMAs, ~260 cycles) ahead
             // (operands in rotating registers — he[t & 1], hw[t % 3] — so that a step neither copies nor overwrites what the
@@ -376,12 +377,29 @@ __global__ __launch_bounds__(512) void headchain_kernel(HeadChainArgs a) {
                 }
             }
             fstamp(p);
-            // B: every wave has read the tile (hand-over of pass p - 1).  (Its scratch stores are wave private and stay in flight.)
-            if (HAND) barrier_lds_only();
+            // B: every wave has read the tile (hand-over of pass p - 1) and this pass's weight block for the last time; the NEXT pass's
+            // block (issued two passes ago) has landed.  (The hand-over's scratch stores are wave private; they are old by now.)
+            __syncthreads();
             fstamp(p);
 #pragma unroll
             for (int nt = 0; nt < NTP; ++nt) tile_put(nt, v[0][nt], v[1][nt]);
-            __syncthreads();                       // A: tile complete; the next pass's weight block has landed
+            // between the barriers: block p + 2 of the layer (or block p - 6 of the next one) into the buffer that just died, and the
+            // next pass's first fragments into registers — the next GEMM starts with its MFMAs
+            auto issue_next = [&] {
+                if (p + 2 < NPASS) lds_copy_async<WP>(Wl + (long)(p + 2) * WP, Wb + (p & 1) * WMAX, wave, lane);
+                else if (Wnext) lds_copy_async<G::wpass(MODE == 1 ? CC : C)>(Wnext + (long)(p + 2 - NPASS) * G::wpass(MODE == 1 ? CC : C), Wb + (p & 1) * WMAX, wave, lane);
+            };
+            if (!LAST) issue_next();          // (last pass: its block still holds the taps of the hand-over below)
+            if (MODE == 1) {
+                if (p + 2 < NPASS) lds_copy_async<ZS>(b.Z + crop * b.z_stride + (long)(p + 2) * ZS, Zr + (p & 1) * ZS, wave, lane);
+                else if (!LAST) lds_copy_async<4 * WDF>(b.WdC, Zr + (p & 1) * ZS, wave, lane);     // the correlation chunks' depthwise weights
+            }
+            if (!LAST || Wnext) {
+                const float* wn = Wb + ((p + 1) & 1) * WMAX;
+                wf0 = *reinterpret_cast<const f32x4*>(wn + lane * 4);
+                wf1 = *reinterpret_cast<const f32x4*>(wn + 256 + lane * 4);
+            }
+            barrier_lds_only();                    // A: tile complete
             fstamp(p);
             if (LAST) {
                 // the layer's last hand-over is not deferred: its results are B fragments of the next layer's first GEMM
@@ -393,6 +411,7 @@ __global__ __launch_bounds__(512) void headchain_kernel(HeadChainArgs a) {
                     else handoff_out(p, nt, n0, n1, integral_constant<int, MODE == 2 ? -1 : C / 16 - NTP + 1>{});
                 }
                 barrier_lds_only();
+                issue_next();
             }
         };
         pass(0, std::false_type{}, std::false_type{});
@@ -406,7 +425,7 @@ __global__ __launch_bounds__(512) void headchain_kernel(HeadChainArgs a) {
         }
         if (MODE == 1) {
             // ---- the 64 correlation channels = input chunks 16..19 of layer 1: hand-over, two chunks a round, to the scratch
-            const float* wdc = Zr + (NPASS & 1) * ZS;           // (copied in during the last pass)
+            const float* wdc = Zr + ((NPASS - 2) & 1) * ZS;     // (copied in after the second to last pass)
 #pragma unroll
             for (int r = 0; r < NTZ / 2; ++r) {
                 tile_put(0, cacc[0][2 * r], cacc[1][2 * r]);

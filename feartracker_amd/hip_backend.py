@@ -260,8 +260,9 @@ class FEARNetHIP:
         bbox, cls = self.track_maps(search, template_features, update)
         return {TARGET_REGRESSION_LABEL_KEY: bbox, TARGET_CLASSIFICATION_KEY: cls}
 
-    @torch.no_grad()
-    def track_maps(self, search, template_features, update=None, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+    def _track_inputs(self, search, template_features, update):
+        """Shared argument checks of `track_maps` / `track_packed`: (search, z, pointer of the optional cls template, n).
+        A single template (N = 1) is broadcast over the batch, as the reference's `expand` does."""
         search = self._prep(search, "search")
         z = self._prep(template_features, "template_features")
         n = search.shape[0]
@@ -271,21 +272,25 @@ class FEARNetHIP:
             z = z.expand(n, -1, -1, -1).contiguous()
         if tuple(z.shape) != (n, self.feat_channels, 8, 8):
             raise ValueError(f"template_features must be ({n},256,8,8), got {tuple(z.shape)}")
-        zu_ptr = None
+        zu = None
         if update is not None:
             zu = self._prep(update, "update")
             if zu.shape[0] == 1 and n > 1:
                 zu = zu.expand(n, -1, -1, -1).contiguous()
             if tuple(zu.shape) != tuple(z.shape):
                 raise ValueError("update template must have the shape of template_features")
-            zu_ptr = zu.data_ptr()
+        return search, z, zu, n
+
+    @torch.no_grad()
+    def track_maps(self, search, template_features, update=None, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+        search, z, zu, n = self._track_inputs(search, template_features, update)
         if out is None:
             bbox = torch.empty((n, 4, 16, 16), dtype=torch.float32, device=self.device)
             cls = torch.empty((n, 1, 16, 16), dtype=torch.float32, device=self.device)
         else:
             bbox, cls = out
         with torch.cuda.device(self.device):
-            self._check(self._lib.fear_track(self._h, search.data_ptr(), z.data_ptr(), zu_ptr, n,
+            self._check(self._lib.fear_track(self._h, search.data_ptr(), z.data_ptr(), zu.data_ptr() if zu is not None else None, n,
                                              bbox.data_ptr(), cls.data_ptr(), self._stream()))
         return bbox, cls
 
@@ -293,30 +298,14 @@ class FEARNetHIP:
     def track_packed(self, search, template_features, update=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """`track` with both maps written into one (N,5,16,16) tensor — bbox in channels 0..3, cls in channel 4 —
         the payload of the multi-GPU all-gather (sharding.py); no pack/cat kernel."""
-        search = self._prep(search, "search")
-        z = self._prep(template_features, "template_features")
-        n = search.shape[0]
-        if tuple(search.shape[1:]) != (3, 256, 256):
-            raise ValueError(f"search must be (N,3,256,256), got {tuple(search.shape)}")
-        if z.shape[0] == 1 and n > 1:
-            z = z.expand(n, -1, -1, -1).contiguous()
-        if tuple(z.shape) != (n, self.feat_channels, 8, 8):
-            raise ValueError(f"template_features must be ({n},256,8,8), got {tuple(z.shape)}")
-        zu_ptr = None
-        if update is not None:
-            zu = self._prep(update, "update")
-            if zu.shape[0] == 1 and n > 1:
-                zu = zu.expand(n, -1, -1, -1).contiguous()
-            if tuple(zu.shape) != tuple(z.shape):
-                raise ValueError("update template must have the shape of template_features")
-            zu_ptr = zu.data_ptr()
+        search, z, zu, n = self._track_inputs(search, template_features, update)
         if out is None:
             out = torch.empty((n, 5, 16, 16), dtype=torch.float32, device=self.device)
         elif tuple(out.shape) != (n, 5, 16, 16) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != self.device:
             raise ValueError("out must be a contiguous fp32 (N,5,16,16) tensor on the engine's device")
         with torch.cuda.device(self.device):
-            self._check(self._lib.fear_track_packed(self._h, search.data_ptr(), z.data_ptr(), zu_ptr, n, out.data_ptr(),
-                                                    self._stream()))
+            self._check(self._lib.fear_track_packed(self._h, search.data_ptr(), z.data_ptr(), zu.data_ptr() if zu is not None else None,
+                                                    n, out.data_ptr(), self._stream()))
         return out
 
     @torch.no_grad()
@@ -342,7 +331,18 @@ class FEARNetHIP:
         """(rc, xywh, score) of `decode` / `decode_smooth` as numpy arrays with ONE device-to-host copy (they are views of one
         buffer; three `.cpu()` calls would be three synchronising transfers)."""
         n = xywh.shape[0]
-        host = torch.empty(0, dtype=torch.uint8, device=xywh.device).set_(xywh.untyped_storage(), xywh.storage_offset() * 8, (n * 44,)).cpu().numpy()
+        # only the exact views `_decode_outputs` makes share one 44-byte-per-crop buffer: check the layout instead of assuming it
+        base = xywh.storage_offset() * 8
+        st = xywh.untyped_storage()
+        ok = (xywh.dtype == torch.float64 and rc.dtype == torch.int32 and score.dtype == torch.float32 and
+              tuple(xywh.shape) == (n, 4) and tuple(rc.shape) == (n, 2) and tuple(score.shape) == (n,) and
+              xywh.is_contiguous() and rc.is_contiguous() and score.is_contiguous() and
+              rc.untyped_storage().data_ptr() == st.data_ptr() and score.untyped_storage().data_ptr() == st.data_ptr() and
+              rc.storage_offset() * 4 == base + n * 32 and score.storage_offset() * 4 == base + n * 40 and
+              st.nbytes() >= base + n * 44)
+        if not ok:              # any other tensors (slices, another backend's outputs): three plain copies
+            return rc.cpu().numpy(), xywh.cpu().numpy(), score.cpu().numpy()
+        host = torch.empty(0, dtype=torch.uint8, device=xywh.device).set_(st, base, (n * 44,)).cpu().numpy()
         return (host[n * 32: n * 40].view(np.int32).reshape(n, 2), host[: n * 32].view(np.float64).reshape(n, 4),
                 host[n * 40: n * 44].view(np.float32))
 

@@ -111,21 +111,34 @@ def track_local_shard(net, search_shard: torch.Tensor, template_shard: torch.Ten
     from .constants import TARGET_CLASSIFICATION_KEY, TARGET_REGRESSION_LABEL_KEY
     cap = (n_global + world - 1) // world
     s_hw = int(getattr(net, "map_size", 16))                  # score-map side (16 for the 256-pixel search crop)
-    dev = getattr(net, "device", search_shard.device)
+    dev = torch.device(getattr(net, "device", search_shard.device))
     if world > 1 and hasattr(net, "track_packed"):
         # the engine writes this rank's maps straight into the head of the (padded) send buffer
         packed = torch.zeros((cap, 5, s_hw, s_hw), dtype=torch.float32, device=dev)
         if hi > lo:
             net.track_packed(search_shard, template_shard, out=packed[: hi - lo])
-    elif hi > lo or world == 1:
-        out = net.track(search_shard, template_shard)
-        bbox, cls = out[TARGET_REGRESSION_LABEL_KEY], out[TARGET_CLASSIFICATION_KEY]
-        if world == 1:
-            return bbox, cls
-        packed = torch.zeros((cap, 5) + tuple(bbox.shape[2:]), dtype=bbox.dtype, device=bbox.device)
-        pack_maps(bbox, cls, packed[: hi - lo])
-    else:                                                     # an empty shard still takes part in the collective
-        packed = torch.zeros((cap, 5, s_hw, s_hw), dtype=torch.float32, device=dev)
+    else:
+        # a net without `track_packed` (any object with the reference's `track`): the shape and dtype of the send buffer come from
+        # the maps themselves, and a rank with an EMPTY shard has none — so the ranks agree on them first (one tiny all-reduce:
+        # map side and a dtype code, MAX over ranks, 0 from empty ones) instead of every empty rank guessing
+        bbox = cls = None
+        if hi > lo or world == 1:
+            out = net.track(search_shard, template_shard)
+            bbox, cls = out[TARGET_REGRESSION_LABEL_KEY], out[TARGET_CLASSIFICATION_KEY]
+            if world == 1:
+                return bbox, cls
+        dtypes = [torch.float32, torch.float16, torch.bfloat16, torch.float64]
+        meta_dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        meta = torch.tensor([bbox.shape[-1], 1 + dtypes.index(bbox.dtype)] if bbox is not None else [0, 0], dtype=torch.int64, device=meta_dev)
+        dist.all_reduce(meta, op=dist.ReduceOp.MAX, group=group)
+        side, code = int(meta[0]), int(meta[1])
+        if bbox is not None and (bbox.shape[-1] != side or dtypes.index(bbox.dtype) + 1 != code):
+            raise ValueError("the ranks' score maps differ in size or dtype")
+        if bbox is None:                                      # an empty shard still takes part in the collective
+            packed = torch.zeros((cap, 5, side, side), dtype=dtypes[code - 1], device=dev if dev.type == meta_dev.type else meta_dev)
+        else:
+            packed = torch.zeros((cap, 5) + tuple(bbox.shape[2:]), dtype=bbox.dtype, device=bbox.device)
+            pack_maps(bbox, cls, packed[: hi - lo])
     gathered = torch.empty((world * cap,) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
     dist.all_gather_into_tensor(gathered, packed, group=group)
     if n_global % world == 0:

@@ -471,8 +471,10 @@ class FEARNetTrainHIP:
                 gflat.record_stream(side)
                 with torch.cuda.stream(side):
                     self._lane = 1
-                    fbwd(zctx, dz, gflat[1])
-                    self._lane = 0
+                    try:
+                        fbwd(zctx, dz, gflat[1])
+                    finally:
+                        self._lane = 0          # (a raising kernel check must not leave later steps on the side lane's workspace)
                 fbwd(xctx, dx, gflat[0])
                 main.wait_stream(side)
             else:

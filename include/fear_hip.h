@@ -115,6 +115,13 @@ int fear_crop_normalize(fear_handle* h, const uint8_t* frame_u8, int frame_h, in
                                /*     fp16 in this mode)                                            */
                                /*   2 activations and weights rounded to bf16, v_mfma_f32_16x16x32_bf16,*/
                                /*     fp32 accumulate: reduced precision (BASELINE config "bf16")  */
+                               /*   Modes 1 / 2 also cover the plain GEMMs of the TRACK plan: the   */
+                               /*   search branch's neck (AdjustLayer) and the two pixel-wise       */
+                               /*   correlations (both operands activations: three MFMAs in mode 1).*/
+                               /*   fear_features (template branch) keeps its neck in fp32 in every */
+                               /*   mode, so template and search features of one net differ in      */
+                               /*   precision in modes 1 / 2 (tolerances: tests/test_gpu_parity.py  */
+                               /*   test_matrix_pipe_split_mode_matches_fp32 / ..._all_math_modes). */
 #define FEAR_OPT_CHAIN 6       /* 1 (default): stride-16 trunk stage + neck as one register-resident chain kernel */
                                /*   (fp32 mode); 0: one fused kernel per block                                 */
 #define FEAR_OPT_SMALL_PASS 7  /* passes of at most this many crops (default 96; 0 = never) run the small-batch plan:      */
