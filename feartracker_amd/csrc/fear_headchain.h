@@ -21,6 +21,9 @@
 // Same products in the same order as the eight sep16 launches it replaces: bit-identical maps (tests/test_gpu_parity.py).
 #pragma once
 #include <vector>
+#ifndef HC_TS
+#define HC_TS 2        // tap steps of the deferred hand-over per MFMA group (1, 2, 3, 4, 6)
+#endif
 #ifndef HC_ABL
 #define HC_ABL 0       // timing ablations for tools/headchain_check only (bit mask); the product always builds with 0
 #endif
@@ -142,14 +145,12 @@ __global__ __launch_bounds__(512) void headchain_kernel(HeadChainArgs a) {
 
     // the tile's halo is zero for the whole kernel (= the convolutions' padding): only the interior is ever rewritten
     for (int i = tid * 4; i < NTP * EBUF; i += 512 * 4) *reinterpret_cast<f32x4*>(Et + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // the weight blocks stream through Wb two passes ahead of their use (block q of the kernel -> Wb[q & 1], issued when block
-    // q - 2 is dead); likewise the template slices of layer 0 through Zr[0 / 1].  Layer 0's own depthwise taps wait behind them.
+    // the weight blocks alternate between Wb[0] and Wb[1] (the next pass's block is copied in during the current GEMM), the template
+    // slices of layer 0 between Zr[0] and Zr[1]; layer 0's own depthwise taps wait behind them
     float* const Wd0s = Zr + 2 * ZS;
     lds_copy_async<G::wpass(C)>(b.W[0], Wb, wave, lane);
-    lds_copy_async<G::wpass(C)>(b.W[0] + G::wpass(C), Wb + WMAX, wave, lane);
     lds_copy_async<C / 16 * WDF>(b.Wd0, Wd0s, wave, lane);
     lds_copy_async<ZS>(b.Z + crop * b.z_stride, Zr, wave, lane);
-    lds_copy_async<ZS>(b.Z + crop * b.z_stride + ZS, Zr + ZS, wave, lane);
 
     f32x4 d[C / 16][2];                 // B fragments of the layer in flight: depthwise result [input chunk][row] of this wave's two rows
 
@@ -193,23 +194,44 @@ __global__ __launch_bounds__(512) void headchain_kernel(HeadChainArgs a) {
         o1 = n1;
     };
 
-    // ---------------- kernel prologue: the neck output -> depthwise of layer 0 -> d[][] (through the tile, two chunks a round)
+    // ---------------- kernel prologue: the neck output -> depthwise of layer 0 -> d[][] (through the tile, two chunks a round).
+    // The 32 loads of the wave's input rows are issued at once, BEHIND the asynchronous weight copies, and the rounds start as soon
+    // as their own two chunks have arrived (vector-memory operations complete in issue order).  The prologue is fetch-bound — 256
+    // workgroups pull 256 KB each at the same moment, ~15 us — not LDS- or barrier-bound: a variant without tile and barriers
+    // (rows above / below from global memory, horizontal neighbours by DPP row shifts; bit-identical) took 16.6-21.5 us, its
+    // 50 % extra halo fetch costing more than the eight rounds it removed.
     {
         const float* X0 = a.X + crop * 256 * a.ldx;
+        __builtin_amdgcn_sched_barrier(0);     // (the copies above stay in front of the loads below: the wait further down counts on it)
 #pragma unroll
-        for (int c = 0; c < C / 16; ++c)
+        for (int c = 0; c < C / 16; ++c) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
                 d[c][mt] = *reinterpret_cast<const f32x4*>(X0 + (long)((y0 + mt) * S + li) * a.ldx + c * 16 + lk * 4);
-        __syncthreads();                       // zero fill done, weight blocks landed
+            __builtin_amdgcn_sched_barrier(0);     // (in chunk order: hipcc would issue the first chunks last)
+        }
+        // zero fill done and weight blocks landed: everything but the youngest 32 operations (the input rows).
+        // (the builtin, not inline asm: hipcc's own wait insertion must SEE that the copies are complete — while it believes an
+        // LDS-writing load is in flight it turns every later wait into vmcnt(0).  gfx9 encoding: vmcnt[3:0] | expcnt << 4 |
+        // lgkmcnt << 8 | vmcnt[5:4] << 14)
+        static_assert(2 * (C / 16) == 32, "waitcnt immediate below");
+        __builtin_amdgcn_s_waitcnt((32 & 15) | (7 << 4) | (0 << 8) | ((32 >> 4) << 14));
+        __builtin_amdgcn_s_barrier();
+        // (inline-asm LDS stores: in front of a plain one hipcc waits for EVERY vector-memory operation in flight — it cannot tell the
+        // store from the asynchronous global -> LDS copies — i.e. for all 32 loads; the asm form waits for the registers it reads)
+        auto tile_put_asm = [&](int s, const f32x4& v0, const f32x4& v1) {
+            const unsigned a0 = (unsigned)(uintptr_t)(Et + s * EBUF + ((y0 + P) * PW + li + P) * EP + lk * EQ);
+            asm volatile("ds_write_b128 %0, %1" : : "v"(a0), "v"(v0) : "memory");
+            asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(a0), "v"(v1), "n"(PW * EP * 4) : "memory");
+        };
 #pragma unroll
         for (int r = 0; r < C / 32; ++r) {
-            tile_put(0, d[2 * r][0], d[2 * r][1]);
-            tile_put(1, d[2 * r + 1][0], d[2 * r + 1][1]);
-            __syncthreads();
+            tile_put_asm(0, d[2 * r][0], d[2 * r][1]);
+            tile_put_asm(1, d[2 * r + 1][0], d[2 * r + 1][1]);
+            barrier_lds_only();
             tile_dw(0, Wd0s + (2 * r) * WDF, d[2 * r][0], d[2 * r][1], a.relu_dw);
             tile_dw(1, Wd0s + (2 * r + 1) * WDF, d[2 * r + 1][0], d[2 * r + 1][1], a.relu_dw);
-            __syncthreads();
+            barrier_lds_only();
         }
     }
     stamp();
@@ -267,7 +289,10 @@ __global__ __launch_bounds__(512) void headchain_kernel(HeadChainArgs a) {
             constexpr bool LAST = decltype(last_tag)::value, HAND = decltype(hand_tag)::value;
             constexpr int DWOFF = NC * NTP * 256 + NTP * 16;     // block: fragments | bias | dw taps of the next layer's chunks 2p-2 .. 2p+1
             constexpr int NG = NC * NTP;                         // MFMA groups (8 MFMAs each)
-            static_assert(NG >= 2 * (NS + 2), "the deferred hand-over needs one group per tap step");
+            // the deferred hand-over: TS tap steps per MFMA group it is dealt to (an MFMA <-> VALU switch costs ~8 cycles each way:
+            // profiles/r03_issue_probe.txt), operands read one group ahead into rotating registers
+            constexpr int TS = HC_TS, GPC = NS / TS + 2, NE = 2 * TS, NW = 2 * TS + 1;
+            static_assert(NS % TS == 0 && NG >= 2 * GPC, "hand-over schedule");
             fstamp(p);
             const float* wb = Wb + (p & 1) * WMAX;
             f32x4 acc[2][NTP];
@@ -281,9 +306,9 @@ __global__ __launch_bounds__(512) void headchain_kernel(HeadChainArgs a) {
             wf[1] = wf1;
             // state of the deferred depthwise: tap step t of chunk h is dealt to group h * (NS + 2) + 1 + t; its LDS reads are issued
             // one group (8 MFMAs, ~260 cycles) ahead
-            // (operands in rotating registers — he[t & 1], hw[t % 3] — so that a step neither copies nor overwrites what the
+            // (operands in rotating registers — he[t % NE], hw[t % NW] — so that a step neither copies nor overwrites what the
             // previous one still multiplies with)
-            f32x4 hn0, hn1, he[2], hw[3];
+            f32x4 hn0, hn1, he[NE], hw[NW];
             const float* hwd = nullptr;
             const float* he0 = nullptr;
 #pragma unroll
@@ -299,24 +324,35 @@ __global__ __launch_bounds__(512) void headchain_kernel(HeadChainArgs a) {
                         acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u % 3][i], b0[i], acc[0][nt], 0, 0, 0);
                         acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u % 3][i], b1[i], acc[1][nt], 0, 0, 0);
                     }
-                    if (HAND && u < 2 * (NS + 2)) {
-                        const int h = u / (NS + 2), g = u % (NS + 2);      // chunk of the pair, position in its schedule
-                        if (g == 0) {                                        // begin: bias, first tap's operands
+                    if (HAND && u < 2 * GPC) {
+                        const int h = u / GPC, g = u % GPC;                  // chunk of the pair, position in its schedule
+                        if (g == 0) {                                        // begin: bias, the first TS tap steps' operands
                             hwd = handoff_wd(p - 1, h, wb + DWOFF) + lk * 4;
                             he0 = Et + h * EBUF + (y0 * PW + li) * EP + lk * EQ;
                             hn0 = *reinterpret_cast<const f32x4*>(hwd + KS * KS * 16);
-                            he[0] = *reinterpret_cast<const f32x4*>(he0);
-                            hw[0] = *reinterpret_cast<const f32x4*>(hwd);
-                        } else if (g <= NS) {
-                            const int t = g - 1, iy = t % (KS + 1);
-                            if (t == 0) hn1 = hn0;
-                            if (t + 1 < NS) {
-                                const int kx2 = (t + 1) / (KS + 1), iy2 = (t + 1) % (KS + 1);
-                                he[(t + 1) & 1] = *reinterpret_cast<const f32x4*>(he0 + (iy2 * PW + kx2) * EP);
-                                if (iy2 < KS) hw[(t + 1) % 3] = *reinterpret_cast<const f32x4*>(hwd + (iy2 * KS + kx2) * 16);
+#pragma unroll
+                            for (int t = 0; t < TS; ++t) {
+                                const int kx = t / (KS + 1), iy = t % (KS + 1);
+                                he[t % NE] = *reinterpret_cast<const f32x4*>(he0 + (iy * PW + kx) * EP);
+                                if (iy < KS) hw[t % NW] = *reinterpret_cast<const f32x4*>(hwd + (iy * KS + kx) * 16);
                             }
-                            if (iy < KS) pk_fma4(hn0, he[t & 1], hw[t % 3]);
-                            if (iy >= 1) pk_fma4(hn1, he[t & 1], hw[(t + 2) % 3]);      // the previous step's tap
+                        } else if (g <= NS / TS) {
+#pragma unroll
+                            for (int j = 0; j < TS; ++j) {                   // operands of the NEXT group's steps
+                                const int t2 = g * TS + j;
+                                if (t2 < NS) {
+                                    const int kx2 = t2 / (KS + 1), iy2 = t2 % (KS + 1);
+                                    he[t2 % NE] = *reinterpret_cast<const f32x4*>(he0 + (iy2 * PW + kx2) * EP);
+                                    if (iy2 < KS) hw[t2 % NW] = *reinterpret_cast<const f32x4*>(hwd + (iy2 * KS + kx2) * 16);
+                                }
+                            }
+#pragma unroll
+                            for (int j = 0; j < TS; ++j) {
+                                const int t = (g - 1) * TS + j, iy = t % (KS + 1);
+                                if (t == 0) hn1 = hn0;
+                                if (iy < KS) pk_fma4(hn0, he[t % NE], hw[t % NW]);
+                                if (iy >= 1) pk_fma4(hn1, he[t % NE], hw[(t + NW - 1) % NW]);      // the previous step's tap
+                            }
                         } else {                                             // end: the chunk's depthwise is complete
                             pk_fma_settle(hn0, hn1);
                             if (MODE != 2 && a.relu_dw) {
@@ -325,6 +361,16 @@ __global__ __launch_bounds__(512) void headchain_kernel(HeadChainArgs a) {
                             }
                             handoff_out(p - 1, h, hn0, hn1, integral_constant<int, -1>{});
                         }
+                    }
+                }
+                if (c == 1) {
+                    // asynchronous copies for the NEXT pass, issued from inside the GEMM (issue slots are free here; between the
+                    // barriers they were ~500 cycles of the critical path): their buffers died at the previous pass's barrier B
+                    if (!LAST) lds_copy_async<WP>(Wl + (long)(p + 1) * WP, Wb + ((p + 1) & 1) * WMAX, wave, lane);
+                    else if (Wnext) lds_copy_async<G::wpass(MODE == 1 ? CC : C)>(Wnext, Wb + ((p + 1) & 1) * WMAX, wave, lane);
+                    if (MODE == 1) {
+                        if (!LAST) lds_copy_async<ZS>(b.Z + crop * b.z_stride + (long)(p + 1) * ZS, Zr + ((p + 1) & 1) * ZS, wave, lane);
+                        else lds_copy_async<4 * WDF>(b.WdC, Zr + ((p + 1) & 1) * ZS, wave, lane);     // the correlation chunks' depthwise weights
                     }
                 }
                 if (CIN > C && c >= 4 && c < 4 + (CIN - C) / 16) {
@@ -378,22 +424,12 @@ __global__ __launch_bounds__(512) void headchain_kernel(HeadChainArgs a) {
             }
             fstamp(p);
             // B: every wave has read the tile (hand-over of pass p - 1) and this pass's weight block for the last time; the NEXT pass's
-            // block (issued two passes ago) has landed.  (The hand-over's scratch stores are wave private; they are old by now.)
+            // block (issued early in this pass's GEMM) has landed.  (The hand-over's scratch stores are wave private; they are old by now.)
             __syncthreads();
             fstamp(p);
 #pragma unroll
             for (int nt = 0; nt < NTP; ++nt) tile_put(nt, v[0][nt], v[1][nt]);
-            // between the barriers: block p + 2 of the layer (or block p - 6 of the next one) into the buffer that just died, and the
-            // next pass's first fragments into registers — the next GEMM starts with its MFMAs
-            auto issue_next = [&] {
-                if (p + 2 < NPASS) lds_copy_async<WP>(Wl + (long)(p + 2) * WP, Wb + (p & 1) * WMAX, wave, lane);
-                else if (Wnext) lds_copy_async<G::wpass(MODE == 1 ? CC : C)>(Wnext + (long)(p + 2 - NPASS) * G::wpass(MODE == 1 ? CC : C), Wb + (p & 1) * WMAX, wave, lane);
-            };
-            if (!LAST) issue_next();          // (last pass: its block still holds the taps of the hand-over below)
-            if (MODE == 1) {
-                if (p + 2 < NPASS) lds_copy_async<ZS>(b.Z + crop * b.z_stride + (long)(p + 2) * ZS, Zr + (p & 1) * ZS, wave, lane);
-                else if (!LAST) lds_copy_async<4 * WDF>(b.WdC, Zr + (p & 1) * ZS, wave, lane);     // the correlation chunks' depthwise weights
-            }
+            // between the barriers: the next pass's first fragments into registers — its GEMM starts with its MFMAs
             if (!LAST || Wnext) {
                 const float* wn = Wb + ((p + 1) & 1) * WMAX;
                 wf0 = *reinterpret_cast<const f32x4*>(wn + lane * 4);
@@ -411,7 +447,6 @@ __global__ __launch_bounds__(512) void headchain_kernel(HeadChainArgs a) {
                     else handoff_out(p, nt, n0, n1, integral_constant<int, MODE == 2 ? -1 : C / 16 - NTP + 1>{});
                 }
                 barrier_lds_only();
-                issue_next();
             }
         };
         pass(0, std::false_type{}, std::false_type{});
@@ -425,7 +460,7 @@ __global__ __launch_bounds__(512) void headchain_kernel(HeadChainArgs a) {
         }
         if (MODE == 1) {
             // ---- the 64 correlation channels = input chunks 16..19 of layer 1: hand-over, two chunks a round, to the scratch
-            const float* wdc = Zr + ((NPASS - 2) & 1) * ZS;     // (copied in after the second to last pass)
+            const float* wdc = Zr + (NPASS & 1) * ZS;           // (copied in during the last pass)
 #pragma unroll
             for (int r = 0; r < NTZ / 2; ++r) {
                 tile_put(0, cacc[0][2 * r], cacc[1][2 * r]);

@@ -248,8 +248,9 @@ def test_training_oracle_head_matches_reference_fixture(golden_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fused", [False, True], ids=["layerwise", "fused_conv_bn"])
-def test_whole_network_training_step_matches_autograd(fused):
+@pytest.mark.parametrize("fused,B", [(False, 2), (True, 2), (False, 16), (True, 16)],
+                         ids=["layerwise_b2", "fused_conv_bn_b2", "layerwise_b16", "fused_conv_bn_b16"])
+def test_whole_network_training_step_matches_autograd(fused, B):
     """BASELINE configs[4] "backbone + xcorr fwd/bwd, random-init": FEARNet.forward((template, search)) in train mode +
     FEARLoss + backward to all 195 parameter tensors on the HIP operators vs torch autograd on the restated graph
     (oracle/fear_train_oracle.py: head pinned by the reference fixture, trunk = FBNet-C blocks with a BatchNorm after every
@@ -259,8 +260,10 @@ def test_whole_network_training_step_matches_autograd(fused):
     sd = random_init_state(5)
     ora = FEARNetTrainOracle().train()
     ora.load_state_dict(sd, strict=False)
-    g = torch.Generator().manual_seed(9)
-    B = 2
+    # B = 16: train-mode BatchNorm couples the crops of a batch, so gradient parity at a batch size is only
+    # shown by running the oracle at THAT size — 16 pairs is what CPU autograd does in seconds; a sample of a larger batch has no
+    # oracle of its own (its statistics are the whole batch's), which is why the 128-pair test below stays a property test
+    g = torch.Generator().manual_seed(9 + B)
     tmpl = torch.randn(B, 3, 128, 128, generator=g)
     srch = torch.randn(B, 3, 256, 256, generator=g)
     gt_reg = torch.rand(B, 4, 16, 16, generator=g) * 60 + 1
