@@ -21,6 +21,7 @@
 #include "../../include/fearw_format.h"
 #include "fear_kernels.h"
 #include "fear_headchain.h"
+#include "fear_headchain_b.h"
 
 namespace {
 
@@ -137,6 +138,7 @@ struct Op {
     float* hc_wd0[2] = {nullptr};
     float* hc_wdc[2] = {nullptr};
     float* hc_pred[2] = {nullptr};
+    float* hc_taps[2][4] = {{nullptr}};   // math 2 (headchain_b_kernel): each layer's own depthwise taps
     int hc_pred_conv[2] = {-1, -1};
     int hc_pred_act[2] = {0, 0};
     char name[64];
@@ -642,6 +644,8 @@ constexpr int kChainXSLds =
 // the whole BoxTower as one launch (fear_headchain.h): 3x3 SepConvs, 256 channels, 64 template positions
 auto* const kHeadChainKernel = headchain_kernel<3>;
 using HeadChainG = HeadChainGeom<3>;
+auto* const kHeadChainBKernel = headchain_b_kernel<3>;      // FEAR_OPT_MATH = 2
+using HeadChainBG = HeadChainBGeom<3>;
 
 // neck weights as MFMA fragments [nt][kg][lane][4] (lane l: W[nt*16 + (l&15)][kg*16 + 4*(l>>4) + 0..3])
 int pack_neck_frags(fear_handle* h, int conv, float** out) {
@@ -1143,11 +1147,12 @@ int build_plan_uncached(fear_handle* h, int hw, bool with_head, int mode, Plan**
         // 116 VGPRs, so one workgroup of each branch fits on a CU at the same time — measured: no gain, the kernels are ALU-bound.
         // ---- the throughput plan in fp32: both branches, all eight SepConvs + correlations + prediction heads in ONE launch
         auto head_chain = [&]() -> bool {
-            if (!h->head_chain || !h->fuse || h->math || small || S != 16 || feat.C != HeadChainG::C || bbox_tower.size() != 2 ||
+            if (!h->head_chain || !h->fuse || h->math == 1 || small || S != 16 || feat.C != HeadChainG::C || bbox_tower.size() != 2 ||
                 cls_tower.size() != 2)
                 return false;
             Op op{};
             op.type = OP_HEADCHAIN;
+            op.math = h->math;          // 0: headchain_kernel (exact fp32) | 2: headchain_b_kernel (bf16 matrix pipe)
             double fl = 0;
             for (int br = 0; br < 2; ++br) {
                 const bool is_cls = br == 0;
@@ -1171,16 +1176,31 @@ int build_plan_uncached(fear_handle* h, int hw, bool with_head, int mode, Plan**
                 if (!pd.is_dw() || !pp.is_pw() || pd.k != 3 || pd.stride != 1 || pd.cout != HeadChainG::C || pd.relu ||
                     pp.cin_g != HeadChainG::C || pp.cout != (is_cls ? 1 : 4) || !pp.has_bias)
                     return false;
-                for (int l = 0; l < 4; ++l) {
-                    const Conv& pw = h->convs[seq[l]->conv[1]];
-                    if (upload(h, headchain_pack(sep[l].data(), l == 1 ? HeadChainG::CC : HeadChainG::C, pw.b.data(),
-                                                 l < 3 ? sep[l + 1].data() : nullptr, 3), &op.hc_w[br][l]) != FEAR_OK)
+                if (h->math == 2) {
+                    // bf16 fragments in the kernel's k order, fp32 bias / taps; prediction head: taps then 8 fragments of its 1x1
+                    for (int l = 0; l < 4; ++l) {
+                        const Conv& d = h->convs[seq[l]->conv[0]];
+                        const Conv& pw = h->convs[seq[l]->conv[1]];
+                        const int cin = l == 1 ? HeadChainG::CC : HeadChainG::C;
+                        if (upload(h, headchain_b_pack(pw.w.data(), cin, HeadChainG::C, pw.b.data()), &op.hc_w[br][l]) != FEAR_OK ||
+                            upload(h, headchain_b_taps(d.w.data(), d.has_bias ? d.b.data() : nullptr, cin, 3), &op.hc_taps[br][l]) != FEAR_OK)
+                            return false;
+                    }
+                    std::vector<float> pwk = headchain_b_taps(pd.w.data(), pd.has_bias ? pd.b.data() : nullptr, HeadChainG::C, 3);
+                    for (int P = 0; P < HeadChainG::C / 32; ++P) headchain_b_push_frag(pwk, pp.w.data(), HeadChainG::C, pp.cout, 0, P);
+                    if (upload(h, pwk, &op.hc_pred[br]) != FEAR_OK) return false;
+                } else {
+                    for (int l = 0; l < 4; ++l) {
+                        const Conv& pw = h->convs[seq[l]->conv[1]];
+                        if (upload(h, headchain_pack(sep[l].data(), l == 1 ? HeadChainG::CC : HeadChainG::C, pw.b.data(),
+                                                     l < 3 ? sep[l + 1].data() : nullptr, 3), &op.hc_w[br][l]) != FEAR_OK)
+                            return false;
+                    }
+                    if (upload(h, headchain_pack_dw(sep[0].data(), 0, HeadChainG::C / 16, 3), &op.hc_wd0[br]) != FEAR_OK ||
+                        upload(h, headchain_pack_dw(sep[1].data(), HeadChainG::C / 16, HeadChainG::TZ / 16, 3), &op.hc_wdc[br]) != FEAR_OK ||
+                        pack_fused16(h, -1, pred->conv[0], pred->conv[1], &op.hc_pred[br]) != FEAR_OK)
                         return false;
                 }
-                if (upload(h, headchain_pack_dw(sep[0].data(), 0, HeadChainG::C / 16, 3), &op.hc_wd0[br]) != FEAR_OK ||
-                    upload(h, headchain_pack_dw(sep[1].data(), HeadChainG::C / 16, HeadChainG::TZ / 16, 3), &op.hc_wdc[br]) != FEAR_OK ||
-                    pack_fused16(h, -1, pred->conv[0], pred->conv[1], &op.hc_pred[br]) != FEAR_OK)
-                    return false;
                 op.hc_pred_conv[br] = pred->conv[1];
                 op.hc_pred_act[br] = pred->act;
                 fl += 2.0 * 256 * ((double)HeadChainG::C * HeadChainG::TZ + (double)HeadChainG::C * 9 + (double)HeadChainG::C * pp.cout);
@@ -1191,7 +1211,7 @@ int build_plan_uncached(fear_handle* h, int hw, bool with_head, int mode, Plan**
             // scratch of the depthwise results, both branches of a crop side by side
             op.out_buf = pool.acquire();
             if ((size_t)2 * HeadChainG::D_FLOATS > max_elems) max_elems = (size_t)2 * HeadChainG::D_FLOATS;
-            snprintf(op.name, sizeof(op.name), "headchain_boxtower_%dx%d", feat.C, tz);
+            snprintf(op.name, sizeof(op.name), h->math == 2 ? "headchain_bf16_boxtower_%dx%d" : "headchain_boxtower_%dx%d", feat.C, tz);
             op.flops = fl;
             op.bytes = 4.0 * (S * S * feat.C + 2.0 * feat.C * tz + 5.0 * S * S);
             ops.push_back(op);
@@ -1355,6 +1375,8 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kChainXSLds));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kHeadChainKernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, HeadChainG::LDS_BYTES));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kHeadChainBKernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, HeadChainBG::LDS_BYTES));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kStemTile.kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kStemTile.lds_bytes));
         h->fused_attr_set = true;
@@ -1561,6 +1583,23 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
                 break;
             }
             case OP_HEADCHAIN: {
+                if (op.math == 2) {
+                    HeadChainBArgs a{};
+                    a.X = buf(op.in_buf) + op.in_off; a.ldx = op.in_ld; a.n_crops = n;
+                    a.relu_dw = op.relu_dw; a.relu_out = op.relu;
+                    for (int br = 0; br < 2; ++br) {
+                        HeadChainBBranch& b = a.br[br];
+                        for (int l = 0; l < 4; ++l) { b.W[l] = op.hc_w[br][l]; b.Wd[l] = op.hc_taps[br][l]; }
+                        b.Z = (br == 0 && ext.tmpl_cls) ? ext.tmpl_cls : ext.tmpl;
+                        b.z_stride = (long)HeadChainG::C * HeadChainG::TZ;
+                        b.P_W = op.hc_pred[br]; b.P_bp = h->convs[op.hc_pred_conv[br]].d_b;
+                        b.P_Y = br == 0 ? ext.cls_out : ext.bbox_out;
+                        b.pred_stride = br == 0 ? ext.cls_stride : ext.bbox_stride;
+                        b.pred_cout = br == 0 ? 1 : 4; b.pred_act = op.hc_pred_act[br];
+                    }
+                    hipLaunchKernelGGL(kHeadChainBKernel, dim3(16u * ((unsigned)(n + 7) / 8)), dim3(512), HeadChainBG::LDS_BYTES, s, a);
+                    break;
+                }
                 HeadChainArgs a{};
                 a.X = buf(op.in_buf) + op.in_off; a.ldx = op.in_ld; a.n_crops = n;
                 a.relu_dw = op.relu_dw; a.relu_out = op.relu;

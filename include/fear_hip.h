@@ -143,10 +143,11 @@ int fear_crop_normalize(fear_handle* h, const uint8_t* frame_u8, int frame_h, in
 #define FEAR_OPT_TINY_SEP 12   /* 1 (default): in the plan of a handful of crops (<= 16) the head's 16-channel SepConv slices and the      */
                                /*   prediction convs run sep16_tiny_kernel (the map cut into row groups as well, one row per wave: 4x the */
                                /*   workgroups, a quarter of the instruction issue per workgroup); 0: sep16_kernel<CIN, 16, KS> (A/B)     */
-#define FEAR_OPT_HEAD_CHAIN 13 /* 1 (default): the throughput plan in fp32 mode runs the whole BoxTower (model/blocks.py:129-194) — both    */
-                               /*   branches, their eight SepConvs, the two pixel-wise correlations and the two prediction heads — as    */
-                               /*   ONE launch (headchain_kernel: activations stay on the CU between layers); 0: eight sep16 launches    */
-                               /*   (A/B; the maps are bit-identical)                                                                    */
+#define FEAR_OPT_HEAD_CHAIN 13 /* 1 (default): the throughput plan runs the whole BoxTower (model/blocks.py:129-194) — both branches,       */
+                               /*   their eight SepConvs, the two pixel-wise correlations and the two prediction heads — as ONE launch   */
+                               /*   whose activations stay on the CU between layers: headchain_kernel in fp32 mode (maps bit-identical   */
+                               /*   to the eight sep16 launches), headchain_b_kernel with FEAR_OPT_MATH = 2 (same bf16 rounding points   */
+                               /*   as the `*_h` launches, another summation order); FEAR_OPT_MATH = 1 keeps the launches.  0: launches  */
 int fear_set_option(fear_handle* h, int option, int64_t value);
 int64_t fear_get_option(fear_handle* h, int option);
 
