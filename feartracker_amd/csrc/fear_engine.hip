@@ -127,6 +127,7 @@ struct Op {
     int math = 0;              // OP_IR16: 1 = fp16-split matrix-pipe kernel
     int pred_cout = 0;         // OP_IR16 prediction head: real output channels (4 / 1), NCHW external output
     int stem = 0;              // OP_IRTILE: stem conv fused in front (reads the caller's NCHW image)
+    int io_bf16 = 0;           // OP_IRTILE: IO_X_BF16 | IO_Y_BF16 | IO_R_BF16 — which of its tensors are stored in bf16 (kTileBf16)
     // OP_CHAIN16: per-block packed weights / projection convs, neck fragments
     float* chain_pk[8] = {nullptr};
     int chain_cp[8] = {0};
@@ -174,6 +175,7 @@ struct fear_handle {
     int tiny_sep = 1;      // FEAR_OPT_TINY_SEP: 1 = the tiny plan's 16-channel SepConv slices run sep16_tiny_kernel
     int tile_v4 = 1;       // FEAR_OPT_TILE_V4: 1 = phase-overlapped tile kernel for the blocks of kFusedTileV4 (throughput plan)
     int chain = 1;         // 1: run the stride-16 trunk stage as one register-resident chain kernel (fp32 mode)
+    int bf16_store = 1;    // FEAR_OPT_BF16_STORE: math 2 keeps the activations of the trunk's HBM-bound front in bf16 between kernels
     int head_chain = 1;    // FEAR_OPT_HEAD_CHAIN: 1 = the whole BoxTower as one launch (headchain_kernel; fp32 mode, throughput plan)
     int small_pass = 96;   // passes of at most this many crops run the small-batch plan (FEAR_OPT_SMALL_PASS; 0: never);
                            // measured crossover with the throughput plan: ~110 crops (1.70 vs 1.93 ms at 96, 2.14 vs 2.01 at 128)
@@ -407,6 +409,25 @@ static_assert(sizeof(kFusedTileB) == sizeof(kFusedTile), "same blocks, same orde
 const FusedTile kStemTile = {16, 16, 16, 3, 1, 0, 128, 32, 16,
                              ir_tile_v2_kernel<27, 16, 16, 3, 1, 32, 16, true, 4, true>,
                              IrT2Geom<27, 16, 16, 3, 1, 32, 16, true>::LDS_BYTES, 8};
+
+// FEAR_OPT_MATH = 2 with FEAR_OPT_BF16_STORE: the HBM-bound front of the trunk keeps its activations in bf16 between kernels (stem
+// output ... input of the 64 -> 32 block).  Storage variants of the tile kernels, keyed by (stem | index into the tile tables) and
+// the IO bits (fear_kernels.h: IO_X_BF16 | IO_Y_BF16 | IO_R_BF16); same tiles and LDS footprints as the entries they stand in for.
+struct TileBf16 { int stem, id, io; void (*kernel)(IrT2Args); };
+const TileBf16 kTileBf16[] = {
+    {1, -1, IO_Y_BF16, ir_tile_v2_kernel<27, 16, 16, 3, 1, 32, 16, true, 4, true, 0, IO_Y_BF16>},
+    {0, 0, IO_X_BF16 | IO_Y_BF16 | IO_R_BF16, ir_tile_v2_kernel<16, 16, 16, 3, 1, 32, 16, false, 4, false, 0, IO_X_BF16 | IO_Y_BF16 | IO_R_BF16>},
+    {0, 0, IO_X_BF16 | IO_Y_BF16, ir_tile_v2_kernel<16, 16, 16, 3, 1, 32, 16, false, 4, false, 0, IO_X_BF16 | IO_Y_BF16>},
+    {0, 1, IO_X_BF16 | IO_Y_BF16, ir_tile_h_kernel<16, 96, 24, 3, 2, 16, 4, true, 4, 2, 2, IO_X_BF16 | IO_Y_BF16>},
+    {0, 2, IO_X_BF16 | IO_Y_BF16 | IO_R_BF16, ir_tile_v2_kernel<24, 32, 24, 3, 1, 16, 16, false, 4, false, 0, IO_X_BF16 | IO_Y_BF16 | IO_R_BF16>},
+    {0, 2, IO_X_BF16 | IO_Y_BF16, ir_tile_v2_kernel<24, 32, 24, 3, 1, 16, 16, false, 4, false, 0, IO_X_BF16 | IO_Y_BF16>},
+    {0, 3, IO_X_BF16, ir_tile_h_kernel<24, 160, 32, 5, 2, 16, 4, true, 4, 2, 2, IO_X_BF16>},
+};
+const TileBf16* find_tile_bf16(int stem, int id, int io) {
+    for (const TileBf16& t : kTileBf16)
+        if (t.stem == stem && (stem || t.id == id) && t.io == io) return &t;
+    return nullptr;
+}
 
 // the same blocks with smaller tiles = more workgroups per crop, for the small-batch plan (same order as kFusedTile)
 const FusedTile kFusedTileSmall[] = {
@@ -1024,6 +1045,27 @@ int build_plan_uncached(fear_handle* h, int hw, bool with_head, int mode, Plan**
             return FEAR_ERR_FORMAT;
         }
     }
+    // ---- bf16 activation storage for the HBM-bound front of the trunk (FEAR_OPT_MATH = 2, FEAR_OPT_BF16_STORE): a tile op writes
+    //      bf16 when its output map is at least 64 x 64 and its consumer has a storage variant that reads it (kTileBf16)
+    if (h->math == 2 && h->bf16_store && with_head && hw == 256 && !small && h->fuse) {
+        auto reads_bf16 = [&](const Op& op) {      // some variant of this op takes a bf16 input (and residual, if it has one)
+            if (op.type != OP_IRTILE || op.stem || op.splitk) return false;
+            const int need = IO_X_BF16 | (op.res_buf >= 0 ? IO_R_BF16 : 0);
+            return find_tile_bf16(0, op.fused_id, need) || find_tile_bf16(0, op.fused_id, need | IO_Y_BF16);
+        };
+        bool cur_bf16 = false;
+        for (size_t i = 0; i < ops.size(); ++i) {
+            Op& op = ops[i];
+            if (op.type != OP_IRTILE || op.splitk) { cur_bf16 = false; continue; }
+            const int in_bits = cur_bf16 ? (IO_X_BF16 | (op.res_buf >= 0 ? IO_R_BF16 : 0)) : 0;
+            const bool want_out = op.Ho >= 64 && i + 1 < ops.size() && reads_bf16(ops[i + 1]);
+            int io = in_bits | (want_out ? IO_Y_BF16 : 0);
+            if (io && !find_tile_bf16(op.stem, op.fused_id, io)) io = in_bits;          // no such variant: keep the output fp32
+            if (io && !find_tile_bf16(op.stem, op.fused_id, io)) return FEAR_ERR_SHAPE;  // (cannot happen: the producer checked reads_bf16)
+            op.io_bf16 = io;
+            cur_bf16 = (io & IO_Y_BF16) != 0;
+        }
+    }
     // ---- head (BoxTower.forward, model/blocks.py:174-194)
     if (with_head) {
         const FearwBlock* role[9] = {nullptr};
@@ -1373,6 +1415,10 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kSep16CorrLds));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kChainXSKernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kChainXSLds));
+        for (const TileBf16& tb : kTileBf16) {
+            const int lds = tb.stem ? kStemTile.lds_bytes : (tb.id == 1 || tb.id == 3) ? kFusedTileB[tb.id].lds_bytes : kFusedTile[tb.id].lds_bytes;
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(tb.kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        }
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kHeadChainKernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, HeadChainG::LDS_BYTES));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kHeadChainBKernel),
@@ -1568,6 +1614,11 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
                     hipLaunchKernelGGL(ks->kernel, dim3((unsigned)n * ta.tiles_x * ta.tiles_y, op.splitk), dim3(512), ks->lds_bytes, s, ta);
                     const long total = (long)ra.M * (ra.N / 4);
                     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ra);
+                    break;
+                }
+                if (op.io_bf16) {      // same tile, storage variant (plan: bf16 front of the trunk)
+                    const TileBf16* tb = find_tile_bf16(op.stem, op.fused_id, op.io_bf16);
+                    hipLaunchKernelGGL(tb->kernel, dim3((unsigned)n * ta.tiles_x * ta.tiles_y), dim3(64 * f.nw), f.lds_bytes, s, ta);
                     break;
                 }
                 hipLaunchKernelGGL(f.kernel, dim3((unsigned)n * ta.tiles_x * ta.tiles_y), dim3(64 * f.nw), f.lds_bytes, s, ta);
@@ -1784,6 +1835,10 @@ int fear_set_option(fear_handle* h, int option, int64_t value) {
             if (value != 0 && value != 1) return FEAR_ERR_SHAPE;
             if (h->head_chain != (int)value) { h->head_chain = (int)value; return drop_plans(h); }
             return FEAR_OK;
+        case FEAR_OPT_BF16_STORE:
+            if (value != 0 && value != 1) return FEAR_ERR_SHAPE;
+            if (h->bf16_store != (int)value) { h->bf16_store = (int)value; return drop_plans(h); }
+            return FEAR_OK;
         default: return FEAR_ERR_SHAPE;
     }
 }
@@ -1804,6 +1859,7 @@ int64_t fear_get_option(fear_handle* h, int option) {
         case FEAR_OPT_TILE_V4: return h->tile_v4;
         case FEAR_OPT_TINY_SEP: return h->tiny_sep;
         case FEAR_OPT_HEAD_CHAIN: return h->head_chain;
+        case FEAR_OPT_BF16_STORE: return h->bf16_store;
         default: return FEAR_ERR_SHAPE;
     }
 }

@@ -39,6 +39,26 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace fear {
 
+// Storage of an activation tensor the tile kernels read / write: fp32 (every mode), or bf16 for the HBM-bound front of the trunk
+// in the bf16 arithmetic mode (FEAR_OPT_MATH = 2 + FEAR_OPT_BF16_STORE: stem output ... input of the 64 -> 32 block).  The tile
+// kernels take the choice as the template parameter IO (bits below); offsets are in ELEMENTS either way.
+constexpr int IO_X_BF16 = 1, IO_Y_BF16 = 2, IO_R_BF16 = 4;
+typedef __bf16 act_bf4 __attribute__((ext_vector_type(4)));
+template <bool BF>
+__device__ __forceinline__ f32x4 ld_act4(const float* base, long off) {
+    if (BF) {
+        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + off);
+        return (f32x4){__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                       __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u)};
+    }
+    return *reinterpret_cast<const f32x4*>(base + off);
+}
+template <bool BF>
+__device__ __forceinline__ void st_act4(float* base, long off, const f32x4& v) {
+    if (BF) *reinterpret_cast<act_bf4*>(reinterpret_cast<unsigned short*>(base) + off) = __builtin_convertvector(v, act_bf4);   // RNE
+    else *reinterpret_cast<f32x4*>(base + off) = v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // 1x1 convolution / correlation on the matrix cores.
 //
@@ -1466,9 +1486,10 @@ struct IrT2Args {
 // (= the block input) only in LDS; the block's residual is read back from that LDS tile.  CIN must be 27.
 // KSPLIT = k > 0 (a handful of crops): gridDim.y workgroups per tile, workgroup y running the k expansion chunks from chunk
 // y*k on and writing its RAW partial projection to Y + y * kc_part_stride (splitk_reduce_kernel adds bias / residual / ReLU).
-template <int CIN, int CEXPP, int COUT, int KS, int ST, int TW, int TH, bool EXPAND, int MINW, bool STEM = false, int KSPLIT = 0>
+template <int CIN, int CEXPP, int COUT, int KS, int ST, int TW, int TH, bool EXPAND, int MINW, bool STEM = false, int KSPLIT = 0, int IO = 0>
 __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
     static_assert(!STEM || (EXPAND && CIN == 27 && ST == 1 && CEXPP == 16), "stem mode");
+    static_assert(IO == 0 || (KSPLIT == 0 && (STEM ? IO == IO_Y_BF16 : !EXPAND)), "bf16 storage: the stem tile's output, the e1 blocks' input / output / residual");
     static_assert(KSPLIT == 0 || (!STEM && EXPAND && KSPLIT >= 2 && (CEXPP / 16) % KSPLIT == 0), "KSPLIT = chunks per workgroup");
     using G = IrT2Geom<CIN, CEXPP, COUT, KS, ST, TW, TH, EXPAND>;
     const Ir2Args& a = t.b;
@@ -1500,7 +1521,8 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
     const int NPIX = CW * CH;
     const float inv_cw = __builtin_amdgcn_rcpf((float)CW);      // 1 ulp is plenty: (q + 0.5) / CW stays 0.5 / CW away from every integer
     const int Wo = t.W / ST, Ho = t.H / ST;
-    const float* Xc = STEM ? a.X + crop * 3 * (2 * t.H) * (2 * t.W) : a.X + crop * t.H * t.W * a.ldx;
+    const float* Xc = STEM ? a.X + crop * 3 * (2 * t.H) * (2 * t.W) : a.X + ((IO & IO_X_BF16) ? 0 : crop * t.H * t.W * a.ldx);
+    const long xbase = (IO & IO_X_BF16) ? crop * t.H * t.W * a.ldx : 0;      // (bf16 input: offsets in elements from a.X)
 
     // stem mode stages the image patch in the E area first (see below) and zeroes the out-of-image positions afterwards
     if (!STEM && !(FEAR_ABL & 1024))
@@ -1618,7 +1640,7 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
 #pragma unroll
             for (int i = 0; i < MTA; ++i) {
                 rx[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (c * 16 + lk * 4 < CIN) rx[i] = *reinterpret_cast<const f32x4*>(Xc + xoff[i] + c * 16 + lk * 4);
+                if (c * 16 + lk * 4 < CIN) rx[i] = ld_act4<(IO & IO_X_BF16) != 0>(Xc, xbase + xoff[i] + c * 16 + lk * 4);
             }
         }
     };
@@ -1765,9 +1787,9 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
             const long m = (crop * Ho + oy) * Wo + ox;
             f32x4 v = accp[r][nt] + b;
             if (STEM) v += *reinterpret_cast<const f32x4*>(E + G::eo((r0 + r + P) * IWR + seg * 16 + li + P, lk));   // NTP == 1: n = 4 * lk
-            else if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
+            else if (a.R) v += ld_act4<(IO & IO_R_BF16) != 0>(a.R, m * a.ldr + n);
             if (a.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            if (!(FEAR_ABL & 2048) || v.x == 1234.5f) *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = v;
+            if (!(FEAR_ABL & 2048) || v.x == 1234.5f) st_act4<(IO & IO_Y_BF16) != 0>(a.Y, m * a.ldy + n, v);
         }
     }
     if ((FEAR_ABL & 4096) && a.P_Y && blockIdx.x == 1000 && lane == 0) {
@@ -2649,8 +2671,9 @@ struct IrTHGeom {
     static constexpr int LDS_BYTES = (EBUF + 2 * (AP + BP)) * 4;
 };
 
-template <int CIN, int CEXPP, int COUT, int KS, int ST, int TW, int TH, bool EXPAND, int NW, int MINW, int MM = 1>
+template <int CIN, int CEXPP, int COUT, int KS, int ST, int TW, int TH, bool EXPAND, int NW, int MINW, int MM = 1, int IO = 0>
 __global__ __launch_bounds__(64 * NW, MINW) void ir_tile_h_kernel(IrT2Args t) {
+    static_assert(IO == 0 || (MM == 2 && EXPAND && (IO & IO_R_BF16) == 0 && CIN % 8 == 0), "bf16 storage: input / output of the bf16-mode expand blocks");
     using MX = MatOps<MM>;
     using V8 = typename MX::V;
     using G = IrTHGeom<CIN, CEXPP, COUT, KS, ST, TW, TH, EXPAND, NW>;
@@ -2715,6 +2738,14 @@ __global__ __launch_bounds__(64 * NW, MINW) void ir_tile_h_kernel(IrT2Args t) {
 #pragma unroll
             for (int kg = 0; kg < KG; ++kg) {
                 const int k = kg * 32 + lk * 8;
+                if (IO & IO_X_BF16) {
+                    // the stored activations ARE the bf16 operands: eight channels = one 16-byte load, no conversion
+                    uint4 u = (uint4){0u, 0u, 0u, 0u};
+                    if (k < CIN) u = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(a.X) + crop * t.H * t.W * a.ldx + xoff[i] + k);
+                    xhi[i][kg] = __builtin_bit_cast(V8, u);
+                    xlo[i][kg] = xhi[i][kg];
+                    continue;
+                }
                 f32x4 v0 = (f32x4){0.f, 0.f, 0.f, 0.f}, v1 = v0;
                 if (k < CIN) v0 = *reinterpret_cast<const f32x4*>(Xc + xoff[i] + k);
                 if (k + 4 < CIN) v1 = *reinterpret_cast<const f32x4*>(Xc + xoff[i] + k + 4);
@@ -2872,7 +2903,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void ir_tile_h_kernel(IrT2Args t) {
             f32x4 v = accp[r][nt] + b;
             if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
             if (a.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = v;
+            st_act4<(IO & IO_Y_BF16) != 0>(a.Y, m * a.ldy + n, v);
         }
     }
 }

@@ -148,6 +148,9 @@ int fear_crop_normalize(fear_handle* h, const uint8_t* frame_u8, int frame_h, in
                                /*   whose activations stay on the CU between layers: headchain_kernel in fp32 mode (maps bit-identical   */
                                /*   to the eight sep16 launches), headchain_b_kernel with FEAR_OPT_MATH = 2 (same bf16 rounding points   */
                                /*   as the `*_h` launches, another summation order); FEAR_OPT_MATH = 1 keeps the launches.  0: launches  */
+#define FEAR_OPT_BF16_STORE 14 /* 1 (default): with FEAR_OPT_MATH = 2 the throughput plan keeps the activations of the trunk's HBM-bound      */
+                               /*   front (stem output ... input of the 64 -> 32 block; maps of 64 x 64 and larger) in bf16 BETWEEN kernels — */
+                               /*   half the traffic of the kernels that are bound by it; 0: fp32 storage (A/B).  No effect in modes 0 / 1.   */
 int fear_set_option(fear_handle* h, int option, int64_t value);
 int64_t fear_get_option(fear_handle* h, int option);
 

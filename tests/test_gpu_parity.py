@@ -470,7 +470,8 @@ def test_head_chain_bf16_mode_against_the_bf16_sepconv_launches_and_fp32():
     """FEAR_OPT_MATH = 2 (BASELINE configs[3]): the one-launch head on v_mfma_f32_16x16x32_bf16 (headchain_b_kernel) rounds the same
     values to bf16 as the sep16 `*_h` launches it replaces — depthwise outputs, template features, weights — so the two agree far
     inside the mode's stated tolerance against fp32 (8e-2 relative on the ltrb maps, 2 % of the logit scale); they are not
-    bit-identical: another fp32 summation order moves a few activations across a bf16 rounding boundary (2^-9 each)."""
+    bit-identical: another fp32 summation order moves a few activations across a bf16 rounding boundary (2^-9 each).  The chained
+    plan also runs with FEAR_OPT_BF16_STORE at its default (the trunk's first activations stored as bf16 between kernels)."""
     from feartracker_amd import FEARNetHIP
     from conftest import WEIGHTS
     nets = {}
@@ -479,6 +480,8 @@ def test_head_chain_bf16_mode_against_the_bf16_sepconv_launches_and_fp32():
         n.set_small_pass(0)
         n.set_math(math)
         n.set_head_chain(chain)
+        if not chain:
+            n.set_bf16_store(False)     # "launches" = round 3's bf16 plan: fp32 storage everywhere, sep16 `*_h` launches
         nets[key] = n
     assert any(nm.startswith("headchain_bf16") for nm, _, _ in nets["bf16_chain"].plan(256, True))
     assert not any(nm.startswith("headchain") for nm, _, _ in nets["bf16_launches"].plan(256, True))
@@ -921,5 +924,7 @@ def test_fear_m_at_the_config_size_512_crops():
     flat = c0.reshape(B, -1)
     top2 = torch.topk(flat, 2, dim=1).values
     need = (top2[:, 0] - top2[:, 1]) > 2 * dev_c
-    assert int(need.sum()) >= B // 4
+    # (how many crops of the seeded-random FEAR-M have such a margin: 150 of 512 at round 3's deviation of 0.08, 111 at round 4's 0.10
+    # — bf16 storage of the trunk's first activations adds its roundings to the mode's; the identity itself holds on every one of them)
+    assert int(need.sum()) >= B // 8
     assert torch.equal(c2.reshape(B, -1).argmax(dim=1)[need], flat.argmax(dim=1)[need])
