@@ -2957,37 +2957,12 @@ __device__ __forceinline__ void chain16_block(const f32x4 (&xin)[2][B::CIN / 16]
     const int li = lane & 15, lk = lane >> 4;
     const int y0 = wave * 2;
 
-    f32x4 ra[NRA], rb[NRB];
-    auto load_a = [&](int c) {
-#pragma unroll
-        for (int r = 0; r < NRA; ++r) {
-            const int idx = tid + r * 512;
-            if (idx < AP4) ra[r] = *reinterpret_cast<const f32x4*>(Wpk + (long)c * CST + idx * 4);
-        }
-    };
-    auto store_a = [&](int c) {
-        float* dst = WA + (c & 1) * AP_MAX;
-#pragma unroll
-        for (int r = 0; r < NRA; ++r) {
-            const int idx = tid + r * 512;
-            if (idx < AP4) *reinterpret_cast<f32x4*>(dst + idx * 4) = ra[r];
-        }
-    };
-    auto load_b = [&](int c) {
-#pragma unroll
-        for (int r = 0; r < NRB; ++r) {
-            const int idx = tid + r * 512;
-            if (idx < BP4) rb[r] = *reinterpret_cast<const f32x4*>(Wpk + (long)c * CST + AP + idx * 4);
-        }
-    };
-    auto store_b = [&](int c) {
-        float* dst = WB + (c & 1) * BP_MAX;
-#pragma unroll
-        for (int r = 0; r < NRB; ++r) {
-            const int idx = tid + r * 512;
-            if (idx < BP4) *reinterpret_cast<f32x4*>(dst + idx * 4) = rb[r];
-        }
-    };
+    // the packed weights go global -> LDS by asynchronous copies (no staging registers, no ds_write: three ds_write_b128 per thread
+    // and interval were ~120 cycles of the SIMD's ALU time, profiles/r03_issue_probe.txt), issued at the start of an interval into
+    // the stage the previous interval read last and complete at the interval's barrier
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    auto stage_a = [&](int c) { lds_copy_async<AP>(Wpk + (long)c * CST, WA + (c & 1) * AP_MAX, wave_s, lane); };
+    auto stage_b = [&](int c) { lds_copy_async<BP>(Wpk + (long)c * CST + AP, WB + (c & 1) * BP_MAX, wave_s, lane); };
     auto phase_a = [&](int c) {
         const float* wa = WA + (c & 1) * AP_MAX;
         float* E = Ebuf + (c & 1) * EBUF;
@@ -3022,25 +2997,21 @@ __device__ __forceinline__ void chain16_block(const f32x4 (&xin)[2][B::CIN / 16]
     }
     // prologue (the previous block / the kernel prologue ended with a barrier: stages and E are free)
     __builtin_amdgcn_sched_barrier(0);      // keep the scheduler from moving code across block boundaries
-    load_a(0);
-    load_b(0);
-    store_a(0);
-    store_b(0);
-    if (NCHUNK > 1) { load_a(1); store_a(1); }
+    stage_a(0);
+    stage_b(0);
+    if (NCHUNK > 1) stage_a(1);
     __syncthreads();
     phase_a(0);
     __syncthreads();
     for (int c = 0; c < NCHUNK; ++c) {
-        if (c + 2 < NCHUNK) load_a(c + 2);
-        if (c + 1 < NCHUNK) load_b(c + 1);
+        if (c + 2 < NCHUNK) stage_a(c + 2);
+        if (c + 1 < NCHUNK) stage_b(c + 1);
         const float* Ec = Ebuf + (c & 1) * EBUF;
         float* En = Ebuf + ((c + 1) & 1) * EBUF;
         const float* wa = WA + ((c + 1) & 1) * AP_MAX;
         const float* wb = WB + (c & 1) * BP_MAX;
         if (c + 1 < NCHUNK) ir16_interval<B::KS, PW, ES, KG, NTP, true>(Ec, En, wa, wb, xin, accp, y0, li, lk, lane, true);
         else ir16_interval<B::KS, PW, ES, KG, NTP, false>(Ec, En, wa, wb, xin, accp, y0, li, lk, lane, true);
-        if (c + 2 < NCHUNK) store_a(c + 2);
-        if (c + 1 < NCHUNK) store_b(c + 1);
         __syncthreads();
     }
 }
