@@ -238,13 +238,13 @@ __global__ __launch_bounds__(512) void headchain_kernel(HeadChainArgs a) {
 
     f32x4 cacc[2][TZ / 16];             // layer 0: correlation accumulators
     f32x4 pacc[2];                      // layer 3: prediction accumulators
-    f32x4 ds[TZ / 16][2];               // layer 1: the streamed B fragments of the correlation chunks (16..19)
+    f32x4 ds[TZ / 16][2];               // layer 1: the B fragments of the correlation chunks (16..19), written by layer 0's last hand-over
     f32x4 wf0, wf1;                     // the first two weight fragments of the next pass (read between its two barriers)
     wf0 = *reinterpret_cast<const f32x4*>(Wb + lane * 4);
     wf1 = *reinterpret_cast<const f32x4*>(Wb + 256 + lane * 4);
 
     // One SepConv layer = 8 passes.  MODE 0: plain, 1: + correlation (layer 0), 2: prediction head instead of a hand-over (layer 3).
-    // On entry d[][] holds the layer's depthwise results (layer 1: chunks 16..19 are streamed from the scratch), Wb[0] its pass-0 block.
+    // On entry d[][] holds the layer's depthwise results (layer 1: chunks 16..19 in ds[][]), Wb[0] its pass-0 block.
     auto layer = [&](auto cin_tag, auto mode_tag, const float* Wl, const float* Wnext) {
         constexpr int CIN = decltype(cin_tag)::value, MODE = decltype(mode_tag)::value;
         constexpr int NC = CIN / 16, WP = G::wpass(CIN);
@@ -373,12 +373,6 @@ __global__ __launch_bounds__(512) void headchain_kernel(HeadChainArgs a) {
                         else lds_copy_async<4 * WDF>(b.WdC, Zr + ((p + 1) & 1) * ZS, wave, lane);     // the correlation chunks' depthwise weights
                     }
                 }
-                if (CIN > C && c >= 4 && c < 4 + (CIN - C) / 16) {
-                    // layer 1: the B fragments of the correlation chunks (16..19) come from the scratch every pass (the registers hold
-                    // 16 chunks); issued here, ~10 chunks (4 us) ahead of their use
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) ds[c - 4][mt] = *dptr(C / 16 + c - 4, mt);
-                }
                 if (LAST && MODE != 2 && c < C / 16 - NTP) {
                     // the layer is over for chunk c: pull the NEXT layer's depthwise result of chunk c into the freed registers
                     // (written to the scratch by this lane in the hand-over of pass c / 2 — the one of pass 6 a few groups ago; the
@@ -459,7 +453,7 @@ __global__ __launch_bounds__(512) void headchain_kernel(HeadChainArgs a) {
             pass(p_last, std::true_type{}, std::true_type{});
         }
         if (MODE == 1) {
-            // ---- the 64 correlation channels = input chunks 16..19 of layer 1: hand-over, two chunks a round, to the scratch
+            // ---- the 64 correlation channels = input chunks 16..19 of layer 1: hand-over, two chunks a round, into ds[][]
             const float* wdc = Zr + (NPASS & 1) * ZS;           // (copied in during the last pass)
 #pragma unroll
             for (int r = 0; r < NTZ / 2; ++r) {
@@ -468,10 +462,8 @@ __global__ __launch_bounds__(512) void headchain_kernel(HeadChainArgs a) {
                 __syncthreads();
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    f32x4 n0, n1;
-                    tile_dw(nt, wdc + (2 * r + nt) * WDF, n0, n1, a.relu_dw);
-                    *dptr(C / 16 + 2 * r + nt, 0) = n0;
-                    *dptr(C / 16 + 2 * r + nt, 1) = n1;
+                    // (straight into the registers layer 1 reads them from: 160 of its B-fragment registers instead of 128 + 32 reloaded every pass)
+                    tile_dw(nt, wdc + (2 * r + nt) * WDF, ds[2 * r + nt][0], ds[2 * r + nt][1], a.relu_dw);
                 }
                 __syncthreads();
             }
