@@ -564,10 +564,14 @@ std::vector<float> pack_fused16_host(const fear_handle* h, int ce, int cd, int c
                 // a last k-group of 8 channels is packed two per lane group (k = 2*(l>>4) + i, i < 2): the tile kernel then
                 // spends two MFMA steps on it instead of four (IrT2Geom::KHALF)
                 const bool khalf = cin % 16 == 8 && kg == kg_n - 1;
+                // the stem's im2col K = 27: MFMA step j = kg * 4 + i takes k = 4 * j + (l >> 4), so that the padding (k = 27..31) is
+                // one lane group of step 6 and the whole of step 7, which the stem tile never issues (7 MFMAs per m-tile, not 8)
+                const bool stemk = e->k > 1 && cin == 27;
                 for (int l = 0; l < 64; ++l)
                     for (int i = 0; i < 4; ++i) {
                         const int n = c0 + (l & 15);
-                        const int k = khalf ? (i < 2 ? kg * 16 + (l >> 4) * 2 + i : cin) : kg * 16 + (l >> 4) * 4 + i;
+                        const int k = stemk ? 4 * (kg * 4 + i) + (l >> 4) :
+                                      khalf ? (i < 2 ? kg * 16 + (l >> 4) * 2 + i : cin) : kg * 16 + (l >> 4) * 4 + i;
                         buf.push_back(n < cexp && k < cin ? e->w[(size_t)n * cin + k] : 0.f);
                     }
             }

@@ -1567,34 +1567,40 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
         // adds, and the im2col tap offsets come from a compile-time table instead of eight k / 9, k % 9 / 3, k % 3 chains.
         const int img_h = 2 * t.H, img_w = 2 * t.W;
         const int row0 = 2 * iy0 - 1, col0 = 2 * ix0 - 2;
-        constexpr int RS = 512 / PF4;                          // row slots: RS * PF4 <= 512 threads stage, the rest idle here
+        constexpr int RS = 512 / PF4, NR = (PR + RS - 1) / RS;  // row slots: RS * PF4 <= 512 threads stage, the rest idle here
         const int rs = tid / PF4, f = tid - rs * PF4;
-        if (rs < RS && !(FEAR_ABL & 512)) {
+        // All 3 * NR loads of a thread are issued back to back and committed to LDS afterwards — with a branch around each load
+        // the compiler had serialised them (load, s_waitcnt vmcnt(0), ds_write, six times: six memory round trips in a row at the
+        // head of every tile).  Buffer loads make them branch free: a lane outside the image (or beyond the patch rows) gets an
+        // out-of-range offset, for which the hardware returns zeros — the conv's zero padding — without touching memory.  The
+        // per-plane part of the address is the instruction's scalar offset: one VGPR offset per row slot.
+        f32x4 pv[3][NR];
+        if (!(FEAR_ABL & 512)) {
+            const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Xc), 0, 3 * img_h * img_w * 4, 0x00020000);
             const int ix = col0 + 4 * f;
-            const bool xin = ix >= 0 && ix < img_w;
+            const bool xin = rs < RS && ix >= 0 && ix < img_w;
+            const int voff = ((row0 + rs) * img_w + ix) * 4;
+            int vo[NR];
 #pragma unroll
-            for (int ci = 0; ci < 3; ++ci) {
-                const float* plane = Xc + (long)ci * img_h * img_w + ix;
-#pragma unroll
-                for (int pr0 = 0; pr0 < PR; pr0 += RS) {
-                    const int pr = pr0 + rs;
-                    const int iy = row0 + pr;
-                    if (pr < PR) {
-                        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        if (xin && iy >= 0 && iy < img_h) v = *reinterpret_cast<const f32x4*>(plane + (long)iy * img_w);
-                        *reinterpret_cast<f32x4*>(E + (ci * PR + pr) * PWID + 4 * f) = v;
-                    }
-                }
+            for (int n = 0; n < NR; ++n) {
+                const int pr = n * RS + rs, iy = row0 + pr;
+                vo[n] = (xin && pr < PR && iy >= 0 && iy < img_h) ? voff + n * RS * img_w * 4 : (int)0x80000000;   // (the range check is on this offset alone: it must not be negative for a valid lane)
             }
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+                for (int n = 0; n < NR; ++n)
+                    pv[ci][n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(img, vo[n], ci * img_h * img_w * 4, 0));
         }
-        // tap j of lane group lk is k = (j >> 2) * 16 + lk * 4 + (j & 3) = (ci * 3 + ky) * 3 + kx; stem pixel (gy, gx) reads image
-        // col 2*gx - 1 + kx = col0 + 2*(gx - ix0) + 1 + kx.  K padding (k >= 27): its weights are zero, any finite value will do
+        // tap j (= MFMA step j) of lane group lk is k = 4 * j + lk = (ci * 3 + ky) * 3 + kx (pack_fused16_host's stem order: the
+        // K padding is lane group 3 of step 6 — zero weights, any finite value will do — and step 7, which is never issued);
+        // stem pixel (gy, gx) reads image col 2*gx - 1 + kx = col0 + 2*(gx - ix0) + 1 + kx
         struct Tab {
             int v[4][8];
             constexpr Tab() : v{} {
                 for (int g = 0; g < 4; ++g)
                     for (int j = 0; j < 8; ++j) {
-                        const int k = (j >> 2) * 16 + g * 4 + (j & 3);
+                        const int k = 4 * j + g;
                         const int kk = k < 27 ? k : 0;
                         v[g][j] = ((kk / 9) * PR + (kk % 9) / 3) * PWID + kk % 3 + 1;
                     }
@@ -1603,10 +1609,50 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
         static constexpr Tab tab{};
 #pragma unroll
         for (int j = 0; j < 8; ++j) s_off[j] = tab.v[lk][j];
+        if (rs < RS && !(FEAR_ABL & 512)) {
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+                for (int n = 0; n < NR; ++n)
+                    if (n * RS + rs < PR) *reinterpret_cast<f32x4*>(E + (ci * PR + n * RS + rs) * PWID + 4 * f) = pv[ci][n];
+        }
         __syncthreads();                               // patch complete
     }
+    if constexpr (STEM) {
+        // m-tile i of this wave is pixels q = (wave + 8 i) * 16 + li of the clipped region (row-major, CW columns).  One division for
+        // i = 0; every further m-tile is 128 pixels on = qa rows + qb columns with at most one wrap, and both offsets a lane needs
+        // (its pixel in the E tile, its pixel in the patch) are linear in (row, column): a compare and three selects per m-tile
+        // instead of a division and three multiplications — the prologue runs once per tile and the stem has ONE chunk, so here it
+        // is a tenth of the kernel's instruction issue.
+        const int q0 = wave * 16 + li;
+        const int cy0 = (int)(((float)q0 + 0.5f) * inv_cw), cx0 = q0 - cy0 * CW;
+        const int qa = 128 / CW, qb = 128 - qa * CW;
+        const int dpe0 = qa * IWR + qb, dpe1 = dpe0 + IWR - CW, dpq0 = qa * PWID + qb, dpq1 = dpq0 + PWID - CW;
+        int cx = cx0;
+        int pe = (cy0 + cy_lo - iy0) * IWR + cx0 + cx_lo - ix0;
+        int pq = (cy0 + cy_lo - iy0) * PWID + cx0 + cx_lo - ix0;
 #pragma unroll
-    for (int i = 0; i < MTA; ++i) {
+        for (int i = 0; i < MTA; ++i) {
+            // lanes beyond the clipped region store to a dummy slot (phase A stays branch free); what they gather is any LDS word
+            eoff[i] = q0 < NPIX - 128 * i ? G::eo(pe, lk) : EBUF + G::NSTAGE * CST + lane * 4;
+            xoff[i] = 0;
+            const float* pp = E + 2 * pq;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) v[j] = pp[s_off[j]];
+            xf[i][0] = (f32x4){v[0], v[1], v[2], v[3]};
+            xf[i][1] = (f32x4){v[4], v[5], v[6], 0.f};
+            if (i + 1 < MTA) {
+                cx += qb;
+                const bool wrap = cx >= CW;
+                cx -= wrap ? CW : 0;
+                pe += wrap ? dpe1 : dpe0;
+                pq += wrap ? dpq1 : dpq0;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < (STEM ? 0 : MTA); ++i) {
         const int q = (wave + 8 * i) * 16 + li;
         const bool valid = q < NPIX;
         const int qq = valid ? q : 0;
@@ -1655,6 +1701,16 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
     for (int r = 0; r < MTC; ++r)
 #pragma unroll
         for (int nt = 0; nt < NTP; ++nt) accp[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // the projection bias: read in the epilogue it is one more exposed memory round trip at the tail of every tile.  The one- and
+    // two-chunk kernels (stem tile, e1 blocks), where that tail is a visible share, fetch it here; the others would pay for the
+    // 4 * NTP registers with occupancy (stage 2: 76 -> 84 VGPRs = two workgroups per CU instead of three, +3 %) and keep it late.
+    constexpr bool BIAS_EARLY = !KSPLIT && NCHUNK <= 2 && !(FEAR_ABL & 16384);
+    f32x4 bpv[NTP];
+#pragma unroll
+    for (int nt = 0; nt < NTP; ++nt) {
+        bpv[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (BIAS_EARLY && nt * 16 + lk * 4 < COUT) bpv[nt] = *reinterpret_cast<const f32x4*>(a.bp + nt * 16 + lk * 4);
+    }
 
     const long long tk_begin = (FEAR_ABL & 4096) ? wall_clock64() : 0;   // kbench -DFEAR_ABL=4096: 10 ns ticks per region
     long long tm[6] = {0, 0, 0, 0, 0, 0};
@@ -1675,7 +1731,7 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
 #pragma unroll
                 for (int kg = 0; kg < KG; ++kg)
 #pragma unroll
-                    for (int q = 0; q < ((KHALF && kg == KG - 1) ? 2 : 4); ++q) {
+                    for (int q = 0; q < ((KHALF && kg == KG - 1) ? 2 : (STEM && kg == 1) ? 3 : 4); ++q) {
                         if (FEAR_ABL & 8) { acc += wf[kg] * xf[i][kg][q]; continue; }
                         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kg][q], xf[i][kg][q], acc, 0, 0, 0);
                     }
@@ -1754,7 +1810,8 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
         }
         const long long tk5 = (FEAR_ABL & 4096) ? wall_clock64() : 0;
         if (c + 1 < NCHUNK && !(FEAR_ABL & 2)) store_w(c + 1);
-        if ((!EXPAND || c + 1 == NCHUNK) && !(FEAR_ABL & 1)) __syncthreads();   // E is rewritten next chunk (EXPAND syncs at loop top)
+        // !EXPAND: E is rewritten by the next chunk (EXPAND syncs at loop top); after the last chunk nothing writes LDS any more
+        if (((!EXPAND && c + 1 < NCHUNK) || ((FEAR_ABL & 8192) && c + 1 == NCHUNK)) && !(FEAR_ABL & 1)) __syncthreads();
         if (FEAR_ABL & 4096) {
             const long long tk6 = wall_clock64();
             tm[0] += tk1 - tk0; tm[1] += tk2 - tk1; tm[2] += tk3 - tk2; tm[3] += tk4 - tk3; tm[4] += tk5 - tk4; tm[5] += tk6 - tk5;
@@ -1776,20 +1833,25 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
         }
         return;
     }
+    // Addresses: the row of a wave is uniform (crop, tile and wave index live in SGPRs), so a store is [scalar base + one 32-bit
+    // lane offset] — the 64-bit pixel index per row cost two v_mad_u64_u32, two v_mul_lo_u32 and a 64-bit add each.  The ReLU is
+    // a max against 0 or -inf (a uniform select) instead of a branch with a register copy on its other side.
+    const long m0 = (crop * Ho + oy0 + r0) * Wo + ox0 + seg * 16;
+    const unsigned ylane = (unsigned)(li * a.ldy + lk * 4), rlane = (unsigned)(li * a.ldr + lk * 4);
+    const float relu_lo = a.relu_out ? 0.f : -3.0e38f;
 #pragma unroll
     for (int nt = 0; nt < NTP; ++nt) {
-        const int n = nt * 16 + lk * 4;
-        if (n >= COUT) continue;
-        const f32x4 b = *reinterpret_cast<const f32x4*>(a.bp + n);
+        if (nt * 16 >= COUT) continue;
+        const bool n_ok = COUT % 16 == 0 || nt * 16 + lk * 4 < COUT;
 #pragma unroll
         for (int r = 0; r < MTC; ++r) {
-            const int oy = oy0 + r0 + r, ox = ox0 + seg * 16 + li;
-            const long m = (crop * Ho + oy) * Wo + ox;
-            f32x4 v = accp[r][nt] + b;
+            const long mrow = m0 + (long)r * Wo;
+            if (!BIAS_EARLY && r == 0 && n_ok) bpv[nt] = *reinterpret_cast<const f32x4*>(a.bp + nt * 16 + lk * 4);
+            f32x4 v = accp[r][nt] + bpv[nt];
             if (STEM) v += *reinterpret_cast<const f32x4*>(E + G::eo((r0 + r + P) * IWR + seg * 16 + li + P, lk));   // NTP == 1: n = 4 * lk
-            else if (a.R) v += ld_act4<(IO & IO_R_BF16) != 0>(a.R, m * a.ldr + n);
-            if (a.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            if (!(FEAR_ABL & 2048) || v.x == 1234.5f) st_act4<(IO & IO_Y_BF16) != 0>(a.Y, m * a.ldy + n, v);
+            else if (a.R && n_ok) v += ld_act4<(IO & IO_R_BF16) != 0>(a.R, mrow * a.ldr + nt * 16 + (long)rlane);
+            v.x = fmaxf(v.x, relu_lo); v.y = fmaxf(v.y, relu_lo); v.z = fmaxf(v.z, relu_lo); v.w = fmaxf(v.w, relu_lo);
+            if (n_ok && (!(FEAR_ABL & 2048) || v.x == 1234.5f)) st_act4<(IO & IO_Y_BF16) != 0>(a.Y, mrow * a.ldy + nt * 16 + (long)ylane, v);
         }
     }
     if ((FEAR_ABL & 4096) && a.P_Y && blockIdx.x == 1000 && lane == 0) {

@@ -202,12 +202,118 @@ static void bench_stem_shape(int crops, int iters) {
     CK(hipFree(y));
 }
 
+
+// -DFEAR_STEM_CHECK: the stem tile against a CPU restatement of stem conv (3x3 s2, 3->16, ReLU) + e1 block (dw3x3 + ReLU, pw 16->16,
+// + residual) on 2 crops — weights packed as fear_engine.hip's pack_fused16_host packs them (stem k order: step j = 4j + lane group).
+static void check_stem() {
+    using G = IrT2Geom<27, 16, 16, 3, 1, 32, 16, true>;
+    const int crops = 2, hw = 128, IH = 256;
+    std::vector<float> img((size_t)crops * 3 * IH * IH), We(16 * 27), be(16), Wd(16 * 9), bd(16), Wp(16 * 16), bp(16);
+    auto rnd = [](float sc) { return sc * ((float)rand() / (float)RAND_MAX - 0.5f); };
+    for (auto& v : img) v = rnd(2.f);
+    for (auto& v : We) v = rnd(0.5f);
+    for (auto& v : be) v = rnd(0.2f);
+    for (auto& v : Wd) v = rnd(0.5f);
+    for (auto& v : bd) v = rnd(0.2f);
+    for (auto& v : Wp) v = rnd(0.5f);
+    for (auto& v : bp) v = rnd(0.2f);
+    std::vector<float> pk;
+    for (int kg = 0; kg < 2; ++kg)
+        for (int l = 0; l < 64; ++l)
+            for (int i = 0; i < 4; ++i) {
+                const int n = l & 15, k = 4 * (kg * 4 + i) + (l >> 4);
+                pk.push_back(k < 27 ? We[n * 27 + k] : 0.f);
+            }
+    for (int c = 0; c < 16; ++c) pk.push_back(be[c]);
+    for (int l = 0; l < 64; ++l)
+        for (int i = 0; i < 4; ++i) pk.push_back(Wp[(l & 15) * 16 + (l >> 4) * 4 + i]);
+    for (int t = 0; t < 9; ++t)
+        for (int c = 0; c < 16; ++c) pk.push_back(Wd[c * 9 + t]);
+    for (int c = 0; c < 16; ++c) pk.push_back(bd[c]);
+    if ((int)pk.size() != G::AP + G::BP) { printf("pack size %zu != %d\n", pk.size(), G::AP + G::BP); return; }
+    // CPU
+    std::vector<float> s0((size_t)crops * hw * hw * 16), ref((size_t)crops * hw * hw * 16);
+    for (int b = 0; b < crops; ++b)
+        for (int y = 0; y < hw; ++y)
+            for (int x = 0; x < hw; ++x)
+                for (int n = 0; n < 16; ++n) {
+                    double acc = be[n];
+                    for (int ci = 0; ci < 3; ++ci)
+                        for (int ky = 0; ky < 3; ++ky)
+                            for (int kx = 0; kx < 3; ++kx) {
+                                const int iy = 2 * y - 1 + ky, ix = 2 * x - 1 + kx;
+                                if (iy < 0 || iy >= IH || ix < 0 || ix >= IH) continue;
+                                acc += (double)We[n * 27 + (ci * 3 + ky) * 3 + kx] * img[((size_t)(b * 3 + ci) * IH + iy) * IH + ix];
+                            }
+                    s0[((size_t)(b * hw + y) * hw + x) * 16 + n] = acc > 0 ? (float)acc : 0.f;
+                }
+    for (int b = 0; b < crops; ++b)
+        for (int y = 0; y < hw; ++y)
+            for (int x = 0; x < hw; ++x) {
+                float d[16];
+                for (int c = 0; c < 16; ++c) {
+                    double acc = bd[c];
+                    for (int ky = 0; ky < 3; ++ky)
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const int yy = y - 1 + ky, xx = x - 1 + kx;
+                            if (yy < 0 || yy >= hw || xx < 0 || xx >= hw) continue;
+                            acc += (double)Wd[c * 9 + ky * 3 + kx] * s0[((size_t)(b * hw + yy) * hw + xx) * 16 + c];
+                        }
+                    d[c] = acc > 0 ? (float)acc : 0.f;
+                }
+                for (int n = 0; n < 16; ++n) {
+                    double acc = bp[n];
+                    for (int c = 0; c < 16; ++c) acc += (double)Wp[n * 16 + c] * d[c];
+                    ref[((size_t)(b * hw + y) * hw + x) * 16 + n] = (float)acc + s0[((size_t)(b * hw + y) * hw + x) * 16 + n];
+                }
+            }
+    float *dX, *dW, *dB, *dY;
+    CK(hipMalloc(&dX, img.size() * 4)); CK(hipMemcpy(dX, img.data(), img.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&dW, pk.size() * 4)); CK(hipMemcpy(dW, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&dB, 64 * 4)); CK(hipMemset(dB, 0, 64 * 4)); CK(hipMemcpy(dB, bp.data(), 16 * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&dY, ref.size() * 4)); CK(hipMemset(dY, 0xff, ref.size() * 4));
+    IrT2Args t{};
+    Ir2Args& a = t.b;
+    a.ldx = 0; a.ldr = 16; a.ldy = 16; a.X = dX; a.Wpk = dW; a.bp = dB; a.Y = dY; a.relu_dw = 1; a.relu_out = 0;
+    t.H = hw; t.W = hw; t.tiles_x = hw / 32; t.tiles_y = hw / 16;
+    auto k = ir_tile_v2_kernel<27, 16, 16, 3, 1, 32, 16, true, 4, true>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+    hipLaunchKernelGGL(k, dim3(crops * t.tiles_x * t.tiles_y), dim3(512), G::LDS_BYTES, 0, t);
+    CK(hipDeviceSynchronize());
+    std::vector<float> out(ref.size());
+    CK(hipMemcpy(out.data(), dY, out.size() * 4, hipMemcpyDeviceToHost));
+    double maxd = 0; size_t bad = 0, first = (size_t)-1;
+    for (size_t i = 0; i < out.size(); ++i) {
+        const double dd = fabs((double)out[i] - ref[i]);
+        if (!(dd <= 1e-3)) { if (first == (size_t)-1) first = i; ++bad; }
+        if (dd > maxd) maxd = dd;
+    }
+    printf("stem check: max |d| %.3g, %zu of %zu beyond 1e-3", maxd, bad, out.size());
+    if (bad) {
+        const size_t px = first / 16;
+        printf("; first: crop %zu y %zu x %zu ch %zu got %g want %g", px / (hw * hw), px / hw % hw, px % hw, first % 16, out[first], ref[first]);
+        // histogram of bad pixels by (y % 16, x % 32)
+        int hy[16] = {0}, hx[32] = {0};
+        for (size_t i = 0; i < out.size(); i += 16) {
+            bool b = false;
+            for (int c = 0; c < 16; ++c) b |= !(fabs((double)out[i + c] - ref[i + c]) <= 1e-3);
+            if (b) { ++hy[i / 16 / hw % 16]; ++hx[i / 16 % 32]; }
+        }
+        printf("\n  bad pixels by y%%16:"); for (int i = 0; i < 16; ++i) printf(" %d", hy[i]);
+        printf("\n  bad pixels by x%%32:"); for (int i = 0; i < 32; ++i) printf(" %d", hx[i]);
+    }
+    printf("\n");
+}
+
 static void bench_stem(int crops, int iters) {
+#ifdef FEAR_STEM_CHECK
+    check_stem();
+#endif
     bench_stem_shape<32, 16, 4>(crops, iters);
 #ifdef FEAR_STEM_SHAPES
-    bench_stem_shape<32, 8, 4>(crops, iters);
-    bench_stem_shape<32, 8, 6>(crops, iters);
     bench_stem_shape<32, 16, 6>(crops, iters);
+    bench_stem_shape<32, 32, 2>(crops, iters);
+    bench_stem_shape<32, 32, 4>(crops, iters);
     bench_stem_shape<32, 16, 4>(crops, iters);
 #endif
 }
@@ -245,6 +351,9 @@ int main(int argc, char** argv) {
     printf("FEAR_ABL=%d\n", FEAR_ABL);
     // the product's tile table (fear_engine.hip kFusedTile), in plan order
     bench_stem(crops, iters);
+#ifdef FEAR_STEM_ONLY
+    return 0;
+#endif
     bench_tile<16, 96, 24, 3, 2, 16, 8, true, 4>("s2  irt_16x96x24_k3s2_hw128", crops, iters, 128);
     bench_tile<24, 32, 24, 3, 1, 16, 16, false, 4>("s45 irt_24x24x24_k3 e1 16x16", crops, iters, 64);
     bench_tile<24, 144, 32, 5, 2, 16, 16, true, 2>("s6  irt_24x144x32_k5s2 16x16", crops, iters, 64);
