@@ -1548,7 +1548,7 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
     load_w(0);
 
     int eoff[MTA];
-    long xoff[MTA];
+    unsigned xoff[MTA];
     f32x4 xf[EXPAND ? MTA : 1][EXPAND ? KG : 1];
     // stem mode: the image patch under the tile's stem-output region (3 planes x (2*IHR+1) rows x PWID floats, zero outside
     // the image) is staged in LDS with aligned 16-byte loads — it aliases the E tile, which is only written after every wave
@@ -1651,31 +1651,40 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
             }
         }
     }
+    if constexpr (!STEM) {
+        // the same stepping for the other tiles: pixel in the E tile and pixel in the input map (a 32-bit offset from the crop's
+        // base: the loads become [scalar base + lane offset]) are both linear in (row, column).  The old form — a division, a
+        // 64-bit multiply-add chain and the tile-local multiplication per m-tile — was 200 vector instructions of prologue in the
+        // stage-2 tile, a tenth of its issue.  Lanes beyond the clipped region read pixel 0 and store to a dummy slot.
+        const int q0 = wave * 16 + li;
+        const int cy0 = (int)(((float)q0 + 0.5f) * inv_cw), cx0 = q0 - cy0 * CW;   // exact for q0 < 2^16, CW <= 64 (garbage past NPIX: masked)
+        const int qa = 128 / CW, qb = 128 - qa * CW;
+        const int dpe0 = qa * IWR + qb, dpe1 = dpe0 + IWR - CW;
+        const int dpx0 = (qa * t.W + qb) * a.ldx, dpx1 = dpx0 + (t.W - CW) * a.ldx;
+        int cx = cx0;
+        int pe = (cy0 + cy_lo - iy0) * IWR + cx0 + cx_lo - ix0;
+        int px = ((cy0 + cy_lo) * t.W + cx0 + cx_lo) * a.ldx;
 #pragma unroll
-    for (int i = 0; i < (STEM ? 0 : MTA); ++i) {
-        const int q = (wave + 8 * i) * 16 + li;
-        const bool valid = q < NPIX;
-        const int qq = valid ? q : 0;
-        const int cy = (int)(((float)qq + 0.5f) * inv_cw), cx = qq - cy * CW;   // exact for qq < 2^16, CW <= 64
-        const int gy = cy_lo + cy, gx = cx_lo + cx;
-        // invalid lanes (beyond the clipped region) store to a dummy slot: phase A stays branch free
-        eoff[i] = valid ? G::eo((gy - iy0) * IWR + (gx - ix0), lk) : EBUF + G::NSTAGE * CST + lane * 4;
-        xoff[i] = ((long)gy * t.W + gx) * a.ldx;
-        if (STEM) {
-            const float* pp = E + 2 * (gy - iy0) * PWID + 2 * (gx - ix0);
-            float v[8];
+        for (int i = 0; i < MTA; ++i) {
+            const bool valid = q0 < NPIX - 128 * i;
+            eoff[i] = valid ? G::eo(pe, lk) : EBUF + G::NSTAGE * CST + lane * 4;
+            xoff[i] = valid ? (unsigned)px : 0u;
+            if (EXPAND) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = pp[s_off[j]];
-            xf[i][0] = (f32x4){v[0], v[1], v[2], v[3]};
-            xf[i][KG > 1 ? 1 : 0] = (f32x4){v[4], v[5], v[6], v[7]};
-        } else if (EXPAND) {
-#pragma unroll
-            for (int kg = 0; kg < KG; ++kg) {
-                xf[i][kg] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (KHALF && kg == KG - 1) {       // 8 channels: lane group lk holds channels 2*lk, 2*lk+1 (k-step q = .x / .y)
-                    const float2 h2 = *reinterpret_cast<const float2*>(Xc + xoff[i] + kg * 16 + lk * 2);
-                    xf[i][kg].x = h2.x; xf[i][kg].y = h2.y;
-                } else if (kg * 16 + lk * 4 < CIN) xf[i][kg] = *reinterpret_cast<const f32x4*>(Xc + xoff[i] + kg * 16 + lk * 4);
+                for (int kg = 0; kg < KG; ++kg) {
+                    xf[i][kg] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (KHALF && kg == KG - 1) {       // 8 channels: lane group lk holds channels 2*lk, 2*lk+1 (k-step q = .x / .y)
+                        const float2 h2 = *reinterpret_cast<const float2*>(Xc + (xoff[i] + (unsigned)(kg * 16 + lk * 2)));
+                        xf[i][kg].x = h2.x; xf[i][kg].y = h2.y;
+                    } else if (kg * 16 + lk * 4 < CIN) xf[i][kg] = *reinterpret_cast<const f32x4*>(Xc + (xoff[i] + (unsigned)(kg * 16 + lk * 4)));
+                }
+            }
+            if (i + 1 < MTA) {
+                cx += qb;
+                const bool wrap = cx >= CW;
+                cx -= wrap ? CW : 0;
+                pe += wrap ? dpe1 : dpe0;
+                px += wrap ? dpx1 : dpx0;
             }
         }
     }
