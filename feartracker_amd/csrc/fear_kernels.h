@@ -2129,24 +2129,37 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v4_kernel(IrT2Args t) {
 
     int eoff[MTA];
     f32x4 xf[MTA][KG];
-    static_for<0, MTA>([&](auto I) {
-        constexpr int i = decltype(I)::value;
-        const int q = (wave + 8 * i) * 16 + li;
-        const bool valid = q < NPIX;
-        const int qq = valid ? q : 0;
-        const int cy = (int)(((float)qq + 0.5f) * inv_cw), cx = qq - cy * CW;
-        const int gy = cy_lo + cy, gx = cx_lo + cx;
-        eoff[i] = valid ? G::eo((gy - iy0) * IWR + (gx - ix0), lk) : (int)(DUMMYP - E) + lane * 4;
-        const long xoff = ((long)gy * t.W + gx) * a.ldx;
+    {   // m-tile i is 128 pixels on from m-tile i - 1: stepped (see ir_tile_v2_kernel), loads as [scalar crop base + lane offset]
+        const int q0 = wave * 16 + li;
+        const int cy0 = (int)(((float)q0 + 0.5f) * inv_cw), cx0 = q0 - cy0 * CW;
+        const int qa = 128 / CW, qb = 128 - qa * CW;
+        const int dpe0 = qa * IWR + qb, dpe1 = dpe0 + IWR - CW;
+        const int dpx0 = (qa * t.W + qb) * a.ldx, dpx1 = dpx0 + (t.W - CW) * a.ldx;
+        int cx = cx0;
+        int pe = (cy0 + cy_lo - iy0) * IWR + cx0 + cx_lo - ix0;
+        int px = ((cy0 + cy_lo) * t.W + cx0 + cx_lo) * a.ldx;
+        static_for<0, MTA>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            const bool valid = q0 < NPIX - 128 * i;
+            eoff[i] = valid ? G::eo(pe, lk) : (int)(DUMMYP - E) + lane * 4;
+            const unsigned xoff = valid ? (unsigned)px : 0u;
 #pragma unroll
-        for (int kg = 0; kg < KG; ++kg) {
-            xf[i][kg] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (KHALF && kg == KG - 1) {       // 8 channels: lane group lk holds channels 2*lk, 2*lk+1 (k-step q = .x / .y)
-                const float2 h2 = *reinterpret_cast<const float2*>(Xc + xoff + kg * 16 + lk * 2);
-                xf[i][kg].x = h2.x; xf[i][kg].y = h2.y;
-            } else if (kg * 16 + lk * 4 < CIN) xf[i][kg] = *reinterpret_cast<const f32x4*>(Xc + xoff + kg * 16 + lk * 4);
-        }
-    });
+            for (int kg = 0; kg < KG; ++kg) {
+                xf[i][kg] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (KHALF && kg == KG - 1) {       // 8 channels: lane group lk holds channels 2*lk, 2*lk+1 (k-step q = .x / .y)
+                    const float2 h2 = *reinterpret_cast<const float2*>(Xc + (xoff + (unsigned)(kg * 16 + lk * 2)));
+                    xf[i][kg].x = h2.x; xf[i][kg].y = h2.y;
+                } else if (kg * 16 + lk * 4 < CIN) xf[i][kg] = *reinterpret_cast<const f32x4*>(Xc + (xoff + (unsigned)(kg * 16 + lk * 4)));
+            }
+            if (i + 1 < MTA) {
+                cx += qb;
+                const bool wrap = cx >= CW;
+                cx -= wrap ? CW : 0;
+                pe += wrap ? dpe1 : dpe0;
+                px += wrap ? dpx1 : dpx0;
+            }
+        });
+    }
 
     auto relu4 = [](f32x4& v) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); };
 
@@ -2181,6 +2194,13 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v4_kernel(IrT2Args t) {
 #pragma unroll
         for (int nt = 0; nt < NTP; ++nt) accp[r][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* const Ebase = E + G::eo((r0 * ST) * IWR + (seg * 16 + li) * ST, lk);
+    // projection bias fetched here, not at the tail: this kernel has its CU to itself, nothing hides a round trip there
+    f32x4 bpv[NTP];
+#pragma unroll
+    for (int nt = 0; nt < NTP; ++nt) {
+        bpv[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (nt * 16 + lk * 4 < COUT) bpv[nt] = *reinterpret_cast<const f32x4*>(a.bp + nt * 16 + lk * 4);
+    }
 
     for (int c = 0; c < NCHUNK; ++c) {
         const bool more = c + 1 < NCHUNK;
@@ -2276,22 +2296,24 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v4_kernel(IrT2Args t) {
 #pragma unroll
                 for (int r = 0; r < MTC; ++r) accp[r][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[q], d[r][q], accp[r][nt], 0, 0, 0);
         }
-        __syncthreads();                       // E holds chunk c + 1; the staged weights have landed
+        if (more) __syncthreads();             // E holds chunk c + 1; the staged weights have landed
     }
 
+    // stores as [scalar row base + 32-bit lane offset], ReLU as a max against 0 / -big (see ir_tile_v2_kernel's epilogue)
+    const long m0 = (crop * Ho + oy0 + r0) * Wo + ox0 + seg * 16;
+    const unsigned ylane = (unsigned)(li * a.ldy + lk * 4), rlane = (unsigned)(li * a.ldr + lk * 4);
+    const float relu_lo = a.relu_out ? 0.f : -3.0e38f;
 #pragma unroll
     for (int nt = 0; nt < NTP; ++nt) {
-        const int n = nt * 16 + lk * 4;
-        if (n >= COUT) continue;
-        const f32x4 b = *reinterpret_cast<const f32x4*>(a.bp + n);
+        if (nt * 16 >= COUT) continue;
+        const bool n_ok = COUT % 16 == 0 || nt * 16 + lk * 4 < COUT;
 #pragma unroll
         for (int r = 0; r < MTC; ++r) {
-            const int oy = oy0 + r0 + r, ox = ox0 + seg * 16 + li;
-            const long m = (crop * Ho + oy) * Wo + ox;
-            f32x4 v = accp[r][nt] + b;
-            if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
-            if (a.relu_out) relu4(v);
-            *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = v;
+            const long mrow = m0 + (long)r * Wo;
+            f32x4 v = accp[r][nt] + bpv[nt];
+            if (a.R && n_ok) v += *reinterpret_cast<const f32x4*>(a.R + (mrow * a.ldr + nt * 16 + (long)rlane));
+            v.x = fmaxf(v.x, relu_lo); v.y = fmaxf(v.y, relu_lo); v.z = fmaxf(v.z, relu_lo); v.w = fmaxf(v.w, relu_lo);
+            if (n_ok) *reinterpret_cast<f32x4*>(a.Y + (mrow * a.ldy + nt * 16 + (long)ylane)) = v;
         }
     }
 }
