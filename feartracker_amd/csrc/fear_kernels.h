@@ -1721,6 +1721,7 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
         if (BIAS_EARLY && nt * 16 + lk * 4 < COUT) bpv[nt] = *reinterpret_cast<const f32x4*>(a.bp + nt * 16 + lk * 4);
     }
 
+    const bool res_from_tile = !EXPAND && !KSPLIT && !(FEAR_ABL & 65536) && a.R == a.X && a.ldr == a.ldx && ST == 1 && CIN == COUT;
     const long long tk_begin = (FEAR_ABL & 4096) ? wall_clock64() : 0;   // kbench -DFEAR_ABL=4096: 10 ns ticks per region
     long long tm[6] = {0, 0, 0, 0, 0, 0};
     for (int c = 0; c < ((FEAR_ABL & 256) ? 0 : NCHUNK); ++c) {
@@ -1804,6 +1805,17 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
                 }
             }
         }
+        // an e1 block's residual IS its input, and the raw input channels 16c .. 16c + 15 are this chunk's E tile: the residual of
+        // output tile c is added here from LDS — the epilogue's global re-read was an exposed L2 round trip at the tail of every tile
+        if (!EXPAND && res_from_tile) {
+#pragma unroll
+            for (int nt = 0; nt < NTP; ++nt)
+                if (c == nt) {
+#pragma unroll
+                    for (int r = 0; r < MTC; ++r)
+                        accp[r][nt] += *reinterpret_cast<const f32x4*>(E + G::eo(((r0 + r) * ST + P) * IWR + (seg * 16 + li) * ST + P, lk));
+                }
+        }
         const long long tk4 = (FEAR_ABL & 4096) ? wall_clock64() : 0;
         // ---- phase C: projection
 #pragma unroll
@@ -1858,7 +1870,7 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v2_kernel(IrT2Args t) {
             if (!BIAS_EARLY && r == 0 && n_ok) bpv[nt] = *reinterpret_cast<const f32x4*>(a.bp + nt * 16 + lk * 4);
             f32x4 v = accp[r][nt] + bpv[nt];
             if (STEM) v += *reinterpret_cast<const f32x4*>(E + G::eo((r0 + r + P) * IWR + seg * 16 + li + P, lk));   // NTP == 1: n = 4 * lk
-            else if (a.R && n_ok) v += ld_act4<(IO & IO_R_BF16) != 0>(a.R, mrow * a.ldr + nt * 16 + (long)rlane);
+            else if (a.R && n_ok && !res_from_tile) v += ld_act4<(IO & IO_R_BF16) != 0>(a.R, mrow * a.ldr + nt * 16 + (long)rlane);
             v.x = fmaxf(v.x, relu_lo); v.y = fmaxf(v.y, relu_lo); v.z = fmaxf(v.z, relu_lo); v.w = fmaxf(v.w, relu_lo);
             if (n_ok && (!(FEAR_ABL & 2048) || v.x == 1234.5f)) st_act4<(IO & IO_Y_BF16) != 0>(a.Y, mrow * a.ldy + nt * 16 + (long)ylane, v);
         }

@@ -71,6 +71,7 @@ static void bench_tile(const char* tag, int crops, int iters, int hw) {
     float* y;
     CK(hipMalloc(&y, (size_t)crops * ho * ho * COUT * sizeof(float)));
     a.Y = y; a.relu_dw = 1; a.relu_out = 0;
+    if (!EXPAND && CIN == COUT && ST == 1) a.R = a.X;     // an e1 block's residual is its input
     float* dbg;
     CK(hipMalloc(&dbg, 80 * sizeof(float)));
     CK(hipMemset(dbg, 0, 80 * sizeof(float)));
@@ -356,6 +357,13 @@ int main(int argc, char** argv) {
 #endif
     bench_tile<16, 96, 24, 3, 2, 16, 8, true, 4>("s2  irt_16x96x24_k3s2_hw128", crops, iters, 128);
     bench_tile<24, 32, 24, 3, 1, 16, 16, false, 4>("s45 irt_24x24x24_k3 e1 16x16", crops, iters, 64);
+#ifdef FEAR_E1_SHAPES
+    bench_tile<24, 32, 24, 3, 1, 16, 16, false, 8>("s45 e1 16x16 w8", crops, iters, 64);
+    bench_tile<24, 32, 24, 3, 1, 16, 16, false, 6>("s45 e1 16x16 w6", crops, iters, 64);
+    bench_tile<24, 32, 24, 3, 1, 32, 16, false, 4>("s45 e1 32x16 w4", crops, iters, 64);
+    bench_tile<24, 32, 24, 3, 1, 16, 8, false, 8>("s45 e1 16x8 w8", crops, iters, 64);
+    bench_tile<24, 32, 24, 3, 1, 16, 8, false, 4>("s45 e1 16x8 w4", crops, iters, 64);
+#endif
     bench_tile<24, 144, 32, 5, 2, 16, 16, true, 2>("s6  irt_24x144x32_k5s2 16x16", crops, iters, 64);
     bench_tile<32, 96, 32, 5, 1, 16, 16, true, 2>("s7  irt_32x96x32_k5 16x16", crops, iters, 32);
     bench_tile<32, 192, 32, 5, 1, 16, 32, true, 2>("s8  irt_32x192x32_k5 16x32", crops, iters, 32);
