@@ -579,6 +579,7 @@ def main() -> None:
                     help="A/B: microseconds the head's second branch is held back behind the first (two streams); -1 = the engine's default")
     ap.add_argument("--no-tile-v4", action="store_true", help="A/B: every tiled block on ir_tile_v2 (no phase-overlapped kernel)")
     ap.add_argument("--no-head-chain", action="store_true", help="A/B: the BoxTower as eight sep16 launches instead of one headchain launch")
+    ap.add_argument("--no-e1-pair", action="store_true", help="A/B: the two 24-channel e1 blocks as one tile-kernel launch each instead of one e1pair launch")
     ap.add_argument("--no-chain", action="store_true", help="A/B: one fused kernel per stride-16 block instead of the chain kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-math", action="store_true",
@@ -663,6 +664,8 @@ def main() -> None:
         net.set_tile_v4(False)
     if args.no_head_chain:
         net.set_head_chain(False)
+    if args.no_e1_pair:
+        net.set_e1_pair(False)
     search_u8, tmpl_u8 = synth_batch(B, rank)
     search = norm_u8(search_u8.to(dev)).contiguous()
     tmpl_feats = net.get_features(norm_u8(tmpl_u8.to(dev)).contiguous())

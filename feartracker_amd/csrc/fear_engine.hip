@@ -22,6 +22,7 @@
 #include "fear_kernels.h"
 #include "fear_headchain.h"
 #include "fear_headchain_b.h"
+#include "fear_e1pair.h"
 
 namespace {
 
@@ -94,7 +95,7 @@ struct Conv {
     bool is_pw() const { return groups == 1 && k == 1; }
 };
 
-enum OpType { OP_STEM, OP_PW, OP_DW, OP_CORR, OP_PW_SMALL, OP_IR16, OP_IRTILE, OP_CHAIN16, OP_HEADCHAIN };
+enum OpType { OP_STEM, OP_PW, OP_DW, OP_CORR, OP_PW_SMALL, OP_IR16, OP_IRTILE, OP_CHAIN16, OP_HEADCHAIN, OP_E1PAIR };
 
 struct Op {
     OpType type;
@@ -176,6 +177,7 @@ struct fear_handle {
     int tile_v4 = 1;       // FEAR_OPT_TILE_V4: 1 = phase-overlapped tile kernel for the blocks of kFusedTileV4 (throughput plan)
     int chain = 1;         // 1: run the stride-16 trunk stage as one register-resident chain kernel (fp32 mode)
     int bf16_store = 1;    // FEAR_OPT_BF16_STORE: math 2 keeps the activations of the trunk's HBM-bound front in bf16 between kernels
+    int e1_pair = 1;       // FEAR_OPT_E1_PAIR: 1 = two consecutive 24-channel e1 blocks as one launch (e1pair_kernel; fp32 mode, throughput plan)
     int head_chain = 1;    // FEAR_OPT_HEAD_CHAIN: 1 = the whole BoxTower as one launch (headchain_kernel; fp32 mode, throughput plan)
     int small_pass = 96;   // passes of at most this many crops run the small-batch plan (FEAR_OPT_SMALL_PASS; 0: never);
                            // measured crossover with the throughput plan: ~110 crops (1.70 vs 1.93 ms at 96, 2.14 vs 2.01 at 128)
@@ -1004,6 +1006,43 @@ int build_plan_uncached(fear_handle* h, int hw, bool with_head, int mode, Plan**
                 }
             }
         }
+        // ---- two consecutive e1 blocks (no expansion, 24 channels, residual) as one launch: the map between them stays in LDS
+        if (h->fuse && h->e1_pair && !h->math && !small && b.kind == FEARW_IR && bi + 1 < h->blocks.size() && cur.C == E1PairGeom::C &&
+            cur.ld == E1PairGeom::C && cur.off == 0 && cur.H == cur.W && cur.H % E1PairGeom::T == 0) {
+            auto is_e1 = [&](const FearwBlock& q) {
+                if (q.kind != FEARW_IR || q.conv[0] >= 0 || !q.residual) return false;
+                const Conv& d = h->convs[q.conv[1]];
+                const Conv& p = h->convs[q.conv[2]];
+                return d.k == 3 && d.stride == 1 && d.cout == E1PairGeom::C && p.cin_g == E1PairGeom::C && p.cout == E1PairGeom::C &&
+                       d.relu && !p.relu && p.has_bias;
+            };
+            if (is_e1(b) && is_e1(h->blocks[bi + 1])) {
+                std::vector<float> pk;
+                for (int j = 0; j < 2; ++j) {
+                    const Conv& d = h->convs[h->blocks[bi + j].conv[1]];
+                    const Conv& p = h->convs[h->blocks[bi + j].conv[2]];
+                    e1pair_pack_block(pk, d.w.data(), d.has_bias ? d.b.data() : nullptr, p.w.data(), p.b.data());
+                }
+                Op op{};
+                op.type = OP_E1PAIR;
+                if (upload(h, pk, &op.d_packed) == FEAR_OK) {
+                    op.in_buf = cur.buf; op.in_ld = cur.ld; op.in_off = 0;
+                    op.H = cur.H; op.W = cur.W; op.Ho = cur.H; op.Wo = cur.W; op.C = cur.C; op.N = cur.C;
+                    T o;
+                    o.buf = pool.acquire(); o.ld = cur.C; o.off = 0; o.C = cur.C; o.H = cur.H; o.W = cur.W;
+                    op.out_buf = o.buf; op.out_ld = o.ld;
+                    snprintf(op.name, sizeof(op.name), "e1pair_%dx%d_k3_hw%d", cur.C, cur.C, cur.H);
+                    op.flops = 2.0 * 2.0 * cur.H * cur.W * (9.0 * cur.C + (double)cur.C * cur.C);
+                    op.bytes = 4.0 * 2.0 * cur.H * cur.W * cur.C;
+                    ops.push_back(op);
+                    track(o);
+                    pool.release(cur.buf);
+                    cur = o;
+                    ++bi;           // two blocks consumed (the loop adds the other one)
+                    continue;
+                }
+            }
+        }
         if (b.kind == FEARW_IR) {
             T x = cur, e = cur, d, o;
             if (add_fused16(b.conv[0], b.conv[1], b.conv[2], x, o, b.residual ? &x : nullptr, 1, 0, 0, "ir16") ||
@@ -1423,6 +1462,7 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
             const int lds = tb.stem ? kStemTile.lds_bytes : (tb.id == 1 || tb.id == 3) ? kFusedTileB[tb.id].lds_bytes : kFusedTile[tb.id].lds_bytes;
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(tb.kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         }
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(e1pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, E1PairGeom::LDS_BYTES));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kHeadChainKernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, HeadChainG::LDS_BYTES));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kHeadChainBKernel),
@@ -1626,6 +1666,13 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
                     break;
                 }
                 hipLaunchKernelGGL(f.kernel, dim3((unsigned)n * ta.tiles_x * ta.tiles_y), dim3(64 * f.nw), f.lds_bytes, s, ta);
+                break;
+            }
+            case OP_E1PAIR: {
+                E1PairArgs a{};
+                a.X = buf(op.in_buf); a.Y = buf(op.out_buf); a.Wpk = op.d_packed;
+                a.H = op.H; a.W = op.W; a.tiles_x = op.W / E1PairGeom::T; a.tiles_y = op.H / E1PairGeom::T;
+                hipLaunchKernelGGL(e1pair_kernel, dim3((unsigned)n * a.tiles_x * a.tiles_y), dim3(512), E1PairGeom::LDS_BYTES, s, a);
                 break;
             }
             case OP_CHAIN16: {
@@ -1839,6 +1886,10 @@ int fear_set_option(fear_handle* h, int option, int64_t value) {
             if (value != 0 && value != 1) return FEAR_ERR_SHAPE;
             if (h->head_chain != (int)value) { h->head_chain = (int)value; return drop_plans(h); }
             return FEAR_OK;
+        case FEAR_OPT_E1_PAIR:
+            if (value != 0 && value != 1) return FEAR_ERR_SHAPE;
+            if (h->e1_pair != (int)value) { h->e1_pair = (int)value; return drop_plans(h); }
+            return FEAR_OK;
         case FEAR_OPT_BF16_STORE:
             if (value != 0 && value != 1) return FEAR_ERR_SHAPE;
             if (h->bf16_store != (int)value) { h->bf16_store = (int)value; return drop_plans(h); }
@@ -1863,6 +1914,7 @@ int64_t fear_get_option(fear_handle* h, int option) {
         case FEAR_OPT_TILE_V4: return h->tile_v4;
         case FEAR_OPT_TINY_SEP: return h->tiny_sep;
         case FEAR_OPT_HEAD_CHAIN: return h->head_chain;
+        case FEAR_OPT_E1_PAIR: return h->e1_pair;
         case FEAR_OPT_BF16_STORE: return h->bf16_store;
         default: return FEAR_ERR_SHAPE;
     }

@@ -41,6 +41,7 @@ FEAR_OPT_TILE_V4 = 11
 FEAR_OPT_TINY_SEP = 12
 FEAR_OPT_HEAD_CHAIN = 13
 FEAR_OPT_BF16_STORE = 14
+FEAR_OPT_E1_PAIR = 15
 
 _lib = None
 
@@ -219,6 +220,11 @@ class FEARNetHIP:
         """A/B switch (FEAR_OPT_BF16_STORE, default on; only with set_math(2)): bf16 storage of the activations between the kernels of
         the trunk's HBM-bound front."""
         self._check(self._lib.fear_set_option(self._h, FEAR_OPT_BF16_STORE, 1 if on else 0))
+
+    def set_e1_pair(self, on: bool) -> None:
+        """A/B switch (FEAR_OPT_E1_PAIR, default on; fp32 mode, throughput plan): two consecutive 24-channel e1 blocks as one launch
+        (the map between them stays in LDS) vs one tile-kernel launch per block."""
+        self._check(self._lib.fear_set_option(self._h, FEAR_OPT_E1_PAIR, 1 if on else 0))
 
     def set_tile_v4(self, on: bool) -> None:
         """Throughput plan: the phase-overlapped tile kernel for the blocks that have one (default on) vs ir_tile_v2 everywhere."""

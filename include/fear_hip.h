@@ -151,6 +151,9 @@ int fear_crop_normalize(fear_handle* h, const uint8_t* frame_u8, int frame_h, in
 #define FEAR_OPT_BF16_STORE 14 /* 1 (default): with FEAR_OPT_MATH = 2 the throughput plan keeps the activations of the trunk's HBM-bound      */
                                /*   front (stem output ... input of the 64 -> 32 block; maps of 64 x 64 and larger) in bf16 BETWEEN kernels — */
                                /*   half the traffic of the kernels that are bound by it; 0: fp32 storage (A/B).  No effect in modes 0 / 1.   */
+#define FEAR_OPT_E1_PAIR 15    /* 1 (default): fp32 mode, throughput plan — two consecutive 24-channel e1 blocks (depthwise 3x3 + pointwise  */
+                               /*   + input, no expansion; model/blocks.py:8-42) run as ONE launch with the map between them in LDS          */
+                               /*   (e1pair_kernel: half the HBM traffic of these two memory-bound blocks); 0: one launch per block (A/B).    */
 int fear_set_option(fear_handle* h, int option, int64_t value);
 int64_t fear_get_option(fear_handle* h, int option);
 

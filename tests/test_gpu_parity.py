@@ -466,6 +466,41 @@ def test_head_chain_matches_the_eight_sepconv_launches_bit_for_bit(oracle_net):
     assert torch.equal(b2, b1) and torch.equal(c2, c1)
 
 
+@pytest.mark.gpu
+def test_e1_pair_kernel_against_the_two_tile_launches_and_the_oracle(oracle_net):
+    """FEAR_OPT_E1_PAIR: the two 24-channel e1 blocks of the 64x64 stage (depthwise 3x3 + ReLU, pointwise, + input —
+    model/blocks.py:8-42 from the fbnet_c table) as ONE launch with the map between them in LDS, vs one tile launch per block.
+    Same products, another order of the last additions (bias and residual after the projection): fp32 rounding apart.  Search
+    crops (64x64 map, 16 tiles) and template crops (32x32 map, 4 tiles: every tile touches the border), ragged crop counts."""
+    from feartracker_amd import FEARNetHIP
+    from conftest import WEIGHTS
+    pair = FEARNetHIP(WEIGHTS, device=0, max_batch=32)
+    pair.set_small_pass(0)
+    two = FEARNetHIP(WEIGHTS, device=0, max_batch=32)
+    two.set_small_pass(0)
+    two.set_e1_pair(False)
+    for hw, head in ((256, True), (128, False)):
+        names_pair = [n for n, _, _ in pair.plan(hw, head)]
+        names_two = [n for n, _, _ in two.plan(hw, head)]
+        assert sum(n.startswith("e1pair") for n in names_pair) == 1 and not any(n.startswith("e1pair") for n in names_two)
+        assert len(names_two) > len(names_pair) and (not head or len(names_two) == len(names_pair) + 1), (names_pair, names_two)
+    g = torch.Generator().manual_seed(78)
+    for n in (1, 5, 32, 33):
+        x = norm_u8(torch.randint(0, 256, (n, 3, 256, 256), dtype=torch.uint8, generator=g)).cuda()
+        t = norm_u8(torch.randint(0, 256, (n, 3, 128, 128), dtype=torch.uint8, generator=g)).cuda()
+        z1, z2 = pair.get_features(t), two.get_features(t)
+        scale = float(z2.abs().max())
+        assert float((z1 - z2).abs().max()) <= 2e-5 * scale, n
+        b1, c1 = pair.track_maps(x, z2)
+        b2, c2 = two.track_maps(x, z2)
+        assert_maps_close(b1, c1, b2.cpu().numpy(), c2.cpu().numpy())
+        if n == 5:
+            ref = oracle_net.track(x.cpu(), z2.cpu())
+            assert_maps_close(b1, c1, ref["TARGET_REGRESSION_LABEL_KEY"], ref["TARGET_CLASSIFICATION_KEY"])
+    b3, c3 = pair.track_maps(x, z2)
+    assert torch.equal(b3, b1) and torch.equal(c3, c1)
+
+
 def test_head_chain_bf16_mode_against_the_bf16_sepconv_launches_and_fp32():
     """FEAR_OPT_MATH = 2 (BASELINE configs[3]): the one-launch head on v_mfma_f32_16x16x32_bf16 (headchain_b_kernel) rounds the same
     values to bf16 as the sep16 `*_h` launches it replaces — depthwise outputs, template features, weights — so the two agree far

@@ -12,6 +12,7 @@
 #define KHDR "../feartracker_amd/csrc/fear_kernels.h"     // -DKHDR='"/path/to/variant.h"' benches a saved variant of the header
 #endif
 #include KHDR
+#include "../feartracker_amd/csrc/fear_e1pair.h"
 
 using namespace fear;
 
@@ -306,6 +307,31 @@ static void check_stem() {
     printf("\n");
 }
 
+
+static void bench_e1pair(int crops, int iters) {
+    using G = E1PairGeom;
+    const int hw = 64;
+    E1PairArgs a{};
+    a.X = dev_rand((size_t)crops * hw * hw * 24, 2.f);
+    a.Wpk = dev_rand(2 * G::WBLK, 0.2f);
+    float* y;
+    CK(hipMalloc(&y, (size_t)crops * hw * hw * 24 * sizeof(float)));
+    a.Y = y; a.H = hw; a.W = hw; a.tiles_x = hw / 16; a.tiles_y = hw / 16;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(e1pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const dim3 grid((unsigned)crops * 16);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(e1pair_kernel, grid, dim3(512), G::LDS_BYTES, 0, a);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(e1pair_kernel, grid, dim3(512), G::LDS_BYTES, 0, a);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("e1pair 24ch hw64 (E1P_ABL=%d)  %8.1f us  (LDS %d B)\n", E1P_ABL, 1e3 * ms / iters, G::LDS_BYTES);
+}
+
 static void bench_stem(int crops, int iters) {
 #ifdef FEAR_STEM_CHECK
     check_stem();
@@ -351,6 +377,10 @@ int main(int argc, char** argv) {
     const bool all = argc > 3;      // any third argument: also the tile-shape sweep and the 16x16 kernels
     printf("FEAR_ABL=%d\n", FEAR_ABL);
     // the product's tile table (fear_engine.hip kFusedTile), in plan order
+#ifdef FEAR_E1PAIR_ONLY
+    bench_e1pair(crops, iters);
+    return 0;
+#endif
     bench_stem(crops, iters);
 #ifdef FEAR_STEM_ONLY
     return 0;
