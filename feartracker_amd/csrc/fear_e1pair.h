@@ -10,8 +10,8 @@
 // i.e. half the HBM traffic for 27 % more arithmetic in block A (324 instead of 256 pixels per tile) — arithmetic these blocks
 // have to spare.  73 KB of LDS per workgroup: two workgroups per CU, one loading while the other computes.
 //
-// Work split (512 threads = 8 waves): block A's 324 pixels are 21 m-tiles of 16 pixels in row-major order over the 18x18 region,
-// dealt round-robin (3, 3, 3, 3, 3, 2, 2, 2); block B's 16 rows are 2 m-tiles per wave.  Per m-tile a lane (pixel li, group lk)
+// Work split (512 threads = 8 waves): block A's 324 pixels are 21 m-tiles of 16 pixels (18 row segments of 16 columns + 3 m-tiles for
+// the two remaining columns), dealt round-robin (3, 3, 3, 3, 3, 2, 2, 2); block B's 16 rows are 2 m-tiles per wave.  Per m-tile a lane (pixel li, group lk)
 // computes the depthwise of channel quad lk (chunk 0: channels 0-15) as one float4 and of channels 16 + 2 lk, + 1 (chunk 1: the
 // remaining 8 channels) as one float2 — those ARE the B fragments of the projection, 4 + 2 MFMA k-steps per 16 output channels
 // (a 16-channel second chunk would spend half its depthwise lanes and MFMA steps on padding).
@@ -192,10 +192,13 @@ __global__ __launch_bounds__(512, 4) void e1pair_kernel(E1PairArgs a) {
         for (int i = 0; i < G::MTA; ++i) {
             const int mt = wave + 8 * i;
             if (mt >= G::NMT_A) break;                                 // wave-uniform
-            const int p = mt * 16 + li;
-            const bool valid = p < G::NPIX_A;
-            const int pc = valid ? p : 0;
-            const int my = pc / MW, mx = pc - my * MW;
+            // m-tiles 0 .. 17 are the first 16 columns of a row (16 consecutive 16-byte units of a plane: conflict-free LDS reads and
+            // stores), m-tiles 18 .. 20 the two remaining columns of the 18 rows, two pixels per row (row-major m-tiles over the
+            // 18-wide region straddled a row end in almost every m-tile: 35 % of the kernel's LDS cycles were bank conflicts)
+            const int j = (mt - MW) * 16 + li;                         // (mt >= 18)
+            const bool valid = mt < MW || j < 2 * MW;
+            const int my = mt < MW ? mt : (valid ? j >> 1 : 0), mx = mt < MW ? li : 16 + (j & 1);
+            const int pc = my * MW + mx;
             const int cpix = (my + 1) * XW + mx + 1;
             f32x4 acc[2], d4[1];
             f32x2 d2[1];

@@ -23,7 +23,7 @@ def main():
                 vals[short(row['Kernel_Name'])][row['Counter_Name']].append(float(row['Counter_Value']))
     counters = sorted({c for k in vals.values() for c in k})
     for k, d in vals.items():
-        if not ('fused' in k or 'chain' in k or 'tile' in k or 'pw_mfma' in k or 'sep16' in k):
+        if not ('fused' in k or 'chain' in k or 'tile' in k or 'pw_mfma' in k or 'sep16' in k or 'e1pair' in k):
             continue
         print(k)
         for c in counters:
