@@ -1007,7 +1007,9 @@ int build_plan_uncached(fear_handle* h, int hw, bool with_head, int mode, Plan**
             }
         }
         // ---- two consecutive e1 blocks (no expansion, 24 channels, residual) as one launch: the map between them stays in LDS
-        if (h->fuse && h->e1_pair && !h->math && !small && b.kind == FEARW_IR && bi + 1 < h->blocks.size() && cur.C == E1PairGeom::C &&
+        //      (search branch only: `get_features` keeps one set of kernels for every batch size — its maps are bit-identical
+        //      whatever the batching, tests/test_gpu_parity.py::test_empty_ragged_and_chunked_batches)
+        if (h->fuse && h->e1_pair && !h->math && !small && with_head && b.kind == FEARW_IR && bi + 1 < h->blocks.size() && cur.C == E1PairGeom::C &&
             cur.ld == E1PairGeom::C && cur.off == 0 && cur.H == cur.W && cur.H % E1PairGeom::T == 0) {
             auto is_e1 = [&](const FearwBlock& q) {
                 if (q.kind != FEARW_IR || q.conv[0] >= 0 || !q.residual) return false;

@@ -2828,33 +2828,49 @@ __global__ __launch_bounds__(64 * NW, MINW) void ir_tile_h_kernel(IrT2Args t) {
     load_w(0);
 
     int eoff[MTA];
-    long xoff[MTA];
+    unsigned xoff[MTA];
     V8 xhi[EXPAND ? MTA : 1][EXPAND ? KG : 1], xlo[EXPAND ? MTA : 1][EXPAND ? KG : 1];
+    {   // m-tile i is 16 * NW pixels on from m-tile i - 1: stepped (see ir_tile_v2_kernel); loads as [scalar crop base + lane offset]
+        constexpr int QS = 16 * NW;
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        const int q0 = wave_u * 16 + li;
+        const int cy0 = (int)(((float)q0 + 0.5f) * inv_cw), cx0 = q0 - cy0 * CW;   // exact for q0 < 2^16, CW <= 64 (garbage past NPIX: masked)
+        const int qa = QS / CW, qb = QS - qa * CW;
+        const int dpe0 = qa * IWR + qb, dpe1 = dpe0 + IWR - CW;
+        const int dpx0 = (qa * t.W + qb) * a.ldx, dpx1 = dpx0 + (t.W - CW) * a.ldx;
+        int cx = cx0;
+        int pe = (cy0 + cy_lo - iy0) * IWR + cx0 + cx_lo - ix0;
+        int px = ((cy0 + cy_lo) * t.W + cx0 + cx_lo) * a.ldx;
+        const unsigned short* Xb = reinterpret_cast<const unsigned short*>(a.X) + crop * t.H * t.W * a.ldx;
 #pragma unroll
-    for (int i = 0; i < MTA; ++i) {
-        const int q = (wave + NW * i) * 16 + li;
-        const bool valid = q < NPIX;
-        const int qq = valid ? q : 0;
-        const int cy = (int)(((float)qq + 0.5f) * inv_cw), cx = qq - cy * CW;   // exact for qq < 2^16, CW <= 64
-        const int gy = cy_lo + cy, gx = cx_lo + cx;
-        eoff[i] = valid ? ((gy - iy0) * IWR + (gx - ix0)) * ES : -1;
-        xoff[i] = ((long)gy * t.W + gx) * a.ldx;
-        if (EXPAND) {
+        for (int i = 0; i < MTA; ++i) {
+            const bool valid = q0 < NPIX - QS * i;
+            eoff[i] = valid ? pe * ES : -1;
+            xoff[i] = valid ? (unsigned)px : 0u;
+            if (EXPAND) {
 #pragma unroll
-            for (int kg = 0; kg < KG; ++kg) {
-                const int k = kg * 32 + lk * 8;
-                if (IO & IO_X_BF16) {
-                    // the stored activations ARE the bf16 operands: eight channels = one 16-byte load, no conversion
-                    uint4 u = (uint4){0u, 0u, 0u, 0u};
-                    if (k < CIN) u = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(a.X) + crop * t.H * t.W * a.ldx + xoff[i] + k);
-                    xhi[i][kg] = __builtin_bit_cast(V8, u);
-                    xlo[i][kg] = xhi[i][kg];
-                    continue;
+                for (int kg = 0; kg < KG; ++kg) {
+                    const int k = kg * 32 + lk * 8;
+                    if (IO & IO_X_BF16) {
+                        // the stored activations ARE the bf16 operands: eight channels = one 16-byte load, no conversion
+                        uint4 u = (uint4){0u, 0u, 0u, 0u};
+                        if (k < CIN) u = *reinterpret_cast<const uint4*>(Xb + (xoff[i] + (unsigned)k));
+                        xhi[i][kg] = __builtin_bit_cast(V8, u);
+                        xlo[i][kg] = xhi[i][kg];
+                        continue;
+                    }
+                    f32x4 v0 = (f32x4){0.f, 0.f, 0.f, 0.f}, v1 = v0;
+                    if (k < CIN) v0 = *reinterpret_cast<const f32x4*>(Xc + (xoff[i] + (unsigned)k));
+                    if (k + 4 < CIN) v1 = *reinterpret_cast<const f32x4*>(Xc + (xoff[i] + (unsigned)(k + 4)));
+                    MX::split(v0, v1, xhi[i][kg], xlo[i][kg]);
                 }
-                f32x4 v0 = (f32x4){0.f, 0.f, 0.f, 0.f}, v1 = v0;
-                if (k < CIN) v0 = *reinterpret_cast<const f32x4*>(Xc + xoff[i] + k);
-                if (k + 4 < CIN) v1 = *reinterpret_cast<const f32x4*>(Xc + xoff[i] + k + 4);
-                MX::split(v0, v1, xhi[i][kg], xlo[i][kg]);
+            }
+            if (i + 1 < MTA) {
+                cx += qb;
+                const bool wrap = cx >= CW;
+                cx -= wrap ? CW : 0;
+                pe += wrap ? dpe1 : dpe0;
+                px += wrap ? dpx1 : dpx0;
             }
         }
     }
@@ -2993,22 +3009,27 @@ __global__ __launch_bounds__(64 * NW, MINW) void ir_tile_h_kernel(IrT2Args t) {
             }
         }
         if (c + 1 < NCHUNK) store_w(c + 1);
-        if (!EXPAND || c + 1 == NCHUNK) __syncthreads();
+        if (!EXPAND && c + 1 < NCHUNK) __syncthreads();     // (after the last chunk nothing writes LDS any more)
     }
 
+    // stores as [scalar row base + 32-bit lane offset], ReLU as a max against 0 / -big (see ir_tile_v2_kernel's epilogue)
+    const int seg_u = __builtin_amdgcn_readfirstlane(seg), r0_u = __builtin_amdgcn_readfirstlane(r0);
+    const long m0 = (crop * Ho + oy0 + r0_u) * Wo + ox0 + seg_u * 16;
+    const unsigned ylane = (unsigned)(li * a.ldy + lk * 4), rlane = (unsigned)(li * a.ldr + lk * 4);
+    const float relu_lo = a.relu_out ? 0.f : -3.0e38f;
 #pragma unroll
     for (int nt = 0; nt < NTP; ++nt) {
-        const int n = nt * 16 + lk * 4;
-        if (n >= COUT) continue;
-        const f32x4 b = *reinterpret_cast<const f32x4*>(a.bp + n);
+        if (nt * 16 >= COUT) continue;
+        const bool n_ok = COUT % 16 == 0 || nt * 16 + lk * 4 < COUT;
+        f32x4 b = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (n_ok) b = *reinterpret_cast<const f32x4*>(a.bp + nt * 16 + lk * 4);
 #pragma unroll
         for (int r = 0; r < MTC; ++r) {
-            const int oy = oy0 + r0 + r, ox = ox0 + seg * 16 + li;
-            const long m = (crop * Ho + oy) * Wo + ox;
+            const long mrow = m0 + (long)r * Wo;
             f32x4 v = accp[r][nt] + b;
-            if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
-            if (a.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            st_act4<(IO & IO_Y_BF16) != 0>(a.Y, m * a.ldy + n, v);
+            if (a.R && n_ok) v += *reinterpret_cast<const f32x4*>(a.R + (mrow * a.ldr + nt * 16 + (long)rlane));
+            v.x = fmaxf(v.x, relu_lo); v.y = fmaxf(v.y, relu_lo); v.z = fmaxf(v.z, relu_lo); v.w = fmaxf(v.w, relu_lo);
+            if (n_ok) st_act4<(IO & IO_Y_BF16) != 0>(a.Y, mrow * a.ldy + nt * 16 + (long)ylane, v);
         }
     }
 }
