@@ -44,7 +44,7 @@ __device__ __forceinline__ f32x4 act4(const f32x4& x, const f32x4& a, const f32x
 
 // ------------------------------------------------------------------------------------------------
 // Column reductions over rows: per-channel sums.  Block = 256 threads = (C/4 channel quads) x (R row lanes); a block reduces
-// `rpb` rows (col_rows_per_block: 64, doubled until there are at most 1024 blocks) into partial[block][2][C];
+// `rpb` rows (col_rows_per_block: 64, doubled until there are at most FEAR_COL_BLOCKS blocks) into partial[block][2][C];
 // col_finalize_kernel adds the partials in double, 64 lanes per column in a fixed order.
 //   MODE 0: s1 = sum x,        s2 = sum x^2   (float64)                      (BatchNorm forward statistics)
 //   MODE 1: g = relu ? (y > 0 ? dy : 0) : dy;  s1 = sum g,  s2 = sum g * xhat,  xhat = (x - mean) * rstd   (BatchNorm backward)
@@ -88,18 +88,16 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(ColArgs a) {
             rs = *reinterpret_cast<const f32x4*>(a.rstd + cq * 4);
             if (a.act_a) { ma = *reinterpret_cast<const f32x4*>(a.act_a + cq * 4); mb = *reinterpret_cast<const f32x4*>(a.act_b + cq * 4); }
         }
-        for (long r = r0 + rl; r < r1; r += R) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(a.A + r * a.lda + cq * 4);
+        // one row of this thread's column quad: the loads of U rows are issued together, the sums taken in row order (the same
+        // order as a row-at-a-time loop: the result does not depend on U).  With one load in flight per thread the kernel ran at
+        // 3.0-3.3 TB/s (16 KB in flight per CU, profiles/r04_train_traffic.txt) against 5.7-6.1 for the elementwise passes.
+        auto accumulate = [&](f32x4 v, const f32x4& y, const f32x4& xin) {
             if (MODE == 0) {
                 const f64x4 d = to_f64(v);
                 s1 += d;
                 s2 += d * d;
             } else if (MODE == 1) {
-                if (a.Yact) {
-                    const f32x4 y = *reinterpret_cast<const f32x4*>(a.Yact + r * a.ldy + cq * 4);
-                    v.x = y.x > 0.f ? v.x : 0.f; v.y = y.y > 0.f ? v.y : 0.f; v.z = y.z > 0.f ? v.z : 0.f; v.w = y.w > 0.f ? v.w : 0.f;
-                }
-                const f32x4 xin = *reinterpret_cast<const f32x4*>(a.X + r * a.ldx + cq * 4);
+                if (a.Yact) { v.x = y.x > 0.f ? v.x : 0.f; v.y = y.y > 0.f ? v.y : 0.f; v.z = y.z > 0.f ? v.z : 0.f; v.w = y.w > 0.f ? v.w : 0.f; }
                 if (a.act_a) {
                     v.x = __builtin_fmaf(xin.x, ma.x, mb.x) > 0.f ? v.x : 0.f; v.y = __builtin_fmaf(xin.y, ma.y, mb.y) > 0.f ? v.y : 0.f;
                     v.z = __builtin_fmaf(xin.z, ma.z, mb.z) > 0.f ? v.z : 0.f; v.w = __builtin_fmaf(xin.w, ma.w, mb.w) > 0.f ? v.w : 0.f;
@@ -110,7 +108,27 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(ColArgs a) {
             } else {
                 s1 += to_f64(v);
             }
-        }
+        };
+        const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        long r = r0 + rl;
+        auto rows = [&](auto utag) {
+            constexpr int U = decltype(utag)::value;
+            for (; r + (long)(U - 1) * R < r1; r += (long)U * R) {
+                f32x4 v[U], y[U], xin[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const long ru = r + (long)u * R;
+                    v[u] = *reinterpret_cast<const f32x4*>(a.A + ru * a.lda + cq * 4);
+                    y[u] = (MODE == 1 && a.Yact) ? *reinterpret_cast<const f32x4*>(a.Yact + ru * a.ldy + cq * 4) : z4;
+                    xin[u] = MODE == 1 ? *reinterpret_cast<const f32x4*>(a.X + ru * a.ldx + cq * 4) : z4;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) accumulate(v[u], y[u], xin[u]);
+            }
+        };
+        if (MODE != 1) rows(std::integral_constant<int, 8>{});     // one load per row: eight rows in flight
+        rows(std::integral_constant<int, 4>{});
+        rows(std::integral_constant<int, 1>{});
     }
     red[0][threadIdx.x] = s1;
     red[1][threadIdx.x] = s2;
@@ -887,9 +905,12 @@ void launch_pw(int nt, dim3 grid, hipStream_t s, const PwArgs& a) {
 // rows are read and written as float4s: every leading dimension is a multiple of 4 floats and covers its row
 bool ld_ok(int ld, int cols) { return ld >= cols && ld % 4 == 0; }
 
+#ifndef FEAR_COL_BLOCKS
+#define FEAR_COL_BLOCKS 1024   // most workgroups a column reduction is cut into (2048 measured no faster, and slows the depthwise weight gradient's slice sums)
+#endif
 int col_rows_per_block(long M) {
     int r = 64;
-    while ((M + r - 1) / r > 1024) r *= 2;
+    while ((M + r - 1) / r > FEAR_COL_BLOCKS) r *= 2;
     return r;
 }
 int col_blocks(long M) { const int r = col_rows_per_block(M); return (int)((M + r - 1) / r); }
@@ -1191,9 +1212,9 @@ extern "C" {
 
 size_t fear_train_workspace_bytes(long rows, int max_channels) {
     // the largest users: pw wgrad partials [slices][N][K] (slices = ceil(rows / rows_per_slice), see wgrad_slices) with
-    // N * K <= max_channels^2; column reductions [blocks <= 1024][2][C] float64; depthwise wgrad [blocks][25][C]
+    // N * K <= max_channels^2; column reductions [blocks <= FEAR_COL_BLOCKS][2][C] float64; depthwise wgrad [blocks][25][C]
     const size_t a = (size_t)wgrad_slices(rows) * (size_t)max_channels * max_channels;
-    const size_t b = (size_t)col_blocks(rows) * 25 * (size_t)max_channels;      // <= 1024 blocks; col partials are 2 doubles = 4 floats
+    const size_t b = (size_t)col_blocks(rows) * 25 * (size_t)max_channels;      // <= FEAR_COL_BLOCKS blocks; col partials are 2 doubles = 4 floats
     return ((a > b ? a : b) + 1024) * sizeof(float);
 }
 
