@@ -89,13 +89,13 @@ __device__ __forceinline__ void e1_load_taps(E1Taps& t, const float* __restrict_
 }
 
 // ReLU of the depthwise result + the 24 -> 24 projection of the 16-pixel m-tile the wave's lanes form:
-// acc[nt] = channels 16 nt + 4 lk .. + 3 of pixel li, without bias
-__device__ __forceinline__ void e1_project(f32x4 d4, f32x2 d2, const f32x4 (&wp)[4], f32x4 (&acc)[2]) {
+// acc[nt] = channels 16 nt + 4 lk .. + 3 of pixel li; the accumulators start from the projection bias
+__device__ __forceinline__ void e1_project(f32x4 d4, f32x2 d2, const f32x4 (&wp)[4], const f32x4 (&bias)[2], f32x4 (&acc)[2]) {
     d4.x = fmaxf(d4.x, 0.f); d4.y = fmaxf(d4.y, 0.f); d4.z = fmaxf(d4.z, 0.f); d4.w = fmaxf(d4.w, 0.f);
     d2.x = fmaxf(d2.x, 0.f); d2.y = fmaxf(d2.y, 0.f);
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 a = bias[nt];
 #pragma unroll
         for (int q = 0; q < 4; ++q) a = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[nt][q], d4[q], a, 0, 0, 0);
 #pragma unroll
@@ -188,6 +188,9 @@ __global__ __launch_bounds__(512, 4) void e1pair_kernel(E1PairArgs a) {
         const float* ws = WSl;
         E1Taps taps;
         e1_load_taps(taps, ws, lk);
+        f32x4 bpv[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) bpv[nt] = *reinterpret_cast<const f32x4*>(ws + (G::BP - G::FRAG) + (nt * 4 + lk) * 4);
 #pragma unroll
         for (int i = 0; i < G::MTA; ++i) {
             const int mt = wave + 8 * i;
@@ -203,16 +206,14 @@ __global__ __launch_bounds__(512, 4) void e1pair_kernel(E1PairArgs a) {
             f32x4 acc[2], d4[1];
             f32x2 d2[1];
             e1_depthwise<XW, XPL, 1>(Xt, cpix, taps, lk, d4, d2);
-            e1_project(d4[0], d2[0], wp[0], acc);
+            e1_project(d4[0], d2[0], wp[0], bpv, acc);
             const int gy = oy0 - 1 + my, gx = ox0 - 1 + mx;
-            const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            const float inside = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? 1.f : 0.f;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 if (nt == 1 && lk >= 2) continue;                      // channels 24 .. 31 do not exist
                 const int qd = nt * 4 + lk;
-                f32x4 v = acc[nt] + *reinterpret_cast<const f32x4*>(ws + (G::BP - G::FRAG) + qd * 4) +
-                          *reinterpret_cast<const f32x4*>(Xt + qd * XPL + cpix * 4);
-                if (!inside) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const f32x4 v = (acc[nt] + *reinterpret_cast<const f32x4*>(Xt + qd * XPL + cpix * 4)) * inside;   // (finite values: x * 0 = 0)
                 if (valid) *reinterpret_cast<f32x4*>(Mt + qd * MPL + pc * 4) = v;
             }
         }
@@ -224,6 +225,9 @@ __global__ __launch_bounds__(512, 4) void e1pair_kernel(E1PairArgs a) {
         const float* ws = WSl + G::WS;
         E1Taps taps;
         e1_load_taps(taps, ws, lk);
+        f32x4 bpv[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) bpv[nt] = *reinterpret_cast<const f32x4*>(ws + (G::BP - G::FRAG) + (nt * 4 + lk) * 4);
         const int row0 = wave * 2;
         const int cpix = (row0 + 1) * MW + li + 1;
         f32x4 d4[2];
@@ -233,14 +237,13 @@ __global__ __launch_bounds__(512, 4) void e1pair_kernel(E1PairArgs a) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             f32x4 acc[2];
-            e1_project(d4[r], d2[r], wp[1], acc);
+            e1_project(d4[r], d2[r], wp[1], bpv, acc);
             float* yrow = Yc + ((long)(oy0 + row0 + r) * a.W + ox0) * C;   // uniform
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 if (nt == 1 && lk >= 2) continue;
                 const int qd = nt * 4 + lk;
-                const f32x4 v = acc[nt] + *reinterpret_cast<const f32x4*>(ws + (G::BP - G::FRAG) + qd * 4) +
-                                *reinterpret_cast<const f32x4*>(Mt + qd * MPL + (cpix + r * MW) * 4);
+                const f32x4 v = acc[nt] + *reinterpret_cast<const f32x4*>(Mt + qd * MPL + (cpix + r * MW) * 4);
                 *reinterpret_cast<f32x4*>(yrow + (ylane + (unsigned)(nt * 16))) = v;
             }
         }
