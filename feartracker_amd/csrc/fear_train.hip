@@ -642,17 +642,45 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(DwDgradArgs a) {
     const int y = (int)(idx % a.H);
     const long b = idx / a.H;
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* gy = a.dY + b * a.Ho * a.Wo * a.lddy + c;
+    const long dybytes = (a.total / ((long)a.H * a.W * c4n)) * a.Ho * a.Wo * a.lddy * 4;      // B x Ho x Wo x lddy floats
+    if (dybytes < (1L << 31)) {
+        // Branch-free: only the taps whose parity matches the stride are visited (ky = ky0 + S j), and one that falls outside the
+        // map is a buffer load with an out-of-range offset (returns zero, no memory access) — all loads of a thread are in flight
+        // together.  With a branch around every tap the stride-2 kernels ran at 2.8-3.4 TB/s (profiles/r04_train_traffic_before.txt).
+        // The products are added in the same (ky, kx) order as before.
+        const __amdgpu_buffer_rsrc_t gyr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dY), 0, (int)dybytes, 0x00020000);
+        constexpr int NT = (KS + S - 1) / S;
+        const int ky0 = (y + P) % S, kx0 = (x + P) % S;
+        const int ty0 = (y + P - ky0) / S, tx0 = (x + P - kx0) / S;          // tap (ky0 + S j, kx0 + S i) reads dY[ty0 - j][tx0 - i]
+        const int base = (int)(b * a.Ho * a.Wo) * a.lddy + c;
 #pragma unroll
-    for (int ky = 0; ky < KS; ++ky) {
-        const int ty = y + P - ky;
-        if (ty < 0 || ty % S != 0 || ty / S >= a.Ho) continue;
+        for (int j = 0; j < NT; ++j) {
+            const int ky = ky0 + S * j, ty = ty0 - j;
+            const bool yok = ky < KS && ty >= 0 && ty < a.Ho;
+            f32x4 v[NT], w[NT];
 #pragma unroll
-        for (int kx = 0; kx < KS; ++kx) {
-            const int tx = x + P - kx;
-            if (tx < 0 || tx % S != 0 || tx / S >= a.Wo) continue;
-            acc += *reinterpret_cast<const f32x4*>(gy + ((long)(ty / S) * a.Wo + tx / S) * a.lddy) *
-                   *reinterpret_cast<const f32x4*>(a.Wt + (long)(ky * KS + kx) * a.C + c);
+            for (int i = 0; i < NT; ++i) {
+                const int kx = kx0 + S * i, tx = tx0 - i;
+                const bool ok = yok && kx < KS && tx >= 0 && tx < a.Wo;
+                v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gyr, ok ? (base + (ty * a.Wo + tx) * a.lddy) * 4 : (int)0x80000000, 0, 0));
+                w[i] = *reinterpret_cast<const f32x4*>(a.Wt + (long)(ok ? ky * KS + kx : 0) * a.C + c);
+            }
+#pragma unroll
+            for (int i = 0; i < NT; ++i) acc += v[i] * w[i];
+        }
+    } else {
+        const float* gy = a.dY + b * a.Ho * a.Wo * a.lddy + c;
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) {
+            const int ty = y + P - ky;
+            if (ty < 0 || ty % S != 0 || ty / S >= a.Ho) continue;
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+                const int tx = x + P - kx;
+                if (tx < 0 || tx % S != 0 || tx / S >= a.Wo) continue;
+                acc += *reinterpret_cast<const f32x4*>(gy + ((long)(ty / S) * a.Wo + tx / S) * a.lddy) *
+                       *reinterpret_cast<const f32x4*>(a.Wt + (long)(ky * KS + kx) * a.C + c);
+            }
         }
     }
     *reinterpret_cast<f32x4*>(a.dX + ((b * a.H + y) * a.W + x) * a.lddx + c) = acc;
