@@ -1286,6 +1286,21 @@ static int wgrad_impl(const float* dy, int lddy, long dy_crop_stride, const floa
     a.dy_crop_stride = dy_crop_stride; a.x_crop_stride = x_crop_stride;
     a.n_tiles = (N + 63) / 64; a.k_tiles = (K + 63) / 64;
     a.rows_per_slice = crops > 1 ? M : wgrad_rows_per_slice(M);
+    if (crops == 1) {
+        // few output tiles (the 16 x 16 maps' layers: 2-22 tiles x 8-32 slices of 1 024 rows) leave most of the 256 CUs idle while
+        // every wave walks its 16 steps of 64 dependent MFMAs: such launches sat on a 31 us floor whatever their size.  Cut the rows
+        // finer — down to 256 per slice — until there are ~768 workgroups, as far as the caller's workspace holds the partials.
+        const long tiles = (FEAR_WGRAD_SMALLK && K <= 32) ? a.n_tiles : (long)a.n_tiles * a.k_tiles;
+        const long want = (768 + tiles - 1) / tiles;
+        const long cap_ws = workspace ? (long)(ws_bytes / ((size_t)N * K * sizeof(float))) : 1;
+        long sl = (M + a.rows_per_slice - 1) / a.rows_per_slice;
+        if (want > sl) sl = want;
+        if (sl > 256) sl = 256;
+        if (sl > cap_ws) sl = cap_ws;
+        long rps = ((M + sl - 1) / sl + 63) / 64 * 64;
+        if (rps < 256) rps = 256;
+        if (rps < a.rows_per_slice) a.rows_per_slice = rps;
+    }
     const int slices = (int)((M + a.rows_per_slice - 1) / a.rows_per_slice);
     const size_t need = (size_t)slices * crops * N * K * sizeof(float);
     if (slices == 1) {
