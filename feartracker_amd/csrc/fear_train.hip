@@ -917,6 +917,30 @@ int train_pick_nt(int n_tiles) {
     return 1;
 }
 
+// Grid of a pointwise GEMM over M rows and n_tiles 16-channel output tiles: one workgroup per 128 rows, and — when that leaves
+// the GPU short of waves (the 16 x 16 maps of a 128-pair batch are 32 768 rows = 256 workgroups, ONE wave per SIMD, every operand
+// fetched from L2 straight in front of the MFMAs that use it) — the output tiles dealt over gridDim.y as well (pw_mfma_kernel
+// walks tiles blockIdx.y * NT, + NT * gridDim.y, ...), with fewer tiles per pass if that is what it takes.
+#ifndef FEAR_PW_WGS
+#define FEAR_PW_WGS 1024
+#endif
+dim3 train_pw_grid(long M, int n_tiles, int* nt_out) {
+    const long wgs = (M + 127) / 128;
+    int nt = train_pick_nt(n_tiles);
+    int y = 1;
+    if (wgs < FEAR_PW_WGS) {
+        const int want = (int)((FEAR_PW_WGS + wgs - 1) / wgs);
+        for (int cand : {8, 7, 6, 4, 3, 2, 1}) {            // the largest tile count per pass that still gives `want` passes
+            if (cand > nt || n_tiles % cand) continue;
+            nt = cand;
+            if (n_tiles / cand >= want) break;
+        }
+        y = n_tiles / nt < want ? n_tiles / nt : want;
+    }
+    *nt_out = nt;
+    return dim3((unsigned)wgs, (unsigned)y);
+}
+
 template <bool WKN>
 void launch_pw(int nt, dim3 grid, hipStream_t s, const PwArgs& a) {
     switch (nt) {
@@ -1253,8 +1277,9 @@ int fear_pw_forward(const float* x, int ldx, const float* w, const float* bias, 
     if (M < 0 || K < 4 || K % 4 || N < 4 || N % 4 || M > 0x7fffffffL || !ld_ok(ldx, K) || !ld_ok(ldy, N)) return FEAR_TRAIN_ERR_SHAPE;
     PwArgs a{};
     a.X = x; a.ldx = ldx; a.W = w; a.bias = bias; a.Y = y; a.ldy = ldy; a.M = (int)M; a.K = K; a.N = N;
-    dim3 grid((unsigned)((M + 127) / 128));
-    launch_pw<false>(train_pick_nt((N + 15) / 16), grid, static_cast<hipStream_t>(stream), a);
+    int nt = 1;
+    const dim3 grid = train_pw_grid(M, (N + 15) / 16, &nt);
+    launch_pw<false>(nt, grid, static_cast<hipStream_t>(stream), a);
     LAUNCH_CHECK();
     return FEAR_TRAIN_OK;
 }
@@ -1271,8 +1296,9 @@ int fear_pw_backward_data(const float* dy, int lddy, const float* w, const float
     a.X = dy; a.ldx = lddy; a.W = w; a.Y = dx; a.ldy = lddx; a.M = (int)M; a.K = N; a.N = K;
     a.R = add; a.ldr = ldadd;
     a.rows_per_crop = (int)M; a.w_crop_stride = 0;
-    dim3 grid((unsigned)((M + 127) / 128));
-    launch_pw<true>(train_pick_nt((K + 15) / 16), grid, static_cast<hipStream_t>(stream), a);
+    int nt = 1;
+    const dim3 grid = train_pw_grid(M, (K + 15) / 16, &nt);
+    launch_pw<true>(nt, grid, static_cast<hipStream_t>(stream), a);
     LAUNCH_CHECK();
     return FEAR_TRAIN_OK;
 }
