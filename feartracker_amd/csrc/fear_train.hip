@@ -960,8 +960,11 @@ bool ld_ok(int ld, int cols) { return ld >= cols && ld % 4 == 0; }
 #ifndef FEAR_COL_BLOCKS
 #define FEAR_COL_BLOCKS 1024   // most workgroups a column reduction is cut into (2048 measured no faster, and slows the depthwise weight gradient's slice sums)
 #endif
+#ifndef FEAR_COL_ROWS
+#define FEAR_COL_ROWS 64      // fewest rows a column-reduction workgroup takes
+#endif
 int col_rows_per_block(long M) {
-    int r = 64;
+    int r = FEAR_COL_ROWS;
     while ((M + r - 1) / r > FEAR_COL_BLOCKS) r *= 2;
     return r;
 }
