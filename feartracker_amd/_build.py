@@ -45,8 +45,13 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     os.replace(LIB + ".tmp", LIB)
     spills = check_spills(res.stderr)
     for name, n in spills:
-        print(f"WARNING: {name} spills {n} VGPRs to scratch (hipcc scheduling is fragile around the fused kernels; "
-              "a spilling build is several times slower)")
+        # a handful of spilled registers outside the hot loops is what the chained head kernels are known to carry (7 and 11:
+        # ten scratch instructions per launch); a spill STORM (hundreds) is what a compiler regression looks like
+        if n <= 16:
+            print(f"note: {name} spills {n} VGPRs to scratch (known, outside its loops)")
+        else:
+            print(f"WARNING: {name} spills {n} VGPRs to scratch (hipcc scheduling is fragile around the fused kernels; "
+                  "a spilling build is several times slower)")
     return LIB
 
 
