@@ -18,6 +18,7 @@
 // LDS tiles are kept as six planes [channel quad][pixel][4 floats]: a wave's 16 pixels are 16 consecutive 16-byte units of a
 // plane (conflict free, MI355X_MICROARCH.md §LDS), the float2 reads of chunk 1 are the two halves of planes 4 and 5.
 #pragma once
+#include <vector>
 
 #ifndef E1P_ABL
 #define E1P_ABL 0      // tools/kbench ablations: 1 no block A, 2 no block B, 4 no input loads, 8 stamps
