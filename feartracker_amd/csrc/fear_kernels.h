@@ -30,6 +30,9 @@
 #endif
 #ifndef FEAR_ABL
 #define FEAR_ABL 0      // timing ablations for tools/kbench only (bit mask); the product always builds with 0
+                        // (tile kernels, round 4: 8192 keep the barrier after the last chunk, 16384 projection bias loaded in the
+                        //  epilogue, 65536 e1 residual re-read from global memory; 4096 = per-phase wall-clock stamps; the other
+                        //  bits are named where they are tested)
 #endif
 
 #include <hip/hip_runtime.h>
