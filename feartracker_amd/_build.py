@@ -12,11 +12,13 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(PKG_DIR, "csrc", "fear_engine.hip")
 SRC_TRAIN = os.path.join(PKG_DIR, "csrc", "fear_train.hip")       # head training-step operators, #included by fear_engine.hip
-DEPS = [SRC, SRC_TRAIN, os.path.join(PKG_DIR, "csrc", "fear_kernels.h"), os.path.join(PKG_DIR, "csrc", "fear_headchain.h"), os.path.join(PKG_DIR, "csrc", "fear_headchain_b.h"), os.path.join(PKG_DIR, "csrc", "fear_e1pair.h"),
+DEPS = [SRC, SRC_TRAIN, os.path.join(PKG_DIR, "csrc", "fear_train_block.h"), os.path.join(PKG_DIR, "csrc", "fear_kernels.h"), os.path.join(PKG_DIR, "csrc", "fear_headchain.h"), os.path.join(PKG_DIR, "csrc", "fear_headchain_b.h"), os.path.join(PKG_DIR, "csrc", "fear_e1pair.h"),
         os.path.join(os.path.dirname(PKG_DIR), "include", "fear_hip.h"),
         os.path.join(os.path.dirname(PKG_DIR), "include", "fear_train.h"),
         os.path.join(os.path.dirname(PKG_DIR), "include", "fearw_format.h")]
 LIB = os.path.join(PKG_DIR, "libfear_hip.so")
+# kernels allowed to spill, and how many VGPRs at most (mangled-name substring -> cap): everything else warns
+KNOWN_SPILLS = {"headchain_kernel": 16, "headchain_b_kernel": 16}
 
 
 def _hipcc() -> str:
@@ -45,9 +47,11 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     os.replace(LIB + ".tmp", LIB)
     spills = check_spills(res.stderr)
     for name, n in spills:
-        # a handful of spilled registers outside the hot loops is what the chained head kernels are known to carry (7 and 11:
-        # ten scratch instructions per launch); a spill STORM (hundreds) is what a compiler regression looks like
-        if n <= 16:
+        # the two chained head kernels are known to carry a handful of spilled registers outside their loops (ten scratch
+        # instructions per launch); the tolerance is theirs alone, by name and count — a new spill in any other fused kernel, or a
+        # spill STORM (hundreds) in these, is what a compiler regression looks like
+        known = next((cap for key, cap in KNOWN_SPILLS.items() if key in name), None)
+        if known is not None and n <= known:
             print(f"note: {name} spills {n} VGPRs to scratch (known, outside its loops)")
         else:
             print(f"WARNING: {name} spills {n} VGPRs to scratch (hipcc scheduling is fragile around the fused kernels; "

@@ -42,6 +42,28 @@ __device__ __forceinline__ f32x4 act4(const f32x4& x, const f32x4& a, const f32x
     return y;
 }
 
+// BatchNorm BACKWARD applied to a gradient operand as it is loaded (block-fused step, fear_train_block.h): the consumer of
+// d(pre) = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat)) never sees that tensor in memory — it loads g (the gradient
+// w.r.t. the BatchNorm's output, already masked by the ReLU behind it unless mask_a is given) and the BatchNorm's raw input E and
+// forms d(pre) in registers from four per-channel vectors: coef = [A | s1 | mu | Q] with A = gamma * rstd, s1 = sum(g) / count,
+// mu = mean, Q = rstd * sum(g * xhat) / count (col_finalize_kernel mode 4 writes them).
+struct BnbIn {
+    const float* E;        // [rows][lde] the BatchNorm's input (raw conv output); nullptr: the operand is used as loaded
+    const float* coef;     // [4][C]
+    const float* mask_a;   // optional: g is first masked where fma(E, mask_a, mask_b) <= 0 (a ReLU between the BatchNorm and g)
+    const float* mask_b;
+    int lde, C;
+};
+
+__device__ __forceinline__ f32x4 bnb4(const f32x4& g, const f32x4& e, const f32x4& A, const f32x4& s1, const f32x4& mu, const f32x4& Q) {
+    return A * (g - s1 - (e - mu) * Q);
+}
+
+__device__ __forceinline__ f32x4 relu_mask4(const f32x4& g, const f32x4& e, const f32x4& ma, const f32x4& mb) {
+    return (f32x4){__builtin_fmaf(e.x, ma.x, mb.x) > 0.f ? g.x : 0.f, __builtin_fmaf(e.y, ma.y, mb.y) > 0.f ? g.y : 0.f,
+                   __builtin_fmaf(e.z, ma.z, mb.z) > 0.f ? g.z : 0.f, __builtin_fmaf(e.w, ma.w, mb.w) > 0.f ? g.w : 0.f};
+}
+
 // ------------------------------------------------------------------------------------------------
 // Column reductions over rows: per-channel sums.  Block = 256 threads = (C/4 channel quads) x (R row lanes); a block reduces
 // `rpb` rows (col_rows_per_block: 64, doubled until there are at most FEAR_COL_BLOCKS blocks) into partial[block][2][C];
@@ -145,7 +167,8 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(ColArgs a) {
 }
 
 // mode 0: mean / rstd (+ running statistics, torch semantics: biased variance normalises, unbiased one is tracked);
-// mode 1: the two sums as they are (sum g -> out1, sum g*xhat -> out2);  mode 2: out1 only
+// mode 1: the two sums as they are (sum g -> out1, sum g*xhat -> out2);  mode 2: out1 only;  mode 3: float64 sums;
+// mode 4: mode 1 + the BnbIn coefficient vectors
 struct ColFinArgs {
     const double* partial;
     float* out1;
@@ -157,6 +180,9 @@ struct ColFinArgs {
     const float* beta;
     float* out_a;
     float* out_b;
+    const float* mean_in;  // mode 4: the BatchNorm's saved mean / rstd (gamma above) ...
+    const float* rstd_in;
+    float* coef;           // ... -> [4][C] = gamma * rstd | s1 / M | mean | rstd * s2 / M  (BnbIn::coef), M = the row count
     int blocks, C, mode, rpb;
     double M, eps, momentum;
 };
@@ -202,6 +228,15 @@ __global__ __launch_bounds__(1024) void col_finalize_kernel(ColFinArgs a) {
     } else if (a.mode == 3) {
         a.dsum[c] = s1;
         a.dsum[a.C + c] = s2;
+    } else if (a.mode == 4) {
+        // BatchNorm backward: d beta = sum g, d gamma = sum g * xhat, and the coefficients its consumers apply on load
+        a.out1[c] = (float)s1;
+        a.out2[c] = (float)s2;
+        const float rs = a.rstd_in[c];
+        a.coef[c] = a.gamma[c] * rs;
+        a.coef[a.C + c] = (float)(s1 / a.M);
+        a.coef[2 * a.C + c] = a.mean_in[c];
+        a.coef[3 * a.C + c] = (float)((double)rs * (s2 / a.M));
     } else {
         a.out1[c] = (float)s1;
         if (a.out2) a.out2[c] = (float)s2;
@@ -332,6 +367,7 @@ struct WgradArgs {
     const float* act_a;  // fused step: X holds a producer's raw output, the operand is max(fma(x, act_a, act_b), 0) / fma(...)
     const float* act_b;
     int act_relu;
+    BnbIn bn;            // block-fused step: the dY operand is the BatchNorm backward of (dY, bn.E), formed on load (crops == 1)
 };
 
 __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs a) {
@@ -354,6 +390,14 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs a) {
     const bool act = a.act_a != nullptr;
     f32x4 ia = zero, ib = zero;
     if (act && kv) { ia = *reinterpret_cast<const f32x4*>(a.act_a + k4); ib = *reinterpret_cast<const f32x4*>(a.act_b + k4); }
+    const bool bnb = a.bn.E != nullptr, bmask = a.bn.mask_a != nullptr;
+    f32x4 cA = zero, cs1 = zero, cmu = zero, cQ = zero, cma = zero, cmb = zero;
+    if (bnb && nv) {
+        cA = *reinterpret_cast<const f32x4*>(a.bn.coef + n4); cs1 = *reinterpret_cast<const f32x4*>(a.bn.coef + a.bn.C + n4);
+        cmu = *reinterpret_cast<const f32x4*>(a.bn.coef + 2 * a.bn.C + n4); cQ = *reinterpret_cast<const f32x4*>(a.bn.coef + 3 * a.bn.C + n4);
+        if (bmask) { cma = *reinterpret_cast<const f32x4*>(a.bn.mask_a + n4); cmb = *reinterpret_cast<const f32x4*>(a.bn.mask_b + n4); }
+    }
+    const float* eb = bnb ? a.bn.E + (nv ? n4 : 0) : nullptr;
     for (long m = m0 + wave * 16; m < m1; m += 64) {
         f32x4 dv[4], xv[4];
 #pragma unroll
@@ -363,6 +407,11 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs a) {
             dv[u] = rv && nv ? *reinterpret_cast<const f32x4*>(dy + r * a.lddy) : zero;
             xv[u] = rv && kv ? *reinterpret_cast<const f32x4*>(x + r * a.ldx) : zero;
             if (act && rv && kv) xv[u] = act4(xv[u], ia, ib, a.act_relu != 0);
+            if (bnb && rv && nv) {
+                const f32x4 ev = *reinterpret_cast<const f32x4*>(eb + r * a.bn.lde);
+                if (bmask) dv[u] = relu_mask4(dv[u], ev, cma, cmb);
+                dv[u] = bnb4(dv[u], ev, cA, cs1, cmu, cQ);
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -441,6 +490,14 @@ __global__ __launch_bounds__(256) void pw_wgrad_smallk_kernel(WgradArgs a) {
         ia[b] = act && kv[b] ? a.act_a[b * 16 + li] : 0.f;
         ib[b] = act && kv[b] ? a.act_b[b * 16 + li] : 0.f;
     }
+    const bool bnb = a.bn.E != nullptr, bmask = a.bn.mask_a != nullptr;
+    f32x4 cA = zero, cs1 = zero, cmu = zero, cQ = zero, cma = zero, cmb = zero;
+    if (bnb && nv) {
+        cA = *reinterpret_cast<const f32x4*>(a.bn.coef + n4); cs1 = *reinterpret_cast<const f32x4*>(a.bn.coef + a.bn.C + n4);
+        cmu = *reinterpret_cast<const f32x4*>(a.bn.coef + 2 * a.bn.C + n4); cQ = *reinterpret_cast<const f32x4*>(a.bn.coef + 3 * a.bn.C + n4);
+        if (bmask) { cma = *reinterpret_cast<const f32x4*>(a.bn.mask_a + n4); cmb = *reinterpret_cast<const f32x4*>(a.bn.mask_b + n4); }
+    }
+    const float* eb = bnb ? a.bn.E + (nv ? n4 : 0) : nullptr;
     for (long m = m0 + wave * 16; m < m1; m += 64) {
         f32x4 dv[4];
         float xs[4][KB];
@@ -449,6 +506,11 @@ __global__ __launch_bounds__(256) void pw_wgrad_smallk_kernel(WgradArgs a) {
             const long r = m + u * 4 + lk;
             const bool rv = r < m1;
             dv[u] = rv && nv ? *reinterpret_cast<const f32x4*>(dy + r * a.lddy) : zero;
+            if (bnb && rv && nv) {
+                const f32x4 ev = *reinterpret_cast<const f32x4*>(eb + r * a.bn.lde);
+                if (bmask) dv[u] = relu_mask4(dv[u], ev, cma, cmb);
+                dv[u] = bnb4(dv[u], ev, cA, cs1, cmu, cQ);
+            }
 #pragma unroll
             for (int b = 0; b < KB; ++b) {
                 float v = rv && kv[b] ? x[b][r * a.ldx] : 0.f;
@@ -1038,7 +1100,9 @@ __global__ __launch_bounds__(256) void pw_stat_kernel(PwStatArgs a) {
     }
     const bool affine = a.in.a != nullptr;
     const int n_tiles = (a.N + 15) >> 4;
-    for (int nc = 0; nc < n_tiles; nc += NT) {
+    // gridDim.y > 1 (16 x 16 maps: few row blocks): the passes over the output tiles are dealt to different workgroups; each
+    // writes its own columns of this row block's partial
+    for (int nc = blockIdx.y * NT; nc < n_tiles; nc += NT * gridDim.y) {
         f32x4 acc[MT][NT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -1160,6 +1224,41 @@ __global__ __launch_bounds__(256) void dw_stat_kernel(DwStatArgs a) {
         const float* xb = a.X + (long)b * a.H * a.W * a.ldx + c;
         const int iy0 = oy0 * S - P;
         const int ix0 = ox * S - P;
+        const long xbytes = (long)a.B * a.H * a.W * a.ldx * 4;
+        if (xbytes < (1L << 31)) {
+            // branch-free taps (dw_conv_kernel's form, fear_kernels.h): a tap outside the map is a buffer load with an out-of-range
+            // offset — no memory access, and all KS loads of a row are in flight together; its ACTIVATION is forced to zero
+            // (act(0) = max(b, 0) is not the padding).  Same products in the same order as the branchy form below.
+            const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, (int)xbytes, 0x00020000);
+            int pix0 = ((b * a.H + iy0) * a.W + ix0) * a.ldx + c;
+            const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int iy = 0; iy < IR; ++iy) {
+                const int y = iy0 + iy;
+                const bool yin = y >= 0 && y < a.H;
+                f32x4 v[KS];
+                bool in[KS];
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) {
+                    const int x = ix0 + kx;
+                    in[kx] = yin && x >= 0 && x < a.W;
+                    v[kx] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, in[kx] ? (pix0 + (iy * a.W + kx) * a.ldx) * 4 : (int)0x80000000, 0, 0));
+                }
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) {
+                    if (affine) v[kx] = in[kx] ? act4(v[kx], ia, ib, a.in.relu != 0) : z4;
+#pragma unroll
+                    for (int r = 0; r < RO; ++r) {
+                        const int ky = iy - r * S;
+                        if (ky >= 0 && ky < KS) acc[r] += v[kx] * w[ky * KS + kx];
+                    }
+                }
+                // two input rows of loads in flight at most: left to itself hipcc hoists all IR x KS buffer loads of a 5 x 5 strip
+                // to the top (220 VGPRs next to the 100 of the taps) and spills hundreds of registers; neither sched_barrier nor a
+                // memory clobber holds them back, a data dependence of the next rows' offsets on this row's sums does
+                if (KS == 5 && (iy & 1) == 1) asm volatile("" : "+v"(pix0) : "v"(acc[0].x), "v"(acc[RO - 1].x), "v"(acc[1].x), "v"(acc[RO - 2].x));
+            }
+        } else {
 #pragma unroll
         for (int iy = 0; iy < IR; ++iy) {
             const int y = iy0 + iy;
@@ -1177,6 +1276,7 @@ __global__ __launch_bounds__(256) void dw_stat_kernel(DwStatArgs a) {
                     if (ky >= 0 && ky < KS) acc[r] += v * w[ky * KS + kx];
                 }
             }
+        }
         }
         f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f}, s2 = s1;
 #pragma unroll
@@ -1308,10 +1408,14 @@ int fear_pw_backward_data(const float* dy, int lddy, const float* w, const float
 
 static int wgrad_impl(const float* dy, int lddy, long dy_crop_stride, const float* x, int ldx, long x_crop_stride, float* dw,
                       float* workspace, size_t ws_bytes, long M, int K, int N, int crops, hipStream_t s, const float* act_a = nullptr,
-                      const float* act_b = nullptr, int act_relu = 0) {
+                      const float* act_b = nullptr, int act_relu = 0, const BnbIn* bn = nullptr) {
     WgradArgs a{};
     a.dY = dy; a.X = x; a.lddy = lddy; a.ldx = ldx; a.N = N; a.K = K; a.M = M; a.crops = crops;
     a.act_a = act_a; a.act_b = act_b; a.act_relu = act_relu;
+    if (bn) {
+        if (crops != 1) return FEAR_TRAIN_ERR_SHAPE;
+        a.bn = *bn;
+    }
     a.dy_crop_stride = dy_crop_stride; a.x_crop_stride = x_crop_stride;
     a.n_tiles = (N + 63) / 64; a.k_tiles = (K + 63) / 64;
     a.rows_per_slice = crops > 1 ? M : wgrad_rows_per_slice(M);
@@ -1321,7 +1425,8 @@ static int wgrad_impl(const float* dy, int lddy, long dy_crop_stride, const floa
         // finer — down to 256 per slice — until there are ~768 workgroups, as far as the caller's workspace holds the partials.
         const long tiles = (FEAR_WGRAD_SMALLK && K <= 32) ? a.n_tiles : (long)a.n_tiles * a.k_tiles;
         const long want = (768 + tiles - 1) / tiles;
-        const long cap_ws = workspace ? (long)(ws_bytes / ((size_t)N * K * sizeof(float))) : 1;
+        long cap_ws = workspace ? (long)(ws_bytes / ((size_t)N * K * sizeof(float))) : 1;
+        if (cap_ws < 1) cap_ws = 1;      // a workspace smaller than one partial: no finer slicing; the size check below reports it
         long sl = (M + a.rows_per_slice - 1) / a.rows_per_slice;
         if (want > sl) sl = want;
         if (sl > 256) sl = 256;
@@ -1950,3 +2055,5 @@ int fear_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
 }
 
 }  // extern "C"
+
+#include "fear_train_block.h"

@@ -1,0 +1,719 @@
+// fear_train_block.h — block-fused operators of the trunk's TRAINING step (BASELINE.json configs[4]; round 5).
+//
+// One C-ABI call per inverted-residual block and direction (model_training/model/blocks.py:22-35 over mobile_cv's
+// conv-BN-ReLU units: expand 1x1 + BN + ReLU, depthwise kxk + BN + ReLU, project 1x1 + BN [+ input]); the call sequences its
+// kernels on the device side of the boundary — the host issues ~70 calls per step instead of ~1 100 launches through ctypes —
+// and no BatchNorm'd activation, no BatchNorm input gradient and no ReLU mask is ever written to memory:
+//
+//   forward    e = W1 x            + column sums of e          (pw_stat_kernel)            saved: e
+//              d = DW act1(e)      + column sums of d          (dw_stat_kernel)            saved: d
+//              p = W3 act2(d)      + column sums of p          (pw_stat_kernel)            saved: p
+//              out = a3 p + b3 [+ x]                           (bn_act_kernel)
+//   backward   sums of (dout, p)                               (col_reduce_kernel<1>)      -> d gamma3, d beta3, coef3
+//              g2 = (dp W3) * [act2(d) > 0], dp = BN3'(dout, p) formed on load, + sums of (g2, dhat)   (pw_bwd_kernel<MS>)
+//              dW3 = dp^T act2(d), both operands formed on load                            (pw_wgrad_kernel)
+//              dd = BN2'(g2, d) formed on load into an LDS tile; g1 = (DW^T dd) * [act1(e) > 0]; d taps = sum dd (x) act1(e);
+//              sums of (g1, ehat) — one pass over g2, d, e                                 (dw_bwd_kernel)
+//              dx = de W1 [+ dout], de = BN1'(g1, e) formed on load                        (pw_bwd_kernel)
+//              dW1 = de^T x                                                                (pw_wgrad_kernel)
+// where BNk'(g, x) = gamma rstd (g - mean(g) - xhat mean(g xhat)) (struct BnbIn).  Passes over the expanded tensors of a block,
+// forward + backward: e 8 (was 14 layer by layer), d 7 (was 14); launches 19 (was ~36).
+//
+// Included at the end of fear_train.hip (same translation unit: it reuses that file's kernels and helpers).
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Y[m][n] = sum_k X'[m][k] Wt[k][n]  with  X' = BnbIn(X) formed on load and Wt K-major ([Kred][Nout] row-major: the [N][K] matrix
+// of the convolution whose INPUT gradient this is).  pw_stat_kernel's tiling (4 waves x 32 rows per workgroup, NT column tiles
+// per pass, passes dealt over gridDim.y).  MS = false: + R, store.  MS = true: Y is masked where fma(D, a, b) <= 0 (the ReLU of
+// the layer whose raw output D is), stored, and its column sums sum(y) / sum(y * dhat), dhat = (D - mean) * rstd, leave in the
+// pass (the next BatchNorm-backward's two reductions): fp32 over a wave's 32 rows, float64 across waves and workgroups.
+struct PwBwdArgs {
+    const float* G;
+    BnbIn bn;
+    const float* W;      // [Kred][Nout]
+    const float* R;      // optional [M][ldr] added to Y (MS = false)
+    float* Y;
+    const float* D;      // MS: [M][ldd] raw tensor behind the ReLU
+    const float* dvec;   // MS: [4][Nout] mean | rstd | a | b of D's BatchNorm
+    double* partial;     // MS: [gridDim.x][2][Nout]
+    int ldg, ldr, ldy, ldd;
+    int M, Kred, Nout;
+};
+
+template <int NT, bool MS>
+__global__ __launch_bounds__(256) void pw_bwd_kernel(PwBwdArgs a) {
+    constexpr int MT = 2;
+    __shared__ double red[MS ? 4 : 1][2][NT * 16];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int m_wave = (blockIdx.x * 4 + wave) * (MT * 16);
+    const float* grow[MT];
+    const float* erow[MT];
+    bool mvalid[MT];
+    const bool bnb = a.bn.E != nullptr, bmask = a.bn.mask_a != nullptr;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int m = m_wave + mt * 16 + li;
+        mvalid[mt] = m < a.M;
+        if (m >= a.M) m = a.M - 1;
+        grow[mt] = a.G + (long)m * a.ldg;
+        erow[mt] = bnb ? a.bn.E + (long)m * a.bn.lde : nullptr;
+    }
+    const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int n_tiles = (a.Nout + 15) >> 4;
+    for (int nc = blockIdx.y * NT; nc < n_tiles; nc += NT * gridDim.y) {
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = zero;
+        int ncol[NT];
+        bool nvalid[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = (nc + nt) * 16 + li;
+            nvalid[nt] = n < a.Nout;
+            ncol[nt] = nvalid[nt] ? n : (a.Nout - 1);
+        }
+        for (int kg = 0; kg < a.Kred; kg += 16) {
+            const int k = kg + lk * 4;
+            const bool kvalid = k < a.Kred;      // Kred is a multiple of 4
+            f32x4 xf[MT], wf[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) xf[mt] = zero;
+            if (kvalid) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) xf[mt] = *reinterpret_cast<const f32x4*>(grow[mt] + k);
+                if (bnb) {
+                    f32x4 ev[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) ev[mt] = *reinterpret_cast<const f32x4*>(erow[mt] + k);
+                    const f32x4 cA = *reinterpret_cast<const f32x4*>(a.bn.coef + k), cs1 = *reinterpret_cast<const f32x4*>(a.bn.coef + a.bn.C + k);
+                    const f32x4 cmu = *reinterpret_cast<const f32x4*>(a.bn.coef + 2 * a.bn.C + k), cQ = *reinterpret_cast<const f32x4*>(a.bn.coef + 3 * a.bn.C + k);
+                    if (bmask) {
+                        const f32x4 cma = *reinterpret_cast<const f32x4*>(a.bn.mask_a + k), cmb = *reinterpret_cast<const f32x4*>(a.bn.mask_b + k);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) xf[mt] = relu_mask4(xf[mt], ev[mt], cma, cmb);
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) xf[mt] = bnb4(xf[mt], ev[mt], cA, cs1, cmu, cQ);
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                wf[nt] = zero;
+                if (kvalid && nvalid[nt]) {
+                    const float* p = a.W + (long)k * a.Nout + ncol[nt];
+                    wf[nt] = (f32x4){p[0], p[a.Nout], p[2 * a.Nout], p[3 * a.Nout]};
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][i], xf[mt][i], acc[mt][nt], 0, 0, 0);
+        }
+        // epilogue: lane holds columns n0 + 4 lk + {0..3} of rows m_wave + mt * 16 + li
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = (nc + nt) * 16 + lk * 4;
+            const bool nok = n < a.Nout;      // Nout is a multiple of 4
+            if (MS) {
+                f32x4 dmu = zero, drs = zero, da = zero, db = zero;
+                if (nok) {
+                    dmu = *reinterpret_cast<const f32x4*>(a.dvec + n); drs = *reinterpret_cast<const f32x4*>(a.dvec + a.Nout + n);
+                    da = *reinterpret_cast<const f32x4*>(a.dvec + 2 * a.Nout + n); db = *reinterpret_cast<const f32x4*>(a.dvec + 3 * a.Nout + n);
+                }
+                f32x4 s1 = zero, s2 = zero;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    if (!mvalid[mt] || !nok) continue;
+                    const long m = m_wave + mt * 16 + li;
+                    const f32x4 dv = *reinterpret_cast<const f32x4*>(a.D + m * a.ldd + n);
+                    const f32x4 v = relu_mask4(acc[mt][nt], dv, da, db);
+                    *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = v;
+                    s1 += v;
+                    s2 += v * ((dv - dmu) * drs);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float t1 = row16_sum(s1[c]), t2 = row16_sum(s2[c]);
+                    if (li == 0) {
+                        red[wave][0][nt * 16 + lk * 4 + c] = (double)t1;
+                        red[wave][1][nt * 16 + lk * 4 + c] = (double)t2;
+                    }
+                }
+            } else {
+                if (!nok) continue;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    if (!mvalid[mt]) continue;
+                    const long m = m_wave + mt * 16 + li;
+                    f32x4 v = acc[mt][nt];
+                    if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
+                    *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = v;
+                }
+            }
+        }
+        if (MS) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < 2 * NT * 16; i += 256) {
+                const int which = i / (NT * 16), col = i % (NT * 16);
+                const int n = nc * 16 + col;
+                if (n < a.Nout)
+                    a.partial[((long)blockIdx.x * 2 + which) * a.Nout + n] =
+                        ((red[0][which][col] + red[1][which][col]) + red[2][which][col]) + red[3][which][col];      // fixed order
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward through  ReLU o BN2 o depthwise o ReLU o BN1  in one pass (the middle of an inverted-residual block).
+//   inputs   G2 [B*Ho*Wo][C]  gradient w.r.t. the depthwise unit's activation, already masked by its ReLU (pw_bwd_kernel<MS>)
+//            D  [B*Ho*Wo][C]  raw depthwise output (BN2's input);  coef2 = BN2's BnbIn coefficients
+//            E  [B*H*W][C]    raw expansion (BN1's input), act1 = [mean | rstd | a | b] of BN1 — or, BN1 = false (blocks without an
+//                             expansion), the block input itself, which is the depthwise conv's operand as it stands
+//   outputs  Y = g1 = (DW^T dd) * [act1(e) > 0]      (BN1)      |   Y = DW^T dd [+ R]    (no BN1: the block's input gradient)
+//            d taps[t][c] = sum dd[o] * act1(e)[o * S + t - P]   (per-workgroup partials, fixed-order final sum)
+//            sum g1, sum g1 * ehat                               (BN1; float64 partials)
+//   with dd = A2 (g2 - s1 - (d - mu2) Q2), never written to memory.
+// A workgroup owns a slab of 4 SQ channels (SQ channel quads) and walks 16 x 16 tiles of the INPUT map: the tile's dd region
+// ((16 + 2P)^2 output pixels at stride 1, (8 + ...)^2 at stride 2; zero outside the map = the convolution's padding) is formed
+// once into LDS, then every thread — a fixed channel quad and a fixed pixel lane — gathers its taps from LDS: the input
+// gradient, and the products for the tap gradients, which stay in registers across all tiles of the workgroup.  At stride 2 a
+// pixel only meets the taps of its parity class (ky = (y + P) mod 2 + 2 j), so a thread keeps ONE class (its pixels are dealt
+// that way) and its register slot (j, i) means tap (ky0 + 2 j, kx0 + 2 i): every register index is a compile-time constant.
+struct DwBwdArgs {
+    const float* G2;
+    const float* D;
+    const float* coef2;   // [4][C]
+    const float* Wt;      // [KS*KS][C]
+    const float* E;
+    const float* act1;    // BN1: [4][C]
+    const float* R;       // no BN1: optional [B*H*W][ldr] added to Y
+    float* Y;
+    float* ptaps;         // [wgs_per_slab][KS*KS][C]
+    double* psums;        // BN1: [wgs_per_slab][2][C]
+    int ldo, lde, ldr, ldy;
+    int B, H, W, Ho, Wo, C;
+    int tiles_x, tiles_y, wgs_per_slab, nslab;
+};
+
+template <int KS, int S, int SQ, bool BN1>
+__global__ __launch_bounds__(256) void dw_bwd_kernel(DwBwdArgs a) {
+    constexpr int P = KS / 2, KK = KS * KS, TS = 16;
+    constexpr int LO = P / S;                          // output rows / columns in front of the tile's first own one
+    constexpr int OR = (TS - 1 + P) / S + LO + 1;      // side of the dd region a tile reads
+    constexpr int NT = (KS + S - 1) / S;               // taps per dimension a pixel meets
+    constexpr int PL = 256 / SQ;                       // pixel lanes
+    constexpr int NCLS = S * S;                        // parity classes
+    constexpr bool WREG = NT * NT <= 9;                // tap weights in registers (else in LDS)
+    __shared__ f32x4 tile[OR * OR * SQ];
+    __shared__ f32x4 wl[WREG ? 1 : KK * SQ];
+    __shared__ f64x4 red64[256];                        // also used as f32x4[256]
+    f32x4* red = reinterpret_cast<f32x4*>(red64);
+    const int tid = threadIdx.x;
+    const int cq_l = tid % SQ, pl = tid / SQ;
+    const int slab = blockIdx.x % a.nslab, wslot = blockIdx.x / a.nslab;
+    const int c = (slab * SQ + cq_l) * 4;
+    const bool cv = c < a.C;
+    const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 cA = zero, cs1 = zero, cmu = zero, cQ = zero, mu1 = zero, rs1 = zero, a1 = zero, b1 = zero;
+    if (cv) {
+        cA = *reinterpret_cast<const f32x4*>(a.coef2 + c); cs1 = *reinterpret_cast<const f32x4*>(a.coef2 + a.C + c);
+        cmu = *reinterpret_cast<const f32x4*>(a.coef2 + 2 * a.C + c); cQ = *reinterpret_cast<const f32x4*>(a.coef2 + 3 * a.C + c);
+        if (BN1) {
+            mu1 = *reinterpret_cast<const f32x4*>(a.act1 + c); rs1 = *reinterpret_cast<const f32x4*>(a.act1 + a.C + c);
+            a1 = *reinterpret_cast<const f32x4*>(a.act1 + 2 * a.C + c); b1 = *reinterpret_cast<const f32x4*>(a.act1 + 3 * a.C + c);
+        }
+    }
+    // this thread's parity class and the first tap it meets in each dimension
+    const int cls = S == 1 ? 0 : (pl & 3);
+    const int py = S == 1 ? 0 : (cls >> 1), px = S == 1 ? 0 : (cls & 1);
+    const int ky0 = (py + P) % S, kx0 = (px + P) % S;
+    f32x4 wreg[WREG ? NT : 1][WREG ? NT : 1];
+    if (WREG) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int ky = ky0 + S * j, kx = kx0 + S * i;
+                wreg[WREG ? j : 0][WREG ? i : 0] = (cv && ky < KS && kx < KS) ? *reinterpret_cast<const f32x4*>(a.Wt + (long)(ky * KS + kx) * a.C + c) : zero;
+            }
+    } else {
+        for (int t = pl; t < KK; t += PL) wl[t * SQ + cq_l] = cv ? *reinterpret_cast<const f32x4*>(a.Wt + (long)t * a.C + c) : zero;
+    }
+    f32x4 acc[NT][NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < NT; ++i) acc[j][i] = zero;
+    f64x4 S1 = (f64x4){0.0, 0.0, 0.0, 0.0}, S2 = S1;
+
+    const long obytes = (long)a.B * a.Ho * a.Wo * a.ldo * 4;      // < 2^31: checked on the host
+    const __amdgpu_buffer_rsrc_t g2r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.G2), 0, (int)obytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.D), 0, (int)obytes, 0x00020000);
+    const int n_items = a.B * a.tiles_y * a.tiles_x;
+    for (int item = wslot; item < n_items; item += a.wgs_per_slab) {
+        const int tx = item % a.tiles_x, ty = (item / a.tiles_x) % a.tiles_y, b = item / (a.tiles_x * a.tiles_y);
+        const int iy0 = ty * TS, ix0 = tx * TS;
+        const int lo_y = iy0 / S - LO, lo_x = ix0 / S - LO;
+        // ---- phase 1: dd of the tile's output region -> LDS (zero outside the map / beyond the channels)
+        constexpr int NIDX = OR * OR * SQ, U = 4;
+        for (int i0 = 0; i0 < NIDX; i0 += 256 * U) {
+            f32x4 gv[U], dv[U];
+            bool in[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = i0 + u * 256 + tid;
+                const int pix = idx / SQ;                 // idx % SQ == cq_l (256 is a multiple of SQ)
+                const int r = pix / OR, cc = pix - r * OR;
+                const int oy = lo_y + r, ox = lo_x + cc;
+                in[u] = idx < NIDX && cv && oy >= 0 && oy < a.Ho && ox >= 0 && ox < a.Wo;
+                const int off = in[u] ? (((b * a.Ho + oy) * a.Wo + ox) * a.ldo + c) * 4 : (int)0x80000000;
+                gv[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g2r, off, 0, 0));
+                dv[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dr, off, 0, 0));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = i0 + u * 256 + tid;
+                if (idx < NIDX) tile[idx] = in[u] ? bnb4(gv[u], dv[u], cA, cs1, cmu, cQ) : zero;
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: SQ sweeps of PL pixels
+#pragma unroll 1
+        for (int s = 0; s < SQ; ++s) {
+            int iy_l, ix_l;
+            if (S == 1) {
+                const int id = s * PL + pl;
+                iy_l = id / TS; ix_l = id % TS;
+            } else {
+                const int id = s * (PL / 4) + (pl >> 2);      // 2 x 2 pixel group of the tile
+                iy_l = 2 * (id / (TS / 2)) + py; ix_l = 2 * (id % (TS / 2)) + px;
+            }
+            const int iy = iy0 + iy_l, ix = ix0 + ix_l;
+            const bool pin = cv && iy < a.H && ix < a.W;
+            const long prow = ((long)b * a.H + iy) * a.W + ix;
+            f32x4 e4 = zero, r4 = zero;
+            if (pin) {
+                e4 = *reinterpret_cast<const f32x4*>(a.E + prow * a.lde + c);
+                if (!BN1 && a.R) r4 = *reinterpret_cast<const f32x4*>(a.R + prow * a.ldr + c);
+            }
+            f32x4 av = e4;                                 // the depthwise conv's operand at this pixel
+            f32x4 pre = zero;
+            if (BN1) {
+                pre = (f32x4){__builtin_fmaf(e4.x, a1.x, b1.x), __builtin_fmaf(e4.y, a1.y, b1.y), __builtin_fmaf(e4.z, a1.z, b1.z), __builtin_fmaf(e4.w, a1.w, b1.w)};
+                av = (f32x4){fmaxf(pre.x, 0.f), fmaxf(pre.y, 0.f), fmaxf(pre.z, 0.f), fmaxf(pre.w, 0.f)};
+            }
+            if (!pin) av = zero;
+            f32x4 de = zero;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int ky = ky0 + S * j;
+                const bool jv = S == 1 || ky < KS;
+                const int rr = jv ? (iy_l + P - ky) / S + LO : 0;       // (iy_l + P - ky) is a multiple of S for this thread's class
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    const int kx = kx0 + S * i;
+                    const bool tv = jv && (S == 1 || kx < KS);
+                    const int cc = tv ? (ix_l + P - kx) / S + LO : 0;
+                    f32x4 v = tile[(rr * OR + cc) * SQ + cq_l];
+                    if (S != 1 && !tv) v = zero;
+                    const f32x4 w = WREG ? wreg[WREG ? j : 0][WREG ? i : 0] : wl[(tv ? ky * KS + kx : 0) * SQ + cq_l];
+                    de += v * w;
+                    acc[j][i] += v * av;
+                }
+            }
+            if (pin) {
+                if (BN1) {
+                    const f32x4 g1 = (f32x4){pre.x > 0.f ? de.x : 0.f, pre.y > 0.f ? de.y : 0.f, pre.z > 0.f ? de.z : 0.f, pre.w > 0.f ? de.w : 0.f};
+                    *reinterpret_cast<f32x4*>(a.Y + prow * a.ldy + c) = g1;
+                    const f32x4 xh = (e4 - mu1) * rs1;
+                    S1 += to_f64(g1);
+                    S2 += to_f64(g1) * to_f64(xh);
+                } else {
+                    *reinterpret_cast<f32x4*>(a.Y + prow * a.ldy + c) = de + r4;
+                }
+            }
+        }
+        __syncthreads();      // the next item overwrites the tile
+    }
+    // ---- the workgroup's partial tap gradients: slot (j, i) of the threads of one class and channel quad, added in lane order
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            __syncthreads();
+            red[tid] = acc[j][i];
+            __syncthreads();
+            if (tid < NCLS * SQ) {
+                const int rc = tid / SQ, q = tid % SQ;
+                f32x4 sum = zero;
+                for (int g = 0; g < PL / NCLS; ++g) sum += red[(g * NCLS + rc) * SQ + q];
+                const int rpy = S == 1 ? 0 : (rc >> 1), rpx = S == 1 ? 0 : (rc & 1);
+                const int ky = (rpy + P) % S + S * j, kx = (rpx + P) % S + S * i;
+                const int cc = (slab * SQ + q) * 4;
+                if (ky < KS && kx < KS && cc < a.C)
+                    *reinterpret_cast<f32x4*>(a.ptaps + ((long)wslot * KK + ky * KS + kx) * a.C + cc) = sum;
+            }
+        }
+    if (BN1) {
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            __syncthreads();
+            red64[tid] = which == 0 ? S1 : S2;
+            __syncthreads();
+            if (tid < SQ) {
+                f64x4 sum = (f64x4){0.0, 0.0, 0.0, 0.0};
+                for (int g = 0; g < PL; ++g) sum += red64[g * SQ + tid];
+                const int cc = (slab * SQ + tid) * 4;
+                if (cc < a.C) *reinterpret_cast<f64x4*>(a.psums + ((long)wslot * 2 + which) * a.C + cc) = sum;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+
+template <bool MS>
+void launch_pw_bwd(const PwBwdArgs& a, dim3 grid, int nt, hipStream_t s) {
+    switch (nt) {
+        case 1: hipLaunchKernelGGL((pw_bwd_kernel<1, MS>), grid, dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((pw_bwd_kernel<2, MS>), grid, dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL((pw_bwd_kernel<3, MS>), grid, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((pw_bwd_kernel<4, MS>), grid, dim3(256), 0, s, a); break;
+        case 6: hipLaunchKernelGGL((pw_bwd_kernel<6, MS>), grid, dim3(256), 0, s, a); break;
+        case 7: hipLaunchKernelGGL((pw_bwd_kernel<7, MS>), grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((pw_bwd_kernel<8, MS>), grid, dim3(256), 0, s, a); break;
+    }
+}
+
+void launch_pw_stat(const PwStatArgs& a, dim3 grid, int nt, hipStream_t s) {
+    switch (nt) {
+        case 1: hipLaunchKernelGGL((pw_stat_kernel<1>), grid, dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((pw_stat_kernel<2>), grid, dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL((pw_stat_kernel<3>), grid, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((pw_stat_kernel<4>), grid, dim3(256), 0, s, a); break;
+        case 6: hipLaunchKernelGGL((pw_stat_kernel<6>), grid, dim3(256), 0, s, a); break;
+        case 7: hipLaunchKernelGGL((pw_stat_kernel<7>), grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((pw_stat_kernel<8>), grid, dim3(256), 0, s, a); break;
+    }
+}
+
+// the workspace of one block call, cut into the regions its kernels use side by side
+struct BlockWs {
+    double* col;      // column-sum partials of whichever producer runs (stream order: its finalize has read them before the next writes)
+    float* wg;        // pointwise weight-gradient row slices
+    float* taps;      // depthwise tap-gradient partials
+    float* coef;      // 3 x [4][Cmax] BnbIn coefficients
+    size_t col_bytes, wg_bytes, taps_bytes, coef_bytes, total;
+};
+
+size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
+int dw_bwd_wgs_per_slab(int n_items, int nslab) {
+    int target = 2048 / nslab;
+    if (target < 1) target = 1;
+    if (target >= n_items) return n_items;
+    const int per = (n_items + target - 1) / target;      // items per workgroup, then as few workgroups as that needs
+    return (n_items + per - 1) / per;
+}
+int dw_bwd_sq(int C) { return C % 32 == 0 ? 8 : 4; }
+
+BlockWs block_ws(long rows_in, long rows_out, int cin, int cexp, int cout, int k, float* base) {
+    BlockWs w{};
+    const long rows = rows_in > rows_out ? rows_in : rows_out;
+    const int cmax = cexp > cout ? (cexp > cin ? cexp : cin) : (cout > cin ? cout : cin);
+    size_t col = fear_train_stats_workspace_bytes(rows, cmax);
+    const size_t colr = (size_t)col_blocks(rows) * 2 * cmax * sizeof(double);
+    if (colr > col) col = colr;
+    const size_t dwp = (size_t)2048 * 2 * cmax * sizeof(double);           // dw_bwd_kernel's sums: <= 2048 workgroups per slab
+    if (dwp > col) col = dwp;
+    w.col_bytes = align256(col);
+    const size_t nk = (size_t)cexp * (cin > cout ? cin : cout);
+    size_t wg = (size_t)wgrad_slices(rows) * nk * sizeof(float);
+    size_t more = (size_t)256 * nk * sizeof(float);
+    if (more > ((size_t)32 << 20)) more = (size_t)32 << 20;
+    if (more > wg) wg = more;
+    w.wg_bytes = align256(wg);
+    const int sq = dw_bwd_sq(cexp);
+    const int nslab = (cexp / 4 + sq - 1) / sq;
+    const int wps = 2048 / nslab > 1 ? 2048 / nslab : 1;                  // most workgroups per slab dw_bwd_wgs_per_slab hands out
+    w.taps_bytes = align256((size_t)wps * k * k * cexp * sizeof(float));
+    w.coef_bytes = align256((size_t)3 * 4 * cmax * sizeof(float));
+    w.total = w.col_bytes + w.wg_bytes + w.taps_bytes + w.coef_bytes;
+    char* p = reinterpret_cast<char*>(base);
+    w.col = reinterpret_cast<double*>(p); p += w.col_bytes;
+    w.wg = reinterpret_cast<float*>(p); p += w.wg_bytes;
+    w.taps = reinterpret_cast<float*>(p); p += w.taps_bytes;
+    w.coef = reinterpret_cast<float*>(p);
+    return w;
+}
+
+// column-sum partials [blocks][2][C] -> mean | rstd | a | b (vec) + running statistics
+void finalize_forward(const double* partial, int blocks, int C, double count, const float* gamma, const float* beta, float* vec,
+                      float* running_mean, float* running_var, double momentum, double eps, hipStream_t s) {
+    ColFinArgs f{};
+    f.partial = partial; f.out1 = vec; f.out2 = vec + C; f.out_a = vec + 2 * C; f.out_b = vec + 3 * C; f.gamma = gamma; f.beta = beta;
+    f.running_mean = running_mean; f.running_var = running_var; f.blocks = blocks; f.C = C; f.mode = 0; f.M = count; f.eps = eps; f.momentum = momentum;
+    hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, s, f);
+}
+
+// column-sum partials of (g, g * xhat) -> d beta, d gamma, BnbIn coefficients
+void finalize_backward(const double* partial, int blocks, int C, double count, const float* gamma, const float* vec, float* dgamma, float* dbeta,
+                       float* coef, hipStream_t s) {
+    ColFinArgs f{};
+    f.partial = partial; f.out1 = dbeta; f.out2 = dgamma; f.gamma = gamma; f.mean_in = vec; f.rstd_in = vec + C; f.coef = coef;
+    f.blocks = blocks; f.C = C; f.mode = 4; f.M = count;
+    hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, s, f);
+}
+
+// Y = act(X) W^T + sums -> vec:  the forward producer of a pointwise unit
+void pw_forward_unit(const float* x, int ldx, const float* in_vec, int in_relu, const float* w, float* y, long M, int K, int N, const float* gamma,
+                     const float* beta, float* vec, float* rm, float* rv, double momentum, double eps, double* col, hipStream_t s) {
+    PwStatArgs a{};
+    a.X = x; a.ldx = ldx; a.W = w; a.Y = y; a.ldy = N; a.M = (int)M; a.K = K; a.N = N;
+    if (in_vec) { a.in.a = in_vec + 2 * K; a.in.b = in_vec + 3 * K; a.in.relu = in_relu; }
+    a.partial = col;
+    int nt = 1;
+    const dim3 grid = train_pw_grid(M, (N + 15) / 16, &nt);
+    launch_pw_stat(a, grid, nt, s);
+    finalize_forward(col, (int)grid.x, N, (double)M, gamma, beta, vec, rm, rv, momentum, eps, s);
+}
+
+// sums of (g, g * xhat) over rows of (dy, x_raw) [mask: a ReLU behind the BatchNorm] -> d beta, d gamma, coef
+void bn_backward_sums(const float* dy, int lddy, const float* raw, int ldx, const float* vec, int relu, const float* gamma, float* dgamma,
+                      float* dbeta, float* coef, long M, int C, double* col, hipStream_t s) {
+    ColArgs a{};
+    a.A = dy; a.lda = lddy; a.X = raw; a.ldx = ldx; a.mean = vec; a.rstd = vec + C;
+    a.act_a = relu ? vec + 2 * C : nullptr; a.act_b = relu ? vec + 3 * C : nullptr;
+    a.partial = col; a.M = M; a.C = C; a.rpb = col_rows_per_block(M);
+    const int blocks = col_blocks(M);
+    hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(blocks), dim3(256), 0, s, a);
+    finalize_backward(col, blocks, C, (double)M, gamma, vec, dgamma, dbeta, coef, s);
+}
+
+template <int KS, int S>
+void launch_dw_bwd_ks(const DwBwdArgs& a, int sq, bool bn1, dim3 grid, hipStream_t s) {
+    if (sq == 8) {
+        if (bn1) hipLaunchKernelGGL((dw_bwd_kernel<KS, S, 8, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((dw_bwd_kernel<KS, S, 8, false>), grid, dim3(256), 0, s, a);
+    } else {
+        if (bn1) hipLaunchKernelGGL((dw_bwd_kernel<KS, S, 4, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((dw_bwd_kernel<KS, S, 4, false>), grid, dim3(256), 0, s, a);
+    }
+}
+
+bool irb_shape_ok(const FearIrbBlock* b, int B, int H, int W) {
+    if (B < 1 || H < 1 || W < 1) return false;
+    if (b->cin < 4 || b->cin % 4 || b->cexp < 4 || b->cexp % 4 || b->cout < 4 || b->cout % 4 || b->cexp > 1024 || b->cout > 1024) return false;
+    if (!(b->k == 3 || b->k == 5) || !(b->stride == 1 || b->stride == 2) || H % b->stride || W % b->stride) return false;
+    if (!b->expand && b->cexp != b->cin) return false;
+    if (b->residual && (b->stride != 1 || b->cin != b->cout)) return false;
+    if ((long)B * H * W * b->cexp * 4 >= (1L << 31)) return false;      // 32-bit buffer offsets in the depthwise kernels
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t fear_irb_workspace_bytes(const FearIrbBlock* b, int B, int H, int W) {
+    if (!b || !irb_shape_ok(b, B, H, W)) return 0;
+    const long rows_in = (long)B * H * W, rows_out = rows_in / (b->stride * b->stride);
+    return block_ws(rows_in, rows_out, b->cin, b->cexp, b->cout, b->k, nullptr).total;
+}
+
+size_t fear_irb_scratch_floats(const FearIrbBlock* b, int B, int H, int W) {
+    if (!b || !irb_shape_ok(b, B, H, W)) return 0;
+    const long rows_in = (long)B * H * W, rows_out = rows_in / (b->stride * b->stride);
+    return (size_t)rows_out * b->cexp + (b->expand ? (size_t)rows_in * b->cexp : 0);
+}
+
+int fear_irb_train_forward(const FearIrbBlock* b, const FearIrbSaved* sv, const float* x, float* out, int B, int H, int W, double momentum,
+                           double eps, float* workspace, size_t ws_bytes, void* stream) {
+    if (!b || !sv || !x || !out || !workspace || !sv->d || !sv->p || !sv->vec[1] || !sv->vec[2] || !b->w_dw || !b->w_pwl) return FEAR_TRAIN_ERR_NULL;
+    if (b->expand && (!sv->e || !sv->vec[0] || !b->w_pw)) return FEAR_TRAIN_ERR_NULL;
+    for (int i = b->expand ? 0 : 1; i < 3; ++i)
+        if (!b->gamma[i] || !b->beta[i]) return FEAR_TRAIN_ERR_NULL;
+    if (!irb_shape_ok(b, B, H, W)) return FEAR_TRAIN_ERR_SHAPE;
+    const long rows_in = (long)B * H * W, rows_out = rows_in / (b->stride * b->stride);
+    const BlockWs ws = block_ws(rows_in, rows_out, b->cin, b->cexp, b->cout, b->k, workspace);
+    if (ws_bytes < ws.total) return FEAR_TRAIN_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int Ho = H / b->stride, Wo = W / b->stride;
+    // expand 1x1 (+ statistics)
+    if (b->expand)
+        pw_forward_unit(x, b->cin, nullptr, 0, b->w_pw, sv->e, rows_in, b->cin, b->cexp, b->gamma[0], b->beta[0], sv->vec[0], b->running_mean[0],
+                        b->running_var[0], momentum, eps, ws.col, s);
+    // depthwise over act1(e) (or over the block input) (+ statistics)
+    {
+        DwStatArgs a{};
+        a.X = b->expand ? sv->e : x; a.ldx = b->cexp; a.Wt = b->w_dw; a.Y = sv->d; a.ldy = b->cexp;
+        a.B = B; a.H = H; a.W = W; a.C = b->cexp; a.Ho = Ho; a.Wo = Wo;
+        if (b->expand) { a.in.a = sv->vec[0] + 2 * b->cexp; a.in.b = sv->vec[0] + 3 * b->cexp; a.in.relu = 1; }
+        const long strips = (Ho + 3) / 4;
+        const long total = (long)B * strips * Wo * (b->cexp / 4);
+        const long blocks = (total + 255) / 256;
+        if ((size_t)blocks * 2 * b->cexp * sizeof(double) > ws.col_bytes) return FEAR_TRAIN_ERR_WORKSPACE;
+        a.partial = ws.col;
+        dim3 grid((unsigned)blocks);
+        if (b->k == 3 && b->stride == 1) hipLaunchKernelGGL((dw_stat_kernel<3, 1, 4>), grid, dim3(256), 0, s, a);
+        else if (b->k == 3) hipLaunchKernelGGL((dw_stat_kernel<3, 2, 4>), grid, dim3(256), 0, s, a);
+        else if (b->stride == 1) hipLaunchKernelGGL((dw_stat_kernel<5, 1, 4>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((dw_stat_kernel<5, 2, 4>), grid, dim3(256), 0, s, a);
+        finalize_forward(ws.col, (int)blocks, b->cexp, (double)rows_out, b->gamma[1], b->beta[1], sv->vec[1], b->running_mean[1], b->running_var[1],
+                         momentum, eps, s);
+    }
+    // project 1x1 over act2(d) (+ statistics)
+    pw_forward_unit(sv->d, b->cexp, sv->vec[1], 1, b->w_pwl, sv->p, rows_out, b->cexp, b->cout, b->gamma[2], b->beta[2], sv->vec[2],
+                    b->running_mean[2], b->running_var[2], momentum, eps, ws.col, s);
+    // block output = BN3(p) [+ x]
+    {
+        BnActArgs k{};
+        k.X = sv->p; k.R = b->residual ? x : nullptr; k.Y = out; k.in.a = sv->vec[2] + 2 * b->cout; k.in.b = sv->vec[2] + 3 * b->cout; k.in.relu = 0;
+        k.M = rows_out; k.C = b->cout; k.ldx = b->cout; k.ldr = b->cin; k.ldy = b->cout;
+        const long n4 = rows_out * (b->cout / 4);
+        hipLaunchKernelGGL(bn_act_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, k);
+    }
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+int fear_irb_train_backward(const FearIrbBlock* b, const FearIrbSaved* sv, const FearIrbGrads* gr, const float* x, const float* dout, float* dx,
+                            float* scratch, int B, int H, int W, float* workspace, size_t ws_bytes, void* stream) {
+    if (!b || !sv || !gr || !x || !dout || !scratch || !workspace || !sv->d || !sv->p || !sv->vec[1] || !sv->vec[2] || !gr->w_dw || !gr->w_pwl)
+        return FEAR_TRAIN_ERR_NULL;
+    if (b->expand && (!sv->e || !sv->vec[0] || !gr->w_pw)) return FEAR_TRAIN_ERR_NULL;
+    if (!b->expand && !dx) return FEAR_TRAIN_ERR_NULL;
+    for (int i = b->expand ? 0 : 1; i < 3; ++i)
+        if (!gr->gamma[i] || !gr->beta[i] || !b->gamma[i]) return FEAR_TRAIN_ERR_NULL;
+    if (!irb_shape_ok(b, B, H, W)) return FEAR_TRAIN_ERR_SHAPE;
+    const long rows_in = (long)B * H * W, rows_out = rows_in / (b->stride * b->stride);
+    const BlockWs ws = block_ws(rows_in, rows_out, b->cin, b->cexp, b->cout, b->k, workspace);
+    if (ws_bytes < ws.total) return FEAR_TRAIN_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int Ho = H / b->stride, Wo = W / b->stride, cexp = b->cexp, cout = b->cout, cin = b->cin;
+    const int cmax = cexp > cout ? (cexp > cin ? cexp : cin) : (cout > cin ? cout : cin);
+    float* coef1 = ws.coef;
+    float* coef2 = ws.coef + 4 * cmax;
+    float* coef3 = ws.coef + 8 * cmax;
+    float* g2 = scratch;
+    float* g1 = scratch + (size_t)rows_out * cexp;
+    // BN3 (no ReLU): sums over (dout, p)
+    bn_backward_sums(dout, cout, sv->p, cout, sv->vec[2], 0, b->gamma[2], gr->gamma[2], gr->beta[2], coef3, rows_out, cout, ws.col, s);
+    BnbIn bn3{};
+    bn3.E = sv->p; bn3.coef = coef3; bn3.lde = cout; bn3.C = cout;
+    // g2 = (dp W3) masked by act2(d) > 0, + sums of (g2, dhat)
+    {
+        PwBwdArgs a{};
+        a.G = dout; a.ldg = cout; a.bn = bn3; a.W = b->w_pwl; a.Y = g2; a.ldy = cexp; a.D = sv->d; a.ldd = cexp; a.dvec = sv->vec[1];
+        a.partial = ws.col; a.M = (int)rows_out; a.Kred = cout; a.Nout = cexp;
+        int nt = 1;
+        const dim3 grid = train_pw_grid(rows_out, (cexp + 15) / 16, &nt);
+        if ((size_t)grid.x * 2 * cexp * sizeof(double) > ws.col_bytes) return FEAR_TRAIN_ERR_WORKSPACE;
+        launch_pw_bwd<true>(a, grid, nt, s);
+        finalize_backward(ws.col, (int)grid.x, cexp, (double)rows_out, b->gamma[1], sv->vec[1], gr->gamma[1], gr->beta[1], coef2, s);
+    }
+    // dW3 = dp^T act2(d)
+    {
+        const int rc = wgrad_impl(dout, cout, 0, sv->d, cexp, 0, gr->w_pwl, ws.wg, ws.wg_bytes, rows_out, cexp, cout, 1, s, sv->vec[1] + 2 * cexp,
+                                  sv->vec[1] + 3 * cexp, 1, &bn3);
+        if (rc != FEAR_TRAIN_OK) return rc;
+    }
+    // depthwise + both BatchNorms around it
+    {
+        DwBwdArgs a{};
+        a.G2 = g2; a.D = sv->d; a.ldo = cexp; a.coef2 = coef2; a.Wt = b->w_dw;
+        a.E = b->expand ? sv->e : x; a.lde = cexp; a.act1 = b->expand ? sv->vec[0] : nullptr;
+        a.R = (!b->expand && b->residual) ? dout : nullptr; a.ldr = cout;
+        a.Y = b->expand ? g1 : dx; a.ldy = cexp;
+        a.ptaps = ws.taps; a.psums = ws.col;
+        a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.C = cexp;
+        a.tiles_x = (W + 15) / 16; a.tiles_y = (H + 15) / 16;
+        const int sq = dw_bwd_sq(cexp);
+        a.nslab = (cexp / 4 + sq - 1) / sq;
+        a.wgs_per_slab = dw_bwd_wgs_per_slab(B * a.tiles_x * a.tiles_y, a.nslab);
+        const dim3 grid((unsigned)(a.wgs_per_slab * a.nslab));
+        if (b->k == 3 && b->stride == 1) launch_dw_bwd_ks<3, 1>(a, sq, b->expand != 0, grid, s);
+        else if (b->k == 3) launch_dw_bwd_ks<3, 2>(a, sq, b->expand != 0, grid, s);
+        else if (b->stride == 1) launch_dw_bwd_ks<5, 1>(a, sq, b->expand != 0, grid, s);
+        else launch_dw_bwd_ks<5, 2>(a, sq, b->expand != 0, grid, s);
+        launch_slice_sum(ws.taps, gr->w_dw, (long)b->k * b->k * cexp, a.wgs_per_slab, s);
+        if (b->expand)
+            finalize_backward(ws.col, a.wgs_per_slab, cexp, (double)rows_in, b->gamma[0], sv->vec[0], gr->gamma[0], gr->beta[0], coef1, s);
+    }
+    if (b->expand) {
+        BnbIn bn1{};
+        bn1.E = sv->e; bn1.coef = coef1; bn1.lde = cexp; bn1.C = cexp;
+        if (dx) {
+            PwBwdArgs a{};
+            a.G = g1; a.ldg = cexp; a.bn = bn1; a.W = b->w_pw; a.R = b->residual ? dout : nullptr; a.ldr = cout; a.Y = dx; a.ldy = cin;
+            a.M = (int)rows_in; a.Kred = cexp; a.Nout = cin;
+            int nt = 1;
+            const dim3 grid = train_pw_grid(rows_in, (cin + 15) / 16, &nt);
+            launch_pw_bwd<false>(a, grid, nt, s);
+        }
+        const int rc = wgrad_impl(g1, cexp, 0, x, cin, 0, gr->w_pw, ws.wg, ws.wg_bytes, rows_in, cin, cexp, 1, s, nullptr, nullptr, 0, &bn1);
+        if (rc != FEAR_TRAIN_OK) return rc;
+    }
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+size_t fear_pwbn_workspace_bytes(long M, int K, int N) {
+    if (M < 1 || K < 4 || N < 4) return 0;
+    return block_ws(M, M, K, N, N, 3, nullptr).total;
+}
+
+int fear_pwbn_train_forward(const float* x, int ldx, const float* w, const float* gamma, const float* beta, float* running_mean,
+                            float* running_var, float* raw, float* vec, int relu, float* out, long M, int K, int N, double momentum, double eps,
+                            float* workspace, size_t ws_bytes, void* stream) {
+    if (!x || !w || !gamma || !beta || !raw || !vec || !out || !workspace) return FEAR_TRAIN_ERR_NULL;
+    if (M <= 0 || K < 4 || K % 4 || N < 4 || N % 4 || N > 1024 || M > 0x7fffffffL || !ld_ok(ldx, K)) return FEAR_TRAIN_ERR_SHAPE;
+    const BlockWs ws = block_ws(M, M, K, N, N, 3, workspace);
+    if (ws_bytes < ws.total) return FEAR_TRAIN_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    pw_forward_unit(x, ldx, nullptr, 0, w, raw, M, K, N, gamma, beta, vec, running_mean, running_var, momentum, eps, ws.col, s);
+    BnActArgs k{};
+    k.X = raw; k.Y = out; k.in.a = vec + 2 * N; k.in.b = vec + 3 * N; k.in.relu = relu; k.M = M; k.C = N; k.ldx = N; k.ldy = N;
+    const long n4 = M * (N / 4);
+    hipLaunchKernelGGL(bn_act_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, k);
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+int fear_pwbn_train_backward(const float* dy, const float* raw, const float* vec, int relu, const float* x, int ldx, const float* w,
+                             const float* gamma, float* dw, float* dgamma, float* dbeta, float* dx, long M, int K, int N, float* workspace,
+                             size_t ws_bytes, void* stream) {
+    if (!dy || !raw || !vec || !x || !w || !gamma || !dw || !dgamma || !dbeta || !workspace) return FEAR_TRAIN_ERR_NULL;
+    if (M <= 0 || K < 4 || K % 4 || N < 4 || N % 4 || N > 1024 || M > 0x7fffffffL || !ld_ok(ldx, K)) return FEAR_TRAIN_ERR_SHAPE;
+    const BlockWs ws = block_ws(M, M, K, N, N, 3, workspace);
+    if (ws_bytes < ws.total) return FEAR_TRAIN_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    bn_backward_sums(dy, N, raw, N, vec, relu, gamma, dgamma, dbeta, ws.coef, M, N, ws.col, s);
+    BnbIn bn{};
+    bn.E = raw; bn.coef = ws.coef; bn.lde = N; bn.C = N;
+    if (relu) { bn.mask_a = vec + 2 * N; bn.mask_b = vec + 3 * N; }
+    if (dx) {
+        PwBwdArgs a{};
+        a.G = dy; a.ldg = N; a.bn = bn; a.W = w; a.Y = dx; a.ldy = K; a.M = (int)M; a.Kred = N; a.Nout = K;
+        int nt = 1;
+        const dim3 grid = train_pw_grid(M, (K + 15) / 16, &nt);
+        launch_pw_bwd<false>(a, grid, nt, s);
+    }
+    const int rc = wgrad_impl(dy, N, 0, x, ldx, 0, dw, ws.wg, ws.wg_bytes, M, K, N, 1, s, nullptr, nullptr, 0, &bn);
+    if (rc != FEAR_TRAIN_OK) return rc;
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+}  // extern "C"

@@ -63,7 +63,36 @@ TRAIN_SYMBOLS = {
     "fear_scale_column": ([_P, _i, _i, _f, _P, _i, _i, _l, _P], _i),
     "fear_add": ([_P, _P, _P, _l, _P], _i),
     "fear_adam_step": ([_P, _P, _P, _P, _l, _d, _d, _d, _d, _d, _i, _P], _i),
+    # block-fused trunk operators (structs below mirror include/fear_train.h)
+    "fear_irb_workspace_bytes": ([_P, _i, _i, _i], _sz),
+    "fear_irb_scratch_floats": ([_P, _i, _i, _i], _sz),
+    "fear_irb_train_forward": ([_P, _P, _P, _P, _i, _i, _i, _d, _d, _P, _sz, _P], _i),
+    "fear_irb_train_backward": ([_P, _P, _P, _P, _P, _P, _P, _i, _i, _i, _P, _sz, _P], _i),
+    "fear_pwbn_workspace_bytes": ([_l, _i, _i], _sz),
+    "fear_pwbn_train_forward": ([_P, _i, _P, _P, _P, _P, _P, _P, _P, _i, _P, _l, _i, _i, _d, _d, _P, _sz, _P], _i),
+    "fear_pwbn_train_backward": ([_P, _P, _P, _i, _P, _i, _P, _P, _P, _P, _P, _P, _l, _i, _i, _P, _sz, _P], _i),
 }
+
+
+class FearIrbBlock(ctypes.Structure):
+    """include/fear_train.h: one inverted-residual block's shape and parameters (device pointers, kernel layouts)."""
+    _fields_ = [("cin", _i), ("cexp", _i), ("cout", _i), ("k", _i), ("stride", _i), ("expand", _i), ("residual", _i), ("reserved", _i),
+                ("w_pw", _P), ("w_dw", _P), ("w_pwl", _P), ("gamma", _P * 3), ("beta", _P * 3), ("running_mean", _P * 3), ("running_var", _P * 3)]
+
+
+class FearIrbSaved(ctypes.Structure):
+    _fields_ = [("e", _P), ("d", _P), ("p", _P), ("vec", _P * 3)]
+
+
+class FearIrbGrads(ctypes.Structure):
+    _fields_ = [("w_pw", _P), ("w_dw", _P), ("w_pwl", _P), ("gamma", _P * 3), ("beta", _P * 3)]
+
+
+class GradDict(dict):
+    """{parameter name: gradient in the reference's layout} whose values are views of ONE flat buffer in the kernels' storage
+    layout (`flat`, the layout of the network's `param_flat`): the all-reduce of several ranks and the optimiser work on `flat`
+    — one collective, one Adam launch — and the views follow."""
+    flat: Optional[torch.Tensor] = None
 
 _bound = None
 
@@ -182,6 +211,32 @@ class BoxTowerTrainHIP:
         self.adjust = sd["adjust"].float().reshape(1).to(self.device)
         self.bias4 = sd["bias"].float().reshape(4).to(self.device)
         self._ws = None
+        self._galloc = None          # set by FEARNetTrainHIP: gradient tensors are views of its flat gradient buffer
+
+    def _layers(self):
+        for br in self.branches.values():
+            for L in [br["enc"], br["corr"]] + br["tower"] + [br["pred"]]:
+                yield L
+
+    def rehome_parameters(self, alloc) -> None:
+        """Move every parameter into storage handed out by `alloc(name, tensor) -> tensor of the same shape holding the same
+        values` (FEARNetTrainHIP: views of one flat buffer, so that the optimiser is one launch); names as `parameter_slots`."""
+        for L in self._layers():
+            L.taps = alloc(L.prefix + ".depthwise.weight", L.taps)
+            if L.dw_bias is not None:
+                L.dw_bias = alloc(L.prefix + ".depthwise.bias", L.dw_bias)
+            L.w = alloc(L.prefix + ".pointwise.weight", L.w)
+            if L.pw_bias is not None:
+                L.pw_bias = alloc(L.prefix + ".pointwise.bias", L.pw_bias)
+            if L.bn_prefix:
+                L.gamma = alloc(L.bn_prefix + ".weight", L.gamma)
+                L.beta = alloc(L.bn_prefix + ".bias", L.beta)
+        self.adjust = alloc("adjust", self.adjust)
+        self.bias4 = alloc("bias", self.bias4)
+
+    def _gnew(self, name: str, *shape) -> torch.Tensor:
+        """Storage of the gradient of parameter `name` (kernel layout)."""
+        return self._galloc(name, *shape) if self._galloc is not None else self._new(*shape)
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, st: int) -> None:
@@ -226,27 +281,27 @@ class BoxTowerTrainHIP:
         ws, wsb = self._workspace(M)
         if L.bn_prefix:
             dp = self._new(M, L.n)
-            dgamma, dbeta = self._new(L.cout), self._new(L.cout)
+            dgamma, dbeta = self._gnew(L.bn_prefix + ".weight", L.cout), self._gnew(L.bn_prefix + ".bias", L.cout)
             self._check(bn_backward(lib, st, ws, wsb, self.sync, dy, lddy, L.y, L.ldy, L.p, L.n, L.mean, L.rstd, L.gamma, dp, L.n,
                                     dgamma, dbeta, M, L.cout))
             grads[L.bn_prefix + ".weight"], grads[L.bn_prefix + ".bias"] = dgamma, dbeta
             lddp = L.n
         else:
             dp, lddp = dy, lddy
-        dw = self._new(L.n, L.cin)
+        dw = self._gnew(L.prefix + ".pointwise.weight", L.n, L.cin)
         self._check(lib.fear_pw_backward_weight(_p(dp), lddp, _p(L.d), L.cin, _p(dw), ws, wsb, M, L.cin, L.n, st))
         grads[L.prefix + ".pointwise.weight"] = dw[: L.cout].reshape(L.cout, L.cin, 1, 1)
         if L.pw_bias is not None:
-            db = self._new(L.n)
+            db = self._gnew(L.prefix + ".pointwise.bias", L.n)
             self._check(lib.fear_col_sum(_p(dp), lddp, _p(db), ws, wsb, M, L.n, st))
             grads[L.prefix + ".pointwise.bias"] = db[: L.cout]
         dd = self._new(M, L.cin)
         self._check(lib.fear_pw_backward_data(_p(dp), lddp, _p(L.w), None, 0, _p(dd), L.cin, M, L.cin, L.n, st))
-        dtaps = self._new(9, L.cin)
+        dtaps = self._gnew(L.prefix + ".depthwise.weight", 9, L.cin)
         self._check(lib.fear_dw_backward_weight(_p(dd), L.cin, _p(L.x), L.ldx, _p(dtaps), ws, wsb, B, self.S, self.S, L.cin, 3, 1, st))
         grads[L.prefix + ".depthwise.weight"] = dtaps.t().reshape(L.cin, 1, 3, 3)
         if L.dw_bias is not None:
-            dbd = self._new(L.cin)
+            dbd = self._gnew(L.prefix + ".depthwise.bias", L.cin)
             self._check(lib.fear_col_sum(_p(dd), L.cin, _p(dbd), ws, wsb, M, L.cin, st))
             grads[L.prefix + ".depthwise.bias"] = dbd
         dx = self._new(M, L.cin)
@@ -299,7 +354,7 @@ class BoxTowerTrainHIP:
             # ---- backward
             grads: Dict[str, torch.Tensor] = {}
             dpred = {}
-            dp_reg, dadj, dbias = self._new(M, 4), self._new(1), self._new(4)
+            dp_reg, dadj, dbias = self._new(M, 4), self._gnew("adjust", 1), self._gnew("bias", 4)
             self._check(lib.fear_exp_head_backward(_p(pred_out["reg"]), _p(self.adjust), _p(bbox_rows), _p(dbbox), _p(dp_reg),
                                                    _p(dadj), _p(dbias), ws, wsb, M, st))
             grads["adjust"], grads["bias"] = dadj, dbias.reshape(1, 4, 1, 1)
@@ -338,6 +393,11 @@ class BoxTowerTrainHIP:
         what Lightning DDP does bucket by bucket for the reference (train/trainer.py:50-52)."""
         import torch.distributed as dist
         if not dist.is_initialized() or dist.get_world_size(group) == 1:
+            return grads
+        flat = getattr(grads, "flat", None)
+        if flat is not None:                       # FEARNetTrainHIP: the gradients ARE one buffer already; its views follow
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            flat /= dist.get_world_size(group)
             return grads
         names = sorted(grads)
         flat = torch.cat([grads[n].reshape(-1) for n in names])

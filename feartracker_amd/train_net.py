@@ -29,7 +29,8 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
-from .train_head import BoxTowerTrainHIP, SyncBN, TrainError, _p, load_train_library
+from .train_head import (BoxTowerTrainHIP, FearIrbBlock, FearIrbGrads, FearIrbSaved, GradDict, SyncBN, TrainError, _p,
+                         load_train_library)
 
 # (cin, cexp, cout, k, stride, expand, residual): fbnet_c stages[1:18]
 TRUNK_BLOCKS = [
@@ -112,13 +113,28 @@ class _ConvBN:
 
 class FEARNetTrainHIP:
     def __init__(self, state_dict: Dict[str, "np.ndarray | torch.Tensor"], device: int = 0, momentum: float = 0.1, eps: float = 1e-5,
-                 coef_cls: float = 1.0, coef_reg: float = 1.0, sync_bn: bool = False, group=None, fused: bool = False,
-                 two_streams: bool = True):
+                 coef_cls: float = 1.0, coef_reg: float = 1.0, sync_bn: bool = False, group=None, fused: Optional[bool] = None,
+                 two_streams: bool = True, mode: Optional[str] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("FEARNetTrainHIP needs a ROCm GPU; there is no CPU fallback")
         self.lib = load_train_library()
         self.device = torch.device(f"cuda:{int(device)}")
         self.momentum, self.eps = momentum, eps
+        # Three implementations of the trunk's conv + BatchNorm units, the same arithmetic (tests/test_train_head.py pins each
+        # against autograd):
+        #   "block"      (default on one rank) one C-ABI call per inverted-residual block and direction, csrc/fear_train_block.h:
+        #                statistics in the producing pass, BatchNorm / its backward / ReLU masks formed on load, the two
+        #                BatchNorms around the depthwise conv and its three gradients in one LDS-tiled pass
+        #   "layerwise"  (fused=False; SyncBatchNorm runs this one: its all-reduces sit between the reductions and the applies)
+        #   "fused"      (fused=True) round 3's per-unit fused operators, the memory-saving form of "layerwise"
+        if mode is None:
+            mode = "fused" if fused else ("layerwise" if (fused is False or sync_bn) else "block")
+        if mode not in ("block", "layerwise", "fused"):
+            raise ValueError(f"unknown mode {mode!r}")
+        if mode == "block" and sync_bn:
+            raise ValueError("mode='block' has no SyncBatchNorm hook; use mode='layerwise' with sync_bn=True")
+        self.mode = mode
+        fused = mode == "fused"
         # fused=True: the trunk runs on the fused conv + BatchNorm operators of include/fear_train.h — a BatchNorm'd activation
         # is never written, consumers apply it on load: 11 instead of 16 passes over every saved tensor and 13.7 instead of
         # 21.7 GB at 128 pairs, the same gradients (tests/test_train_head.py) — and, measured, NOT faster: 33.8 vs 31.6 ms of
@@ -160,7 +176,26 @@ class FEARNetTrainHIP:
             for key, n in ((L.conv_key, L.w.numel()), (L.bn_key + ".weight", L.cout), (L.bn_key + ".bias", L.cout)):
                 self._goff[key] = total
                 total += (n + 3) // 4 * 4                      # 16-byte aligned slots
-        self._gtotal = total
+        self._gtotal = total                                   # the trunk's share: what the two passes both write
+        # every parameter (kernel layout) lives in ONE flat buffer — trunk first, then the head — and every gradient in a buffer
+        # of the same layout: the optimiser is one launch over (param_flat, grad flat, moments), several ranks all-reduce the
+        # gradient buffer as it stands
+        for name, (t, _, _) in self.head.parameter_slots().items():
+            self._goff["connect_model." + name] = total
+            total += (t.numel() + 3) // 4 * 4
+        self._ptotal = total
+        self.param_flat = torch.zeros(total, dtype=torch.float32, device=dev)
+
+        def home(name: str, t: torch.Tensor) -> torch.Tensor:
+            v = self.param_flat[self._goff[name]: self._goff[name] + t.numel()].view(t.shape)
+            v.copy_(t)
+            return v
+        for L in self._trunk_layers():
+            L.w, L.gamma, L.beta = home(L.conv_key, L.w), home(L.bn_key + ".weight", L.gamma), home(L.bn_key + ".bias", L.beta)
+        self.head.rehome_parameters(lambda name, t: home("connect_model." + name, t))
+        self._gcur = None
+        self.head._galloc = lambda name, *shape: self._gslot(self._gcur, "connect_model." + name, *shape)
+        self._irb = None                                       # block mode: ctypes descriptors, built on first use
 
     def _trunk_layers(self) -> List["_ConvBN"]:
         layers = [self.stem]
@@ -398,6 +433,122 @@ class FEARNetTrainHIP:
                 d = self._bwd_f(saved[i], d, gbuf, add=dres if i == start else None)     # the block's first unit also takes the skip's gradient
         self._bwd_f(saved[0], d, gbuf, need_dx=False)                # stem: the image needs no gradient
 
+    # ------------------------------------------------------------------ block-fused trunk (mode "block")
+    def _irb_descriptors(self):
+        """ctypes mirrors of FearIrbBlock for the 16 blocks (the parameter tensors are views of param_flat: stable addresses)."""
+        if self._irb is None:
+            descs = []
+            for (cin, cexp, cout, k, stride, expand, residual), blk in zip(TRUNK_BLOCKS, self.blocks):
+                d = FearIrbBlock()
+                d.cin, d.cexp, d.cout, d.k, d.stride, d.expand, d.residual = cin, cexp, cout, k, stride, int(expand), int(residual)
+                units = (blk["pw"], blk["dw"], blk["pwl"])
+                d.w_pw = units[0].w.data_ptr() if expand else None
+                d.w_dw, d.w_pwl = units[1].w.data_ptr(), units[2].w.data_ptr()
+                for i, L in enumerate(units):
+                    if L is None:
+                        continue
+                    d.gamma[i], d.beta[i] = L.gamma.data_ptr(), L.beta.data_ptr()
+                    d.running_mean[i], d.running_var[i] = L.running_mean.data_ptr(), L.running_var.data_ptr()
+                descs.append(d)
+            self._irb = descs
+        return self._irb
+
+    def _block_buffers(self, B: int, H: int):
+        """(workspace pointer, bytes, scratch tensor) of this lane for a pass over B crops of H x H pixels."""
+        import ctypes
+        lib = self.lib
+        need, scratch = int(lib.fear_pwbn_workspace_bytes(B * (H // 2) ** 2, 28, 16)), 0
+        h = H // 2
+        for d in self._irb_descriptors():
+            need = max(need, int(lib.fear_irb_workspace_bytes(ctypes.byref(d), B, h, h)))
+            scratch = max(scratch, int(lib.fear_irb_scratch_floats(ctypes.byref(d), B, h, h)))
+            h //= d.stride
+        need = max(need, int(lib.fear_pwbn_workspace_bytes(B * h * h, 112, 256)))
+        ws, wsb = self._lane_workspace(need)
+        key = ("scratch", self._lane)
+        sc = self._ws_lanes.get(key)
+        if sc is None or sc.numel() < scratch:
+            self._ws_lanes[key] = None
+            sc = self._ws_lanes[key] = torch.empty(scratch, dtype=torch.float32, device=self.device)
+        return ws, wsb, sc
+
+    def _features_forward_b(self, img: torch.Tensor):
+        """Block-fused form of `_features_forward`: one call per block (csrc/fear_train_block.h)."""
+        import ctypes
+        lib, st = self.lib, self._stream()
+        B, H = img.shape[0], img.shape[2]
+        ws, wsb, _ = self._block_buffers(B, H)
+        h = H // 2
+        col = self._new(B * h * h, 28)
+        self._check(lib.fear_stem_im2col(_p(img), _p(col), B, H, H, st))
+        S = self.stem
+        stem_raw, stem_vec, x = self._new(B * h * h, 16), self._new(4 * 16), self._new(B * h * h, 16)
+        self._check(lib.fear_pwbn_train_forward(_p(col), 28, _p(S.w), _p(S.gamma), _p(S.beta), _p(S.running_mean), _p(S.running_var), _p(stem_raw),
+                                                _p(stem_vec), 1, _p(x), B * h * h, 28, 16, self.momentum, self.eps, ws, wsb, st))
+        recs = [dict(L=S, pre=stem_raw, act=(stem_vec[32:48], stem_vec[48:64], 1), B=B, H=h)]     # what relu_patterns reads
+        blocks = []
+        for d, blk in zip(self._irb_descriptors(), self.blocks):
+            ho = h // d.stride
+            sv = FearIrbSaved()
+            e = self._new(B * h * h, d.cexp) if d.expand else None
+            dd, pp = self._new(B * ho * ho, d.cexp), self._new(B * ho * ho, d.cout)
+            vec = [self._new(4 * d.cexp) if d.expand else None, self._new(4 * d.cexp), self._new(4 * d.cout)]
+            sv.e, sv.d, sv.p = (e.data_ptr() if e is not None else None), dd.data_ptr(), pp.data_ptr()
+            for i in range(3):
+                sv.vec[i] = vec[i].data_ptr() if vec[i] is not None else None
+            out = self._new(B * ho * ho, d.cout)
+            self._check(lib.fear_irb_train_forward(ctypes.byref(d), ctypes.byref(sv), _p(x), _p(out), B, h, h, self.momentum, self.eps, ws, wsb, st))
+            C = d.cexp
+            if d.expand:
+                recs.append(dict(L=blk["pw"], pre=e, act=(vec[0][2 * C: 3 * C], vec[0][3 * C:], 1), B=B, H=h))
+            recs.append(dict(L=blk["dw"], pre=dd, act=(vec[1][2 * C: 3 * C], vec[1][3 * C:], 1), B=B, H=h))
+            blocks.append((d, sv, x, h, (e, dd, pp, vec)))          # (the tensors are kept alive next to their pointers)
+            x, h = out, ho
+        N = self.neck
+        neck_raw, neck_vec, feats = self._new(B * h * h, 256), self._new(4 * 256), self._new(B * h * h, 256)
+        self._check(lib.fear_pwbn_train_forward(_p(x), 112, _p(N.w), _p(N.gamma), _p(N.beta), _p(N.running_mean), _p(N.running_var), _p(neck_raw),
+                                                _p(neck_vec), 0, _p(feats), B * h * h, 112, 256, self.momentum, self.eps, ws, wsb, st))
+        return feats, (recs, dict(B=B, H=H, col=col, stem=(stem_raw, stem_vec), blocks=blocks, neck=(x, neck_raw, neck_vec, h)))
+
+    def _features_backward_b(self, ctx, dfeat: torch.Tensor, gbuf: torch.Tensor) -> None:
+        import ctypes
+        lib, st = self.lib, self._stream()
+        c = ctx[1]
+        B, H = c["B"], c["H"]
+        ws, wsb, scratch = self._block_buffers(B, H)
+        g = lambda key, n: _p(self._gslot(gbuf, key, n))
+        N = self.neck
+        x_neck, neck_raw, neck_vec, h = c["neck"]
+        d = self._new(B * h * h, 112)
+        self._check(lib.fear_pwbn_train_backward(_p(dfeat), _p(neck_raw), _p(neck_vec), 0, _p(x_neck), 112, _p(N.w), _p(N.gamma),
+                                                 g(N.conv_key, 256 * 112), g(N.bn_key + ".weight", 256), g(N.bn_key + ".bias", 256), _p(d),
+                                                 B * h * h, 112, 256, ws, wsb, st))
+        for (desc, sv, x, hin, _keep), blk in zip(reversed(c["blocks"]), reversed(self.blocks)):
+            gr = FearIrbGrads()
+            units = (blk["pw"], blk["dw"], blk["pwl"])
+            for i, L in enumerate(units):
+                if L is None:
+                    continue
+                w = self._gslot(gbuf, L.conv_key, L.w.numel()).data_ptr()
+                if i == 0:
+                    gr.w_pw = w
+                elif i == 1:
+                    gr.w_dw = w
+                else:
+                    gr.w_pwl = w
+                gr.gamma[i] = self._gslot(gbuf, L.bn_key + ".weight", L.cout).data_ptr()
+                gr.beta[i] = self._gslot(gbuf, L.bn_key + ".bias", L.cout).data_ptr()
+            dx = self._new(B * hin * hin, desc.cin)
+            self._check(lib.fear_irb_train_backward(ctypes.byref(desc), ctypes.byref(sv), ctypes.byref(gr), _p(x), _p(d), _p(dx), _p(scratch),
+                                                    B, hin, hin, ws, wsb, st))
+            d = dx
+        S = self.stem
+        stem_raw, stem_vec = c["stem"]
+        hs = H // 2
+        self._check(lib.fear_pwbn_train_backward(_p(d), _p(stem_raw), _p(stem_vec), 1, _p(c["col"]), 28, _p(S.w), _p(S.gamma),
+                                                 g(S.conv_key, 16 * 28), g(S.bn_key + ".weight", 16), g(S.bn_key + ".bias", 16), None,
+                                                 B * hs * hs, 28, 16, ws, wsb, st))
+
     # ------------------------------------------------------------------ trunk + neck
     def _features_forward(self, img: torch.Tensor):
         """img (B,3,H,H) NCHW -> (feature rows [B*(H/16)^2][256], saved records for the backward)."""
@@ -444,8 +595,12 @@ class FEARNetTrainHIP:
             raise ValueError("expected template (B,3,128,128) and search (B,3,256,256)")
         with torch.cuda.device(dev):
             st = self._stream()
-            ffwd = self._features_forward_f if self.fused else self._features_forward
-            fbwd = self._features_backward_f if self.fused else self._features_backward
+            ffwd = {"block": self._features_forward_b, "fused": self._features_forward_f, "layerwise": self._features_forward}[self.mode]
+            fbwd = {"block": self._features_backward_b, "fused": self._features_backward_f, "layerwise": self._features_backward}[self.mode]
+            # every gradient of the step lives in one buffer in param_flat's layout (the template pass's trunk gradients behind it)
+            gall = torch.zeros(self._ptotal + self._gtotal, dtype=torch.float32, device=dev)      # fresh per step: the caller keeps `grads`
+            gflat = (gall[: self._ptotal], gall[self._ptotal:])
+            self._gcur = gflat[0]
             main = torch.cuda.current_stream(dev)
             if self.two_streams and self._side is None:
                 self._side = torch.cuda.Stream(device=dev)
@@ -459,16 +614,16 @@ class FEARNetTrainHIP:
             self._check(self.lib.fear_nhwc_to_nchw(_p(zrows), _p(z), B, 256, 64, 256, 0, st))
             self._check(self.lib.fear_nhwc_to_nchw(_p(xrows), _p(x), B, 256, 256, 256, 0, st))
             out = self.head.step(x, z, gt_reg, gt_cls, gt_weight)
-            grads = {"connect_model." + k: v for k, v in out["grads"].items()}
+            grads = GradDict({"connect_model." + k: v for k, v in out["grads"].items()})
+            grads.flat = gflat[0]
             dx = self._new(B * 256, 256)
             dz = self._new(B * 64, 256)
             self._check(self.lib.fear_nchw_to_nhwc(_p(out["grad_search"]), _p(dx), B, 256, 256, 256, 0, st))
             self._check(self.lib.fear_nchw_to_nhwc(_p(out["grad_template"].contiguous()), _p(dz), B, 256, 64, 256, 0, st))
-            gflat = torch.empty(2, self._gtotal, dtype=torch.float32, device=dev)      # fresh per step: the caller keeps `grads`
             if side is not None:
                 side.wait_stream(main)                               # dz and the gradient buffer exist
                 dz.record_stream(side)
-                gflat.record_stream(side)
+                gall.record_stream(side)
                 with torch.cuda.stream(side):
                     self._lane = 1
                     try:
@@ -480,7 +635,7 @@ class FEARNetTrainHIP:
             else:
                 fbwd(xctx, dx, gflat[0])
                 fbwd(zctx, dz, gflat[1])
-            self._check(self.lib.fear_add(_p(gflat[0]), _p(gflat[1]), _p(gflat[0]), self._gtotal, st))   # shared parameters: the two passes add up
+            self._check(self.lib.fear_add(_p(gflat[0]), _p(gflat[1]), _p(gflat[0]), self._gtotal, st))   # shared parameters: the two passes add up (the trunk's slots come first)
             for L in self._trunk_layers():
                 gw = self._gslot(gflat[0], L.conv_key, *L.w.shape)
                 if L.kind == "dw":

@@ -176,6 +176,55 @@ int fear_add(const float* a, const float* b, float* out, long n, void* stream);
 int fear_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, double lr, double beta1, double beta2,
                    double eps, double weight_decay, int step, void* stream);
 
+/* ---- block-fused operators of the trunk's training step (round 5; csrc/fear_train_block.h) --------------------------------------
+ * One call per inverted-residual block and direction — model_training/model/blocks.py:22-35 over mobile_cv's conv-BN-ReLU units:
+ * expand 1x1 + BN + ReLU (absent when `expand` = 0: cexp = cin), depthwise kxk stride s + BN + ReLU, project 1x1 + BN [+ input when
+ * `residual`].  The call sequences its kernels itself; BatchNorm'd activations, BatchNorm input gradients and ReLU masks are formed
+ * in registers by whichever kernel needs them (forward: statistics in the producing pass, normalisation on load in the consumer;
+ * backward: the BatchNorm backward applied on load from the pair (gradient, raw tensor)); what is written is the raw conv outputs
+ * e / d / p (saved for the backward) and, in the backward, two masked gradients in `scratch`.  Same arithmetic as the operators
+ * above composed unit by unit (tests/test_train_head.py pins both against autograd).  One rank (no SyncBatchNorm hook). */
+typedef struct FearIrbBlock {
+    int cin, cexp, cout, k, stride, expand, residual, reserved;
+    const float* w_pw;             /* [cexp][cin]   (NULL without expansion) */
+    const float* w_dw;             /* [k*k][cexp]   depthwise taps, tap-major */
+    const float* w_pwl;            /* [cout][cexp] */
+    const float* gamma[3];         /* BatchNorm of the expand | depthwise | project unit ([0] unused without expansion) */
+    const float* beta[3];
+    float* running_mean[3];        /* updated by the forward like fear_bn_train_forward (may be NULL) */
+    float* running_var[3];
+} FearIrbBlock;
+typedef struct FearIrbSaved {      /* written by the forward, read by the backward; caller-allocated */
+    float* e;                      /* [B*H*W][cexp]            raw expansion (NULL without expansion) */
+    float* d;                      /* [B*(H/s)*(W/s)][cexp]    raw depthwise output */
+    float* p;                      /* [B*(H/s)*(W/s)][cout]    raw projection */
+    float* vec[3];                 /* per BatchNorm 4*C floats: mean | rstd | a = gamma*rstd | b = beta - mean*a */
+} FearIrbSaved;
+typedef struct FearIrbGrads {      /* parameter gradients, kernel layouts of FearIrbBlock */
+    float* w_pw;
+    float* w_dw;
+    float* w_pwl;
+    float* gamma[3];
+    float* beta[3];
+} FearIrbGrads;
+size_t fear_irb_workspace_bytes(const FearIrbBlock* blk, int B, int H, int W);     /* 0: unsupported shape */
+size_t fear_irb_scratch_floats(const FearIrbBlock* blk, int B, int H, int W);      /* `scratch` of the backward */
+/* x [B*H*W][cin] -> out [B*(H/s)*(W/s)][cout] */
+int fear_irb_train_forward(const FearIrbBlock* blk, const FearIrbSaved* saved, const float* x, float* out, int B, int H, int W,
+                           double momentum, double eps, float* workspace, size_t ws_bytes, void* stream);
+/* dout = gradient w.r.t. `out`; dx (may be NULL when the block has an expansion and its input needs no gradient) = gradient w.r.t. x */
+int fear_irb_train_backward(const FearIrbBlock* blk, const FearIrbSaved* saved, const FearIrbGrads* grads, const float* x, const float* dout,
+                            float* dx, float* scratch, int B, int H, int W, float* workspace, size_t ws_bytes, void* stream);
+/* a lone pointwise conv + BatchNorm [+ ReLU] in the same style (the stem on its im2col rows, the AdjustLayer neck blocks.py:75-88):
+ * raw = x w^T, vec as above, out = act(raw) materialised;  backward from dy = gradient w.r.t. out */
+size_t fear_pwbn_workspace_bytes(long M, int K, int N);
+int fear_pwbn_train_forward(const float* x, int ldx, const float* w, const float* gamma, const float* beta, float* running_mean,
+                            float* running_var, float* raw, float* vec, int relu, float* out, long M, int K, int N, double momentum, double eps,
+                            float* workspace, size_t ws_bytes, void* stream);
+int fear_pwbn_train_backward(const float* dy, const float* raw, const float* vec, int relu, const float* x, int ldx, const float* w,
+                             const float* gamma, float* dw, float* dgamma, float* dbeta, float* dx, long M, int K, int N, float* workspace,
+                             size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -248,8 +248,8 @@ def test_training_oracle_head_matches_reference_fixture(golden_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fused,B", [(False, 2), (True, 2), (False, 16), (True, 16)],
-                         ids=["layerwise_b2", "fused_conv_bn_b2", "layerwise_b16", "fused_conv_bn_b16"])
+@pytest.mark.parametrize("fused,B", [(False, 2), (True, 2), ("block", 2), (False, 16), (True, 16), ("block", 16)],
+                         ids=["layerwise_b2", "fused_conv_bn_b2", "block_b2", "layerwise_b16", "fused_conv_bn_b16", "block_b16"])
 def test_whole_network_training_step_matches_autograd(fused, B):
     """BASELINE configs[4] "backbone + xcorr fwd/bwd, random-init": FEARNet.forward((template, search)) in train mode +
     FEARLoss + backward to all 195 parameter tensors on the HIP operators vs torch autograd on the restated graph
@@ -269,7 +269,9 @@ def test_whole_network_training_step_matches_autograd(fused, B):
     gt_reg = torch.rand(B, 4, 16, 16, generator=g) * 60 + 1
     gt_cls = (torch.rand(B, 1, 16, 16, generator=g) > 0.8).float()
     gt_w = (torch.rand(B, 16, 16, generator=g) > 0.85).float()
-    net = FEARNetTrainHIP(sd, device=0, fused=fused)      # both implementations of the trunk's conv + BatchNorm units
+    # all three implementations of the trunk's conv + BatchNorm units ("block": one call per inverted-residual block, the default)
+    net = FEARNetTrainHIP(sd, device=0, mode="block") if fused == "block" else FEARNetTrainHIP(sd, device=0, fused=fused)
+    assert net.mode == {False: "layerwise", True: "fused", "block": "block"}[fused]
     out = net.step(tmpl, srch, gt_reg, gt_cls, gt_w)
     torch.cuda.synchronize()
     # the oracle's backward runs on the HIP forward's ReLU activity pattern (oracle/fear_train_oracle.py::MaskableReLU: the
@@ -493,11 +495,17 @@ def test_fused_training_step_equals_the_layerwise_one():
     gt_w = (torch.rand(B, 16, 16, generator=g) > 0.9).float()
     sd = random_init_state(9)
     outs, stats = {}, {}
-    for fused in (False, True):
-        net = FEARNetTrainHIP(sd, device=0, fused=fused)
+    for fused in (False, True, "block"):
+        net = FEARNetTrainHIP(sd, device=0, mode="block") if fused == "block" else FEARNetTrainHIP(sd, device=0, fused=fused)
         outs[fused] = net.step(tmpl, srch, gt_reg, gt_cls, gt_w)
         stats[fused] = {k: v.cpu() for k, v in net.running_stats().items()}
         torch.cuda.synchronize()
+    for other in (True, "block"):
+        _compare_steps(outs[False], outs[other], stats[False], stats[other], str(other))
+
+
+def _compare_steps(out_ref, out_got, stats_ref, stats_got, tag):
+    outs, stats = {False: out_ref, True: out_got}, {False: stats_ref, True: stats_got}
     for k in ("loss_cls", "loss_reg"):
         assert abs(float(outs[True][k]) - float(outs[False][k])) <= 1e-5 * abs(float(outs[False][k])), k
     assert set(outs[True]["grads"]) == set(outs[False]["grads"]) and len(outs[True]["grads"]) == 195
@@ -522,7 +530,7 @@ def test_fused_training_step_equals_the_layerwise_one():
         assert float((stats[True][k] - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max())), k
     # the two forwards differ by roundings that flip a few ReLUs at pre-activations of ~1e-7; everything behind them moves by 1e-3
     assert float(np.median(errs)) < 1e-2, float(np.median(errs))
-    print(f"fused vs layer-wise: median relative gradient difference {np.median(errs):.2e}, worst {worst:.2e}")
+    print(f"{tag} vs layer-wise: median relative gradient difference {np.median(errs):.2e}, worst {worst:.2e}")
 
 
 @pytest.mark.gpu
@@ -541,19 +549,19 @@ def test_training_step_at_the_config_size_is_finite_and_reproducible():
     gt_w = (torch.rand(B, 16, 16, generator=g) > 0.9).float().to(dev)
     sd = random_init_state(3)
     runs = []
-    for fused in (False, False, True, True):
-        net = FEARNetTrainHIP(sd, device=0, fused=fused)
+    for fused in (False, False, True, True, "block", "block"):
+        net = FEARNetTrainHIP(sd, device=0, mode="block") if fused == "block" else FEARNetTrainHIP(sd, device=0, fused=fused)
         out = net.step(tmpl, srch, gt_reg, gt_cls, gt_w)
         torch.cuda.synchronize()
         runs.append({k: v.clone() for k, v in out["grads"].items()} | {"loss": torch.tensor([float(out["loss_cls"]), float(out["loss_reg"])])})
         del net, out
         torch.cuda.empty_cache()
-    for i in (0, 2):                                          # the layer-wise step, then the fused one
+    for i in (0, 2, 4):                                       # the layer-wise step, the fused one, the block-fused one
         assert torch.isfinite(runs[i]["loss"]).all()
         for k, v in runs[i].items():
             assert torch.isfinite(v).all(), k
             assert torch.equal(v, runs[i + 1][k]), f"{k} differs between two runs of the same step (fused={i > 0})"
-    assert float((runs[0]["loss"] - runs[2]["loss"]).abs().max()) < 1e-4
+    assert float((runs[0]["loss"] - runs[2]["loss"]).abs().max()) < 1e-4 and float((runs[0]["loss"] - runs[4]["loss"]).abs().max()) < 1e-4
     # two half batches, sums added = the full batch (16 -> 96 channels at 128x128: 2.1 M rows)
     lib = load_train_library()
     M, K, N = B * 128 * 128, 16, 96
