@@ -1071,6 +1071,7 @@ struct PwStatArgs {
     ActIn in;
     double* partial;     // [gridDim.x][2][N]
     int ldx, ldy, M, K, N;
+    int row_tiles;       // 128-row tiles per workgroup (0 = 1): the large maps cut their millions of rows into <= ~2 048 partials
 };
 
 __device__ __forceinline__ float row16_sum(float v) {      // sum over the 16 lanes that share lane >> 4
@@ -1088,26 +1089,12 @@ __global__ __launch_bounds__(256) void pw_stat_kernel(PwStatArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    const int m_wave = (blockIdx.x * 4 + wave) * (MT * 16);
-    const float* xrow[MT];
-    bool mvalid[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        int m = m_wave + mt * 16 + li;
-        mvalid[mt] = m < a.M;
-        if (m >= a.M) m = a.M - 1;
-        xrow[mt] = a.X + (long)m * a.ldx;
-    }
+    const int row_tiles = a.row_tiles > 0 ? a.row_tiles : 1;
     const bool affine = a.in.a != nullptr;
     const int n_tiles = (a.N + 15) >> 4;
     // gridDim.y > 1 (16 x 16 maps: few row blocks): the passes over the output tiles are dealt to different workgroups; each
     // writes its own columns of this row block's partial
     for (int nc = blockIdx.y * NT; nc < n_tiles; nc += NT * gridDim.y) {
-        f32x4 acc[MT][NT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         int nrow[NT];
         bool nvalid[NT];
 #pragma unroll
@@ -1116,55 +1103,80 @@ __global__ __launch_bounds__(256) void pw_stat_kernel(PwStatArgs a) {
             nvalid[nt] = n < a.N;
             nrow[nt] = nvalid[nt] ? n : (a.N - 1);
         }
-        for (int kg = 0; kg < a.K; kg += 16) {
-            const int k = kg + lk * 4;
-            const bool kvalid = k < a.K;
-            f32x4 xf[MT], wf[NT];
-            f32x4 ia = (f32x4){1.f, 1.f, 1.f, 1.f}, ib = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (affine && kvalid) {
-                ia = *reinterpret_cast<const f32x4*>(a.in.a + k);
-                ib = *reinterpret_cast<const f32x4*>(a.in.b + k);
-            }
+        // float64 column sums of this workgroup's rows: slot (wave, nt * 16 + 4 lk + c) belongs to lane (li = 0, lk) of that wave
+        if (li == 0) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { red[wave][0][nt * 16 + lk * 4 + c] = 0.0; red[wave][1][nt * 16 + lk * 4 + c] = 0.0; }
+        }
+        for (int rt = 0; rt < row_tiles; ++rt) {
+            const int m_wave = ((blockIdx.x * row_tiles + rt) * 4 + wave) * (MT * 16);
+            if (m_wave >= a.M) break;      // (wave-uniform; no barrier inside this loop)
+            const float* xrow[MT];
+            bool mvalid[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                xf[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (kvalid) {
-                    xf[mt] = *reinterpret_cast<const f32x4*>(xrow[mt] + k);
-                    if (affine) xf[mt] = act4(xf[mt], ia, ib, a.in.relu != 0);
-                }
+                int m = m_wave + mt * 16 + li;
+                mvalid[mt] = m < a.M;
+                if (m >= a.M) m = a.M - 1;
+                xrow[mt] = a.X + (long)m * a.ldx;
             }
+            f32x4 acc[MT][NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int kg = 0; kg < a.K; kg += 16) {
+                const int k = kg + lk * 4;
+                const bool kvalid = k < a.K;
+                f32x4 xf[MT], wf[NT];
+                f32x4 ia = (f32x4){1.f, 1.f, 1.f, 1.f}, ib = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (affine && kvalid) {
+                    ia = *reinterpret_cast<const f32x4*>(a.in.a + k);
+                    ib = *reinterpret_cast<const f32x4*>(a.in.b + k);
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    xf[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (kvalid) {
+                        xf[mt] = *reinterpret_cast<const f32x4*>(xrow[mt] + k);
+                        if (affine) xf[mt] = act4(xf[mt], ia, ib, a.in.relu != 0);
+                    }
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    wf[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (kvalid && nvalid[nt]) wf[nt] = *reinterpret_cast<const f32x4*>(a.W + (long)nrow[nt] * a.K + k);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][i], xf[mt][i], acc[mt][nt], 0, 0, 0);
+            }
+            // store + statistics: lane holds channels n0 + 4*lk + {0..3} of pixels m_wave + mt*16 + li
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                wf[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (kvalid && nvalid[nt]) wf[nt] = *reinterpret_cast<const f32x4*>(a.W + (long)nrow[nt] * a.K + k);
-            }
+                const int n = (nc + nt) * 16 + lk * 4;
+                f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f}, s2 = s1;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int mt = 0; mt < MT; ++mt) {
+                    if (!mvalid[mt]) continue;
+                    const f32x4 v = acc[mt][nt];
+                    s1 += v;
+                    s2 += v * v;
+                    if (n < a.N) *reinterpret_cast<f32x4*>(a.Y + (long)(m_wave + mt * 16 + li) * a.ldy + n) = v;
+                }
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][i], xf[mt][i], acc[mt][nt], 0, 0, 0);
-        }
-        // store + statistics: lane holds channels n0 + 4*lk + {0..3} of pixels m_wave + mt*16 + li
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int n = (nc + nt) * 16 + lk * 4;
-            f32x4 s1 = (f32x4){0.f, 0.f, 0.f, 0.f}, s2 = s1;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                if (!mvalid[mt]) continue;
-                const f32x4 v = acc[mt][nt];
-                s1 += v;
-                s2 += v * v;
-                if (n < a.N) *reinterpret_cast<f32x4*>(a.Y + (long)(m_wave + mt * 16 + li) * a.ldy + n) = v;
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float t1 = row16_sum(s1[c]), t2 = row16_sum(s2[c]);
-                if (li == 0) {
-                    red[wave][0][nt * 16 + lk * 4 + c] = (double)t1;
-                    red[wave][1][nt * 16 + lk * 4 + c] = (double)t2;
+                for (int c = 0; c < 4; ++c) {
+                    const float t1 = row16_sum(s1[c]), t2 = row16_sum(s2[c]);
+                    if (li == 0) {
+                        red[wave][0][nt * 16 + lk * 4 + c] += (double)t1;
+                        red[wave][1][nt * 16 + lk * 4 + c] += (double)t2;
+                    }
                 }
             }
         }

@@ -40,6 +40,7 @@ struct PwBwdArgs {
     double* partial;     // MS: [gridDim.x][2][Nout]
     int ldg, ldr, ldy, ldd;
     int M, Kred, Nout;
+    int row_tiles;       // 128-row tiles per workgroup (0 = 1)
 };
 
 template <int NT, bool MS>
@@ -49,27 +50,11 @@ __global__ __launch_bounds__(256) void pw_bwd_kernel(PwBwdArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    const int m_wave = (blockIdx.x * 4 + wave) * (MT * 16);
-    const float* grow[MT];
-    const float* erow[MT];
-    bool mvalid[MT];
+    const int row_tiles = a.row_tiles > 0 ? a.row_tiles : 1;
     const bool bnb = a.bn.E != nullptr, bmask = a.bn.mask_a != nullptr;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        int m = m_wave + mt * 16 + li;
-        mvalid[mt] = m < a.M;
-        if (m >= a.M) m = a.M - 1;
-        grow[mt] = a.G + (long)m * a.ldg;
-        erow[mt] = bnb ? a.bn.E + (long)m * a.bn.lde : nullptr;
-    }
     const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int n_tiles = (a.Nout + 15) >> 4;
     for (int nc = blockIdx.y * NT; nc < n_tiles; nc += NT * gridDim.y) {
-        f32x4 acc[MT][NT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = zero;
         int ncol[NT];
         bool nvalid[NT];
 #pragma unroll
@@ -78,85 +63,111 @@ __global__ __launch_bounds__(256) void pw_bwd_kernel(PwBwdArgs a) {
             nvalid[nt] = n < a.Nout;
             ncol[nt] = nvalid[nt] ? n : (a.Nout - 1);
         }
-        for (int kg = 0; kg < a.Kred; kg += 16) {
-            const int k = kg + lk * 4;
-            const bool kvalid = k < a.Kred;      // Kred is a multiple of 4
-            f32x4 xf[MT], wf[NT];
+        if (MS && li == 0) {      // float64 column sums of this workgroup's rows (pw_stat_kernel's scheme)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) xf[mt] = zero;
-            if (kvalid) {
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) xf[mt] = *reinterpret_cast<const f32x4*>(grow[mt] + k);
-                if (bnb) {
-                    f32x4 ev[MT];
+                for (int c = 0; c < 4; ++c) { red[wave][0][nt * 16 + lk * 4 + c] = 0.0; red[wave][1][nt * 16 + lk * 4 + c] = 0.0; }
+        }
+        for (int rt = 0; rt < row_tiles; ++rt) {
+            const int m_wave = ((blockIdx.x * row_tiles + rt) * 4 + wave) * (MT * 16);
+            if (m_wave >= a.M) break;      // (wave-uniform; no barrier inside this loop)
+            const float* grow[MT];
+            const float* erow[MT];
+            bool mvalid[MT];
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) ev[mt] = *reinterpret_cast<const f32x4*>(erow[mt] + k);
-                    const f32x4 cA = *reinterpret_cast<const f32x4*>(a.bn.coef + k), cs1 = *reinterpret_cast<const f32x4*>(a.bn.coef + a.bn.C + k);
-                    const f32x4 cmu = *reinterpret_cast<const f32x4*>(a.bn.coef + 2 * a.bn.C + k), cQ = *reinterpret_cast<const f32x4*>(a.bn.coef + 3 * a.bn.C + k);
-                    if (bmask) {
-                        const f32x4 cma = *reinterpret_cast<const f32x4*>(a.bn.mask_a + k), cmb = *reinterpret_cast<const f32x4*>(a.bn.mask_b + k);
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) xf[mt] = relu_mask4(xf[mt], ev[mt], cma, cmb);
-                    }
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) xf[mt] = bnb4(xf[mt], ev[mt], cA, cs1, cmu, cQ);
-                }
+            for (int mt = 0; mt < MT; ++mt) {
+                int m = m_wave + mt * 16 + li;
+                mvalid[mt] = m < a.M;
+                if (m >= a.M) m = a.M - 1;
+                grow[mt] = a.G + (long)m * a.ldg;
+                erow[mt] = bnb ? a.bn.E + (long)m * a.bn.lde : nullptr;
             }
+            f32x4 acc[MT][NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = zero;
+            for (int kg = 0; kg < a.Kred; kg += 16) {
+                const int k = kg + lk * 4;
+                const bool kvalid = k < a.Kred;      // Kred is a multiple of 4
+                f32x4 xf[MT], wf[NT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) xf[mt] = zero;
+                if (kvalid) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) xf[mt] = *reinterpret_cast<const f32x4*>(grow[mt] + k);
+                    if (bnb) {
+                        f32x4 ev[MT];
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) ev[mt] = *reinterpret_cast<const f32x4*>(erow[mt] + k);
+                        const f32x4 cA = *reinterpret_cast<const f32x4*>(a.bn.coef + k), cs1 = *reinterpret_cast<const f32x4*>(a.bn.coef + a.bn.C + k);
+                        const f32x4 cmu = *reinterpret_cast<const f32x4*>(a.bn.coef + 2 * a.bn.C + k), cQ = *reinterpret_cast<const f32x4*>(a.bn.coef + 3 * a.bn.C + k);
+                        if (bmask) {
+                            const f32x4 cma = *reinterpret_cast<const f32x4*>(a.bn.mask_a + k), cmb = *reinterpret_cast<const f32x4*>(a.bn.mask_b + k);
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt) xf[mt] = relu_mask4(xf[mt], ev[mt], cma, cmb);
+                        }
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) xf[mt] = bnb4(xf[mt], ev[mt], cA, cs1, cmu, cQ);
+                    }
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    wf[nt] = zero;
+                    if (kvalid && nvalid[nt]) {
+                        const float* p = a.W + (long)k * a.Nout + ncol[nt];
+                        wf[nt] = (f32x4){p[0], p[a.Nout], p[2 * a.Nout], p[3 * a.Nout]};
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][i], xf[mt][i], acc[mt][nt], 0, 0, 0);
+            }
+            // epilogue: lane holds columns n0 + 4 lk + {0..3} of rows m_wave + mt * 16 + li
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                wf[nt] = zero;
-                if (kvalid && nvalid[nt]) {
-                    const float* p = a.W + (long)k * a.Nout + ncol[nt];
-                    wf[nt] = (f32x4){p[0], p[a.Nout], p[2 * a.Nout], p[3 * a.Nout]};
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][i], xf[mt][i], acc[mt][nt], 0, 0, 0);
-        }
-        // epilogue: lane holds columns n0 + 4 lk + {0..3} of rows m_wave + mt * 16 + li
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int n = (nc + nt) * 16 + lk * 4;
-            const bool nok = n < a.Nout;      // Nout is a multiple of 4
-            if (MS) {
-                f32x4 dmu = zero, drs = zero, da = zero, db = zero;
-                if (nok) {
-                    dmu = *reinterpret_cast<const f32x4*>(a.dvec + n); drs = *reinterpret_cast<const f32x4*>(a.dvec + a.Nout + n);
-                    da = *reinterpret_cast<const f32x4*>(a.dvec + 2 * a.Nout + n); db = *reinterpret_cast<const f32x4*>(a.dvec + 3 * a.Nout + n);
-                }
-                f32x4 s1 = zero, s2 = zero;
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    if (!mvalid[mt] || !nok) continue;
-                    const long m = m_wave + mt * 16 + li;
-                    const f32x4 dv = *reinterpret_cast<const f32x4*>(a.D + m * a.ldd + n);
-                    const f32x4 v = relu_mask4(acc[mt][nt], dv, da, db);
-                    *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = v;
-                    s1 += v;
-                    s2 += v * ((dv - dmu) * drs);
-                }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float t1 = row16_sum(s1[c]), t2 = row16_sum(s2[c]);
-                    if (li == 0) {
-                        red[wave][0][nt * 16 + lk * 4 + c] = (double)t1;
-                        red[wave][1][nt * 16 + lk * 4 + c] = (double)t2;
+                const int n = (nc + nt) * 16 + lk * 4;
+                const bool nok = n < a.Nout;      // Nout is a multiple of 4
+                if (MS) {
+                    f32x4 dmu = zero, drs = zero, da = zero, db = zero;
+                    if (nok) {
+                        dmu = *reinterpret_cast<const f32x4*>(a.dvec + n); drs = *reinterpret_cast<const f32x4*>(a.dvec + a.Nout + n);
+                        da = *reinterpret_cast<const f32x4*>(a.dvec + 2 * a.Nout + n); db = *reinterpret_cast<const f32x4*>(a.dvec + 3 * a.Nout + n);
                     }
-                }
-            } else {
-                if (!nok) continue;
+                    f32x4 s1 = zero, s2 = zero;
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    if (!mvalid[mt]) continue;
-                    const long m = m_wave + mt * 16 + li;
-                    f32x4 v = acc[mt][nt];
-                    if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
-                    *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = v;
+                    for (int mt = 0; mt < MT; ++mt) {
+                        if (!mvalid[mt] || !nok) continue;
+                        const long m = m_wave + mt * 16 + li;
+                        const f32x4 dv = *reinterpret_cast<const f32x4*>(a.D + m * a.ldd + n);
+                        const f32x4 v = relu_mask4(acc[mt][nt], dv, da, db);
+                        *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = v;
+                        s1 += v;
+                        s2 += v * ((dv - dmu) * drs);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float t1 = row16_sum(s1[c]), t2 = row16_sum(s2[c]);
+                        if (li == 0) {
+                            red[wave][0][nt * 16 + lk * 4 + c] += (double)t1;
+                            red[wave][1][nt * 16 + lk * 4 + c] += (double)t2;
+                        }
+                    }
+                } else {
+                    if (!nok) continue;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        if (!mvalid[mt]) continue;
+                        const long m = m_wave + mt * 16 + li;
+                        f32x4 v = acc[mt][nt];
+                        if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
+                        *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = v;
+                    }
                 }
             }
         }
@@ -207,18 +218,22 @@ struct DwBwdArgs {
 };
 
 template <int KS, int S, int SQ, bool BN1>
-__global__ __launch_bounds__(256) void dw_bwd_kernel(DwBwdArgs a) {
+__global__ __launch_bounds__(256, 2) void dw_bwd_kernel(DwBwdArgs a) {
     constexpr int P = KS / 2, KK = KS * KS, TS = 16;
     constexpr int LO = P / S;                          // output rows / columns in front of the tile's first own one
     constexpr int OR = (TS - 1 + P) / S + LO + 1;      // side of the dd region a tile reads
+    constexpr int PITCH = (OR + 1) * SQ;               // float4s per region row: one pixel of padding turns consecutive rows by half
+                                                       // the LDS banks, so the lanes of a ds_read_b128 group (consecutive rows) differ
     constexpr int NT = (KS + S - 1) / S;               // taps per dimension a pixel meets
     constexpr int PL = 256 / SQ;                       // pixel lanes
     constexpr int NCLS = S * S;                        // parity classes
     constexpr bool WREG = NT * NT <= 9;                // tap weights in registers (else in LDS)
-    __shared__ f32x4 tile[OR * OR * SQ];
+    constexpr int T = KS == 5 ? 2 : 4;                 // stride 1: a thread takes runs of T pixels along x (register window over the taps)
+    constexpr int SMEM = OR * PITCH > 512 ? OR * PITCH : 512;
+    __shared__ f32x4 tile[SMEM];                        // the dd region; after the last tile, the reduction buffer
     __shared__ f32x4 wl[WREG ? 1 : KK * SQ];
-    __shared__ f64x4 red64[256];                        // also used as f32x4[256]
-    f32x4* red = reinterpret_cast<f32x4*>(red64);
+    f32x4* red = tile;
+    f64x4* red64 = reinterpret_cast<f64x4*>(tile);
     const int tid = threadIdx.x;
     const int cq_l = tid % SQ, pl = tid / SQ;
     const int slab = blockIdx.x % a.nslab, wslot = blockIdx.x / a.nslab;
@@ -265,6 +280,9 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(DwBwdArgs a) {
         const int tx = item % a.tiles_x, ty = (item / a.tiles_x) % a.tiles_y, b = item / (a.tiles_x * a.tiles_y);
         const int iy0 = ty * TS, ix0 = tx * TS;
         const int lo_y = iy0 / S - LO, lo_x = ix0 / S - LO;
+        f32x4 s1f = zero, s2f = zero;      // this tile's share of the two sums (at most 16 values per lane), then float64
+        int wq = cq_l;                      // index of this thread's weights in LDS, opaque to the compiler: it would otherwise hoist
+        asm volatile("" : "+v"(wq));        // all 25 LDS weight reads out of the tile loop into 100 registers
         // ---- phase 1: dd of the tile's output region -> LDS (zero outside the map / beyond the channels)
         constexpr int NIDX = OR * OR * SQ, U = 4;
         for (int i0 = 0; i0 < NIDX; i0 += 256 * U) {
@@ -284,66 +302,128 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(DwBwdArgs a) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int idx = i0 + u * 256 + tid;
-                if (idx < NIDX) tile[idx] = in[u] ? bnb4(gv[u], dv[u], cA, cs1, cmu, cQ) : zero;
+                const int pix = idx / SQ;
+                const int r = pix / OR, cc = pix - r * OR;
+                if (idx < NIDX) tile[r * PITCH + cc * SQ + cq_l] = in[u] ? bnb4(gv[u], dv[u], cA, cs1, cmu, cQ) : zero;
             }
         }
         __syncthreads();
-        // ---- phase 2: SQ sweeps of PL pixels
+        // ---- phase 2
+        if (S == 1) {
+            // runs of T pixels along x: per tap row a window of T + KS - 1 region columns is read once and serves all T x KS
+            // (pixel, tap) pairs; consecutive pixel lanes are consecutive rows
+            constexpr int RPS = PL / (TS / T);             // rows per sweep
 #pragma unroll 1
-        for (int s = 0; s < SQ; ++s) {
-            int iy_l, ix_l;
-            if (S == 1) {
-                const int id = s * PL + pl;
-                iy_l = id / TS; ix_l = id % TS;
-            } else {
-                const int id = s * (PL / 4) + (pl >> 2);      // 2 x 2 pixel group of the tile
-                iy_l = 2 * (id / (TS / 2)) + py; ix_l = 2 * (id % (TS / 2)) + px;
-            }
-            const int iy = iy0 + iy_l, ix = ix0 + ix_l;
-            const bool pin = cv && iy < a.H && ix < a.W;
-            const long prow = ((long)b * a.H + iy) * a.W + ix;
-            f32x4 e4 = zero, r4 = zero;
-            if (pin) {
-                e4 = *reinterpret_cast<const f32x4*>(a.E + prow * a.lde + c);
-                if (!BN1 && a.R) r4 = *reinterpret_cast<const f32x4*>(a.R + prow * a.ldr + c);
-            }
-            f32x4 av = e4;                                 // the depthwise conv's operand at this pixel
-            f32x4 pre = zero;
-            if (BN1) {
-                pre = (f32x4){__builtin_fmaf(e4.x, a1.x, b1.x), __builtin_fmaf(e4.y, a1.y, b1.y), __builtin_fmaf(e4.z, a1.z, b1.z), __builtin_fmaf(e4.w, a1.w, b1.w)};
-                av = (f32x4){fmaxf(pre.x, 0.f), fmaxf(pre.y, 0.f), fmaxf(pre.z, 0.f), fmaxf(pre.w, 0.f)};
-            }
-            if (!pin) av = zero;
-            f32x4 de = zero;
+            for (int sw = 0; sw < TS / RPS; ++sw) {
+                const int iy_l = sw * RPS + pl % RPS, ix_l = (pl / RPS) * T;
+                const int iy = iy0 + iy_l;
+                const long prow = ((long)b * a.H + iy) * a.W + ix0 + ix_l;
+                bool pin[T];
+                f32x4 e4[T], av[T], de[T];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int ky = ky0 + S * j;
-                const bool jv = S == 1 || ky < KS;
-                const int rr = jv ? (iy_l + P - ky) / S + LO : 0;       // (iy_l + P - ky) is a multiple of S for this thread's class
+                for (int i = 0; i < T; ++i) {
+                    pin[i] = cv && iy < a.H && ix0 + ix_l + i < a.W;
+                    e4[i] = pin[i] ? *reinterpret_cast<const f32x4*>(a.E + (prow + i) * a.lde + c) : zero;
+                }
 #pragma unroll
-                for (int i = 0; i < NT; ++i) {
-                    const int kx = kx0 + S * i;
-                    const bool tv = jv && (S == 1 || kx < KS);
-                    const int cc = tv ? (ix_l + P - kx) / S + LO : 0;
-                    f32x4 v = tile[(rr * OR + cc) * SQ + cq_l];
-                    if (S != 1 && !tv) v = zero;
-                    const f32x4 w = WREG ? wreg[WREG ? j : 0][WREG ? i : 0] : wl[(tv ? ky * KS + kx : 0) * SQ + cq_l];
-                    de += v * w;
-                    acc[j][i] += v * av;
+                for (int i = 0; i < T; ++i) {
+                    av[i] = e4[i];
+                    if (BN1) {
+                        const f32x4 pre = act4(e4[i], a1, b1, false);
+                        av[i] = (f32x4){fmaxf(pre.x, 0.f), fmaxf(pre.y, 0.f), fmaxf(pre.z, 0.f), fmaxf(pre.w, 0.f)};
+                    }
+                    if (!pin[i]) av[i] = zero;
+                    de[i] = zero;
+                }
+                int lb = (iy_l + 2 * P) * PITCH + ix_l * SQ + cq_l;
+#pragma unroll
+                for (int ky = 0; ky < KS; ++ky) {
+                    const int base = lb - ky * PITCH;
+                    f32x4 win[T + KS - 1];
+#pragma unroll
+                    for (int j = 0; j < T + KS - 1; ++j) win[j] = tile[base + j * SQ];
+#pragma unroll
+                    for (int kx = 0; kx < KS; ++kx) {
+                        const f32x4 w = WREG ? wreg[WREG ? ky : 0][WREG ? kx : 0] : wl[(ky * KS + kx) * SQ + wq];
+#pragma unroll
+                        for (int i = 0; i < T; ++i) {
+                            const f32x4 v = win[i + KS - 1 - kx];
+                            de[i] += v * w;
+                            acc[ky][kx] += v * av[i];
+                        }
+                    }
+                    // one tap row's window in flight: hipcc hoists all KS of them (100+ registers, spills at two workgroups per
+                    // CU) and neither sched_barrier nor the loop structure stops it; a data dependence of the next row's address does
+                    if (KS == 5) asm volatile("" : "+v"(lb), "+v"(wq) : "v"(de[0]), "v"(de[T - 1]), "v"(acc[ky][0]), "v"(acc[ky][1]), "v"(acc[ky][2]), "v"(acc[ky][KS - 2]), "v"(acc[ky][KS - 1]));
+                    else asm volatile("" : "+v"(lb), "+v"(wq) : "v"(de[0]), "v"(de[1]), "v"(de[T - 2]), "v"(de[T - 1]), "v"(acc[ky][0]), "v"(acc[ky][1]), "v"(acc[ky][KS - 1]));
+                }
+#pragma unroll
+                for (int i = 0; i < T; ++i) {
+                    if (!pin[i]) continue;
+                    if (BN1) {
+                        const f32x4 pre = act4(e4[i], a1, b1, false);
+                        const f32x4 g1 = (f32x4){pre.x > 0.f ? de[i].x : 0.f, pre.y > 0.f ? de[i].y : 0.f, pre.z > 0.f ? de[i].z : 0.f, pre.w > 0.f ? de[i].w : 0.f};
+                        *reinterpret_cast<f32x4*>(a.Y + (prow + i) * a.ldy + c) = g1;
+                        s1f += g1;
+                        s2f += g1 * ((e4[i] - mu1) * rs1);
+                    } else {
+                        f32x4 r4 = zero;
+                        if (a.R) r4 = *reinterpret_cast<const f32x4*>(a.R + (prow + i) * a.ldr + c);
+                        *reinterpret_cast<f32x4*>(a.Y + (prow + i) * a.ldy + c) = de[i] + r4;
+                    }
                 }
             }
-            if (pin) {
+        } else {
+#pragma unroll 1
+            for (int sw = 0; sw < SQ; ++sw) {
+                const int id = sw * (PL / 4) + (pl >> 2);      // 2 x 2 pixel group of the tile
+                const int iy_l = 2 * (id / (TS / 2)) + py, ix_l = 2 * (id % (TS / 2)) + px;
+                const int iy = iy0 + iy_l, ix = ix0 + ix_l;
+                const bool pin = cv && iy < a.H && ix < a.W;
+                const long prow = ((long)b * a.H + iy) * a.W + ix;
+                f32x4 e4 = zero, r4 = zero;
+                if (pin) {
+                    e4 = *reinterpret_cast<const f32x4*>(a.E + prow * a.lde + c);
+                    if (!BN1 && a.R) r4 = *reinterpret_cast<const f32x4*>(a.R + prow * a.ldr + c);
+                }
+                f32x4 av = e4;                                 // the depthwise conv's operand at this pixel
+                f32x4 pre = zero;
                 if (BN1) {
-                    const f32x4 g1 = (f32x4){pre.x > 0.f ? de.x : 0.f, pre.y > 0.f ? de.y : 0.f, pre.z > 0.f ? de.z : 0.f, pre.w > 0.f ? de.w : 0.f};
-                    *reinterpret_cast<f32x4*>(a.Y + prow * a.ldy + c) = g1;
-                    const f32x4 xh = (e4 - mu1) * rs1;
-                    S1 += to_f64(g1);
-                    S2 += to_f64(g1) * to_f64(xh);
-                } else {
-                    *reinterpret_cast<f32x4*>(a.Y + prow * a.ldy + c) = de + r4;
+                    pre = act4(e4, a1, b1, false);
+                    av = (f32x4){fmaxf(pre.x, 0.f), fmaxf(pre.y, 0.f), fmaxf(pre.z, 0.f), fmaxf(pre.w, 0.f)};
+                }
+                if (!pin) av = zero;
+                f32x4 de = zero;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int ky = ky0 + S * j;
+                    const bool jv = ky < KS;
+                    const int rr = jv ? (iy_l + P - ky) / S + LO : 0;       // (iy_l + P - ky) is a multiple of S for this thread's class
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) {
+                        const int kx = kx0 + S * i;
+                        const bool tv = jv && kx < KS;
+                        const int cc = tv ? (ix_l + P - kx) / S + LO : 0;
+                        f32x4 v = tile[rr * PITCH + cc * SQ + cq_l];
+                        if (!tv) v = zero;
+                        const f32x4 w = WREG ? wreg[WREG ? j : 0][WREG ? i : 0] : wl[(tv ? ky * KS + kx : 0) * SQ + wq];
+                        de += v * w;
+                        acc[j][i] += v * av;
+                    }
+                }
+                if (pin) {
+                    if (BN1) {
+                        const f32x4 g1 = (f32x4){pre.x > 0.f ? de.x : 0.f, pre.y > 0.f ? de.y : 0.f, pre.z > 0.f ? de.z : 0.f, pre.w > 0.f ? de.w : 0.f};
+                        *reinterpret_cast<f32x4*>(a.Y + prow * a.ldy + c) = g1;
+                        s1f += g1;
+                        s2f += g1 * ((e4 - mu1) * rs1);
+                    } else {
+                        *reinterpret_cast<f32x4*>(a.Y + prow * a.ldy + c) = de + r4;
+                    }
                 }
             }
         }
+        if (BN1) { S1 += to_f64(s1f); S2 += to_f64(s2f); }
         __syncthreads();      // the next item overwrites the tile
     }
     // ---- the workgroup's partial tap gradients: slot (j, i) of the threads of one class and channel quad, added in lane order
@@ -377,6 +457,159 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(DwBwdArgs a) {
                 const int cc = (slab * SQ + tid) * 4;
                 if (cc < a.C) *reinterpret_cast<f64x4*>(a.psums + ((long)wslot * 2 + which) * a.C + cc) = sum;
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Depthwise conv FORWARD of the block-fused step: Y = DW act(X) with the input activation applied once per input pixel as the
+// tile's input region goes to LDS (zero outside the map: the padding pads the ACTIVATION), and the column sums sum(y), sum(y^2)
+// of the raw output — float64 per thread over all tiles of a persistent workgroup, ONE partial row per workgroup (the
+// thread-per-strip dw_stat_kernel wrote one per 256 threads: 58 MB of partials for a 672-channel 16 x 16 map, and ran at one
+// wave per SIMD).  Same slab / tile / lane scheme as dw_bwd_kernel; output tiles of 16 x 16 (stride 1) or 8 x 8 (stride 2).
+struct DwFwdArgs {
+    const float* X;
+    ActIn in;
+    const float* Wt;      // [KS*KS][C]
+    float* Y;
+    double* psums;        // [wgs_per_slab][2][C]
+    int ldx, ldy;
+    int B, H, W, Ho, Wo, C;
+    int tiles_x, tiles_y, wgs_per_slab, nslab;
+};
+
+template <int KS, int S, int SQ>
+__global__ __launch_bounds__(256, 2) void dw_fwd_kernel(DwFwdArgs a) {
+    constexpr int P = KS / 2, KK = KS * KS;
+    constexpr int TO = S == 1 ? 16 : 8;                // output tile side
+    constexpr int IR = (TO - 1) * S + KS;              // input region side
+    constexpr int PITCH = (IR + 1) * SQ;
+    constexpr int PL = 256 / SQ;
+    constexpr int T = S == 1 ? 4 : 1;                  // output pixels per thread and sweep (a run along x)
+    constexpr int SMEM = IR * PITCH > 512 ? IR * PITCH : 512;
+    __shared__ f32x4 tile[SMEM];
+    f64x4* red64 = reinterpret_cast<f64x4*>(tile);
+    const int tid = threadIdx.x;
+    const int cq_l = tid % SQ, pl = tid / SQ;
+    const int slab = blockIdx.x % a.nslab, wslot = blockIdx.x / a.nslab;
+    const int c = (slab * SQ + cq_l) * 4;
+    const bool cv = c < a.C;
+    const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool affine = a.in.a != nullptr;
+    f32x4 ia = zero, ib = zero;
+    if (affine && cv) { ia = *reinterpret_cast<const f32x4*>(a.in.a + c); ib = *reinterpret_cast<const f32x4*>(a.in.b + c); }
+    constexpr bool WREG = KK <= 9;                      // 3 x 3 taps in registers, 5 x 5 in LDS (100 registers otherwise)
+    __shared__ f32x4 wl[WREG ? 1 : KK * SQ];
+    f32x4 wr[WREG ? KK : 1];
+    if (WREG) {
+#pragma unroll
+        for (int t = 0; t < KK; ++t) wr[WREG ? t : 0] = cv ? *reinterpret_cast<const f32x4*>(a.Wt + (long)t * a.C + c) : zero;
+    } else {
+        for (int t = pl; t < KK; t += PL) wl[t * SQ + cq_l] = cv ? *reinterpret_cast<const f32x4*>(a.Wt + (long)t * a.C + c) : zero;
+    }
+    f64x4 S1 = (f64x4){0.0, 0.0, 0.0, 0.0}, S2 = S1;
+    const long xbytes = (long)a.B * a.H * a.W * a.ldx * 4;      // < 2^31: checked on the host
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, (int)xbytes, 0x00020000);
+    const int n_items = a.B * a.tiles_y * a.tiles_x;
+    for (int item = wslot; item < n_items; item += a.wgs_per_slab) {
+        const int tx = item % a.tiles_x, ty = (item / a.tiles_x) % a.tiles_y, b = item / (a.tiles_x * a.tiles_y);
+        const int oy0 = ty * TO, ox0 = tx * TO;
+        const int iy0 = oy0 * S - P, ix0 = ox0 * S - P;
+        f32x4 s1f = zero, s2f = zero;      // this tile's share of the sums (at most 16 values per lane), then float64
+        int wq = cq_l;
+        asm volatile("" : "+v"(wq));        // (LDS weight index, opaque: see dw_bwd_kernel)
+        constexpr int NIDX = IR * IR * SQ, U = 4;
+        for (int i0 = 0; i0 < NIDX; i0 += 256 * U) {
+            f32x4 xv[U];
+            bool in[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = i0 + u * 256 + tid;
+                const int pix = idx / SQ;
+                const int r = pix / IR, cc = pix - r * IR;
+                const int y = iy0 + r, x = ix0 + cc;
+                in[u] = idx < NIDX && cv && y >= 0 && y < a.H && x >= 0 && x < a.W;
+                const int off = in[u] ? (((b * a.H + y) * a.W + x) * a.ldx + c) * 4 : (int)0x80000000;
+                xv[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = i0 + u * 256 + tid;
+                const int pix = idx / SQ;
+                const int r = pix / IR, cc = pix - r * IR;
+                f32x4 v = xv[u];
+                if (affine) v = act4(v, ia, ib, a.in.relu != 0);
+                if (idx < NIDX) tile[r * PITCH + cc * SQ + cq_l] = in[u] ? v : zero;
+            }
+        }
+        __syncthreads();
+        if (S == 1) {
+            constexpr int RPS = PL / (TO / T);             // output rows per sweep; consecutive pixel lanes are consecutive rows
+#pragma unroll 1
+            for (int sw = 0; sw < TO / RPS; ++sw) {
+                const int oy_l = sw * RPS + pl % RPS, ox_l = (pl / RPS) * T;
+                f32x4 out[T];
+#pragma unroll
+                for (int i = 0; i < T; ++i) out[i] = zero;
+                int lb = oy_l * PITCH + ox_l * SQ + cq_l;
+#pragma unroll
+                for (int ky = 0; ky < KS; ++ky) {
+                    const int base = lb + ky * PITCH;
+                    f32x4 win[T + KS - 1];
+#pragma unroll
+                    for (int j = 0; j < T + KS - 1; ++j) win[j] = tile[base + j * SQ];
+#pragma unroll
+                    for (int kx = 0; kx < KS; ++kx) {
+                        const f32x4 w = WREG ? wr[WREG ? ky * KS + kx : 0] : wl[(ky * KS + kx) * SQ + wq];
+#pragma unroll
+                        for (int i = 0; i < T; ++i) out[i] += win[i + kx] * w;
+                    }
+                    asm volatile("" : "+v"(lb), "+v"(wq) : "v"(out[0]), "v"(out[1]), "v"(out[T - 2]), "v"(out[T - 1]));      // (see dw_bwd_kernel)
+                }
+                const int oy = oy0 + oy_l;
+#pragma unroll
+                for (int i = 0; i < T; ++i) {
+                    const int ox = ox0 + ox_l + i;
+                    if (cv && oy < a.Ho && ox < a.Wo) {
+                        *reinterpret_cast<f32x4*>(a.Y + (((long)b * a.Ho + oy) * a.Wo + ox) * a.ldy + c) = out[i];
+                        s1f += out[i];
+                        s2f += out[i] * out[i];
+                    }
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int sw = 0; sw < TO * TO / PL; ++sw) {
+                const int id = sw * PL + pl;
+                const int oy_l = id / TO, ox_l = id % TO;
+                f32x4 out = zero;
+#pragma unroll
+                for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < KS; ++kx)
+                        out += tile[(oy_l * S + ky) * PITCH + (ox_l * S + kx) * SQ + cq_l] * (WREG ? wr[WREG ? ky * KS + kx : 0] : wl[(ky * KS + kx) * SQ + wq]);
+                const int oy = oy0 + oy_l, ox = ox0 + ox_l;
+                if (cv && oy < a.Ho && ox < a.Wo) {
+                    *reinterpret_cast<f32x4*>(a.Y + (((long)b * a.Ho + oy) * a.Wo + ox) * a.ldy + c) = out;
+                    s1f += out;
+                    s2f += out * out;
+                }
+            }
+        }
+        S1 += to_f64(s1f);
+        S2 += to_f64(s2f);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        __syncthreads();
+        red64[tid] = which == 0 ? S1 : S2;
+        __syncthreads();
+        if (tid < SQ) {
+            f64x4 sum = (f64x4){0.0, 0.0, 0.0, 0.0};
+            for (int g = 0; g < PL; ++g) sum += red64[g * SQ + tid];
+            const int cc = (slab * SQ + tid) * 4;
+            if (cc < a.C) *reinterpret_cast<f64x4*>(a.psums + ((long)wslot * 2 + which) * a.C + cc) = sum;
         }
     }
 }
@@ -476,6 +709,38 @@ void finalize_backward(const double* partial, int blocks, int C, double count, c
     hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, s, f);
 }
 
+// Grid of the row-tiled GEMMs with a statistics epilogue: train_pw_grid's, with the row blocks of the large maps fattened to
+// `row_tiles` 128-row tiles each so that a launch leaves at most ~2 048 partial rows for its finalize (a 128 x 128 map of 128
+// crops has 16 384 tiles: 25 MB of float64 partials at 96 channels, a 130 us finalize)
+dim3 dgrad_grid(long M, int Kred, int Nout, int* nt);
+dim3 stat_grid(long M, int K, int N, int* nt, int* row_tiles) {
+    dim3 g = dgrad_grid(M, K, N, nt);      // (a projection 672 -> 112 re-reads its normalised-on-load operand once per pass as well)
+    int rt = (int)((g.x + 2047) / 2048);
+    if (rt < 1) rt = 1;
+    *row_tiles = rt;
+    g.x = (g.x + rt - 1) / rt;
+    return g;
+}
+
+// input-gradient GEMM (reduction over Kred, Nout output columns): when the reduction side is the wide one (an expansion's
+// gradient coming back to cin channels) the operand — two tensors with the BatchNorm backward formed on load — is what costs,
+// so all output tiles go in ONE pass (NT = n_tiles) instead of train_pw_grid's passes of one tile dealt over gridDim.y, which
+// re-read it once per pass (672 -> 112 at 16 x 16: 228 us for a 31 us GEMM)
+dim3 dgrad_grid(long M, int Kred, int Nout, int* nt) {
+    const int n_tiles = (Nout + 15) / 16;
+    if (Kred >= 2 * Nout && n_tiles <= 8 && train_pick_nt(n_tiles) == n_tiles) {
+        *nt = n_tiles;
+        return dim3((unsigned)((M + 127) / 128), 1);
+    }
+    return train_pw_grid(M, n_tiles, nt);
+}
+
+template <int KS, int S>
+void launch_dw_fwd_ks(const DwFwdArgs& a, int sq, dim3 grid, hipStream_t s) {
+    if (sq == 8) hipLaunchKernelGGL((dw_fwd_kernel<KS, S, 8>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((dw_fwd_kernel<KS, S, 4>), grid, dim3(256), 0, s, a);
+}
+
 // Y = act(X) W^T + sums -> vec:  the forward producer of a pointwise unit
 void pw_forward_unit(const float* x, int ldx, const float* in_vec, int in_relu, const float* w, float* y, long M, int K, int N, const float* gamma,
                      const float* beta, float* vec, float* rm, float* rv, double momentum, double eps, double* col, hipStream_t s) {
@@ -484,7 +749,7 @@ void pw_forward_unit(const float* x, int ldx, const float* in_vec, int in_relu, 
     if (in_vec) { a.in.a = in_vec + 2 * K; a.in.b = in_vec + 3 * K; a.in.relu = in_relu; }
     a.partial = col;
     int nt = 1;
-    const dim3 grid = train_pw_grid(M, (N + 15) / 16, &nt);
+    const dim3 grid = stat_grid(M, K, N, &nt, &a.row_tiles);
     launch_pw_stat(a, grid, nt, s);
     finalize_forward(col, (int)grid.x, N, (double)M, gamma, beta, vec, rm, rv, momentum, eps, s);
 }
@@ -499,6 +764,20 @@ void bn_backward_sums(const float* dy, int lddy, const float* raw, int ldx, cons
     const int blocks = col_blocks(M);
     hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(blocks), dim3(256), 0, s, a);
     finalize_backward(col, blocks, C, (double)M, gamma, vec, dgamma, dbeta, coef, s);
+}
+
+// running statistics of a BatchNorm from its saved vec = [mean | rstd | a | b] (the forward ran with running_mean = NULL so that
+// two passes of the shared trunk can overlap on two streams; torch's order — template pass first — is restored by applying the
+// search pass's update afterwards): biased variance = 1 / rstd^2 - eps, tracked unbiased
+__global__ __launch_bounds__(256) void bn_running_update_kernel(const float* vec, float* rm, float* rv, int C, double count, double momentum, double eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mean = (double)vec[c], rs = (double)vec[C + c];
+    double var = 1.0 / (rs * rs) - eps;
+    if (var < 0.0) var = 0.0;
+    rm[c] = (float)((1.0 - momentum) * (double)rm[c] + momentum * mean);
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    rv[c] = (float)((1.0 - momentum) * (double)rv[c] + momentum * unbiased);
 }
 
 template <int KS, int S>
@@ -556,22 +835,23 @@ int fear_irb_train_forward(const FearIrbBlock* b, const FearIrbSaved* sv, const 
                         b->running_var[0], momentum, eps, ws.col, s);
     // depthwise over act1(e) (or over the block input) (+ statistics)
     {
-        DwStatArgs a{};
+        DwFwdArgs a{};
         a.X = b->expand ? sv->e : x; a.ldx = b->cexp; a.Wt = b->w_dw; a.Y = sv->d; a.ldy = b->cexp;
         a.B = B; a.H = H; a.W = W; a.C = b->cexp; a.Ho = Ho; a.Wo = Wo;
         if (b->expand) { a.in.a = sv->vec[0] + 2 * b->cexp; a.in.b = sv->vec[0] + 3 * b->cexp; a.in.relu = 1; }
-        const long strips = (Ho + 3) / 4;
-        const long total = (long)B * strips * Wo * (b->cexp / 4);
-        const long blocks = (total + 255) / 256;
-        if ((size_t)blocks * 2 * b->cexp * sizeof(double) > ws.col_bytes) return FEAR_TRAIN_ERR_WORKSPACE;
-        a.partial = ws.col;
-        dim3 grid((unsigned)blocks);
-        if (b->k == 3 && b->stride == 1) hipLaunchKernelGGL((dw_stat_kernel<3, 1, 4>), grid, dim3(256), 0, s, a);
-        else if (b->k == 3) hipLaunchKernelGGL((dw_stat_kernel<3, 2, 4>), grid, dim3(256), 0, s, a);
-        else if (b->stride == 1) hipLaunchKernelGGL((dw_stat_kernel<5, 1, 4>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((dw_stat_kernel<5, 2, 4>), grid, dim3(256), 0, s, a);
-        finalize_forward(ws.col, (int)blocks, b->cexp, (double)rows_out, b->gamma[1], b->beta[1], sv->vec[1], b->running_mean[1], b->running_var[1],
-                         momentum, eps, s);
+        const int to = b->stride == 1 ? 16 : 8;
+        a.tiles_x = (Wo + to - 1) / to; a.tiles_y = (Ho + to - 1) / to;
+        const int sq = dw_bwd_sq(b->cexp);
+        a.nslab = (b->cexp / 4 + sq - 1) / sq;
+        a.wgs_per_slab = dw_bwd_wgs_per_slab(B * a.tiles_x * a.tiles_y, a.nslab);
+        a.psums = ws.col;
+        const dim3 grid((unsigned)(a.wgs_per_slab * a.nslab));
+        if (b->k == 3 && b->stride == 1) launch_dw_fwd_ks<3, 1>(a, sq, grid, s);
+        else if (b->k == 3) launch_dw_fwd_ks<3, 2>(a, sq, grid, s);
+        else if (b->stride == 1) launch_dw_fwd_ks<5, 1>(a, sq, grid, s);
+        else launch_dw_fwd_ks<5, 2>(a, sq, grid, s);
+        finalize_forward(ws.col, a.wgs_per_slab, b->cexp, (double)rows_out, b->gamma[1], b->beta[1], sv->vec[1], b->running_mean[1],
+                         b->running_var[1], momentum, eps, s);
     }
     // project 1x1 over act2(d) (+ statistics)
     pw_forward_unit(sv->d, b->cexp, sv->vec[1], 1, b->w_pwl, sv->p, rows_out, b->cexp, b->cout, b->gamma[2], b->beta[2], sv->vec[2],
@@ -618,7 +898,7 @@ int fear_irb_train_backward(const FearIrbBlock* b, const FearIrbSaved* sv, const
         a.G = dout; a.ldg = cout; a.bn = bn3; a.W = b->w_pwl; a.Y = g2; a.ldy = cexp; a.D = sv->d; a.ldd = cexp; a.dvec = sv->vec[1];
         a.partial = ws.col; a.M = (int)rows_out; a.Kred = cout; a.Nout = cexp;
         int nt = 1;
-        const dim3 grid = train_pw_grid(rows_out, (cexp + 15) / 16, &nt);
+        const dim3 grid = stat_grid(rows_out, cout, cexp, &nt, &a.row_tiles);
         if ((size_t)grid.x * 2 * cexp * sizeof(double) > ws.col_bytes) return FEAR_TRAIN_ERR_WORKSPACE;
         launch_pw_bwd<true>(a, grid, nt, s);
         finalize_backward(ws.col, (int)grid.x, cexp, (double)rows_out, b->gamma[1], sv->vec[1], gr->gamma[1], gr->beta[1], coef2, s);
@@ -659,12 +939,22 @@ int fear_irb_train_backward(const FearIrbBlock* b, const FearIrbSaved* sv, const
             a.G = g1; a.ldg = cexp; a.bn = bn1; a.W = b->w_pw; a.R = b->residual ? dout : nullptr; a.ldr = cout; a.Y = dx; a.ldy = cin;
             a.M = (int)rows_in; a.Kred = cexp; a.Nout = cin;
             int nt = 1;
-            const dim3 grid = train_pw_grid(rows_in, (cin + 15) / 16, &nt);
+            const dim3 grid = dgrad_grid(rows_in, cexp, cin, &nt);
             launch_pw_bwd<false>(a, grid, nt, s);
         }
         const int rc = wgrad_impl(g1, cexp, 0, x, cin, 0, gr->w_pw, ws.wg, ws.wg_bytes, rows_in, cin, cexp, 1, s, nullptr, nullptr, 0, &bn1);
         if (rc != FEAR_TRAIN_OK) return rc;
     }
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+int fear_bn_running_update(const float* vec, double count, float* running_mean, float* running_var, double momentum, double eps, int C,
+                           void* stream) {
+    if (!vec || !running_mean || !running_var) return FEAR_TRAIN_ERR_NULL;
+    if (C < 1 || !(count >= 1.0)) return FEAR_TRAIN_ERR_SHAPE;
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3((C + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), vec, running_mean,
+                       running_var, C, count, momentum, eps);
     LAUNCH_CHECK();
     return FEAR_TRAIN_OK;
 }
@@ -707,7 +997,7 @@ int fear_pwbn_train_backward(const float* dy, const float* raw, const float* vec
         PwBwdArgs a{};
         a.G = dy; a.ldg = N; a.bn = bn; a.W = w; a.Y = dx; a.ldy = K; a.M = (int)M; a.Kred = N; a.Nout = K;
         int nt = 1;
-        const dim3 grid = train_pw_grid(M, (K + 15) / 16, &nt);
+        const dim3 grid = dgrad_grid(M, N, K, &nt);
         launch_pw_bwd<false>(a, grid, nt, s);
     }
     const int rc = wgrad_impl(dy, N, 0, x, ldx, 0, dw, ws.wg, ws.wg_bytes, M, K, N, 1, s, nullptr, nullptr, 0, &bn);

@@ -472,8 +472,10 @@ class FEARNetTrainHIP:
             sc = self._ws_lanes[key] = torch.empty(scratch, dtype=torch.float32, device=self.device)
         return ws, wsb, sc
 
-    def _features_forward_b(self, img: torch.Tensor):
-        """Block-fused form of `_features_forward`: one call per block (csrc/fear_train_block.h)."""
+    def _features_forward_b(self, img: torch.Tensor, defer_running: bool = False):
+        """Block-fused form of `_features_forward`: one call per block (csrc/fear_train_block.h).  `defer_running`: leave the
+        BatchNorm running statistics alone and list (vec, rows, unit) in the context instead — `_apply_running` updates them
+        later (the search pass, while the template pass runs on the other stream)."""
         import ctypes
         lib, st = self.lib, self._stream()
         B, H = img.shape[0], img.shape[2]
@@ -482,12 +484,25 @@ class FEARNetTrainHIP:
         col = self._new(B * h * h, 28)
         self._check(lib.fear_stem_im2col(_p(img), _p(col), B, H, H, st))
         S = self.stem
+        run = (lambda L: (None, None)) if defer_running else (lambda L: (_p(L.running_mean), _p(L.running_var)))
+        pending = []
         stem_raw, stem_vec, x = self._new(B * h * h, 16), self._new(4 * 16), self._new(B * h * h, 16)
-        self._check(lib.fear_pwbn_train_forward(_p(col), 28, _p(S.w), _p(S.gamma), _p(S.beta), _p(S.running_mean), _p(S.running_var), _p(stem_raw),
+        self._check(lib.fear_pwbn_train_forward(_p(col), 28, _p(S.w), _p(S.gamma), _p(S.beta), *run(S), _p(stem_raw),
                                                 _p(stem_vec), 1, _p(x), B * h * h, 28, 16, self.momentum, self.eps, ws, wsb, st))
+        pending.append((stem_vec, B * h * h, S))
         recs = [dict(L=S, pre=stem_raw, act=(stem_vec[32:48], stem_vec[48:64], 1), B=B, H=h)]     # what relu_patterns reads
         blocks = []
-        for d, blk in zip(self._irb_descriptors(), self.blocks):
+        descs = self._irb_descriptors()
+        if defer_running:
+            if getattr(self, "_irb_norun", None) is None:
+                self._irb_norun = []
+                for d in descs:
+                    c = FearIrbBlock.from_buffer_copy(d)
+                    for i in range(3):
+                        c.running_mean[i], c.running_var[i] = None, None
+                    self._irb_norun.append(c)
+            descs = self._irb_norun
+        for d, blk in zip(descs, self.blocks):
             ho = h // d.stride
             sv = FearIrbSaved()
             e = self._new(B * h * h, d.cexp) if d.expand else None
@@ -501,14 +516,26 @@ class FEARNetTrainHIP:
             C = d.cexp
             if d.expand:
                 recs.append(dict(L=blk["pw"], pre=e, act=(vec[0][2 * C: 3 * C], vec[0][3 * C:], 1), B=B, H=h))
+                pending.append((vec[0], B * h * h, blk["pw"]))
             recs.append(dict(L=blk["dw"], pre=dd, act=(vec[1][2 * C: 3 * C], vec[1][3 * C:], 1), B=B, H=h))
+            pending += [(vec[1], B * ho * ho, blk["dw"]), (vec[2], B * ho * ho, blk["pwl"])]
             blocks.append((d, sv, x, h, (e, dd, pp, vec)))          # (the tensors are kept alive next to their pointers)
             x, h = out, ho
         N = self.neck
         neck_raw, neck_vec, feats = self._new(B * h * h, 256), self._new(4 * 256), self._new(B * h * h, 256)
-        self._check(lib.fear_pwbn_train_forward(_p(x), 112, _p(N.w), _p(N.gamma), _p(N.beta), _p(N.running_mean), _p(N.running_var), _p(neck_raw),
+        self._check(lib.fear_pwbn_train_forward(_p(x), 112, _p(N.w), _p(N.gamma), _p(N.beta), *run(N), _p(neck_raw),
                                                 _p(neck_vec), 0, _p(feats), B * h * h, 112, 256, self.momentum, self.eps, ws, wsb, st))
-        return feats, (recs, dict(B=B, H=H, col=col, stem=(stem_raw, stem_vec), blocks=blocks, neck=(x, neck_raw, neck_vec, h)))
+        pending.append((neck_vec, B * h * h, N))
+        return feats, (recs, dict(B=B, H=H, col=col, stem=(stem_raw, stem_vec), blocks=blocks, neck=(x, neck_raw, neck_vec, h),
+                                  pending=pending if defer_running else []))
+
+    def _apply_running(self, ctx) -> None:
+        """The deferred running-statistics updates of a `_features_forward_b(..., defer_running=True)` pass, on the current stream."""
+        st = self._stream()
+        for vec, rows, L in ctx[1]["pending"]:
+            vec.record_stream(torch.cuda.current_stream(self.device))
+            self._check(self.lib.fear_bn_running_update(_p(vec), float(rows), _p(L.running_mean), _p(L.running_var), self.momentum, self.eps,
+                                                        L.cout, st))
 
     def _features_backward_b(self, ctx, dfeat: torch.Tensor, gbuf: torch.Tensor) -> None:
         import ctypes
@@ -605,10 +632,32 @@ class FEARNetTrainHIP:
             if self.two_streams and self._side is None:
                 self._side = torch.cuda.Stream(device=dev)
             side = self._side if self.two_streams else None
-            # (the FORWARD passes stay in order on one stream: both update the shared trunk's BatchNorm running statistics,
-            # template first — torch's two forward calls — and that read-modify-write must not race)
-            zrows, zctx = ffwd(t)                                    # template first, like FEARNet.forward
-            xrows, xctx = ffwd(s)
+            if side is not None and self.mode == "block":
+                # both trunk passes at once: the template pass (a quarter of the work, launch-bound small maps) on the side stream
+                # under the search pass's bandwidth-bound kernels.  Both update the shared trunk's BatchNorm running statistics,
+                # template first (torch's two forward calls): the search pass leaves them alone and its updates follow the template
+                # pass on the side stream, next to the head
+                side.wait_stream(main)
+                t.record_stream(side)
+                with torch.cuda.stream(side):
+                    self._lane = 1
+                    try:
+                        zrows, zctx = ffwd(t)
+                    finally:
+                        self._lane = 0
+                    z_done = side.record_event()
+                xrows, xctx = ffwd(s, defer_running=True)
+                x_done = main.record_event()
+                with torch.cuda.stream(side):
+                    side.wait_event(x_done)
+                    self._apply_running(xctx)
+                main.wait_event(z_done)
+                zrows.record_stream(main)
+            else:
+                # (the FORWARD passes stay in order on one stream: both update the shared trunk's BatchNorm running statistics,
+                # template first — torch's two forward calls — and that read-modify-write must not race)
+                zrows, zctx = ffwd(t)                                    # template first, like FEARNet.forward
+                xrows, xctx = ffwd(s)
             z = self._new(B, 256, 8, 8)
             x = self._new(B, 256, 16, 16)
             self._check(self.lib.fear_nhwc_to_nchw(_p(zrows), _p(z), B, 256, 64, 256, 0, st))

@@ -215,6 +215,11 @@ int fear_irb_train_forward(const FearIrbBlock* blk, const FearIrbSaved* saved, c
 /* dout = gradient w.r.t. `out`; dx (may be NULL when the block has an expansion and its input needs no gradient) = gradient w.r.t. x */
 int fear_irb_train_backward(const FearIrbBlock* blk, const FearIrbSaved* saved, const FearIrbGrads* grads, const float* x, const float* dout,
                             float* dx, float* scratch, int B, int H, int W, float* workspace, size_t ws_bytes, void* stream);
+/* The running statistics of one BatchNorm from the `vec` its forward saved (mean | rstd | a | b), for forwards that ran with
+ * running_mean = NULL: the shared trunk's two passes (template, search: model/fear_net.py:83-88) may then overlap on two streams,
+ * and torch's update order — template pass first — is restored by applying the search pass's update afterwards. */
+int fear_bn_running_update(const float* vec, double count, float* running_mean, float* running_var, double momentum, double eps, int C,
+                           void* stream);
 /* a lone pointwise conv + BatchNorm [+ ReLU] in the same style (the stem on its im2col rows, the AdjustLayer neck blocks.py:75-88):
  * raw = x w^T, vec as above, out = act(raw) materialised;  backward from dy = gradient w.r.t. out */
 size_t fear_pwbn_workspace_bytes(long M, int K, int N);
