@@ -398,19 +398,26 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs a) {
         if (bmask) { cma = *reinterpret_cast<const f32x4*>(a.bn.mask_a + n4); cmb = *reinterpret_cast<const f32x4*>(a.bn.mask_b + n4); }
     }
     const float* eb = bnb ? a.bn.E + (nv ? n4 : 0) : nullptr;
-    for (long m = m0 + wave * 16; m < m1; m += 64) {
-        f32x4 dv[4], xv[4];
+    // row loop, software pipelined by hand: the 16 rows of step i + 1 are requested before the 64 MFMAs of step i are issued
+    // (two register sets, ping-pong) — a wave otherwise waits out a memory round trip per step with nothing to issue
+    auto load = [&](long m, f32x4 (&dv)[4], f32x4 (&xv)[4], f32x4 (&ev)[4]) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const long r = m + u * 4 + lk;
             const bool rv = r < m1;
             dv[u] = rv && nv ? *reinterpret_cast<const f32x4*>(dy + r * a.lddy) : zero;
             xv[u] = rv && kv ? *reinterpret_cast<const f32x4*>(x + r * a.ldx) : zero;
+            ev[u] = bnb && rv && nv ? *reinterpret_cast<const f32x4*>(eb + r * a.bn.lde) : zero;
+        }
+    };
+    auto compute = [&](long m, f32x4 (&dv)[4], f32x4 (&xv)[4], const f32x4 (&ev)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool rv = m + u * 4 + lk < m1;
             if (act && rv && kv) xv[u] = act4(xv[u], ia, ib, a.act_relu != 0);
             if (bnb && rv && nv) {
-                const f32x4 ev = *reinterpret_cast<const f32x4*>(eb + r * a.bn.lde);
-                if (bmask) dv[u] = relu_mask4(dv[u], ev, cma, cmb);
-                dv[u] = bnb4(dv[u], ev, cA, cs1, cmu, cQ);
+                if (bmask) dv[u] = relu_mask4(dv[u], ev[u], cma, cmb);
+                dv[u] = bnb4(dv[u], ev[u], cA, cs1, cmu, cQ);
             }
         }
 #pragma unroll
@@ -419,6 +426,20 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs a) {
             for (int p = 0; p < 4; ++p)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[u][p], xv[u][q], acc[p][q], 0, 0, 0);
+    };
+    {
+        f32x4 dA[4], xA[4], eA[4], dB[4], xB[4], eB[4];
+        long m = m0 + wave * 16;
+        if (m < m1) load(m, dA, xA, eA);
+        for (; m < m1; m += 128) {
+            const bool hasB = m + 64 < m1;
+            if (hasB) load(m + 64, dB, xB, eB);
+            compute(m, dA, xA, eA);
+            if (hasB) {
+                if (m + 128 < m1) load(m + 128, dA, xA, eA);
+                compute(m + 64, dB, xB, eB);
+            }
+        }
     }
     // (w0 + w2) + (w1 + w3), fixed order
     if (wave >= 2) {
@@ -1441,7 +1462,11 @@ static int wgrad_impl(const float* dy, int lddy, long dy_crop_stride, const floa
         if (cap_ws < 1) cap_ws = 1;      // a workspace smaller than one partial: no finer slicing; the size check below reports it
         long sl = (M + a.rows_per_slice - 1) / a.rows_per_slice;
         if (want > sl) sl = want;
-        if (sl > 256) sl = 256;
+        // at most 256 slices — 1 024 where the partial is small (N * K <= 8 192: the stem and the 16-32-channel layers of the
+        // 128 x 128 / 64 x 64 maps): those layers have millions of rows and ONE or two output tiles, 256 workgroups streamed them
+        // at 1.1 TB/s (the stem's weight gradient: 425 us for 500 MB)
+        const long max_sl = (long)N * K <= 8192 ? 1024 : 256;
+        if (sl > max_sl) sl = max_sl;
         if (sl > cap_ws) sl = cap_ws;
         long rps = ((M + sl - 1) / sl + 63) / 64 * 64;
         if (rps < 256) rps = 256;

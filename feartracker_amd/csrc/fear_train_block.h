@@ -673,7 +673,7 @@ BlockWs block_ws(long rows_in, long rows_out, int cin, int cexp, int cout, int k
     w.col_bytes = align256(col);
     const size_t nk = (size_t)cexp * (cin > cout ? cin : cout);
     size_t wg = (size_t)wgrad_slices(rows) * nk * sizeof(float);
-    size_t more = (size_t)256 * nk * sizeof(float);
+    size_t more = (size_t)1024 * nk * sizeof(float);      // room for wgrad_impl's finer row slicing (up to 1 024 slices of small partials)
     if (more > ((size_t)32 << 20)) more = (size_t)32 << 20;
     if (more > wg) wg = more;
     w.wg_bytes = align256(wg);

@@ -211,8 +211,14 @@ class BoxTowerTrainHIP:
                 pred=_Sep(self, pred, None, sd, pad_out_to=4))
         self.adjust = sd["adjust"].float().reshape(1).to(self.device)
         self.bias4 = sd["bias"].float().reshape(4).to(self.device)
-        self._ws = None
+        self._ws = {}                # per stream lane
+        self._lane = 0
         self._galloc = None          # set by FEARNetTrainHIP: gradient tensors are views of its flat gradient buffer
+        # a second HIP stream for the regression branch: the two towers are independent between the shared input features and the
+        # loss (forward) and between the loss gradient and the sum of their input gradients (backward), and every kernel of a 16 x 16
+        # map is a 256-workgroup launch that leaves most of a 256-CU device idle.  Not with SyncBatchNorm (its collectives must be
+        # issued in one order on every rank).  Set by FEARNetTrainHIP (two_streams); None = one stream.
+        self.side_stream = None
 
     def _layers(self):
         for br in self.branches.values():
@@ -253,9 +259,11 @@ class BoxTowerTrainHIP:
     def _workspace(self, rows: int):
         need = int(self.lib.fear_train_workspace_bytes(rows, 320))
         need = max(need, (8 * rows + rows // 8 + 4096) * 4)
-        if self._ws is None or self._ws.numel() * 4 < need:
-            self._ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
-        return _p(self._ws), self._ws.numel() * 4
+        ws = self._ws.get(self._lane)
+        if ws is None or ws.numel() * 4 < need:
+            self._ws[self._lane] = None
+            ws = self._ws[self._lane] = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
+        return _p(ws), ws.numel() * 4
 
     # ------------------------------------------------------------------ one SepConv [+ BN + ReLU]
     def _sep_forward(self, L: _Sep, x: torch.Tensor, ldx: int, B: int, out: Optional[torch.Tensor] = None, ld_out: int = 0):
@@ -331,15 +339,42 @@ class BoxTowerTrainHIP:
             self._check(lib.fear_nchw_to_nhwc(_p(xs), _p(x), B, 256, P, 256, 0, st))
             saved = {}
             pred_out = {}
-            for name, br in self.branches.items():
+            main = torch.cuda.current_stream(dev)
+            side = self.side_stream if self.sync is None else None
+
+            def on_branch_streams(fn):
+                """fn(name, branch) for both towers: "reg" on the side stream (lane 1), "cls" on this one; joined on return."""
+                items = list(self.branches.items())
+                if side is None:
+                    for name, br in items:
+                        fn(name, br)
+                    return
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self._lane = 1
+                    try:
+                        fn(*items[1])
+                    finally:
+                        self._lane = 0
+                fn(*items[0])
+                main.wait_stream(side)
+
+            def forward_branch(name, br):
+                st_ = self._stream()
                 cat = self._new(M, 320)                                   # [encode output | correlation] without a concat kernel
                 self._sep_forward(br["enc"], x, 256, B, out=cat, ld_out=320)
-                self._check(lib.fear_xcorr_forward(_p(cat), 320, _p(zs), _p(cat, 256), 320, B, P, 256, J, st))
+                self._check(lib.fear_xcorr_forward(_p(cat), 320, _p(zs), _p(cat, 256), 320, B, P, 256, J, st_))
                 a = self._sep_forward(br["corr"], cat, 320, B)
                 for L in br["tower"]:
                     a = self._sep_forward(L, a, 256, B)
                 pred_out[name] = self._sep_forward(br["pred"], a, 256, B)   # [M][4] (cls: column 0 is real)
                 saved[name] = cat
+            if side is not None:
+                x.record_stream(side)
+                zs.record_stream(side)
+            on_branch_streams(forward_branch)
+            if side is not None:
+                pred_out["reg"].record_stream(main)
             bbox_rows = self._new(M, 4)
             self._check(lib.fear_exp_head_forward(_p(pred_out["reg"]), _p(self.adjust), _p(self.bias4), _p(bbox_rows), M, st))
             cls_rows = self._new(M)
@@ -363,8 +398,10 @@ class BoxTowerTrainHIP:
             dp_cls = torch.zeros((M, 4), dtype=torch.float32, device=dev)
             self._check(lib.fear_scale_column(_p(dcls), 1, 0, 0.1, _p(dp_cls), 4, 0, M, st))
             dpred["cls"] = dp_cls
-            dx_total, dz_total = None, None
-            for name, br in self.branches.items():
+            dxz = {}
+
+            def backward_branch(name, br):
+                st_ = self._stream()
                 da = self._sep_backward(br["pred"], dpred[name], 4, B, grads)
                 for L in reversed(br["tower"]):
                     da = self._sep_backward(L, da, 256, B, grads)
@@ -372,13 +409,17 @@ class BoxTowerTrainHIP:
                 cat = saved[name]
                 denc, dz = self._new(M, 256), self._new(B, 256, self.TZ, self.TZ)
                 self._check(lib.fear_xcorr_backward(_p(dcat, 256), 320, _p(cat), 320, _p(zs), _p(dcat), 320, _p(denc), 256, _p(dz),
-                                                    B, P, 256, J, st))
-                dx = self._sep_backward(br["enc"], denc, 256, B, grads)
-                if dx_total is None:
-                    dx_total, dz_total = dx, dz
-                else:
-                    self._check(lib.fear_add(_p(dx_total), _p(dx), _p(dx_total), dx.numel(), st))
-                    self._check(lib.fear_add(_p(dz_total), _p(dz), _p(dz_total), dz.numel(), st))
+                                                    B, P, 256, J, st_))
+                dxz[name] = (self._sep_backward(br["enc"], denc, 256, B, grads), dz)
+            if side is not None:
+                dpred["reg"].record_stream(side)
+            on_branch_streams(backward_branch)
+            (dx_total, dz_total), (dx, dz) = dxz["cls"], dxz["reg"]
+            if side is not None:
+                dx.record_stream(main)
+                dz.record_stream(main)
+            self._check(lib.fear_add(_p(dx_total), _p(dx), _p(dx_total), dx.numel(), st))
+            self._check(lib.fear_add(_p(dz_total), _p(dz), _p(dz_total), dz.numel(), st))
             grad_search = self._new(B, 256, self.S, self.S)
             self._check(lib.fear_nhwc_to_nchw(_p(dx_total), _p(grad_search), B, 256, P, 256, 0, st))
             bbox = self._new(B, 4, self.S, self.S)

@@ -631,6 +631,7 @@ class FEARNetTrainHIP:
             main = torch.cuda.current_stream(dev)
             if self.two_streams and self._side is None:
                 self._side = torch.cuda.Stream(device=dev)
+                self.head.side_stream = self._side         # the head runs its two towers on the two streams as well
             side = self._side if self.two_streams else None
             if side is not None and self.mode == "block":
                 # both trunk passes at once: the template pass (a quarter of the work, launch-bound small maps) on the side stream
