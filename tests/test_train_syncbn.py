@@ -95,7 +95,8 @@ def test_sync_bn_step_with_a_one_rank_group_equals_the_plain_step():
         gt_reg = torch.rand(B, 4, 16, 16, generator=g) * 60 + 1
         gt_cls = (torch.rand(B, 1, 16, 16, generator=g) > 0.8).float()
         gt_w = (torch.rand(B, 16, 16, generator=g) > 0.85).float()
-        plain = FEARNetTrainHIP(sd, device=0).step(tmpl, srch, gt_reg, gt_cls, gt_w)
+        # (SyncBatchNorm runs the layer-wise implementation of the trunk; the one-rank default is the block-fused one)
+        plain = FEARNetTrainHIP(sd, device=0, mode="layerwise").step(tmpl, srch, gt_reg, gt_cls, gt_w)
         net = FEARNetTrainHIP(sd, device=0, sync_bn=True)
         synced = net.step(tmpl, srch, gt_reg, gt_cls, gt_w)
         torch.cuda.synchronize()
