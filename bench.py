@@ -303,7 +303,8 @@ def config5_train_step(dev, batch: int = 128, steps: int = 5, warmup: int = 2):
     on the HIP operators of include/fear_train.h (feartracker_amd/train_net.py), random init, synthetic crops and targets.  With
     several ranks the gradients are averaged by one all-reduce of the flat 1.37 M-float buffer (not part of this 1-GPU number).
     Correctness: tests/test_train_head.py (every gradient vs autograd; the head additionally vs the reference's own classes).
-    One kernel per layer and direction (HBM-bound passes; DESIGN.md §7 N3 lists what fusing them would save)."""
+    The trunk runs block-fused (one C-ABI call per inverted-residual block and direction, csrc/fear_train_block.h), the template
+    pass and the regression tower on a second HIP stream; DESIGN.md §7 N3 has the per-kernel map."""
     from feartracker_amd.train_net import FEARNetTrainHIP, random_init_state
     g = torch.Generator().manual_seed(7)
     net = FEARNetTrainHIP(random_init_state(3), device=dev.index)
@@ -330,23 +331,41 @@ def config5_train_step(dev, batch: int = 128, steps: int = 5, warmup: int = 2):
         opt.step(out["grads"])
     torch.cuda.synchronize()
     adam_ms = 1e3 * (time.perf_counter() - ta) / steps
-    # roofline of the step's dominant kernel symbol (pw_wgrad_kernel: 12.6 % of the kernel time, profiles/r03_train_kernel_stats.csv):
-    # every launch of it bracketed with events on the stream it runs on, in extra steps after the timed ones
-    net.timing = []
-    for _ in range(2):
-        net.step(tmpl, srch, gt_reg, gt_cls, gt_w)
+    # roofline of the step's dominant kernel symbol (pw_wgrad_kernel: 11 % of the kernel time, profiles/r05_train_kernel_stats.csv) on
+    # its heaviest shape in the step — the weight gradient of a 112 -> 672 expansion at 16 x 16 (32 768 rows per 128 pairs), whose dY
+    # operand is the BatchNorm backward formed on load in the block-fused step, i.e. three tensors are read — through the same C-ABI
+    # operator the step calls, bracketed with events on the stream it runs on
+    from feartracker_amd.train_head import _p
+    lib = net.lib
+    Mw, Kw, Nw = batch * 256, 112, 672
+    gw = torch.Generator().manual_seed(11)
+    dyw, xw = torch.randn(Mw, Nw, generator=gw).to(dev), torch.randn(Mw, Kw, generator=gw).to(dev)
+    dww = torch.empty(Nw, Kw, device=dev)
+    wsw = torch.empty(int(lib.fear_train_workspace_bytes(Mw, 672)) // 4 + 1024, device=dev)
+    reps = 20
+    call = lambda: lib.fear_pw_backward_weight(_p(dyw), Nw, _p(xw), Kw, _p(dww), _p(wsw), wsw.numel() * 4, Mw, Kw, Nw, None)
+    for _ in range(3):
+        call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        assert call() == 0
+    e1.record()
     torch.cuda.synchronize()
-    wg_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in net.timing)
-    wg_bytes = sum(b for _, _, b, _ in net.timing)
-    wg_flops = sum(f for _, _, _, f in net.timing)
-    n_wg = len(net.timing)
-    net.timing = None
-    gbs = wg_bytes / (wg_ms * 1e-3) / 1e9
-    train_roof = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
-                  "kernel": "pw_wgrad_kernel (pointwise-conv weight gradients of the trunk, both passes)", "launches": n_wg,
-                  "avg_launch_ms": wg_ms / max(n_wg, 1), "share_of_step": (wg_ms / 2) / (1e3 * dt),
-                  "arithmetic_intensity_flop_per_byte": wg_flops / wg_bytes, "tflops_of_that_kernel": wg_flops / (wg_ms * 1e-3) / 1e12,
-                  "note": "dW[n][k] = sum over millions of rows of dY[m][n] X[m][k] with N, K <= 672: a few FLOP per byte, HBM-side"}
+    wg_ms = e0.elapsed_time(e1) / reps          # (includes the fixed-order slice sum that follows every launch)
+    wg_bytes = 4.0 * (Mw * Nw + Mw * Kw + Nw * Kw)
+    wg_flops = 2.0 * Mw * Nw * Kw
+    ai = wg_flops / wg_bytes
+    bound = "mfma" if ai > PEAK_FP32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9) else "hbm"
+    ach = wg_flops / (wg_ms * 1e-3) / 1e12 if bound == "mfma" else wg_bytes / (wg_ms * 1e-3) / 1e9
+    peak = PEAK_FP32_MFMA_TFLOPS if bound == "mfma" else PEAK_HBM_GBS
+    train_roof = {"bound": bound, "achieved": ach, "peak": peak, "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": ach / peak,
+                  "traffic": None, "kernel": "pw_wgrad_kernel (pointwise-conv weight gradients; dominant symbol of the step)",
+                  "shape": f"dW[{Nw}][{Kw}] = sum over {Mw} rows", "avg_launch_ms": wg_ms,
+                  "arithmetic_intensity_flop_per_byte": ai,
+                  "note": "measured on the step's heaviest weight-gradient shape through the C-ABI operator; per-kernel times and PMC "
+                          "traffic of the whole step: profiles/r05_train_kernel_stats.csv, r05_train_traffic.txt"}
+    del dyw, xw, dww, wsw
     fwd_macs = 461_393_920 + 75_970_000           # search path + template path, forward MACs per pair
     nparams = sum(v.numel() for v in out["grads"].values())
     return {"workload": f"FEARNet training step (trunk + neck on both crops, correlation head, FEARLoss; forward in train mode + "
@@ -355,7 +374,8 @@ def config5_train_step(dev, batch: int = 128, steps: int = 5, warmup: int = 2):
             "approx_tflops": 3 * 2 * fwd_macs * batch / dt / 1e12,
             "loss": [float(out["loss_cls"]), float(out["loss_reg"])], "dtype": "f32",
             "parameter_tensors_with_gradients": len(out["grads"]), "parameters": nparams, "adam_update_ms": adam_ms, "roofline": train_roof,
-            "template_backward_on_second_stream": bool(net.two_streams),
+            "trunk_implementation": net.mode, "adam_launches": 1 if getattr(net, "param_flat", None) is not None else len(out["grads"]),
+            "two_streams": bool(net.two_streams),
             "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
 
 
@@ -535,6 +555,11 @@ def pmc_traffic(op_name: str, tag: str = ""):
                                   if tag or not any(t in os.path.basename(f) for t in ("_fear_m_", "_train_")))[-1]
         per_op = pick(f"r*{suf}_per_op.csv")
         traffic = pick(f"r*{suf}_traffic.json")
+        # both files must come from the same profiling round: a traffic file older than the newest per-op table describes
+        # kernels that may no longer exist (or their predecessors of the same name) — no number is better than a stale one
+        rnd = lambda f: os.path.basename(f).split("_")[0]
+        if rnd(per_op) != rnd(traffic):
+            return None, None
         sym = None
         with open(per_op) as fh:
             for r in csv.DictReader(fh):
