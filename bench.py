@@ -809,6 +809,22 @@ def main() -> None:
         del net_b, lanes
         torch.cuda.empty_cache()
 
+    # supplementary: the same K steps with FEAR_OPT_SPLIT_STREAMS (each call issued as two half-batches on two streams of the SAME
+    # handle, joined before the call returns to its stream; bit-identical maps — tests/test_gpu_parity.py).  A serving option: `value`
+    # stays the single-stream number so that every per-kernel figure of this line is a full-grid launch.
+    elapsed_split = None
+    if not args.no_pipelined and not use_dist:
+        net.set_split_streams(True)
+        for _ in range(max(4, args.warmup // 2)):
+            net.track_maps(search, tmpl_feats, out=(bbox, cls))
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        for _ in range(args.steps):
+            net.track_maps(search, tmpl_feats, out=(bbox, cls))
+        torch.cuda.synchronize()
+        elapsed_split = time.perf_counter() - tp
+        net.set_split_streams(False)
+
     # the same K steps in the other arithmetic mode (supplementary number, same protocol)
     other = 1 - args.math
     elapsed_other = None
@@ -903,6 +919,11 @@ def main() -> None:
                         "flight); supplementary, never `value`",
                 "value": B * args.steps / elapsed_pipe, "unit": "crops/s", "ms_per_step": 1e3 * elapsed_pipe / args.steps,
                 "outputs_identical_between_handles": same}
+        if elapsed_split is not None:
+            out["split_streams_option"] = {
+                "what": "FEAR_OPT_SPLIT_STREAMS = 1: every fear_track call as two half-batches on two streams of one handle "
+                        "(bit-identical maps); supplementary, never `value`",
+                "value": B * args.steps / elapsed_split, "unit": "crops/s", "ms_per_step": 1e3 * elapsed_split / args.steps}
         if ddp_train is not None:
             out["config5_train_step_data_parallel"] = ddp_train
         if use_dist:

@@ -201,6 +201,9 @@ struct fear_handle {
     std::vector<hipEvent_t> event_pool;   // recycled profiling events (creation is slow enough to perturb timing)
     hipStream_t branch_stream = nullptr;  // second stream for the bbox branch of the head at small batch sizes
     hipEvent_t branch_fork = nullptr, branch_join = nullptr;
+    int split_streams = 0;                // FEAR_OPT_SPLIT_STREAMS: a throughput pass runs as two half-batches on two streams
+    hipStream_t split_stream = nullptr;
+    hipEvent_t split_fork = nullptr, split_join = nullptr;
 };
 
 namespace {
@@ -1098,18 +1101,36 @@ int build_plan_uncached(fear_handle* h, int hw, bool with_head, int mode, Plan**
             const int need = IO_X_BF16 | (op.res_buf >= 0 ? IO_R_BF16 : 0);
             return find_tile_bf16(0, op.fused_id, need) || find_tile_bf16(0, op.fused_id, need | IO_Y_BF16);
         };
-        bool cur_bf16 = false;
-        for (size_t i = 0; i < ops.size(); ++i) {
-            Op& op = ops[i];
-            if (op.type != OP_IRTILE || op.splitk) { cur_bf16 = false; continue; }
-            const int in_bits = cur_bf16 ? (IO_X_BF16 | (op.res_buf >= 0 ? IO_R_BF16 : 0)) : 0;
-            const bool want_out = op.Ho >= 64 && i + 1 < ops.size() && reads_bf16(ops[i + 1]);
-            int io = in_bits | (want_out ? IO_Y_BF16 : 0);
-            if (io && !find_tile_bf16(op.stem, op.fused_id, io)) io = in_bits;          // no such variant: keep the output fp32
-            if (io && !find_tile_bf16(op.stem, op.fused_id, io)) return FEAR_ERR_SHAPE;  // (cannot happen: the producer checked reads_bf16)
-            op.io_bf16 = io;
-            cur_bf16 = (io & IO_Y_BF16) != 0;
+        // writes[i]: op i stores its output as bf16.  Start from every candidate, then clear flags until each op has a storage
+        // variant for the (input, residual, output) combination it ends up with: a consumer may exist only as "bf16 in AND out"
+        // (kTileBf16 is a list of measured instantiations, not a full cross product), and whether ITS output goes out as bf16
+        // depends on the op behind it.  A combination without a variant is never an error of the plan — this is an optional
+        // optimisation — the producer in front of it just keeps fp32.
+        std::vector<char> writes(ops.size(), 0);
+        for (size_t i = 0; i + 1 < ops.size(); ++i)
+            writes[i] = ops[i].type == OP_IRTILE && !ops[i].splitk && ops[i].Ho >= 64 && reads_bf16(ops[i + 1]);
+        auto bits = [&](size_t i) {
+            const Op& op = ops[i];
+            const bool in_bf = i > 0 && writes[i - 1];
+            return (in_bf ? (IO_X_BF16 | (op.res_buf >= 0 ? IO_R_BF16 : 0)) : 0) | (writes[i] ? IO_Y_BF16 : 0);
+        };
+        for (bool changed = true; changed;) {
+            changed = false;
+            for (size_t i = 0; i < ops.size(); ++i) {
+                const Op& op = ops[i];
+                if (op.type != OP_IRTILE || op.splitk) {
+                    if (i > 0 && writes[i - 1]) { writes[i - 1] = 0; changed = true; }      // its input must be fp32
+                    continue;
+                }
+                const int io = bits(i);
+                if (!io || find_tile_bf16(op.stem, op.fused_id, io)) continue;
+                if (writes[i]) writes[i] = 0;                  // first try this op with an fp32 output ...
+                else if (i > 0 && writes[i - 1]) writes[i - 1] = 0;   // ... then hand it an fp32 input
+                changed = true;
+            }
         }
+        for (size_t i = 0; i < ops.size(); ++i)
+            if (ops[i].type == OP_IRTILE && !ops[i].splitk) ops[i].io_bf16 = bits(i);
     }
     // ---- head (BoxTower.forward, model/blocks.py:174-194)
     if (with_head) {
@@ -1237,6 +1258,14 @@ int build_plan_uncached(fear_handle* h, int hw, bool with_head, int mode, Plan**
             if (!h->head_chain || !h->fuse || h->math == 1 || small || S != 16 || feat.C != HeadChainG::C || bbox_tower.size() != 2 ||
                 cls_tower.size() != 2)
                 return false;
+            // a later shape check or upload may still fail (and the plan then falls back to the sep16 launches): whatever this
+            // attempt uploaded is freed again — up to twenty packed weight buffers per branch would otherwise stay booked in
+            // plan_allocs until the plans are dropped, once per plan rebuild
+            const size_t allocs0 = h->plan_allocs.size();
+            auto undo = [&]() {
+                while (h->plan_allocs.size() > allocs0) { hipFree(h->plan_allocs.back()); h->plan_allocs.pop_back(); }
+                return false;
+            };
             Op op{};
             op.type = OP_HEADCHAIN;
             op.math = h->math;          // 0: headchain_kernel (exact fp32) | 2: headchain_b_kernel (bf16 matrix pipe)
@@ -1254,7 +1283,7 @@ int build_plan_uncached(fear_handle* h, int hw, bool with_head, int mode, Plan**
                     // SepConv + BN + ReLU: depthwise 3x3 s1 without activation, pointwise to 256 with bias and ReLU
                     if (!d.is_dw() || !pw.is_pw() || d.k != 3 || d.stride != 1 || d.cout != cin || d.relu || pw.cin_g != cin ||
                         pw.cout != HeadChainG::C || !pw.has_bias || !pw.relu)
-                        return false;
+                        return undo();
                     sep[l] = pack_fused16_host(h, -1, seq[l]->conv[0], seq[l]->conv[1]);
                     fl += 2.0 * 256 * ((double)cin * 9 + (double)cin * HeadChainG::C);
                 }
@@ -1262,7 +1291,7 @@ int build_plan_uncached(fear_handle* h, int hw, bool with_head, int mode, Plan**
                 const Conv& pp = h->convs[pred->conv[1]];
                 if (!pd.is_dw() || !pp.is_pw() || pd.k != 3 || pd.stride != 1 || pd.cout != HeadChainG::C || pd.relu ||
                     pp.cin_g != HeadChainG::C || pp.cout != (is_cls ? 1 : 4) || !pp.has_bias)
-                    return false;
+                    return undo();
                 if (h->math == 2) {
                     // bf16 fragments in the kernel's k order, fp32 bias / taps; prediction head: taps then 8 fragments of its 1x1
                     for (int l = 0; l < 4; ++l) {
@@ -1271,22 +1300,22 @@ int build_plan_uncached(fear_handle* h, int hw, bool with_head, int mode, Plan**
                         const int cin = l == 1 ? HeadChainG::CC : HeadChainG::C;
                         if (upload(h, headchain_b_pack(pw.w.data(), cin, HeadChainG::C, pw.b.data()), &op.hc_w[br][l]) != FEAR_OK ||
                             upload(h, headchain_b_taps(d.w.data(), d.has_bias ? d.b.data() : nullptr, cin, 3), &op.hc_taps[br][l]) != FEAR_OK)
-                            return false;
+                            return undo();
                     }
                     std::vector<float> pwk = headchain_b_taps(pd.w.data(), pd.has_bias ? pd.b.data() : nullptr, HeadChainG::C, 3);
                     for (int P = 0; P < HeadChainG::C / 32; ++P) headchain_b_push_frag(pwk, pp.w.data(), HeadChainG::C, pp.cout, 0, P);
-                    if (upload(h, pwk, &op.hc_pred[br]) != FEAR_OK) return false;
+                    if (upload(h, pwk, &op.hc_pred[br]) != FEAR_OK) return undo();
                 } else {
                     for (int l = 0; l < 4; ++l) {
                         const Conv& pw = h->convs[seq[l]->conv[1]];
                         if (upload(h, headchain_pack(sep[l].data(), l == 1 ? HeadChainG::CC : HeadChainG::C, pw.b.data(),
                                                      l < 3 ? sep[l + 1].data() : nullptr, 3), &op.hc_w[br][l]) != FEAR_OK)
-                            return false;
+                            return undo();
                     }
                     if (upload(h, headchain_pack_dw(sep[0].data(), 0, HeadChainG::C / 16, 3), &op.hc_wd0[br]) != FEAR_OK ||
                         upload(h, headchain_pack_dw(sep[1].data(), HeadChainG::C / 16, HeadChainG::TZ / 16, 3), &op.hc_wdc[br]) != FEAR_OK ||
                         pack_fused16(h, -1, pred->conv[0], pred->conv[1], &op.hc_pred[br]) != FEAR_OK)
-                        return false;
+                        return undo();
                 }
                 op.hc_pred_conv[br] = pred->conv[1];
                 op.hc_pred_act[br] = pred->act;
@@ -1415,7 +1444,10 @@ __global__ void delay_kernel(long long ticks) {
     for (int i = 0; i < 100000 && wall_clock64() - t0 < ticks; ++i) __builtin_amdgcn_s_sleep(16);
 }
 
-int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main) {
+// crop0 / sub: the second half of a split pass (FEAR_OPT_SPLIT_STREAMS) — its crops use the workspace behind the first half's
+// (every pool buffer is sized for a full pass at the largest per-crop footprint, so crop c0's share starts c0 footprints in), and the
+// caller (track_impl) does the stream bookkeeping around both halves
+int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main, size_t crop0 = 0, bool sub = false) {
     if (!h->fused_attr_set) {
         for (const Fused16& f : kFused16) {
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(f.kernel),
@@ -1477,11 +1509,13 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
     // (the event was recorded on the previous call's stream at the END of that call, below: the old stream handle is only
     // compared here, never used — the caller may have destroyed that stream since)
     if (!h->stream_switch) HIP_TRY(h, hipEventCreateWithFlags(&h->stream_switch, hipEventDisableTiming));
-    if (h->last_stream_valid && h->last_stream != s_main) HIP_TRY(h, hipStreamWaitEvent(s_main, h->stream_switch, 0));
-    h->last_stream = s_main;
-    h->last_stream_valid = true;
+    if (!sub) {
+        if (h->last_stream_valid && h->last_stream != s_main) HIP_TRY(h, hipStreamWaitEvent(s_main, h->stream_switch, 0));
+        h->last_stream = s_main;
+        h->last_stream_valid = true;
+    }
     const size_t slab = p.buf_floats_per_crop * pass_cap(h, p);
-    auto buf = [&](int id) -> float* { return h->workspace + (size_t)id * slab; };
+    auto buf = [&](int id) -> float* { return h->workspace + (size_t)id * slab + crop0 * p.buf_floats_per_crop; };
     // head branches on two streams (plans built for small passes only; per-op profiling keeps everything on one stream)
     // (bracketing ONE op with events keeps the two streams — the events go to the stream the op runs on; the all-ops table of
     // FEAR_OPT_PROFILE_OP = -1 serialises the plan so that per-op times do not overlap)
@@ -1743,7 +1777,7 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main)
         HIP_TRY(h, hipEventRecord(h->branch_join, h->branch_stream));
         HIP_TRY(h, hipStreamWaitEvent(s_main, h->branch_join, 0));
     }
-    HIP_TRY(h, hipEventRecord(h->stream_switch, s_main));      // what a later call on ANOTHER stream waits for (see above)
+    if (!sub) HIP_TRY(h, hipEventRecord(h->stream_switch, s_main));      // what a later call on ANOTHER stream waits for (see above)
     HIP_TRY(h, hipGetLastError());
     return FEAR_OK;
 }
@@ -1823,6 +1857,9 @@ int fear_destroy(fear_handle* h) {
     hipDeviceSynchronize();
     drain_events(h);
     for (hipEvent_t e : h->event_pool) hipEventDestroy(e);
+    if (h->split_stream) hipStreamDestroy(h->split_stream);
+    if (h->split_fork) hipEventDestroy(h->split_fork);
+    if (h->split_join) hipEventDestroy(h->split_join);
     if (h->branch_stream) hipStreamDestroy(h->branch_stream);
     if (h->branch_fork) hipEventDestroy(h->branch_fork);
     if (h->branch_join) hipEventDestroy(h->branch_join);
@@ -1896,6 +1933,10 @@ int fear_set_option(fear_handle* h, int option, int64_t value) {
             if (value != 0 && value != 1) return FEAR_ERR_SHAPE;
             if (h->bf16_store != (int)value) { h->bf16_store = (int)value; return drop_plans(h); }
             return FEAR_OK;
+        case FEAR_OPT_SPLIT_STREAMS:
+            if (value != 0 && value != 1) return FEAR_ERR_SHAPE;
+            h->split_streams = (int)value;      // (same plans: only how a pass is issued changes)
+            return FEAR_OK;
         default: return FEAR_ERR_SHAPE;
     }
 }
@@ -1918,6 +1959,7 @@ int64_t fear_get_option(fear_handle* h, int option) {
         case FEAR_OPT_HEAD_CHAIN: return h->head_chain;
         case FEAR_OPT_E1_PAIR: return h->e1_pair;
         case FEAR_OPT_BF16_STORE: return h->bf16_store;
+        case FEAR_OPT_SPLIT_STREAMS: return h->split_streams;
         default: return FEAR_ERR_SHAPE;
     }
 }
@@ -1981,7 +2023,42 @@ static int track_impl(fear_handle* h, const float* search, const float* tmpl, co
         ext.cls_out = cls + (size_t)b0 * cls_stride;
         ext.bbox_stride = bbox_stride;
         ext.cls_stride = cls_stride;
-        st = run_plan(h, *p, nb, ext, static_cast<hipStream_t>(stream));
+        hipStream_t s_main = static_cast<hipStream_t>(stream);
+        // FEAR_OPT_SPLIT_STREAMS: the pass as two half-batches, the second on the handle's own stream.  The crops of a batch are
+        // independent and every kernel computes a crop the same way whatever its neighbours (tests: batch invariance, bit for bit),
+        // so the maps are identical; what changes is that one half's launch boundaries, prologues and memory-side kernels fall into
+        // the other half's ALU-bound stretches.  Only when both halves still run the throughput plan, and never while profiling
+        // (per-op events assume one stream).
+        const int nA = (nb + 1) / 2, nB = nb - nA;
+        if (h->split_streams && !h->profile && small_pass(h, nb) == 0 && nB > 0 && small_pass(h, nB) == 0) {
+            if (!h->split_stream) {
+                HIP_TRY(h, hipStreamCreateWithFlags(&h->split_stream, hipStreamNonBlocking));
+                HIP_TRY(h, hipEventCreateWithFlags(&h->split_fork, hipEventDisableTiming));
+                HIP_TRY(h, hipEventCreateWithFlags(&h->split_join, hipEventDisableTiming));
+            }
+            // per-call bookkeeping of run_plan, done here around both halves: a previous call on another stream is waited for
+            if (!h->stream_switch) HIP_TRY(h, hipEventCreateWithFlags(&h->stream_switch, hipEventDisableTiming));
+            if (h->last_stream_valid && h->last_stream != s_main) HIP_TRY(h, hipStreamWaitEvent(s_main, h->stream_switch, 0));
+            h->last_stream = s_main;
+            h->last_stream_valid = true;
+            HIP_TRY(h, hipEventRecord(h->split_fork, s_main));               // inputs ready, the workspace free
+            HIP_TRY(h, hipStreamWaitEvent(h->split_stream, h->split_fork, 0));
+            st = run_plan(h, *p, nA, ext, s_main, 0, true);
+            if (st != FEAR_OK) return st;
+            Ext eb = ext;
+            eb.img = ext.img + (size_t)nA * 3 * hw * hw;
+            eb.tmpl = ext.tmpl + (size_t)nA * tz;
+            eb.tmpl_cls = ext.tmpl_cls ? ext.tmpl_cls + (size_t)nA * tz : nullptr;
+            eb.bbox_out = ext.bbox_out + (size_t)nA * bbox_stride;
+            eb.cls_out = ext.cls_out + (size_t)nA * cls_stride;
+            st = run_plan(h, *p, nB, eb, h->split_stream, (size_t)nA, true);
+            if (st != FEAR_OK) return st;
+            HIP_TRY(h, hipEventRecord(h->split_join, h->split_stream));      // the caller's stream continues once both halves are done
+            HIP_TRY(h, hipStreamWaitEvent(s_main, h->split_join, 0));
+            HIP_TRY(h, hipEventRecord(h->stream_switch, s_main));
+        } else {
+            st = run_plan(h, *p, nb, ext, s_main);
+        }
         if (st != FEAR_OK) return st;
     }
     return FEAR_OK;

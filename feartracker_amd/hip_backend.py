@@ -42,6 +42,7 @@ FEAR_OPT_TINY_SEP = 12
 FEAR_OPT_HEAD_CHAIN = 13
 FEAR_OPT_BF16_STORE = 14
 FEAR_OPT_E1_PAIR = 15
+FEAR_OPT_SPLIT_STREAMS = 16
 
 _lib = None
 
@@ -212,8 +213,11 @@ class FEARNetHIP:
         self._check(self._lib.fear_set_option(self._h, FEAR_OPT_DUAL_HEAD, 1 if on else 0))
 
     def set_head_chain(self, on: bool) -> None:
-        """A/B switch for the one-launch BoxTower (FEAR_OPT_HEAD_CHAIN, default on; fp32 mode, throughput plan): off = the eight
-        sep16 launches it replaces.  The maps are bit-identical either way."""
+        """A/B switch for the one-launch BoxTower (FEAR_OPT_HEAD_CHAIN, default on; throughput plan): off = the eight sep16
+        launches it replaces.  fp32 mode (set_math(0)): headchain_kernel, maps bit-identical either way.  bf16 mode (set_math(2)):
+        headchain_b_kernel, same rounding points as the launches but another summation order — NOT bit-identical (2e-3 relative on
+        the maps; tests/test_gpu_parity.py).  set_math(1) keeps the launches.  While the chain is on, set_dual_head has no effect
+        on the throughput plan (there are no separate branch launches to put on two streams)."""
         self._check(self._lib.fear_set_option(self._h, FEAR_OPT_HEAD_CHAIN, 1 if on else 0))
 
     def set_bf16_store(self, on: bool) -> None:
@@ -225,6 +229,12 @@ class FEARNetHIP:
         """A/B switch (FEAR_OPT_E1_PAIR, default on; fp32 mode, throughput plan): two consecutive 24-channel e1 blocks as one launch
         (the map between them stays in LDS) vs one tile-kernel launch per block."""
         self._check(self._lib.fear_set_option(self._h, FEAR_OPT_E1_PAIR, 1 if on else 0))
+
+    def set_split_streams(self, on: bool) -> None:
+        """FEAR_OPT_SPLIT_STREAMS (default off): a throughput pass of `track` / `track_maps` runs as two half-batches on two HIP
+        streams of the same handle — a serving option (+3 % crops/s at 256 crops), bit-identical maps; bench.py keeps it off for
+        `value` so that its per-kernel figures stay full-grid launches and prints its number beside it."""
+        self._check(self._lib.fear_set_option(self._h, FEAR_OPT_SPLIT_STREAMS, 1 if on else 0))
 
     def set_tile_v4(self, on: bool) -> None:
         """Throughput plan: the phase-overlapped tile kernel for the blocks that have one (default on) vs ir_tile_v2 everywhere."""

@@ -128,17 +128,26 @@ def track_local_shard(net, search_shard: torch.Tensor, template_shard: torch.Ten
             if world == 1:
                 return bbox, cls
         dtypes = [torch.float32, torch.float16, torch.bfloat16, torch.float64]
-        meta_dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-        meta = torch.tensor([bbox.shape[-1], 1 + dtypes.index(bbox.dtype)] if bbox is not None else [0, 0], dtype=torch.int64, device=meta_dev)
+        # the device the collectives run on: CUDA whenever the group's backend can take CUDA tensors ("nccl", or a composite
+        # "cuda:nccl,cpu:gloo"), for empty and non-empty ranks alike — never chosen per rank from what a rank happens to hold
+        uses_cuda = "nccl" in str(dist.get_backend(group)).lower()
+        meta_dev = torch.device("cuda", torch.cuda.current_device()) if uses_cuda else torch.device("cpu")
+        # an unknown dtype is a code of its own (-1 sorts below every valid one, so it is reported through MIN): every rank still
+        # enters the all-reduce — raising before it would leave the other ranks hanging in the collective — and all raise after it
+        code_mine = (1 + dtypes.index(bbox.dtype) if bbox.dtype in dtypes else -1) if bbox is not None else 0
+        meta = torch.tensor([bbox.shape[-1] if bbox is not None else 0, code_mine, -code_mine], dtype=torch.int64, device=meta_dev)
         dist.all_reduce(meta, op=dist.ReduceOp.MAX, group=group)
-        side, code = int(meta[0]), int(meta[1])
-        if bbox is not None and (bbox.shape[-1] != side or dtypes.index(bbox.dtype) + 1 != code):
+        side, code, bad = int(meta[0]), int(meta[1]), int(meta[2]) > 0
+        if bad or code < 1:
+            raise ValueError("a rank's score maps have an unsupported dtype (expected one of float32 / float16 / bfloat16 / float64)"
+                             if bad else "no rank produced score maps")
+        if bbox is not None and (bbox.shape[-1] != side or code_mine != code):
             raise ValueError("the ranks' score maps differ in size or dtype")
         if bbox is None:                                      # an empty shard still takes part in the collective
-            packed = torch.zeros((cap, 5, side, side), dtype=dtypes[code - 1], device=dev if dev.type == meta_dev.type else meta_dev)
+            packed = torch.zeros((cap, 5, side, side), dtype=dtypes[code - 1], device=meta_dev)
         else:
-            packed = torch.zeros((cap, 5) + tuple(bbox.shape[2:]), dtype=bbox.dtype, device=bbox.device)
-            pack_maps(bbox, cls, packed[: hi - lo])
+            packed = torch.zeros((cap, 5) + tuple(bbox.shape[2:]), dtype=bbox.dtype, device=meta_dev)
+            pack_maps(bbox.to(meta_dev), cls.to(meta_dev), packed[: hi - lo])
     gathered = torch.empty((world * cap,) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
     dist.all_gather_into_tensor(gathered, packed, group=group)
     if n_global % world == 0:

@@ -154,6 +154,12 @@ int fear_crop_normalize(fear_handle* h, const uint8_t* frame_u8, int frame_h, in
 #define FEAR_OPT_E1_PAIR 15    /* 1 (default): fp32 mode, throughput plan — two consecutive 24-channel e1 blocks (depthwise 3x3 + pointwise  */
                                /*   + input, no expansion; model/blocks.py:8-42) run as ONE launch with the map between them in LDS          */
                                /*   (e1pair_kernel: half the HBM traffic of these two memory-bound blocks); 0: one launch per block (A/B).    */
+#define FEAR_OPT_SPLIT_STREAMS 16 /* 1: a throughput pass of fear_track / fear_track_packed is issued as two half-batches, the second on a  */
+                               /*   stream of the handle's own, joined before the call returns to the caller's stream: one half's launch    */
+                               /*   boundaries and memory-bound kernels overlap the other's ALU-bound ones (+3 % crops/s at 256 crops).     */
+                               /*   Same plans, same kernels per crop: bit-identical maps.  0 (default): one stream — every per-kernel      */
+                               /*   figure of bench.py (the roofline object first of all) is then a full-grid launch.  Only when both        */
+                               /*   halves still exceed FEAR_OPT_SMALL_PASS; ignored while FEAR_OPT_PROFILE is on.                           */
 int fear_set_option(fear_handle* h, int option, int64_t value);
 int64_t fear_get_option(fear_handle* h, int option);
 

@@ -919,6 +919,40 @@ def test_dual_stream_head_in_the_throughput_plan(hip_net):
         assert torch.equal(b1, b2) and torch.equal(c1, c2)
 
 
+def test_split_streams_option_gives_bit_identical_maps():
+    """FEAR_OPT_SPLIT_STREAMS (serving option, off for bench.py's `value`): a throughput pass as two half-batches on two streams of
+    the same handle — same kernels per crop, so the maps equal the single-stream call bit for bit: full batch of 256, a ragged one
+    (201 crops = 101 + 100), the packed entry point, a separate classification template, calls repeated back to back (the
+    halves' workspaces must not race), on the caller's non-default stream; a batch whose halves would fall under the small-pass
+    threshold runs unsplit."""
+    from feartracker_amd import FEARNetHIP
+    from conftest import WEIGHTS
+    g = torch.Generator().manual_seed(14)
+    B = 256
+    x = norm_u8(torch.randint(0, 256, (B, 3, 256, 256), dtype=torch.uint8, generator=g)).cuda()
+    one, two = FEARNetHIP(WEIGHTS, device=0, max_batch=B), FEARNetHIP(WEIGHTS, device=0, max_batch=B)
+    z = one.get_features(norm_u8(torch.randint(0, 256, (B, 3, 128, 128), dtype=torch.uint8, generator=g)).cuda())
+    zc = torch.roll(z, 1, 0).contiguous()
+    two.set_split_streams(True)
+    for n in (256, 201, 150):                                     # 150: halves of 75 <= FEAR_OPT_SMALL_PASS: not split
+        b1, c1 = one.track_maps(x[:n], z[:n])
+        for _ in range(4):
+            b2, c2 = two.track_maps(x[:n], z[:n])
+            assert torch.equal(b1, b2) and torch.equal(c1, c2), n
+    b1, c1 = one.track_maps(x, z, zc)
+    b2, c2 = two.track_maps(x, z, zc)
+    assert torch.equal(b1, b2) and torch.equal(c1, c2)
+    p1, p2 = torch.empty(B, 5, 16, 16, device="cuda"), torch.empty(B, 5, 16, 16, device="cuda")
+    one.track_packed(x, z, out=p1)
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        for _ in range(3):
+            two.track_packed(x, z, out=p2)
+    torch.cuda.synchronize()
+    assert torch.equal(p1, p2) and torch.equal(p1[:, :4], one.track_maps(x, z)[0])
+
+
 def test_fear_m_at_the_config_size_512_crops():
     """BASELINE configs[3] at ITS size — synthetic FEAR-M, B = 512, bf16 matrix-pipe mode (what bench.py times) — through
     size-independent properties: finite maps; batch invariance (crop i alone = crop i inside the batch, bit for bit, in the
