@@ -1394,6 +1394,8 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a) {
     *reinterpret_cast<f32x4*>(a.Y + r * a.ldy + c) = y;
 }
 
+#include "fear_train_gemm.h"
+
 }  // namespace
 
 extern "C" {
@@ -1411,6 +1413,13 @@ int fear_pw_forward(const float* x, int ldx, const float* w, const float* bias, 
     if (M == 0) return FEAR_TRAIN_OK;
     if (!x || !w || !y) return FEAR_TRAIN_ERR_NULL;
     if (M < 0 || K < 4 || K % 4 || N < 4 || N % 4 || M > 0x7fffffffL || !ld_ok(ldx, K) || !ld_ok(ldy, N)) return FEAR_TRAIN_ERR_SHAPE;
+    if (gemm_lds_applies(M, K, N)) {      // the head's 256 / 320-channel GEMMs at 16 x 16: LDS-staged, pipelined (fear_train_gemm.h)
+        GemmArgs g{};
+        g.X = x; g.ldx = ldx; g.W = w; g.bias = bias; g.Y = y; g.ldy = ldy; g.M = (int)M; g.K = K; g.N = N;
+        launch_gemm_lds<0, 0, false>(g, static_cast<hipStream_t>(stream), nullptr);
+        LAUNCH_CHECK();
+        return FEAR_TRAIN_OK;
+    }
     PwArgs a{};
     a.X = x; a.ldx = ldx; a.W = w; a.bias = bias; a.Y = y; a.ldy = ldy; a.M = (int)M; a.K = K; a.N = N;
     int nt = 1;
@@ -1428,6 +1437,13 @@ int fear_pw_backward_data(const float* dy, int lddy, const float* w, const float
         return FEAR_TRAIN_ERR_SHAPE;
     // dX[m][k] = sum_n dY[m][n] W[n][k]: a pointwise conv with "input channels" N, "output channels" K and the weight matrix
     // read K-major (W[n][k] row-major IS the K-major layout of that conv)
+    if (gemm_lds_applies(M, N, K)) {
+        GemmArgs g{};
+        g.X = dy; g.ldx = lddy; g.W = w; g.R = add; g.ldr = ldadd; g.Y = dx; g.ldy = lddx; g.M = (int)M; g.K = N; g.N = K;
+        launch_gemm_lds<0, 0, true>(g, static_cast<hipStream_t>(stream), nullptr);
+        LAUNCH_CHECK();
+        return FEAR_TRAIN_OK;
+    }
     PwArgs a{};
     a.X = dy; a.ldx = lddy; a.W = w; a.Y = dx; a.ldy = lddx; a.M = (int)M; a.K = N; a.N = K;
     a.R = add; a.ldr = ldadd;

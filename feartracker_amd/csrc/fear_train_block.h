@@ -284,7 +284,9 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_kernel(DwBwdArgs a) {
         int wq = cq_l;                      // index of this thread's weights in LDS, opaque to the compiler: it would otherwise hoist
         asm volatile("" : "+v"(wq));        // all 25 LDS weight reads out of the tile loop into 100 registers
         // ---- phase 1: dd of the tile's output region -> LDS (zero outside the map / beyond the channels)
-        constexpr int NIDX = OR * OR * SQ, U = 4;
+        // (U loads of each tensor in flight per round: the region is 12.5 float4 per thread and tensor for a 5 x 5 stride-1 tile
+        //  with 32-channel slabs — at U = 4 that was four memory round trips per tile on a kernel whose tiles are short)
+        constexpr int NIDX = OR * OR * SQ, U = (NIDX + 255) / 256 > 8 ? 7 : 4;
         for (int i0 = 0; i0 < NIDX; i0 += 256 * U) {
             f32x4 gv[U], dv[U];
             bool in[U];
@@ -668,6 +670,8 @@ BlockWs block_ws(long rows_in, long rows_out, int cin, int cexp, int cout, int k
     size_t col = fear_train_stats_workspace_bytes(rows, cmax);
     const size_t colr = (size_t)col_blocks(rows) * 2 * cmax * sizeof(double);
     if (colr > col) col = colr;
+    const size_t lds = rows <= 65536 ? (size_t)((rows + 63) / 64) * 2 * cmax * sizeof(double) : 0;      // gemm_lds_kernel: 64-row blocks
+    if (lds > col) col = lds;
     const size_t dwp = (size_t)2048 * 2 * cmax * sizeof(double);           // dw_bwd_kernel's sums: <= 2048 workgroups per slab
     if (dwp > col) col = dwp;
     w.col_bytes = align256(col);
@@ -744,6 +748,15 @@ void launch_dw_fwd_ks(const DwFwdArgs& a, int sq, dim3 grid, hipStream_t s) {
 // Y = act(X) W^T + sums -> vec:  the forward producer of a pointwise unit
 void pw_forward_unit(const float* x, int ldx, const float* in_vec, int in_relu, const float* w, float* y, long M, int K, int N, const float* gamma,
                      const float* beta, float* vec, float* rm, float* rv, double momentum, double eps, double* col, hipStream_t s) {
+    if (gemm_lds_applies(M, K, N)) {      // few row blocks: the LDS-staged, pipelined GEMM (fear_train_gemm.h), same epilogue
+        GemmArgs g{};
+        g.X = x; g.ldx = ldx; g.W = w; g.Y = y; g.ldy = N; g.M = (int)M; g.K = K; g.N = N; g.partial = col;
+        if (in_vec) { g.in.a = in_vec + 2 * K; g.in.b = in_vec + 3 * K; g.in.relu = in_relu; }
+        int blocks = 0;
+        launch_gemm_lds<1, 1, false>(g, s, &blocks);
+        finalize_forward(col, blocks, N, (double)M, gamma, beta, vec, rm, rv, momentum, eps, s);
+        return;
+    }
     PwStatArgs a{};
     a.X = x; a.ldx = ldx; a.W = w; a.Y = y; a.ldy = N; a.M = (int)M; a.K = K; a.N = N;
     if (in_vec) { a.in.a = in_vec + 2 * K; a.in.b = in_vec + 3 * K; a.in.relu = in_relu; }
@@ -893,7 +906,15 @@ int fear_irb_train_backward(const FearIrbBlock* b, const FearIrbSaved* sv, const
     BnbIn bn3{};
     bn3.E = sv->p; bn3.coef = coef3; bn3.lde = cout; bn3.C = cout;
     // g2 = (dp W3) masked by act2(d) > 0, + sums of (g2, dhat)
-    {
+    if (gemm_lds_applies(rows_out, cout, cexp)) {
+        GemmArgs g{};
+        g.X = dout; g.ldx = cout; g.bn = bn3; g.W = b->w_pwl; g.Y = g2; g.ldy = cexp; g.D = sv->d; g.ldd = cexp; g.dvec = sv->vec[1];
+        g.partial = ws.col; g.M = (int)rows_out; g.K = cout; g.N = cexp;
+        int blocks = 0;
+        launch_gemm_lds<2, 2, true>(g, s, &blocks);
+        if ((size_t)blocks * 2 * cexp * sizeof(double) > ws.col_bytes) return FEAR_TRAIN_ERR_WORKSPACE;
+        finalize_backward(ws.col, blocks, cexp, (double)rows_out, b->gamma[1], sv->vec[1], gr->gamma[1], gr->beta[1], coef2, s);
+    } else {
         PwBwdArgs a{};
         a.G = dout; a.ldg = cout; a.bn = bn3; a.W = b->w_pwl; a.Y = g2; a.ldy = cexp; a.D = sv->d; a.ldd = cexp; a.dvec = sv->vec[1];
         a.partial = ws.col; a.M = (int)rows_out; a.Kred = cout; a.Nout = cexp;
@@ -934,7 +955,12 @@ int fear_irb_train_backward(const FearIrbBlock* b, const FearIrbSaved* sv, const
     if (b->expand) {
         BnbIn bn1{};
         bn1.E = sv->e; bn1.coef = coef1; bn1.lde = cexp; bn1.C = cexp;
-        if (dx) {
+        if (dx && gemm_lds_applies(rows_in, cexp, cin)) {
+            GemmArgs g{};
+            g.X = g1; g.ldx = cexp; g.bn = bn1; g.W = b->w_pw; g.R = b->residual ? dout : nullptr; g.ldr = cout; g.Y = dx; g.ldy = cin;
+            g.M = (int)rows_in; g.K = cexp; g.N = cin;
+            launch_gemm_lds<2, 0, true>(g, s, nullptr);
+        } else if (dx) {
             PwBwdArgs a{};
             a.G = g1; a.ldg = cexp; a.bn = bn1; a.W = b->w_pw; a.R = b->residual ? dout : nullptr; a.ldr = cout; a.Y = dx; a.ldy = cin;
             a.M = (int)rows_in; a.Kred = cexp; a.Nout = cin;
@@ -993,7 +1019,11 @@ int fear_pwbn_train_backward(const float* dy, const float* raw, const float* vec
     BnbIn bn{};
     bn.E = raw; bn.coef = ws.coef; bn.lde = N; bn.C = N;
     if (relu) { bn.mask_a = vec + 2 * N; bn.mask_b = vec + 3 * N; }
-    if (dx) {
+    if (dx && gemm_lds_applies(M, N, K)) {
+        GemmArgs g{};
+        g.X = dy; g.ldx = N; g.bn = bn; g.W = w; g.Y = dx; g.ldy = K; g.M = (int)M; g.K = N; g.N = K;
+        launch_gemm_lds<2, 0, true>(g, s, nullptr);
+    } else if (dx) {
         PwBwdArgs a{};
         a.G = dy; a.ldg = N; a.bn = bn; a.W = w; a.Y = dx; a.ldy = K; a.M = (int)M; a.Kred = N; a.Nout = K;
         int nt = 1;

@@ -1,0 +1,263 @@
+// fear_train_gemm.h — LDS-staged, double-buffered fp32 MFMA GEMM of the training step's small-map layers (round 5).
+//
+//     Y[m][n] = sum_k X'[m][k] W'[k][n]        M = pixels of a 16 x 16 / 8 x 8 map of a batch (8 192 ... 65 536 rows), K, N = 16 ... 672
+//
+// The first-generation training GEMMs (pw_mfma_kernel, pw_stat_kernel, pw_bwd_kernel) fetch every MFMA fragment straight from
+// L1 / L2 right in front of the MFMAs that consume it: fine where a launch is thousands of workgroups deep and bandwidth bound (the
+// 128 x 128 ... 32 x 32 maps), but the stride-16 stage and the head are 256 row blocks — one wave per SIMD — and every trip of the
+// k loop there is a memory round trip followed by its MFMAs: 35-55 TFLOP/s of the 157 (profiles/r05_train_kernel_stats.csv before
+// this kernel: the 672 -> 112 projection 178 us for 31 us of MFMAs).  Here a workgroup of four waves owns a (64 MT) x (16 NTW)
+// tile; per k-group of 16 the X tile and the W tile are staged in LDS in fragment order ([k quad][row][4]: a wave's
+// ds_read_b128 of one fragment is 16 consecutive 16-byte words per lane group, conflict free), two buffers, and the global loads of
+// k-group g + 1 are issued BEFORE the MFMAs of group g and committed to the other buffer after them: one barrier per k-group,
+// no load on the critical path.  Weight fragments are read once per workgroup from global memory instead of once per wave, and a
+// K-major weight matrix (the input-gradient GEMMs) is transposed on its way into LDS instead of gathered with four scalar
+// loads per fragment.
+//
+// The fused prologues / epilogues are the first-generation kernels', applied where an element passes through registers anyway:
+//   XT  = 0 plain | 1 activation on load, max(fma(x, a, b), 0) (ActIn) | 2 BatchNorm backward on load (BnbIn)
+//   EPI = 0 (+ bias) (+ R) -> Y | 1 Y + column sums sum(y), sum(y^2) | 2 Y masked by act(D) > 0 + column sums sum(y), sum(y * dhat)
+// Same products in the same k order as those kernels (k ascending, four per MFMA).
+//
+// Included by fear_train.hip inside its anonymous namespace.
+
+struct GemmArgs {
+    const float* X;      // [M][ldx]
+    const float* W;      // WKN ? [K][N] row-major : [N][K] row-major
+    const float* bias;   // EPI 0: [N] or nullptr
+    const float* R;      // EPI 0: optional [M][ldr] added
+    float* Y;            // [M][ldy]
+    ActIn in;            // XT 1
+    BnbIn bn;            // XT 2
+    const float* D;      // EPI 2: [M][ldd] raw tensor behind the ReLU that masks Y
+    const float* dvec;   // EPI 2: [4][N] mean | rstd | a | b of D's BatchNorm
+    double* partial;     // EPI 1, 2: [gridDim.x][2][N]
+    int ldx, ldr, ldy, ldd;
+    int M, K, N;
+    int relu;            // EPI 0: max(., 0) on the way out
+};
+
+template <int MT, int NTW, int XT, int EPI, bool WKN>
+__global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs a) {
+    constexpr int BM = 64 * MT, BN = 16 * NTW;
+    constexpr int XQ = BM * 4;                 // float4s of an X stage
+    constexpr int WQ = BN * 4;                 // float4s of a W stage
+    constexpr int XL = MT;                     // X float4s per thread and stage
+    constexpr int WL = (WQ + 255) / 256;       // W float4s per thread and stage
+    __shared__ f32x4 Xs[2][4][BM];             // [buffer][k quad][row]
+    __shared__ f32x4 Ws[2][4][BN];             // [buffer][k quad][column]
+    __shared__ double red[EPI ? 4 : 1][2][EPI ? BN : 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool xact = XT == 1 && a.in.a != nullptr;
+    const bool bmask = XT == 2 && a.bn.mask_a != nullptr;
+
+    // ---- staging registers: thread t stages k quad t & 3 of rows (t >> 2) + 64 j; the per-channel vectors of the prologue travel
+    //      with the stage (requested with its loads, used when it is committed)
+    f32x4 xr[XL], er[XT == 2 ? XL : 1], wr[WL], pv[XT == 2 ? 6 : (XT == 1 ? 2 : 1)];
+    const int kq = tid & 3, row_t = tid >> 2;
+    bool x_ok[XL];
+#pragma unroll
+    for (int j = 0; j < XL; ++j) x_ok[j] = m0 + row_t + 64 * j < a.M;
+    auto stage_load = [&](int k0) {
+        const int k = k0 + 4 * kq;
+        const bool kok = k < a.K;                        // K is a multiple of 4
+#pragma unroll
+        for (int j = 0; j < XL; ++j) {
+            const bool ok = x_ok[j] && kok;
+            const long off = (long)(m0 + row_t + 64 * j);
+            xr[j] = ok ? *reinterpret_cast<const f32x4*>(a.X + off * a.ldx + k) : zero;
+            if (XT == 2) er[XT == 2 ? j : 0] = ok ? *reinterpret_cast<const f32x4*>(a.bn.E + off * a.bn.lde + k) : zero;
+        }
+        if (XT == 1 && xact && kok) {
+            pv[0] = *reinterpret_cast<const f32x4*>(a.in.a + k);
+            pv[XT == 1 ? 1 : 0] = *reinterpret_cast<const f32x4*>(a.in.b + k);
+        }
+        if (XT == 2 && kok) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pv[XT == 2 ? q : 0] = *reinterpret_cast<const f32x4*>(a.bn.coef + q * a.bn.C + k);
+            if (bmask) {
+                pv[XT == 2 ? 4 : 0] = *reinterpret_cast<const f32x4*>(a.bn.mask_a + k);
+                pv[XT == 2 ? 5 : 0] = *reinterpret_cast<const f32x4*>(a.bn.mask_b + k);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WL; ++j) {
+            const int idx = tid + 256 * j;
+            wr[j] = zero;
+            if (idx < WQ) {
+                if (WKN) {
+                    // W[K][N]: float4 along n of row k0 + kk
+                    const int kk = idx / (BN / 4), n4 = idx - kk * (BN / 4);
+                    const int n = n0 + 4 * n4;
+                    if (k0 + kk < a.K && n < a.N) wr[j] = *reinterpret_cast<const f32x4*>(a.W + (long)(k0 + kk) * a.N + n);      // N is a multiple of 4
+                } else {
+                    const int col = idx >> 2;
+                    if (n0 + col < a.N && kok) wr[j] = *reinterpret_cast<const f32x4*>(a.W + (long)(n0 + col) * a.K + k);      // (idx & 3 == kq)
+                }
+            }
+        }
+    };
+    auto stage_store = [&](int k0, int buf) {
+        const bool kok = k0 + 4 * kq < a.K;
+#pragma unroll
+        for (int j = 0; j < XL; ++j) {
+            f32x4 v = xr[j];
+            if (x_ok[j] && kok) {
+                if (XT == 1 && xact) {
+                    v = act4(v, pv[0], pv[XT == 1 ? 1 : 0], a.in.relu != 0);
+                } else if (XT == 2) {
+                    const f32x4 e = er[XT == 2 ? j : 0];
+                    if (bmask) v = relu_mask4(v, e, pv[XT == 2 ? 4 : 0], pv[XT == 2 ? 5 : 0]);
+                    v = bnb4(v, e, pv[0], pv[XT == 2 ? 1 : 0], pv[XT == 2 ? 2 : 0], pv[XT == 2 ? 3 : 0]);
+                }
+            }
+            Xs[buf][kq][row_t + 64 * j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < WL; ++j) {
+            const int idx = tid + 256 * j;
+            if (idx < WQ) {
+                if (WKN) {
+                    const int kk = idx / (BN / 4), n4 = idx - kk * (BN / 4);
+                    float* dst = reinterpret_cast<float*>(&Ws[buf][kk >> 2][4 * n4]) + (kk & 3);      // column 4 n4 + c, component kk & 3
+                    dst[0] = wr[j].x; dst[4] = wr[j].y; dst[8] = wr[j].z; dst[12] = wr[j].w;
+                } else {
+                    Ws[buf][kq][idx >> 2] = wr[j];
+                }
+            }
+        }
+    };
+
+    f32x4 acc[MT][NTW];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = zero;
+
+    const int nk = (a.K + 15) >> 4;
+    stage_load(0);
+    stage_store(0, 0);
+    __syncthreads();
+    for (int kg = 0; kg < nk; ++kg) {
+        const int buf = kg & 1;
+        if (kg + 1 < nk) stage_load((kg + 1) * 16);
+        f32x4 xf[MT], wf[NTW];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) xf[mt] = Xs[buf][lk][wave * 16 * MT + mt * 16 + li];
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) wf[nt] = Ws[buf][lk][nt * 16 + li];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][i], xf[mt][i], acc[mt][nt], 0, 0, 0);
+        if (kg + 1 < nk) stage_store((kg + 1) * 16, buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds columns n0 + nt * 16 + 4 lk + {0..3} of rows m0 + wave * 16 MT + mt * 16 + li
+    const int mw = m0 + wave * 16 * MT;
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int n = n0 + nt * 16 + lk * 4;
+        const bool nok = n < a.N;
+        if (EPI == 0) {
+            if (!nok) continue;
+            f32x4 b4 = zero;
+            if (a.bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const long m = mw + mt * 16 + li;
+                if (m >= a.M) continue;
+                f32x4 v = acc[mt][nt] + b4;
+                if (a.R) v += *reinterpret_cast<const f32x4*>(a.R + m * a.ldr + n);
+                if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = v;
+            }
+        } else {
+            f32x4 dmu = zero, drs = zero, da = zero, db = zero;
+            if (EPI == 2 && nok) {
+                dmu = *reinterpret_cast<const f32x4*>(a.dvec + n); drs = *reinterpret_cast<const f32x4*>(a.dvec + a.N + n);
+                da = *reinterpret_cast<const f32x4*>(a.dvec + 2 * a.N + n); db = *reinterpret_cast<const f32x4*>(a.dvec + 3 * a.N + n);
+            }
+            f32x4 s1 = zero, s2 = zero;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const long m = mw + mt * 16 + li;
+                if (m >= a.M || !nok) continue;
+                f32x4 v = acc[mt][nt];
+                if (EPI == 2) {
+                    const f32x4 dv = *reinterpret_cast<const f32x4*>(a.D + m * a.ldd + n);
+                    v = relu_mask4(v, dv, da, db);
+                    s2 += v * ((dv - dmu) * drs);
+                } else {
+                    s2 += v * v;
+                }
+                s1 += v;
+                *reinterpret_cast<f32x4*>(a.Y + m * a.ldy + n) = v;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float t1 = row16_sum(s1[c]), t2 = row16_sum(s2[c]);
+                if (li == 0) {
+                    red[EPI ? wave : 0][0][EPI ? nt * 16 + lk * 4 + c : 0] = (double)t1;
+                    red[EPI ? wave : 0][1][EPI ? nt * 16 + lk * 4 + c : 0] = (double)t2;
+                }
+            }
+        }
+    }
+    if (EPI) {
+        __syncthreads();
+        for (int i = tid; i < 2 * BN; i += 256) {
+            const int which = i / BN, col = i - which * BN;
+            const int n = n0 + col;
+            if (n < a.N)
+                a.partial[((long)blockIdx.x * 2 + which) * a.N + n] =
+                    ((red[0][which][EPI ? col : 0] + red[EPI ? 1 : 0][which][EPI ? col : 0]) + red[EPI ? 2 : 0][which][EPI ? col : 0]) +
+                    red[EPI ? 3 : 0][which][EPI ? col : 0];      // fixed order
+        }
+    }
+}
+
+// which launches run on the LDS-staged kernel: few row blocks (the first-generation kernels are bandwidth bound and fine above
+// that) and a reduction long enough for the pipeline to matter
+bool gemm_lds_applies(long M, int K, int N) { return M <= 65536 && K >= 32 && N >= 16; }
+
+// column tiles per workgroup: the widest of {8, 7, 6, 4} that divides the tile count, else 8 with a ragged last column block
+int gemm_lds_ntw(int n_tiles) {
+    for (int c : {8, 7, 6, 4})
+        if (n_tiles % c == 0) return c;
+    return n_tiles < 4 ? 4 : 8;
+}
+
+template <int XT, int EPI, bool WKN>
+int launch_gemm_lds(const GemmArgs& a, hipStream_t s, int* row_blocks) {
+    const int n_tiles = (a.N + 15) / 16;
+    const int ntw = gemm_lds_ntw(n_tiles);
+    const int col_blocks_ = (n_tiles + ntw - 1) / ntw;
+    // 128-row tiles when that still gives every CU two workgroups, else 64-row tiles
+    const bool mt2 = (long)((a.M + 127) / 128) * col_blocks_ >= 512;
+    const int bm = mt2 ? 128 : 64;
+    const dim3 grid((unsigned)((a.M + bm - 1) / bm), (unsigned)col_blocks_);
+    if (row_blocks) *row_blocks = (int)grid.x;
+#define FEAR_GEMM_CASE(NTW_)                                                                                          \
+    case NTW_:                                                                                                        \
+        if (mt2) hipLaunchKernelGGL((gemm_lds_kernel<2, NTW_, XT, EPI, WKN>), grid, dim3(256), 0, s, a);              \
+        else hipLaunchKernelGGL((gemm_lds_kernel<1, NTW_, XT, EPI, WKN>), grid, dim3(256), 0, s, a);                  \
+        break;
+    switch (ntw) {
+        FEAR_GEMM_CASE(4)
+        FEAR_GEMM_CASE(6)
+        FEAR_GEMM_CASE(7)
+        default:
+        FEAR_GEMM_CASE(8)
+    }
+#undef FEAR_GEMM_CASE
+    return 0;
+}

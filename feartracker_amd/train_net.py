@@ -196,6 +196,7 @@ class FEARNetTrainHIP:
         self._gcur = None
         self.head._galloc = lambda name, *shape: self._gslot(self._gcur, "connect_model." + name, *shape)
         self._irb = None                                       # block mode: ctypes descriptors, built on first use
+        self.phase_marks = None                                # set to [] to have `step` record events at its phase boundaries
 
     def _trunk_layers(self) -> List["_ConvBN"]:
         layers = [self.stem]
@@ -633,6 +634,14 @@ class FEARNetTrainHIP:
                 self._side = torch.cuda.Stream(device=dev)
                 self.head.side_stream = self._side         # the head runs its two towers on the two streams as well
             side = self._side if self.two_streams else None
+            marks = [] if self.phase_marks is not None else None      # (tools/train_prof.py: where the step's time goes)
+
+            def mark(name):
+                if marks is not None:
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record(main)
+                    marks.append((name, e))
+            mark("start")
             if side is not None and self.mode == "block":
                 # both trunk passes at once: the template pass (a quarter of the work, launch-bound small maps) on the side stream
                 # under the search pass's bandwidth-bound kernels.  Both update the shared trunk's BatchNorm running statistics,
@@ -659,6 +668,7 @@ class FEARNetTrainHIP:
                 # template first — torch's two forward calls — and that read-modify-write must not race)
                 zrows, zctx = ffwd(t)                                    # template first, like FEARNet.forward
                 xrows, xctx = ffwd(s)
+            mark("trunk forward (search pass; template pass beside it)")
             z = self._new(B, 256, 8, 8)
             x = self._new(B, 256, 16, 16)
             self._check(self.lib.fear_nhwc_to_nchw(_p(zrows), _p(z), B, 256, 64, 256, 0, st))
@@ -666,6 +676,7 @@ class FEARNetTrainHIP:
             out = self.head.step(x, z, gt_reg, gt_cls, gt_weight)
             grads = GradDict({"connect_model." + k: v for k, v in out["grads"].items()})
             grads.flat = gflat[0]
+            mark("head forward + loss + backward")
             dx = self._new(B * 256, 256)
             dz = self._new(B * 64, 256)
             self._check(self.lib.fear_nchw_to_nhwc(_p(out["grad_search"]), _p(dx), B, 256, 256, 256, 0, st))
@@ -696,6 +707,9 @@ class FEARNetTrainHIP:
                     grads[L.conv_key] = gw.reshape(L.cout, L.cin, 1, 1)
                 grads[L.bn_key + ".weight"] = self._gslot(gflat[0], L.bn_key + ".weight", L.cout)
                 grads[L.bn_key + ".bias"] = self._gslot(gflat[0], L.bn_key + ".bias", L.cout)
+            mark("trunk backward (search pass; template pass beside it)")
+            if marks is not None:
+                self.phase_marks = marks
             self.last_contexts = (zctx, xctx)          # saved activations of the two trunk passes (tests read the ReLU patterns)
         return {"loss_cls": out["loss_cls"], "loss_reg": out["loss_reg"], "bbox": out["bbox"], "cls": out["cls"], "grads": grads}
 

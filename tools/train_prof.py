@@ -36,3 +36,10 @@ t_issue = time.perf_counter() - t0
 torch.cuda.synchronize()
 print(f"mode={mode} two_streams={int(two)}: {1e3 * (time.perf_counter() - t0) / steps:.2f} ms/step wall, {e0.elapsed_time(e1) / steps:.2f} ms/step on the stream, "
       f"host issue {1e3 * t_issue / steps:.2f} ms/step, batch {batch}, peak {torch.cuda.max_memory_allocated() / 2**30:.1f} GB", file=sys.stderr)
+# where the time goes: events at the phase boundaries of one more step (main stream)
+net.phase_marks = []
+net.step(tmpl, srch, gt_reg, gt_cls, gt_w)
+torch.cuda.synchronize()
+marks = net.phase_marks
+for (n0, a), (n1, b) in zip(marks, marks[1:]):
+    print(f"  {a.elapsed_time(b):7.2f} ms  {n1}", file=sys.stderr)
