@@ -1467,6 +1467,15 @@ static int wgrad_impl(const float* dy, int lddy, long dy_crop_stride, const floa
     }
     a.dy_crop_stride = dy_crop_stride; a.x_crop_stride = x_crop_stride;
     a.n_tiles = (N + 63) / 64; a.k_tiles = (K + 63) / 64;
+    // 128 x 128 tiles with the rows staged through LDS (wgrad_lds_kernel, fear_train_gemm.h) where both sides are wide enough for
+    // the sharing to matter and the launch is one problem, not a batch of per-crop ones
+#ifndef FEAR_WGRAD_LDS
+#define FEAR_WGRAD_LDS 1
+#endif
+    // (launches of a few thousand rows are a handful of stages per workgroup: the staged kernel's prologue and its two
+    //  barriers-per-stage floor — 29 us measured — lose against the 14 us of the register-only kernel there)
+    const bool lds_tile = FEAR_WGRAD_LDS && crops == 1 && K > 32 && N >= 32 && M >= 16384;
+    if (lds_tile) { a.n_tiles = (N + 127) / 128; a.k_tiles = (K + 127) / 128; }
     a.rows_per_slice = crops > 1 ? M : wgrad_rows_per_slice(M);
     if (crops == 1) {
         // few output tiles (the 16 x 16 maps' layers: 2-22 tiles x 8-32 slices of 1 024 rows) leave most of the 256 CUs idle while
@@ -1498,6 +1507,7 @@ static int wgrad_impl(const float* dy, int lddy, long dy_crop_stride, const floa
     }
     if (FEAR_WGRAD_SMALLK && K <= 16) hipLaunchKernelGGL(pw_wgrad_smallk_kernel<1>, dim3(a.n_tiles, slices, crops), dim3(256), 0, s, a);
     else if (FEAR_WGRAD_SMALLK && K <= 32) hipLaunchKernelGGL(pw_wgrad_smallk_kernel<2>, dim3(a.n_tiles, slices, crops), dim3(256), 0, s, a);
+    else if (lds_tile) hipLaunchKernelGGL(wgrad_lds_kernel<0>, dim3(a.n_tiles * a.k_tiles, slices), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(pw_wgrad_kernel, dim3(a.n_tiles * a.k_tiles, slices, crops), dim3(256), 0, s, a);
     if (slices > 1) {
         const long count = (long)crops * N * K;

@@ -261,3 +261,116 @@ int launch_gemm_lds(const GemmArgs& a, hipStream_t s, int* row_blocks) {
 #undef FEAR_GEMM_CASE
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient dW[n][k] = sum_m dY'[m][n] X'[m][k] on a 128 (n) x 128 (k) workgroup tile, rows staged through LDS.
+// pw_wgrad_kernel's workgroup owns a 64 x 64 tile and its four waves split the ROWS: every dY element is fetched once per 64
+// columns of k and every X element once per 64 of n — for dW[672][112] over 32 768 rows that is 513 MB through L2 per call (with
+// the BatchNorm-backward operand), 5 TB/s at the 100 us the call takes: the kernel is bound by L2, not by its 31 us of MFMAs.
+// Here the four waves split the TILE (2 x 2 sub-tiles of 64 x 64) and share the rows: a stage of 16 rows of dY (128 channels) and
+// X (128 channels) is loaded once per workgroup into LDS — half the L2 traffic per output element twice over — double buffered
+// like gemm_lds_kernel (next stage's loads in flight under this stage's 64 MFMAs per wave, one barrier per stage), and no
+// cross-wave reduction at the end: every wave owns its sub-tile.  Fragments by pw_wgrad_kernel's trick: lane (li, lk) reads the
+// float4s dY[row 4 s + lk][64 wn + 4 li ..] and X[row 4 s + lk][64 wk + 4 li ..]; MFMA (p, q) takes component p of the first as A and
+// q of the second as B.  Operand prologues as in WgradArgs (activation on X, BatchNorm backward on dY).  One rank, crops == 1.
+template <int DUMMY>
+__global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(WgradArgs a) {
+    constexpr int R = 16, TC = 128;
+    __shared__ f32x4 Ds[2][R][TC / 4];
+    __shared__ f32x4 Xs[2][R][TC / 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int nt = blockIdx.x / a.k_tiles, kt = blockIdx.x % a.k_tiles;        // 128-wide tiles here
+    const int slice = blockIdx.y;
+    const int n0 = nt * TC, k0 = kt * TC;
+    const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // staging: thread t stages channel quad t & 31 of rows (t >> 5) and (t >> 5) + 8
+    const int c4 = tid & 31, r_t = tid >> 5;
+    const int nch = n0 + 4 * c4, kch = k0 + 4 * c4;
+    const bool nv = nch < a.N, kv = kch < a.K;
+    const bool act = a.act_a != nullptr, bnb = a.bn.E != nullptr, bmask = a.bn.mask_a != nullptr;
+    f32x4 ia = zero, ib = zero, cA = zero, cs1 = zero, cmu = zero, cQ = zero, cma = zero, cmb = zero;
+    if (act && kv) { ia = *reinterpret_cast<const f32x4*>(a.act_a + kch); ib = *reinterpret_cast<const f32x4*>(a.act_b + kch); }
+    if (bnb && nv) {
+        cA = *reinterpret_cast<const f32x4*>(a.bn.coef + nch); cs1 = *reinterpret_cast<const f32x4*>(a.bn.coef + a.bn.C + nch);
+        cmu = *reinterpret_cast<const f32x4*>(a.bn.coef + 2 * a.bn.C + nch); cQ = *reinterpret_cast<const f32x4*>(a.bn.coef + 3 * a.bn.C + nch);
+        if (bmask) { cma = *reinterpret_cast<const f32x4*>(a.bn.mask_a + nch); cmb = *reinterpret_cast<const f32x4*>(a.bn.mask_b + nch); }
+    }
+    const long m0 = (long)slice * a.rows_per_slice;
+    const long m1 = m0 + a.rows_per_slice < a.M ? m0 + a.rows_per_slice : a.M;
+    // two register sets: the loads of stage s + 2 are issued before the MFMAs of stage s and committed to LDS after those of
+    // stage s + 1 — a stage is 64 MFMAs per wave (0.85 us), less than a memory round trip, so a prefetch distance of one stage
+    // left every stage waiting for its successor's data (33 us floor on launches of 16 stages)
+    f32x4 dr[2][2], er[2][2], xr[2][2];
+    auto stage_load = [&](long m, int set) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long r = m + r_t + 8 * j;
+            const bool rv = r < m1;
+            dr[set][j] = rv && nv ? *reinterpret_cast<const f32x4*>(a.dY + r * a.lddy + nch) : zero;
+            er[set][j] = bnb && rv && nv ? *reinterpret_cast<const f32x4*>(a.bn.E + r * a.bn.lde + nch) : zero;
+            xr[set][j] = rv && kv ? *reinterpret_cast<const f32x4*>(a.X + r * a.ldx + kch) : zero;
+        }
+    };
+    auto stage_store = [&](long m, int buf, int set) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool rv = m + r_t + 8 * j < m1;
+            f32x4 d = dr[set][j], x = xr[set][j];
+            if (bnb && rv && nv) {
+                if (bmask) d = relu_mask4(d, er[set][j], cma, cmb);
+                d = bnb4(d, er[set][j], cA, cs1, cmu, cQ);
+            }
+            if (act && rv && kv) x = act4(x, ia, ib, a.act_relu != 0);
+            Ds[buf][r_t + 8 * j][c4] = d;
+            Xs[buf][r_t + 8 * j][c4] = x;
+        }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[p][q] = zero;
+    // a wave whose 64 x 64 sub-tile lies outside dW altogether (the ragged last tiles) only takes part in the staging
+    const bool live = n0 + 64 * wn < a.N && k0 + 64 * wk < a.K;
+    const long nst = (m1 - m0 + R - 1) / R;
+    if (nst > 0) {
+        stage_load(m0, 0);
+        if (nst > 1) stage_load(m0 + R, 1);
+        stage_store(m0, 0, 0);
+    }
+    __syncthreads();
+    auto step = [&](long st, int set_cur) {      // set_cur = st & 1, a compile-time constant at both call sites
+        const int buf = set_cur;
+        if (st + 2 < nst) stage_load(m0 + (st + 2) * R, set_cur);            // (stage st left this register set one step ago)
+        if (live) {
+#pragma unroll
+            for (int s4 = 0; s4 < R / 4; ++s4) {
+                const f32x4 dv = Ds[buf][4 * s4 + lk][16 * wn + li];
+                const f32x4 xv = Xs[buf][4 * s4 + lk][16 * wk + li];
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[p], xv[q], acc[p][q], 0, 0, 0);
+            }
+        }
+        if (st + 1 < nst) stage_store(m0 + (st + 1) * R, buf ^ 1, set_cur ^ 1);
+        __syncthreads();
+    };
+    for (long st = 0; st < nst; st += 2) {
+        step(st, 0);
+        if (st + 1 < nst) step(st + 1, 1);
+    }
+    if (!live) return;
+    // acc[p][q] lane (li, lk), component r  =  dW[n0 + 64 wn + 16 lk + 4 r + p][k0 + 64 wk + 4 li + q]
+    float* P = a.P + (long)slice * a.N * a.K;
+    const int kcol = k0 + 64 * wk + 4 * li;
+    if (kcol >= a.K) return;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int nn = n0 + 64 * wn + lk * 16 + r * 4 + p;
+            if (nn < a.N) *reinterpret_cast<f32x4*>(P + (long)nn * a.K + kcol) = (f32x4){acc[p][0][r], acc[p][1][r], acc[p][2][r], acc[p][3][r]};
+        }
+}
