@@ -226,9 +226,15 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_kernel(DwBwdArgs a) {
                                                        // the LDS banks, so the lanes of a ds_read_b128 group (consecutive rows) differ
     constexpr int NT = (KS + S - 1) / S;               // taps per dimension a pixel meets
     constexpr int PL = 256 / SQ;                       // pixel lanes
-    constexpr int NCLS = S * S;                        // parity classes
     constexpr bool WREG = NT * NT <= 9;                // tap weights in registers (else in LDS)
     constexpr int T = KS == 5 ? 2 : 4;                 // stride 1: a thread takes runs of T pixels along x (register window over the taps)
+    // 5 x 5 stride 1: TWO lanes share a run — lane half h takes the tap rows ky = KH h ... KH h + KH - 1 (3 + 2) — so that a lane
+    // carries 15 tap-gradient accumulators instead of 25 (60 registers instead of 100: 170 instead of 256 per lane, three
+    // workgroups per CU instead of two at one wave per SIMD each); the halves of the input gradient meet through one shuffle
+    constexpr bool HS = S == 1 && KS == 5;
+    constexpr int KH = (KS + 1) / 2;
+    constexpr int AJ = HS ? KH : NT;                   // accumulator rows per lane
+    constexpr int NCLS = HS ? 2 : S * S;               // lane classes whose accumulator slots mean different taps (halves / parities)
     constexpr int SMEM = OR * PITCH > 512 ? OR * PITCH : 512;
     __shared__ f32x4 tile[SMEM];                        // the dd region; after the last tile, the reduction buffer
     __shared__ f32x4 wl[WREG ? 1 : KK * SQ];
@@ -265,9 +271,9 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_kernel(DwBwdArgs a) {
     } else {
         for (int t = pl; t < KK; t += PL) wl[t * SQ + cq_l] = cv ? *reinterpret_cast<const f32x4*>(a.Wt + (long)t * a.C + c) : zero;
     }
-    f32x4 acc[NT][NT];
+    f32x4 acc[AJ][NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int j = 0; j < AJ; ++j)
 #pragma unroll
         for (int i = 0; i < NT; ++i) acc[j][i] = zero;
     f64x4 S1 = (f64x4){0.0, 0.0, 0.0, 0.0}, S2 = S1;
@@ -286,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_kernel(DwBwdArgs a) {
         // ---- phase 1: dd of the tile's output region -> LDS (zero outside the map / beyond the channels)
         // (U loads of each tensor in flight per round: the region is 12.5 float4 per thread and tensor for a 5 x 5 stride-1 tile
         //  with 32-channel slabs — at U = 4 that was four memory round trips per tile on a kernel whose tiles are short)
-        constexpr int NIDX = OR * OR * SQ, U = (NIDX + 255) / 256 > 8 ? 7 : 4;
+        constexpr int NIDX = OR * OR * SQ, U = (!HS && (NIDX + 255) / 256 > 8) ? 7 : 4;
         for (int i0 = 0; i0 < NIDX; i0 += 256 * U) {
             f32x4 gv[U], dv[U];
             bool in[U];
@@ -311,7 +317,80 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_kernel(DwBwdArgs a) {
         }
         __syncthreads();
         // ---- phase 2
-        if (S == 1) {
+        if (HS) {
+            const int half = pl & 1, prl = pl >> 1;
+            constexpr int RPS = (PL / 2) / (TS / T);       // rows per sweep
+#pragma unroll 1
+            for (int sw = 0; sw < TS / RPS; ++sw) {
+                const int iy_l = sw * RPS + prl % RPS, ix_l = (prl / RPS) * T;
+                const int iy = iy0 + iy_l;
+                const long prow = ((long)b * a.H + iy) * a.W + ix0 + ix_l;
+                bool pin[T];
+                f32x4 e4[T], av[T], de[T];
+#pragma unroll
+                for (int i = 0; i < T; ++i) {
+                    pin[i] = cv && iy < a.H && ix0 + ix_l + i < a.W;
+                    e4[i] = pin[i] ? *reinterpret_cast<const f32x4*>(a.E + (prow + i) * a.lde + c) : zero;
+                }
+#pragma unroll
+                for (int i = 0; i < T; ++i) {
+                    av[i] = e4[i];
+                    if (BN1) {
+                        const f32x4 pre = act4(e4[i], a1, b1, false);
+                        av[i] = (f32x4){fmaxf(pre.x, 0.f), fmaxf(pre.y, 0.f), fmaxf(pre.z, 0.f), fmaxf(pre.w, 0.f)};
+                    }
+                    if (!pin[i]) av[i] = zero;
+                    de[i] = zero;
+                }
+                const int ky_first = half * KH;
+                int lb = (iy_l + 2 * P - ky_first) * PITCH + ix_l * SQ + cq_l;
+#pragma unroll
+                for (int jj = 0; jj < KH; ++jj) {
+                    const bool kyv = ky_first + jj < KS;           // (the second half's last row does not exist)
+                    const int base = kyv ? lb - jj * PITCH : lb;
+                    f32x4 win[T + KS - 1];
+#pragma unroll
+                    for (int j = 0; j < T + KS - 1; ++j) {
+                        win[j] = tile[base + j * SQ];
+                        if (!kyv) win[j] = zero;
+                    }
+                    const int wrow = (kyv ? ky_first + jj : 0) * KS;
+#pragma unroll
+                    for (int kx = 0; kx < KS; ++kx) {
+                        const f32x4 w = wl[(wrow + kx) * SQ + wq];
+#pragma unroll
+                        for (int i = 0; i < T; ++i) {
+                            const f32x4 v = win[i + KS - 1 - kx];
+                            de[i] += v * w;
+                            acc[jj][kx] += v * av[i];
+                        }
+                    }
+                    asm volatile("" : "+v"(lb), "+v"(wq) : "v"(de[0]), "v"(de[T - 1]), "v"(acc[jj][0]), "v"(acc[jj][1]), "v"(acc[jj][2]), "v"(acc[jj][KS - 2]), "v"(acc[jj][KS - 1]));
+                }
+#pragma unroll
+                for (int i = 0; i < T; ++i) {                      // the other half's tap rows (its lane is SQ lanes away)
+                    de[i].x += __shfl_xor(de[i].x, SQ, 64); de[i].y += __shfl_xor(de[i].y, SQ, 64);
+                    de[i].z += __shfl_xor(de[i].z, SQ, 64); de[i].w += __shfl_xor(de[i].w, SQ, 64);
+                }
+                if (half == 0) {
+#pragma unroll
+                    for (int i = 0; i < T; ++i) {
+                        if (!pin[i]) continue;
+                        if (BN1) {
+                            const f32x4 pre = act4(e4[i], a1, b1, false);
+                            const f32x4 g1 = (f32x4){pre.x > 0.f ? de[i].x : 0.f, pre.y > 0.f ? de[i].y : 0.f, pre.z > 0.f ? de[i].z : 0.f, pre.w > 0.f ? de[i].w : 0.f};
+                            *reinterpret_cast<f32x4*>(a.Y + (prow + i) * a.ldy + c) = g1;
+                            s1f += g1;
+                            s2f += g1 * ((e4[i] - mu1) * rs1);
+                        } else {
+                            f32x4 r4 = zero;
+                            if (a.R) r4 = *reinterpret_cast<const f32x4*>(a.R + (prow + i) * a.ldr + c);
+                            *reinterpret_cast<f32x4*>(a.Y + (prow + i) * a.ldy + c) = de[i] + r4;
+                        }
+                    }
+                }
+            }
+        } else if (S == 1) {
             // runs of T pixels along x: per tap row a window of T + KS - 1 region columns is read once and serves all T x KS
             // (pixel, tap) pairs; consecutive pixel lanes are consecutive rows
             constexpr int RPS = PL / (TS / T);             // rows per sweep
@@ -351,12 +430,12 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_kernel(DwBwdArgs a) {
                         for (int i = 0; i < T; ++i) {
                             const f32x4 v = win[i + KS - 1 - kx];
                             de[i] += v * w;
-                            acc[ky][kx] += v * av[i];
+                            acc[HS ? 0 : ky][kx] += v * av[i];
                         }
                     }
                     // one tap row's window in flight: hipcc hoists all KS of them (100+ registers, spills at two workgroups per
                     // CU) and neither sched_barrier nor the loop structure stops it; a data dependence of the next row's address does
-                    if (KS == 5) asm volatile("" : "+v"(lb), "+v"(wq) : "v"(de[0]), "v"(de[T - 1]), "v"(acc[ky][0]), "v"(acc[ky][1]), "v"(acc[ky][2]), "v"(acc[ky][KS - 2]), "v"(acc[ky][KS - 1]));
+                    if (KS == 5) asm volatile("" : "+v"(lb), "+v"(wq) : "v"(de[0]), "v"(de[T - 1]), "v"(acc[HS ? 0 : ky][0]), "v"(acc[HS ? 0 : ky][1]), "v"(acc[HS ? 0 : ky][2]), "v"(acc[HS ? 0 : ky][KS - 2]), "v"(acc[HS ? 0 : ky][KS - 1]));
                     else asm volatile("" : "+v"(lb), "+v"(wq) : "v"(de[0]), "v"(de[1]), "v"(de[T - 2]), "v"(de[T - 1]), "v"(acc[ky][0]), "v"(acc[ky][1]), "v"(acc[ky][KS - 1]));
                 }
 #pragma unroll
@@ -430,7 +509,7 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_kernel(DwBwdArgs a) {
     }
     // ---- the workgroup's partial tap gradients: slot (j, i) of the threads of one class and channel quad, added in lane order
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int j = 0; j < AJ; ++j)
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             __syncthreads();
@@ -441,7 +520,7 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_kernel(DwBwdArgs a) {
                 f32x4 sum = zero;
                 for (int g = 0; g < PL / NCLS; ++g) sum += red[(g * NCLS + rc) * SQ + q];
                 const int rpy = S == 1 ? 0 : (rc >> 1), rpx = S == 1 ? 0 : (rc & 1);
-                const int ky = (rpy + P) % S + S * j, kx = (rpx + P) % S + S * i;
+                const int ky = HS ? rc * KH + j : (rpy + P) % S + S * j, kx = (rpx + P) % S + S * i;
                 const int cc = (slab * SQ + q) * 4;
                 if (ky < KS && kx < KS && cc < a.C)
                     *reinterpret_cast<f32x4*>(a.ptaps + ((long)wslot * KK + ky * KS + kx) * a.C + cc) = sum;
