@@ -883,6 +883,26 @@ void launch_dw_bwd_ks(const DwBwdArgs& a, int sq, bool bn1, dim3 grid, hipStream
     }
 }
 
+// Events that order the weight-gradient stream behind the kernels that produce its operands: a ring, created on first use and
+// never destroyed (a wait refers to the record that preceded it, so re-recording an event later does not disturb waits already
+// enqueued; 512 is far more than a step has in flight)
+hipEvent_t ring_event() {
+    static hipEvent_t ring[512];
+    static unsigned pos = 0;
+    hipEvent_t& e = ring[pos++ % 512];
+    if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    return e;
+}
+// `to` waits for everything issued on `from` so far
+bool stream_follow(hipStream_t to, hipStream_t from) {
+    hipEvent_t e = ring_event();
+    return e && hipEventRecord(e, from) == hipSuccess && hipStreamWaitEvent(to, e, 0) == hipSuccess;
+}
+
+int irb_cmax(const FearIrbBlock* b) {
+    return b->cexp > b->cout ? (b->cexp > b->cin ? b->cexp : b->cin) : (b->cout > b->cin ? b->cout : b->cin);
+}
+
 bool irb_shape_ok(const FearIrbBlock* b, int B, int H, int W) {
     if (B < 1 || H < 1 || W < 1) return false;
     if (b->cin < 4 || b->cin % 4 || b->cexp < 4 || b->cexp % 4 || b->cout < 4 || b->cout % 4 || b->cexp > 1024 || b->cout > 1024) return false;
@@ -906,7 +926,9 @@ size_t fear_irb_workspace_bytes(const FearIrbBlock* b, int B, int H, int W) {
 size_t fear_irb_scratch_floats(const FearIrbBlock* b, int B, int H, int W) {
     if (!b || !irb_shape_ok(b, B, H, W)) return 0;
     const long rows_in = (long)B * H * W, rows_out = rows_in / (b->stride * b->stride);
-    return (size_t)rows_out * b->cexp + (b->expand ? (size_t)rows_in * b->cexp : 0);
+    // g2 | g1 | the three BatchNorms' backward coefficient vectors (3 x [4][cmax]; they must outlive the call when the weight
+    // gradients run on their own stream, so they do not live in the shared workspace)
+    return (size_t)rows_out * b->cexp + (b->expand ? (size_t)rows_in * b->cexp : 0) + (size_t)12 * irb_cmax(b);
 }
 
 int fear_irb_train_forward(const FearIrbBlock* b, const FearIrbSaved* sv, const float* x, float* out, int B, int H, int W, double momentum,
@@ -961,7 +983,7 @@ int fear_irb_train_forward(const FearIrbBlock* b, const FearIrbSaved* sv, const 
 }
 
 int fear_irb_train_backward(const FearIrbBlock* b, const FearIrbSaved* sv, const FearIrbGrads* gr, const float* x, const float* dout, float* dx,
-                            float* scratch, int B, int H, int W, float* workspace, size_t ws_bytes, void* stream) {
+                            float* scratch, int B, int H, int W, float* workspace, size_t ws_bytes, void* stream, void* wgrad_stream) {
     if (!b || !sv || !gr || !x || !dout || !scratch || !workspace || !sv->d || !sv->p || !sv->vec[1] || !sv->vec[2] || !gr->w_dw || !gr->w_pwl)
         return FEAR_TRAIN_ERR_NULL;
     if (b->expand && (!sv->e || !sv->vec[0] || !gr->w_pw)) return FEAR_TRAIN_ERR_NULL;
@@ -974,12 +996,16 @@ int fear_irb_train_backward(const FearIrbBlock* b, const FearIrbSaved* sv, const
     if (ws_bytes < ws.total) return FEAR_TRAIN_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int Ho = H / b->stride, Wo = W / b->stride, cexp = b->cexp, cout = b->cout, cin = b->cin;
-    const int cmax = cexp > cout ? (cexp > cin ? cexp : cin) : (cout > cin ? cout : cin);
-    float* coef1 = ws.coef;
-    float* coef2 = ws.coef + 4 * cmax;
-    float* coef3 = ws.coef + 8 * cmax;
+    const int cmax = irb_cmax(b);
     float* g2 = scratch;
     float* g1 = scratch + (size_t)rows_out * cexp;
+    float* coef1 = g1 + (b->expand ? (size_t)rows_in * cexp : 0);
+    float* coef2 = coef1 + 4 * cmax;
+    float* coef3 = coef1 + 8 * cmax;
+    // the two pointwise weight gradients are off the chain that leads to dx: with a `wgrad_stream` they are issued there, behind
+    // an event that follows the kernels producing their operands, and overlap the rest of this block's (and the next blocks')
+    // backward — every kernel of a 16 x 16 map is a few hundred workgroups and leaves most of the device idle on its own
+    hipStream_t sw = wgrad_stream ? static_cast<hipStream_t>(wgrad_stream) : s;
     // BN3 (no ReLU): sums over (dout, p)
     bn_backward_sums(dout, cout, sv->p, cout, sv->vec[2], 0, b->gamma[2], gr->gamma[2], gr->beta[2], coef3, rows_out, cout, ws.col, s);
     BnbIn bn3{};
@@ -1005,7 +1031,8 @@ int fear_irb_train_backward(const FearIrbBlock* b, const FearIrbSaved* sv, const
     }
     // dW3 = dp^T act2(d)
     {
-        const int rc = wgrad_impl(dout, cout, 0, sv->d, cexp, 0, gr->w_pwl, ws.wg, ws.wg_bytes, rows_out, cexp, cout, 1, s, sv->vec[1] + 2 * cexp,
+        if (sw != s && !stream_follow(sw, s)) return FEAR_TRAIN_ERR_HIP;      // coef3 exists
+        const int rc = wgrad_impl(dout, cout, 0, sv->d, cexp, 0, gr->w_pwl, ws.wg, ws.wg_bytes, rows_out, cexp, cout, 1, sw, sv->vec[1] + 2 * cexp,
                                   sv->vec[1] + 3 * cexp, 1, &bn3);
         if (rc != FEAR_TRAIN_OK) return rc;
     }
@@ -1034,6 +1061,9 @@ int fear_irb_train_backward(const FearIrbBlock* b, const FearIrbSaved* sv, const
     if (b->expand) {
         BnbIn bn1{};
         bn1.E = sv->e; bn1.coef = coef1; bn1.lde = cexp; bn1.C = cexp;
+        if (sw != s && !stream_follow(sw, s)) return FEAR_TRAIN_ERR_HIP;          // g1 and coef1 exist
+        const int rc = wgrad_impl(g1, cexp, 0, x, cin, 0, gr->w_pw, ws.wg, ws.wg_bytes, rows_in, cin, cexp, 1, sw, nullptr, nullptr, 0, &bn1);
+        if (rc != FEAR_TRAIN_OK) return rc;
         if (dx && gemm_lds_applies(rows_in, cexp, cin)) {
             GemmArgs g{};
             g.X = g1; g.ldx = cexp; g.bn = bn1; g.W = b->w_pw; g.R = b->residual ? dout : nullptr; g.ldr = cout; g.Y = dx; g.ldy = cin;
@@ -1047,8 +1077,6 @@ int fear_irb_train_backward(const FearIrbBlock* b, const FearIrbSaved* sv, const
             const dim3 grid = dgrad_grid(rows_in, cexp, cin, &nt);
             launch_pw_bwd<false>(a, grid, nt, s);
         }
-        const int rc = wgrad_impl(g1, cexp, 0, x, cin, 0, gr->w_pw, ws.wg, ws.wg_bytes, rows_in, cin, cexp, 1, s, nullptr, nullptr, 0, &bn1);
-        if (rc != FEAR_TRAIN_OK) return rc;
     }
     LAUNCH_CHECK();
     return FEAR_TRAIN_OK;
@@ -1088,12 +1116,16 @@ int fear_pwbn_train_forward(const float* x, int ldx, const float* w, const float
 
 int fear_pwbn_train_backward(const float* dy, const float* raw, const float* vec, int relu, const float* x, int ldx, const float* w,
                              const float* gamma, float* dw, float* dgamma, float* dbeta, float* dx, long M, int K, int N, float* workspace,
-                             size_t ws_bytes, void* stream) {
+                             size_t ws_bytes, void* stream, void* wgrad_stream) {
     if (!dy || !raw || !vec || !x || !w || !gamma || !dw || !dgamma || !dbeta || !workspace) return FEAR_TRAIN_ERR_NULL;
     if (M <= 0 || K < 4 || K % 4 || N < 4 || N % 4 || N > 1024 || M > 0x7fffffffL || !ld_ok(ldx, K)) return FEAR_TRAIN_ERR_SHAPE;
     const BlockWs ws = block_ws(M, M, K, N, N, 3, workspace);
     if (ws_bytes < ws.total) return FEAR_TRAIN_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    hipStream_t sw = wgrad_stream ? static_cast<hipStream_t>(wgrad_stream) : s;
+    // (this unit's coefficient vectors live in the shared workspace: whatever an earlier call left running on the weight-gradient
+    //  stream may still read them — it is waited for first)
+    if (sw != s && !stream_follow(s, sw)) return FEAR_TRAIN_ERR_HIP;
     bn_backward_sums(dy, N, raw, N, vec, relu, gamma, dgamma, dbeta, ws.coef, M, N, ws.col, s);
     BnbIn bn{};
     bn.E = raw; bn.coef = ws.coef; bn.lde = N; bn.C = N;
@@ -1109,7 +1141,8 @@ int fear_pwbn_train_backward(const float* dy, const float* raw, const float* vec
         const dim3 grid = dgrad_grid(M, N, K, &nt);
         launch_pw_bwd<false>(a, grid, nt, s);
     }
-    const int rc = wgrad_impl(dy, N, 0, x, ldx, 0, dw, ws.wg, ws.wg_bytes, M, K, N, 1, s, nullptr, nullptr, 0, &bn);
+    if (sw != s && !stream_follow(sw, s)) return FEAR_TRAIN_ERR_HIP;
+    const int rc = wgrad_impl(dy, N, 0, x, ldx, 0, dw, ws.wg, ws.wg_bytes, M, K, N, 1, sw, nullptr, nullptr, 0, &bn);
     if (rc != FEAR_TRAIN_OK) return rc;
     LAUNCH_CHECK();
     return FEAR_TRAIN_OK;

@@ -150,6 +150,7 @@ class FEARNetTrainHIP:
         # keeps one stream (its collectives must be issued in the same order on every rank).
         self.two_streams = bool(two_streams) and not sync_bn
         self._side = None
+        self._aux = None
         self._lane = 0
         self._ws_lanes = {}
         self.timing = None        # a list: every pointwise weight-gradient launch is bracketed with events and appended (bench.py's roofline)
@@ -538,20 +539,41 @@ class FEARNetTrainHIP:
             self._check(self.lib.fear_bn_running_update(_p(vec), float(rows), _p(L.running_mean), _p(L.running_var), self.momentum, self.eps,
                                                         L.cout, st))
 
-    def _features_backward_b(self, ctx, dfeat: torch.Tensor, gbuf: torch.Tensor) -> None:
+    def _features_backward_b(self, ctx, dfeat: torch.Tensor, gbuf: torch.Tensor, aux=None) -> None:
+        """`aux`: a torch stream for the pointwise weight gradients (they do not feed the chain of input gradients): every block
+        then gets a scratch of its own, and the caller joins `aux` before the gradients are used."""
         import ctypes
         lib, st = self.lib, self._stream()
         c = ctx[1]
         B, H = c["B"], c["H"]
         ws, wsb, scratch = self._block_buffers(B, H)
+        aux_p = ctypes.c_void_p(aux.cuda_stream) if aux is not None else None
+        if aux is not None:
+            # one scratch per block (the gradient tensors a block leaves there are still being read by its weight gradients on
+            # `aux` while the next blocks run): carved out of one allocation of the summed sizes
+            sizes, h = [], H // 2
+            for desc in self._irb_descriptors():
+                sizes.append((int(lib.fear_irb_scratch_floats(ctypes.byref(desc), B, h, h)) + 63) // 64 * 64)
+                h //= desc.stride
+            key = ("scratch_all", self._lane)
+            big = self._ws_lanes.get(key)
+            if big is None or big.numel() < sum(sizes):
+                self._ws_lanes[key] = None
+                big = self._ws_lanes[key] = torch.empty(sum(sizes), dtype=torch.float32, device=self.device)
+            offs = np.cumsum([0] + sizes)
+            per_block = [big[offs[i]: offs[i + 1]] for i in range(len(sizes))]
+            big.record_stream(aux)
+            gbuf.record_stream(aux)
         g = lambda key, n: _p(self._gslot(gbuf, key, n))
         N = self.neck
         x_neck, neck_raw, neck_vec, h = c["neck"]
         d = self._new(B * h * h, 112)
         self._check(lib.fear_pwbn_train_backward(_p(dfeat), _p(neck_raw), _p(neck_vec), 0, _p(x_neck), 112, _p(N.w), _p(N.gamma),
                                                  g(N.conv_key, 256 * 112), g(N.bn_key + ".weight", 256), g(N.bn_key + ".bias", 256), _p(d),
-                                                 B * h * h, 112, 256, ws, wsb, st))
-        for (desc, sv, x, hin, _keep), blk in zip(reversed(c["blocks"]), reversed(self.blocks)):
+                                                 B * h * h, 112, 256, ws, wsb, st, aux_p))
+        if aux is not None:
+            dfeat.record_stream(aux)
+        for bi, ((desc, sv, x, hin, _keep), blk) in enumerate(zip(reversed(c["blocks"]), reversed(self.blocks))):
             gr = FearIrbGrads()
             units = (blk["pw"], blk["dw"], blk["pwl"])
             for i, L in enumerate(units):
@@ -567,15 +589,20 @@ class FEARNetTrainHIP:
                 gr.gamma[i] = self._gslot(gbuf, L.bn_key + ".weight", L.cout).data_ptr()
                 gr.beta[i] = self._gslot(gbuf, L.bn_key + ".bias", L.cout).data_ptr()
             dx = self._new(B * hin * hin, desc.cin)
-            self._check(lib.fear_irb_train_backward(ctypes.byref(desc), ctypes.byref(sv), ctypes.byref(gr), _p(x), _p(d), _p(dx), _p(scratch),
-                                                    B, hin, hin, ws, wsb, st))
+            sc = per_block[len(self.blocks) - 1 - bi] if aux is not None else scratch
+            if aux is not None:
+                d.record_stream(aux)           # (read by this block's weight gradient on `aux` after this loop has dropped it)
+            self._check(lib.fear_irb_train_backward(ctypes.byref(desc), ctypes.byref(sv), ctypes.byref(gr), _p(x), _p(d), _p(dx), _p(sc),
+                                                    B, hin, hin, ws, wsb, st, aux_p))
             d = dx
         S = self.stem
         stem_raw, stem_vec = c["stem"]
         hs = H // 2
         self._check(lib.fear_pwbn_train_backward(_p(d), _p(stem_raw), _p(stem_vec), 1, _p(c["col"]), 28, _p(S.w), _p(S.gamma),
                                                  g(S.conv_key, 16 * 28), g(S.bn_key + ".weight", 16), g(S.bn_key + ".bias", 16), None,
-                                                 B * hs * hs, 28, 16, ws, wsb, st))
+                                                 B * hs * hs, 28, 16, ws, wsb, st, aux_p))
+        if aux is not None:
+            d.record_stream(aux)
 
     # ------------------------------------------------------------------ trunk + neck
     def _features_forward(self, img: torch.Tensor):
@@ -691,7 +718,14 @@ class FEARNetTrainHIP:
                         fbwd(zctx, dz, gflat[1])
                     finally:
                         self._lane = 0          # (a raising kernel check must not leave later steps on the side lane's workspace)
-                fbwd(xctx, dx, gflat[0])
+                if self.mode == "block":
+                    # third stream: the search pass's pointwise weight gradients, off the chain of input gradients
+                    if self._aux is None:
+                        self._aux = torch.cuda.Stream(device=dev)
+                    fbwd(xctx, dx, gflat[0], aux=self._aux)
+                    main.wait_stream(self._aux)
+                else:
+                    fbwd(xctx, dx, gflat[0])
                 main.wait_stream(side)
             else:
                 fbwd(xctx, dx, gflat[0])

@@ -213,8 +213,13 @@ size_t fear_irb_scratch_floats(const FearIrbBlock* blk, int B, int H, int W);   
 int fear_irb_train_forward(const FearIrbBlock* blk, const FearIrbSaved* saved, const float* x, float* out, int B, int H, int W,
                            double momentum, double eps, float* workspace, size_t ws_bytes, void* stream);
 /* dout = gradient w.r.t. `out`; dx (may be NULL when the block has an expansion and its input needs no gradient) = gradient w.r.t. x */
+/* `wgrad_stream` (may be NULL = `stream`): the block's two pointwise weight gradients do not feed dx; given a second stream they are
+ * issued there — ordered behind the kernels that produce their operands by events — and overlap the rest of the backward pass.  The
+ * caller then keeps `scratch` private to this call, and makes whatever consumes the gradients (or reuses scratch / workspace / the
+ * tensors handed in) wait for that stream. */
 int fear_irb_train_backward(const FearIrbBlock* blk, const FearIrbSaved* saved, const FearIrbGrads* grads, const float* x, const float* dout,
-                            float* dx, float* scratch, int B, int H, int W, float* workspace, size_t ws_bytes, void* stream);
+                            float* dx, float* scratch, int B, int H, int W, float* workspace, size_t ws_bytes, void* stream,
+                            void* wgrad_stream);
 /* The running statistics of one BatchNorm from the `vec` its forward saved (mean | rstd | a | b), for forwards that ran with
  * running_mean = NULL: the shared trunk's two passes (template, search: model/fear_net.py:83-88) may then overlap on two streams,
  * and torch's update order — template pass first — is restored by applying the search pass's update afterwards. */
@@ -228,7 +233,7 @@ int fear_pwbn_train_forward(const float* x, int ldx, const float* w, const float
                             float* workspace, size_t ws_bytes, void* stream);
 int fear_pwbn_train_backward(const float* dy, const float* raw, const float* vec, int relu, const float* x, int ldx, const float* w,
                              const float* gamma, float* dw, float* dgamma, float* dbeta, float* dx, long M, int K, int N, float* workspace,
-                             size_t ws_bytes, void* stream);
+                             size_t ws_bytes, void* stream, void* wgrad_stream);
 
 #ifdef __cplusplus
 }

@@ -119,7 +119,7 @@ def test_irb_block_forward_backward_vs_autograd(cfg, B, H):
         gr.gamma[i], gr.beta[i] = gg[i].data_ptr(), gb[i].data_ptr()
     dx = torch.full((B * H * H, cin), float("nan"), device=dev)
     assert lib.fear_irb_train_backward(ctypes.byref(blk), ctypes.byref(sv), ctypes.byref(gr), _p(xd), _p(D(rows(dout))), _p(dx), _p(scratch),
-                                       B, H, H, _p(ws), ws.numel() * 4, None) == 0
+                                       B, H, H, _p(ws), ws.numel() * 4, None, None) == 0
     torch.cuda.synchronize()
     errs["dx"] = _rel(dx, rows(x.grad))
     errs["d w_dw"] = _rel(gw_dw, p["w_dw"].grad)
@@ -136,10 +136,18 @@ def test_irb_block_forward_backward_vs_autograd(cfg, B, H):
     dx2 = torch.empty_like(dx)
     gw2 = torch.empty_like(gw_dw)
     gr.w_dw = gw2.data_ptr()
+    # ... with the two pointwise weight gradients on a second stream (`wgrad_stream`): same numbers
+    gw_pwl2 = torch.full_like(gw_pwl, float("nan"))
+    gr.w_pwl = gw_pwl2.data_ptr()
+    gw_pw2 = torch.full_like(gw_pw, float("nan")) if expand else None
+    if expand:
+        gr.w_pw = gw_pw2.data_ptr()
+    aux = torch.cuda.Stream()
     assert lib.fear_irb_train_backward(ctypes.byref(blk), ctypes.byref(sv), ctypes.byref(gr), _p(xd), _p(keep[-1]), _p(dx2), _p(scratch),
-                                       B, H, H, _p(ws), ws.numel() * 4, None) == 0
+                                       B, H, H, _p(ws), ws.numel() * 4, None, ctypes.c_void_p(aux.cuda_stream)) == 0
     torch.cuda.synchronize()
-    assert torch.equal(dx2, dx) and torch.equal(gw2, gw_dw)
+    assert torch.equal(dx2, dx) and torch.equal(gw2, gw_dw) and torch.equal(gw_pwl2, gw_pwl)
+    assert not expand or torch.equal(gw_pw2, gw_pw)
 
 
 @pytest.mark.gpu
@@ -169,7 +177,7 @@ def test_pwbn_unit_forward_backward_vs_autograd(M, K, N, relu, need_dx):
     dw, dg, db = torch.empty(N, K, device=dev), torch.empty(N, device=dev), torch.empty(N, device=dev)
     dx = torch.empty(M, K, device=dev) if need_dx else None
     assert lib.fear_pwbn_train_backward(_p(dyd), _p(raw), _p(vec), relu, _p(xd), K, _p(wd), _p(gd), _p(dw), _p(dg), _p(db), _p(dx), M, K, N,
-                                        _p(ws), ws.numel() * 4, None) == 0
+                                        _p(ws), ws.numel() * 4, None, None) == 0
     torch.cuda.synchronize()
     errs = {"out": _rel(out, y), "running_mean": _rel(rm, rm_ref), "running_var": _rel(rv, rv_ref), "dw": _rel(dw, w.grad),
             "dgamma": _rel(dg, gamma.grad), "dbeta": _rel(db, beta.grad)}
