@@ -740,7 +740,9 @@ int dw_bwd_wgs_per_slab(int n_items, int nslab) {
     const int per = (n_items + target - 1) / target;      // items per workgroup, then as few workgroups as that needs
     return (n_items + per - 1) / per;
 }
-int dw_bwd_sq(int C) { return C % 32 == 0 ? 8 : 4; }
+// 32-channel slabs (128-byte rows per pixel and tensor) from 64 channels up, a ragged last slab included (144 = 4.5 slabs: 11 % of
+// the lanes idle, against 64-byte segments for all of them with 16-channel slabs: the 24 -> 144 block's pass ran at 3 TB/s)
+int dw_bwd_sq(int C) { return C >= 64 ? 8 : 4; }
 
 BlockWs block_ws(long rows_in, long rows_out, int cin, int cexp, int cout, int k, float* base) {
     BlockWs w{};
@@ -798,6 +800,8 @@ void finalize_backward(const double* partial, int blocks, int C, double count, c
 dim3 dgrad_grid(long M, int Kred, int Nout, int* nt);
 dim3 stat_grid(long M, int K, int N, int* nt, int* row_tiles) {
     dim3 g = dgrad_grid(M, K, N, nt);      // (a projection 672 -> 112 re-reads its normalised-on-load operand once per pass as well)
+    // (three tiles per pass instead of six for the narrow reductions of the large maps — twice the occupancy, the small operand
+    //  read once more — measured no better: 395 vs 343 us for 16 -> 96 at 128 x 128)
     int rt = (int)((g.x + 2047) / 2048);
     if (rt < 1) rt = 1;
     *row_tiles = rt;
