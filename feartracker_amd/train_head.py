@@ -300,9 +300,18 @@ class BoxTowerTrainHIP:
         dw = self._gnew(L.prefix + ".pointwise.weight", L.n, L.cin)
         self._check(lib.fear_pw_backward_weight(_p(dp), lddp, _p(L.d), L.cin, _p(dw), ws, wsb, M, L.cin, L.n, st))
         grads[L.prefix + ".pointwise.weight"] = dw[: L.cout].reshape(L.cout, L.cin, 1, 1)
+        # A bias in front of a BatchNorm has an exactly-zero gradient (the normalisation removes any per-channel constant: the
+        # column sums of d(pre) vanish, and with them those of the depthwise bias one conv further up); torch's autograd yields
+        # rounding noise of 1e-9 there.  Those sums are not taken — two reductions and four launches per layer — the gradient is
+        # the zero it is.  Only the prediction heads (no BatchNorm behind them) have bias gradients.
+        zero_bias = L.bn_prefix is not None
         if L.pw_bias is not None:
             db = self._gnew(L.prefix + ".pointwise.bias", L.n)
-            self._check(lib.fear_col_sum(_p(dp), lddp, _p(db), ws, wsb, M, L.n, st))
+            if zero_bias:
+                if self._galloc is None:          # (FEARNetTrainHIP's gradient buffer starts from zeros)
+                    db.zero_()
+            else:
+                self._check(lib.fear_col_sum(_p(dp), lddp, _p(db), ws, wsb, M, L.n, st))
             grads[L.prefix + ".pointwise.bias"] = db[: L.cout]
         dd = self._new(M, L.cin)
         self._check(lib.fear_pw_backward_data(_p(dp), lddp, _p(L.w), None, 0, _p(dd), L.cin, M, L.cin, L.n, st))
@@ -311,7 +320,11 @@ class BoxTowerTrainHIP:
         grads[L.prefix + ".depthwise.weight"] = dtaps.t().reshape(L.cin, 1, 3, 3)
         if L.dw_bias is not None:
             dbd = self._gnew(L.prefix + ".depthwise.bias", L.cin)
-            self._check(lib.fear_col_sum(_p(dd), L.cin, _p(dbd), ws, wsb, M, L.cin, st))
+            if zero_bias:
+                if self._galloc is None:
+                    dbd.zero_()
+            else:
+                self._check(lib.fear_col_sum(_p(dd), L.cin, _p(dbd), ws, wsb, M, L.cin, st))
             grads[L.prefix + ".depthwise.bias"] = dbd
         dx = self._new(M, L.cin)
         self._check(lib.fear_dw_backward_data(_p(dd), L.cin, _p(L.taps), _p(dx), L.cin, B, self.S, self.S, L.cin, 3, 1, st))
