@@ -296,7 +296,7 @@ def config4_fear_m(dev, steps: int = 20, warmup: int = 5, batch: int = 512):
             "roofline": res.get("roofline")}
 
 
-def config5_train_step(dev, batch: int = 128, steps: int = 5, warmup: int = 2):
+def config5_train_step(dev, batch: int = 128, steps: int = 20, warmup: int = 4):
     """BASELINE.json configs[4] ("training step: backbone+xcorr fwd/bwd, random-init, batch=1024 on 8xMI355X"): ONE data-parallel
     rank's share (1024 / 8 = 128 template/search pairs) of the full training step — FEARNet.forward((template, search)) in train
     mode (both crops through the trunk + neck, BatchNorm on batch statistics), FEARLoss, backward to all 195 parameter tensors —
@@ -306,6 +306,7 @@ def config5_train_step(dev, batch: int = 128, steps: int = 5, warmup: int = 2):
     The trunk runs block-fused (one C-ABI call per inverted-residual block and direction, csrc/fear_train_block.h), the template
     pass and the regression tower on a second HIP stream; DESIGN.md §7 N3 has the per-kernel map."""
     from feartracker_amd.train_net import FEARNetTrainHIP, random_init_state
+    torch.cuda.empty_cache()          # (the other configurations' buffers: the step allocates ~13 GB of saved activations per call)
     g = torch.Generator().manual_seed(7)
     net = FEARNetTrainHIP(random_init_state(3), device=dev.index)
     tmpl = torch.randn(batch, 3, 128, 128, generator=g).to(dev)
