@@ -21,6 +21,7 @@
 #include "../../include/fear_train.h"
 
 namespace {
+static int dbg_skip() { static int v = getenv("FEAR_DBG_SKIP") ? atoi(getenv("FEAR_DBG_SKIP")) : 0; return v; }
 
 using namespace fear;
 
@@ -183,6 +184,8 @@ struct ColFinArgs {
     const float* mean_in;  // mode 4: the BatchNorm's saved mean / rstd (gamma above) ...
     const float* rstd_in;
     float* coef;           // ... -> [4][C] = gamma * rstd | s1 / M | mean | rstd * s2 / M  (BnbIn::coef), M = the row count
+    const float* mean_shift;   // mode 0, optional: a per-channel constant the producer left out in front of the BatchNorm (a conv
+                               // bias: it cancels in the normalisation) — only the tracked mean sees it
     int blocks, C, mode, rpb;
     double M, eps, momentum;
 };
@@ -221,7 +224,8 @@ __global__ __launch_bounds__(1024) void col_finalize_kernel(ColFinArgs a) {
             a.out_b[c] = __builtin_fmaf(-mf, av, a.beta[c]);
         }
         if (a.running_mean) {
-            a.running_mean[c] = (float)((1.0 - a.momentum) * (double)a.running_mean[c] + a.momentum * mean);
+            const double tracked = a.mean_shift ? mean + (double)a.mean_shift[c] : mean;
+            a.running_mean[c] = (float)((1.0 - a.momentum) * (double)a.running_mean[c] + a.momentum * tracked);
             const double unbiased = a.M > 1.0 ? var * a.M / (a.M - 1.0) : var;
             a.running_var[c] = (float)((1.0 - a.momentum) * (double)a.running_var[c] + a.momentum * unbiased);
         }
@@ -603,6 +607,7 @@ __global__ __launch_bounds__(256) void slice_sum_kernel(const float* P, float* o
 }
 
 void launch_slice_sum(const float* P, float* out, long count, int slices, hipStream_t s) {
+    if (dbg_skip() & 2) return;
     const int lanes = slices >= 64 ? 16 : 1;
     const int per = 256 / lanes;
     hipLaunchKernelGGL(slice_sum_kernel, dim3((unsigned)((count / 4 + per - 1) / per)), dim3(256), 0, s, P, out, count, slices, lanes);
@@ -1458,6 +1463,7 @@ int fear_pw_backward_data(const float* dy, int lddy, const float* w, const float
 static int wgrad_impl(const float* dy, int lddy, long dy_crop_stride, const float* x, int ldx, long x_crop_stride, float* dw,
                       float* workspace, size_t ws_bytes, long M, int K, int N, int crops, hipStream_t s, const float* act_a = nullptr,
                       const float* act_b = nullptr, int act_relu = 0, const BnbIn* bn = nullptr) {
+    if (dbg_skip() & 16) return FEAR_TRAIN_OK;
     WgradArgs a{};
     a.dY = dy; a.X = x; a.lddy = lddy; a.ldx = ldx; a.N = N; a.K = K; a.M = M; a.crops = crops;
     a.act_a = act_a; a.act_b = act_b; a.act_relu = act_relu;
@@ -1571,23 +1577,27 @@ int fear_dw_forward(const float* x, int ldx, const float* w_taps, const float* b
     return dw_impl(x, ldx, w_taps, bias, y, ldy, B, H, W, C, k, stride, static_cast<hipStream_t>(stream));
 }
 
-int fear_dw_backward_data(const float* dy, int lddy, const float* w_taps, float* dx, int lddx, int B, int H, int W, int C, int k,
-                          int stride, void* stream) {
-    if (B == 0) return FEAR_TRAIN_OK;
-    if (!dy || !w_taps || !dx) return FEAR_TRAIN_ERR_NULL;
-    if (!dw_shape_ok(B, H, W, C, k, stride)) return FEAR_TRAIN_ERR_SHAPE;
-    if (!ld_ok(lddy, C) || !ld_ok(lddx, C)) return FEAR_TRAIN_ERR_SHAPE;      // float4 rows
+static int dw_dgrad_impl(const float* dy, int lddy, const float* w_taps, float* dx, int lddx, int B, int H, int W, int C, int k, int stride,
+                         hipStream_t s) {
     DwDgradArgs a{};
     a.dY = dy; a.Wt = w_taps; a.dX = dx; a.H = H; a.W = W; a.Ho = H / stride; a.Wo = W / stride; a.C = C; a.lddy = lddy; a.lddx = lddx;
     a.total = (long)B * H * W * (C / 4);
     dim3 grid((unsigned)((a.total + 255) / 256));
-    hipStream_t s = static_cast<hipStream_t>(stream);
     if (k == 3 && stride == 1) hipLaunchKernelGGL((dw_dgrad_kernel<3, 1>), grid, dim3(256), 0, s, a);
     else if (k == 3) hipLaunchKernelGGL((dw_dgrad_kernel<3, 2>), grid, dim3(256), 0, s, a);
     else if (stride == 1) hipLaunchKernelGGL((dw_dgrad_kernel<5, 1>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((dw_dgrad_kernel<5, 2>), grid, dim3(256), 0, s, a);
     LAUNCH_CHECK();
     return FEAR_TRAIN_OK;
+}
+
+int fear_dw_backward_data(const float* dy, int lddy, const float* w_taps, float* dx, int lddx, int B, int H, int W, int C, int k,
+                          int stride, void* stream) {
+    if (B == 0) return FEAR_TRAIN_OK;
+    if (!dy || !w_taps || !dx) return FEAR_TRAIN_ERR_NULL;
+    if (!dw_shape_ok(B, H, W, C, k, stride)) return FEAR_TRAIN_ERR_SHAPE;
+    if (!ld_ok(lddy, C) || !ld_ok(lddx, C)) return FEAR_TRAIN_ERR_SHAPE;      // float4 rows
+    return dw_dgrad_impl(dy, lddy, w_taps, dx, lddx, B, H, W, C, k, stride, static_cast<hipStream_t>(stream));
 }
 
 static int dw_wgrad_impl(const float* dy, int lddy, const float* x, int ldx, float* dw_taps, float* workspace, size_t ws_bytes, int B,

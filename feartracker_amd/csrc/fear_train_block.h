@@ -778,10 +778,12 @@ BlockWs block_ws(long rows_in, long rows_out, int cin, int cexp, int cout, int k
 
 // column-sum partials [blocks][2][C] -> mean | rstd | a | b (vec) + running statistics
 void finalize_forward(const double* partial, int blocks, int C, double count, const float* gamma, const float* beta, float* vec,
-                      float* running_mean, float* running_var, double momentum, double eps, hipStream_t s) {
+                      float* running_mean, float* running_var, double momentum, double eps, hipStream_t s, const float* mean_shift = nullptr) {
     ColFinArgs f{};
+    f.mean_shift = mean_shift;
     f.partial = partial; f.out1 = vec; f.out2 = vec + C; f.out_a = vec + 2 * C; f.out_b = vec + 3 * C; f.gamma = gamma; f.beta = beta;
     f.running_mean = running_mean; f.running_var = running_var; f.blocks = blocks; f.C = C; f.mode = 0; f.M = count; f.eps = eps; f.momentum = momentum;
+    if (dbg_skip() & 1) return;
     hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, s, f);
 }
 
@@ -791,6 +793,7 @@ void finalize_backward(const double* partial, int blocks, int C, double count, c
     ColFinArgs f{};
     f.partial = partial; f.out1 = dbeta; f.out2 = dgamma; f.gamma = gamma; f.mean_in = vec; f.rstd_in = vec + C; f.coef = coef;
     f.blocks = blocks; f.C = C; f.mode = 4; f.M = count;
+    if (dbg_skip() & 1) return;
     hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, s, f);
 }
 
@@ -830,14 +833,15 @@ void launch_dw_fwd_ks(const DwFwdArgs& a, int sq, dim3 grid, hipStream_t s) {
 
 // Y = act(X) W^T + sums -> vec:  the forward producer of a pointwise unit
 void pw_forward_unit(const float* x, int ldx, const float* in_vec, int in_relu, const float* w, float* y, long M, int K, int N, const float* gamma,
-                     const float* beta, float* vec, float* rm, float* rv, double momentum, double eps, double* col, hipStream_t s) {
+                     const float* beta, float* vec, float* rm, float* rv, double momentum, double eps, double* col, hipStream_t s,
+                     const float* mean_shift = nullptr) {
     if (gemm_lds_applies(M, K, N)) {      // few row blocks: the LDS-staged, pipelined GEMM (fear_train_gemm.h), same epilogue
         GemmArgs g{};
         g.X = x; g.ldx = ldx; g.W = w; g.Y = y; g.ldy = N; g.M = (int)M; g.K = K; g.N = N; g.partial = col;
         if (in_vec) { g.in.a = in_vec + 2 * K; g.in.b = in_vec + 3 * K; g.in.relu = in_relu; }
         int blocks = 0;
         launch_gemm_lds<1, 1, false>(g, s, &blocks);
-        finalize_forward(col, blocks, N, (double)M, gamma, beta, vec, rm, rv, momentum, eps, s);
+        finalize_forward(col, blocks, N, (double)M, gamma, beta, vec, rm, rv, momentum, eps, s, mean_shift);
         return;
     }
     PwStatArgs a{};
@@ -847,7 +851,7 @@ void pw_forward_unit(const float* x, int ldx, const float* in_vec, int in_relu, 
     int nt = 1;
     const dim3 grid = stat_grid(M, K, N, &nt, &a.row_tiles);
     launch_pw_stat(a, grid, nt, s);
-    finalize_forward(col, (int)grid.x, N, (double)M, gamma, beta, vec, rm, rv, momentum, eps, s);
+    finalize_forward(col, (int)grid.x, N, (double)M, gamma, beta, vec, rm, rv, momentum, eps, s, mean_shift);
 }
 
 // sums of (g, g * xhat) over rows of (dy, x_raw) [mask: a ReLU behind the BatchNorm] -> d beta, d gamma, coef
@@ -858,7 +862,7 @@ void bn_backward_sums(const float* dy, int lddy, const float* raw, int ldx, cons
     a.act_a = relu ? vec + 2 * C : nullptr; a.act_b = relu ? vec + 3 * C : nullptr;
     a.partial = col; a.M = M; a.C = C; a.rpb = col_rows_per_block(M);
     const int blocks = col_blocks(M);
-    hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(blocks), dim3(256), 0, s, a);
+    if (!(dbg_skip() & 8)) hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(blocks), dim3(256), 0, s, a);
     finalize_backward(col, blocks, C, (double)M, gamma, vec, dgamma, dbeta, coef, s);
 }
 
@@ -1065,6 +1069,7 @@ int fear_irb_train_backward(const FearIrbBlock* b, const FearIrbSaved* sv, const
     if (b->expand) {
         BnbIn bn1{};
         bn1.E = sv->e; bn1.coef = coef1; bn1.lde = cexp; bn1.C = cexp;
+        if (dbg_skip() & 32) bn1 = BnbIn{};
         if (sw != s && !stream_follow(sw, s)) return FEAR_TRAIN_ERR_HIP;          // g1 and coef1 exist
         const int rc = wgrad_impl(g1, cexp, 0, x, cin, 0, gr->w_pw, ws.wg, ws.wg_bytes, rows_in, cin, cexp, 1, sw, nullptr, nullptr, 0, &bn1);
         if (rc != FEAR_TRAIN_OK) return rc;
@@ -1072,6 +1077,7 @@ int fear_irb_train_backward(const FearIrbBlock* b, const FearIrbSaved* sv, const
             GemmArgs g{};
             g.X = g1; g.ldx = cexp; g.bn = bn1; g.W = b->w_pw; g.R = b->residual ? dout : nullptr; g.ldr = cout; g.Y = dx; g.ldy = cin;
             g.M = (int)rows_in; g.K = cexp; g.N = cin;
+            if (dbg_skip() & 32) launch_gemm_lds<0, 0, true>(g, s, nullptr); else
             launch_gemm_lds<2, 0, true>(g, s, nullptr);
         } else if (dx) {
             PwBwdArgs a{};
@@ -1090,7 +1096,7 @@ int fear_bn_running_update(const float* vec, double count, float* running_mean, 
                            void* stream) {
     if (!vec || !running_mean || !running_var) return FEAR_TRAIN_ERR_NULL;
     if (C < 1 || !(count >= 1.0)) return FEAR_TRAIN_ERR_SHAPE;
-    hipLaunchKernelGGL(bn_running_update_kernel, dim3((C + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), vec, running_mean,
+    if (!(dbg_skip() & 4)) hipLaunchKernelGGL(bn_running_update_kernel, dim3((C + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), vec, running_mean,
                        running_var, C, count, momentum, eps);
     LAUNCH_CHECK();
     return FEAR_TRAIN_OK;
@@ -1147,6 +1153,114 @@ int fear_pwbn_train_backward(const float* dy, const float* raw, const float* vec
     }
     if (sw != s && !stream_follow(sw, s)) return FEAR_TRAIN_ERR_HIP;
     const int rc = wgrad_impl(dy, N, 0, x, ldx, 0, dw, ws.wg, ws.wg_bytes, M, K, N, 1, sw, nullptr, nullptr, 0, &bn);
+    if (rc != FEAR_TRAIN_OK) return rc;
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SepConv (depthwise 3 x 3 + pointwise, both with bias) + BatchNorm + ReLU — the layer the head's towers are made of
+// (model_training/model/blocks.py:97-101, 115-119, 151-161) — one call per direction, in the style of the trunk's blocks:
+//   forward   d = dw(x) + b_dw;  raw = d W^T (statistics in the GEMM's epilogue; the pointwise bias is left out: it cancels in the
+//             normalisation and only shifts the tracked mean);  out = relu(a raw + b)
+//   backward  sums over (dy masked, raw) -> coefficients;  dd = bnb(dy) W (the BatchNorm backward formed on load);  dx = DW^T dd;
+//             d W = bnb(dy)^T d and the tap gradients on `wgrad_stream`, off the chain of input gradients
+// workspace regions: col (stream) | wg, taps (wgrad stream only)
+struct SepWs {
+    double* col;
+    float* wg;
+    float* taps;
+    size_t col_bytes, wg_bytes, taps_bytes, total;
+};
+
+static SepWs sep_ws(long M, int cin, int cout, float* base) {
+    SepWs w{};
+    const int cmax = cin > cout ? cin : cout;
+    size_t col = fear_train_stats_workspace_bytes(M, cmax);
+    const size_t colr = (size_t)col_blocks(M) * 2 * cmax * sizeof(double);
+    if (colr > col) col = colr;
+    const size_t lds = M <= 65536 ? (size_t)((M + 63) / 64) * 2 * cmax * sizeof(double) : 0;
+    if (lds > col) col = lds;
+    w.col_bytes = align256(col);
+    const size_t nk = (size_t)cin * cout;
+    size_t wg = (size_t)wgrad_slices(M) * nk * sizeof(float);
+    size_t more = (size_t)1024 * nk * sizeof(float);
+    if (more > ((size_t)32 << 20)) more = (size_t)32 << 20;
+    if (more > wg) wg = more;
+    w.wg_bytes = align256(wg);
+    w.taps_bytes = align256((size_t)col_blocks(M) * 9 * cin * sizeof(float));
+    w.total = w.col_bytes + w.wg_bytes + w.taps_bytes;
+    char* p = reinterpret_cast<char*>(base);
+    w.col = reinterpret_cast<double*>(p); p += w.col_bytes;
+    w.wg = reinterpret_cast<float*>(p); p += w.wg_bytes;
+    w.taps = reinterpret_cast<float*>(p);
+    return w;
+}
+
+static bool sep_shape_ok(const FearSepLayer* L, int B, int H, int W) {
+    return L && B >= 1 && H >= 1 && W >= 1 && L->cin >= 4 && L->cin % 4 == 0 && L->cin <= 1024 && L->cout >= 4 && L->cout % 4 == 0 &&
+           L->cout <= 1024 && (long)B * H * W * (L->cin > L->cout ? L->cin : L->cout) * 4 < 0x7fffffffL;
+}
+
+size_t fear_sepbn_workspace_bytes(const FearSepLayer* L, int B, int H, int W) {
+    if (!sep_shape_ok(L, B, H, W)) return 0;
+    return sep_ws((long)B * H * W, L->cin, L->cout, nullptr).total;
+}
+
+int fear_sepbn_train_forward(const FearSepLayer* L, const float* x, int ldx, float* d, float* raw, float* vec, float* out, int ldo, int B,
+                             int H, int W, double momentum, double eps, float* workspace, size_t ws_bytes, void* stream) {
+    if (!L || !x || !d || !raw || !vec || !out || !workspace || !L->w_dw || !L->w_pw || !L->gamma || !L->beta) return FEAR_TRAIN_ERR_NULL;
+    if (!sep_shape_ok(L, B, H, W) || !ld_ok(ldx, L->cin) || !ld_ok(ldo, L->cout)) return FEAR_TRAIN_ERR_SHAPE;
+    const long M = (long)B * H * W;
+    const int K = L->cin, N = L->cout;
+    const SepWs ws = sep_ws(M, K, N, workspace);
+    if (ws_bytes < ws.total) return FEAR_TRAIN_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc = dw_impl(x, ldx, L->w_dw, L->b_dw, d, K, B, H, W, K, 3, 1, s);
+    if (rc != FEAR_TRAIN_OK) return rc;
+    pw_forward_unit(d, K, nullptr, 0, L->w_pw, raw, M, K, N, L->gamma, L->beta, vec, L->running_mean, L->running_var, momentum, eps, ws.col, s,
+                    L->b_pw);
+    BnActArgs k{};
+    k.X = raw; k.Y = out; k.in.a = vec + 2 * N; k.in.b = vec + 3 * N; k.in.relu = 1; k.M = M; k.C = N; k.ldx = N; k.ldy = ldo;
+    const long n4 = M * (N / 4);
+    hipLaunchKernelGGL(bn_act_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, k);
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+int fear_sepbn_train_backward(const FearSepLayer* L, const FearSepGrads* gr, const float* x, int ldx, const float* d, const float* raw,
+                              const float* vec, const float* dy, float* dd, float* coef, float* dx, int B, int H, int W, float* workspace,
+                              size_t ws_bytes, void* stream, void* wgrad_stream) {
+    if (!L || !gr || !x || !d || !raw || !vec || !dy || !dd || !coef || !dx || !workspace || !L->w_dw || !L->w_pw || !L->gamma)
+        return FEAR_TRAIN_ERR_NULL;
+    if (!gr->w_dw || !gr->w_pw || !gr->gamma || !gr->beta) return FEAR_TRAIN_ERR_NULL;
+    if (!sep_shape_ok(L, B, H, W) || !ld_ok(ldx, L->cin)) return FEAR_TRAIN_ERR_SHAPE;
+    const long M = (long)B * H * W;
+    const int K = L->cin, N = L->cout;
+    const SepWs ws = sep_ws(M, K, N, workspace);
+    if (ws_bytes < ws.total) return FEAR_TRAIN_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipStream_t sw = wgrad_stream ? static_cast<hipStream_t>(wgrad_stream) : s;
+    bn_backward_sums(dy, N, raw, N, vec, 1, L->gamma, gr->gamma, gr->beta, coef, M, N, ws.col, s);
+    BnbIn bn{};
+    bn.E = raw; bn.coef = coef; bn.lde = N; bn.C = N; bn.mask_a = vec + 2 * N; bn.mask_b = vec + 3 * N;
+    if (gemm_lds_applies(M, N, K)) {
+        GemmArgs g{};
+        g.X = dy; g.ldx = N; g.bn = bn; g.W = L->w_pw; g.Y = dd; g.ldy = K; g.M = (int)M; g.K = N; g.N = K;
+        launch_gemm_lds<2, 0, true>(g, s, nullptr);
+    } else {
+        PwBwdArgs a{};
+        a.G = dy; a.ldg = N; a.bn = bn; a.W = L->w_pw; a.Y = dd; a.ldy = K; a.M = (int)M; a.Kred = N; a.Nout = K;
+        int nt = 1;
+        const dim3 grid = dgrad_grid(M, N, K, &nt);
+        launch_pw_bwd<false>(a, grid, nt, s);
+    }
+    if (sw != s && !stream_follow(sw, s)) return FEAR_TRAIN_ERR_HIP;
+    int rc = wgrad_impl(dy, N, 0, d, K, 0, gr->w_pw, ws.wg, ws.wg_bytes, M, K, N, 1, sw, nullptr, nullptr, 0, &bn);
+    if (rc != FEAR_TRAIN_OK) return rc;
+    rc = dw_wgrad_impl(dd, K, x, ldx, gr->w_dw, ws.taps, ws.taps_bytes, B, H, W, K, 3, 1, sw, nullptr, nullptr, 0);
+    if (rc != FEAR_TRAIN_OK) return rc;
+    rc = dw_dgrad_impl(dd, K, L->w_dw, dx, K, B, H, W, K, 3, 1, s);
     if (rc != FEAR_TRAIN_OK) return rc;
     LAUNCH_CHECK();
     return FEAR_TRAIN_OK;

@@ -72,6 +72,10 @@ TRAIN_SYMBOLS = {
     "fear_pwbn_workspace_bytes": ([_l, _i, _i], _sz),
     "fear_pwbn_train_forward": ([_P, _i, _P, _P, _P, _P, _P, _P, _P, _i, _P, _l, _i, _i, _d, _d, _P, _sz, _P], _i),
     "fear_pwbn_train_backward": ([_P, _P, _P, _i, _P, _i, _P, _P, _P, _P, _P, _P, _l, _i, _i, _P, _sz, _P, _P], _i),
+    # the head's SepConv + BatchNorm + ReLU layer, one call per direction
+    "fear_sepbn_workspace_bytes": ([_P, _i, _i, _i], _sz),
+    "fear_sepbn_train_forward": ([_P, _P, _i, _P, _P, _P, _P, _i, _i, _i, _i, _d, _d, _P, _sz, _P], _i),
+    "fear_sepbn_train_backward": ([_P, _P, _P, _i, _P, _P, _P, _P, _P, _P, _P, _i, _i, _i, _P, _sz, _P, _P], _i),
 }
 
 
@@ -87,6 +91,16 @@ class FearIrbSaved(ctypes.Structure):
 
 class FearIrbGrads(ctypes.Structure):
     _fields_ = [("w_pw", _P), ("w_dw", _P), ("w_pwl", _P), ("gamma", _P * 3), ("beta", _P * 3)]
+
+
+class FearSepLayer(ctypes.Structure):
+    """include/fear_train.h: one SepConv + BatchNorm + ReLU layer of the head (device pointers, kernel layouts)."""
+    _fields_ = [("cin", _i), ("cout", _i), ("w_dw", _P), ("b_dw", _P), ("w_pw", _P), ("b_pw", _P), ("gamma", _P), ("beta", _P),
+                ("running_mean", _P), ("running_var", _P)]
+
+
+class FearSepGrads(ctypes.Structure):
+    _fields_ = [("w_dw", _P), ("w_pw", _P), ("gamma", _P), ("beta", _P)]
 
 
 class GradDict(dict):
@@ -194,9 +208,14 @@ class BoxTowerTrainHIP:
     S, TZ = 16, 8           # search feature map 16x16, template feature map 8x8 (256 / 128 px crops, stride 16)
 
     def __init__(self, state_dict: Dict[str, "np.ndarray | torch.Tensor"], device: int = 0, momentum: float = 0.1,
-                 eps: float = 1e-5, coef_cls: float = 1.0, coef_reg: float = 1.0, sync_bn: bool = False, group=None):
+                 eps: float = 1e-5, coef_cls: float = 1.0, coef_reg: float = 1.0, sync_bn: bool = False, group=None,
+                 fused: bool = True):
+        """`fused` (default): every SepConv + BatchNorm + ReLU layer is one call per direction (`fear_sepbn_train_*`: statistics in
+        the GEMM's epilogue, the BatchNorm backward formed on load, weight gradients on `aux_stream`); False — and always with
+        SyncBatchNorm, whose collectives sit between the passes — one operator per pass, as rounds 2-4 ran it."""
         if not torch.cuda.is_available():
             raise RuntimeError("BoxTowerTrainHIP needs a ROCm GPU; there is no CPU fallback")
+        self.fused = bool(fused) and not sync_bn
         self.lib = load_train_library()
         self.sync = SyncBN(group) if sync_bn else None
         self.device = torch.device(f"cuda:{int(device)}")
@@ -219,6 +238,11 @@ class BoxTowerTrainHIP:
         # map is a 256-workgroup launch that leaves most of a 256-CU device idle.  Not with SyncBatchNorm (its collectives must be
         # issued in one order on every rank).  Set by FEARNetTrainHIP (two_streams); None = one stream.
         self.side_stream = None
+        # a stream for the weight gradients of the SepConv layers (they feed nothing in the backward pass: the chain of input
+        # gradients — four 256-workgroup kernels a layer — runs on without them).  `aux_join`: wait for it at the end of step();
+        # FEARNetTrainHIP shares the stream with its trunk and joins once, after the trunk's backward.  None = in line.
+        self.aux_stream = None
+        self.aux_join = True
 
     def _layers(self):
         for br in self.branches.values():
@@ -229,6 +253,7 @@ class BoxTowerTrainHIP:
         """Move every parameter into storage handed out by `alloc(name, tensor) -> tensor of the same shape holding the same
         values` (FEARNetTrainHIP: views of one flat buffer, so that the optimiser is one launch); names as `parameter_slots`."""
         for L in self._layers():
+            L.desc = None
             L.taps = alloc(L.prefix + ".depthwise.weight", L.taps)
             if L.dw_bias is not None:
                 L.dw_bias = alloc(L.prefix + ".depthwise.bias", L.dw_bias)
@@ -266,8 +291,39 @@ class BoxTowerTrainHIP:
         return _p(ws), ws.numel() * 4
 
     # ------------------------------------------------------------------ one SepConv [+ BN + ReLU]
+    def _sep_desc(self, L: _Sep) -> "FearSepLayer":
+        if getattr(L, "desc", None) is None:
+            ptr = lambda t: None if t is None else t.data_ptr()
+            L.desc = FearSepLayer(L.cin, L.cout, ptr(L.taps), ptr(L.dw_bias), ptr(L.w), ptr(L.pw_bias), ptr(L.gamma), ptr(L.beta),
+                                  ptr(L.running_mean), ptr(L.running_var))
+        return L.desc
+
+    def _sep_workspace(self, L: _Sep, B: int):
+        """The workspace of the one-call SepConv + BN layers of this stream lane (its weight-gradient regions belong to the
+        weight-gradient stream: kept apart from the lane's other workspace)."""
+        need = int(self.lib.fear_sepbn_workspace_bytes(ctypes.byref(self._sep_desc(L)), B, self.S, self.S))
+        if need == 0:
+            raise TrainError(f"{L.prefix}: shape not supported by fear_sepbn_train_*")
+        key = ("sep", self._lane)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() * 4 < need:
+            self._ws[key] = None
+            ws = self._ws[key] = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
+        return _p(ws), ws.numel() * 4
+
     def _sep_forward(self, L: _Sep, x: torch.Tensor, ldx: int, B: int, out: Optional[torch.Tensor] = None, ld_out: int = 0):
         lib, st, M = self.lib, self._stream(), B * self.S * self.S
+        if L.bn_prefix and self.fused:
+            # one call: depthwise, pointwise with the statistics in its epilogue, finalize, activation (csrc/fear_train_block.h)
+            ws, wsb = self._sep_workspace(L, B)
+            L.x, L.ldx = x, ldx
+            L.d, L.p, L.vec = self._new(M, L.cin), self._new(M, L.cout), self._new(4 * L.cout)
+            if out is None:
+                out, ld_out = self._new(M, L.cout), L.cout
+            self._check(lib.fear_sepbn_train_forward(ctypes.byref(self._sep_desc(L)), _p(x), ldx, _p(L.d), _p(L.p), _p(L.vec), _p(out),
+                                                     ld_out, B, self.S, self.S, self.momentum, self.eps, ws, wsb, st))
+            L.y, L.ldy = out, ld_out                   # (FEARNetTrainHIP.relu_patterns reads the activation)
+            return out
         ws, wsb = self._workspace(M)
         L.x, L.ldx = x, ldx
         L.d = self._new(M, L.cin)
@@ -287,6 +343,30 @@ class BoxTowerTrainHIP:
     def _sep_backward(self, L: _Sep, dy: torch.Tensor, lddy: int, B: int, grads: Dict[str, torch.Tensor]) -> torch.Tensor:
         """dy = gradient w.r.t. the layer's output (after BN+ReLU when it has them); returns d(input) as [M][cin]."""
         lib, st, M = self.lib, self._stream(), B * self.S * self.S
+        if L.bn_prefix and self.fused and lddy == L.cout:
+            ws, wsb = self._sep_workspace(L, B)
+            dd, coef, dx = self._new(M, L.cin), self._new(4 * L.cout), self._new(M, L.cin)
+            dtaps, dw = self._gnew(L.prefix + ".depthwise.weight", 9, L.cin), self._gnew(L.prefix + ".pointwise.weight", L.n, L.cin)
+            dgamma, dbeta = self._gnew(L.bn_prefix + ".weight", L.cout), self._gnew(L.bn_prefix + ".bias", L.cout)
+            gr = FearSepGrads(dtaps.data_ptr(), dw.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr())
+            aux = self.aux_stream
+            self._check(lib.fear_sepbn_train_backward(ctypes.byref(self._sep_desc(L)), ctypes.byref(gr), _p(L.x), L.ldx, _p(L.d), _p(L.p),
+                                                      _p(L.vec), _p(dy), _p(dd), _p(coef), _p(dx), B, self.S, self.S, ws, wsb, st,
+                                                      ctypes.c_void_p(aux.cuda_stream) if aux is not None else None))
+            if aux is not None:
+                for t in (dy, dd, coef, L.x, L.d, L.p, L.vec, dtaps, dw):
+                    t.record_stream(aux)
+            grads[L.bn_prefix + ".weight"], grads[L.bn_prefix + ".bias"] = dgamma, dbeta
+            grads[L.prefix + ".pointwise.weight"] = dw[: L.cout].reshape(L.cout, L.cin, 1, 1)
+            grads[L.prefix + ".depthwise.weight"] = dtaps.t().reshape(L.cin, 1, 3, 3)
+            # (biases in front of a BatchNorm: exactly-zero gradients, see below)
+            for key, bias, n in ((".pointwise.bias", L.pw_bias, L.n), (".depthwise.bias", L.dw_bias, L.cin)):
+                if bias is not None:
+                    db = self._gnew(L.prefix + key, n)
+                    if self._galloc is None:
+                        db.zero_()
+                    grads[L.prefix + key] = db[: L.cout] if key == ".pointwise.bias" else db
+            return dx
         ws, wsb = self._workspace(M)
         if L.bn_prefix:
             dp = self._new(M, L.n)
@@ -340,16 +420,36 @@ class BoxTowerTrainHIP:
         "grad_template"}."""
         lib, dev = self.lib, self.device
         xs = search_feats.to(dev, torch.float32).contiguous()
-        zs = template_feats.to(dev, torch.float32).contiguous()
         B = xs.shape[0]
-        if tuple(xs.shape[1:]) != (256, self.S, self.S) or tuple(zs.shape) != (B, 256, self.TZ, self.TZ):
+        if tuple(xs.shape[1:]) != (256, self.S, self.S):
             raise ValueError("expected search features (B,256,16,16) and template features (B,256,8,8)")
+        P = self.S * self.S
+        with torch.cuda.device(dev):
+            st = self._stream()
+            x = self._new(B * P, 256)
+            self._check(lib.fear_nchw_to_nhwc(_p(xs), _p(x), B, 256, P, 256, 0, st))
+            out = self.step_rows(x, template_feats, gt_reg, gt_cls, gt_weight)
+            grad_search = self._new(B, 256, self.S, self.S)
+            self._check(lib.fear_nhwc_to_nchw(_p(out.pop("grad_search_rows")), _p(grad_search), B, 256, P, 256, 0, st))
+        out["grad_search"] = grad_search
+        return out
+
+    @torch.no_grad()
+    def step_rows(self, x: torch.Tensor, template_feats: torch.Tensor, gt_reg: torch.Tensor, gt_cls: torch.Tensor,
+                  gt_weight: torch.Tensor) -> Dict[str, object]:
+        """`step` on the search features as the trunk leaves them — pixel rows [B*256][256] (channels last) — returning
+        "grad_search_rows" in the same layout instead of "grad_search": FEARNetTrainHIP's trunk works on rows on both sides of the
+        head, and the two layout passes each way were 0.2 ms of its step.  The template features stay (B,256,8,8) NCHW: the
+        correlation reads them as [B][256][64] matrices."""
+        lib, dev = self.lib, self.device
+        zs = template_feats.to(dev, torch.float32).contiguous()
+        B = zs.shape[0]
         M, P, J = B * self.S * self.S, self.S * self.S, self.TZ * self.TZ
+        if tuple(zs.shape) != (B, 256, self.TZ, self.TZ) or tuple(x.shape) != (M, 256) or not x.is_contiguous() or x.device != dev:
+            raise ValueError("expected search feature rows (B*256,256) on the device and template features (B,256,8,8)")
         with torch.cuda.device(dev):
             st = self._stream()
             ws, wsb = self._workspace(M)
-            x = self._new(M, 256)
-            self._check(lib.fear_nchw_to_nhwc(_p(xs), _p(x), B, 256, P, 256, 0, st))
             saved = {}
             pred_out = {}
             main = torch.cuda.current_stream(dev)
@@ -433,12 +533,12 @@ class BoxTowerTrainHIP:
                 dz.record_stream(main)
             self._check(lib.fear_add(_p(dx_total), _p(dx), _p(dx_total), dx.numel(), st))
             self._check(lib.fear_add(_p(dz_total), _p(dz), _p(dz_total), dz.numel(), st))
-            grad_search = self._new(B, 256, self.S, self.S)
-            self._check(lib.fear_nhwc_to_nchw(_p(dx_total), _p(grad_search), B, 256, P, 256, 0, st))
             bbox = self._new(B, 4, self.S, self.S)
             self._check(lib.fear_nhwc_to_nchw(_p(bbox_rows), _p(bbox), B, 4, P, 4, 0, st))
+            if self.aux_stream is not None and self.aux_join:
+                main.wait_stream(self.aux_stream)
         return {"loss_cls": losses[0], "loss_reg": losses[1], "bbox": bbox, "cls": cls_rows.reshape(B, 1, self.S, self.S),
-                "grads": grads, "grad_search": grad_search, "grad_template": dz_total}
+                "grads": grads, "grad_search_rows": dx_total, "grad_template": dz_total}
 
     # ------------------------------------------------------------------ several ranks
     @staticmethod

@@ -166,7 +166,7 @@ class FEARNetTrainHIP:
         self.neck = _ConvBN("neck.downsample", "pw", sd, dev, relu=False, conv_key=".0.weight", bn_key=".1")
         self.head = BoxTowerTrainHIP({k[len("connect_model."):]: v for k, v in sd.items() if k.startswith("connect_model.")},
                                      device=device, momentum=momentum, eps=eps, coef_cls=coef_cls, coef_reg=coef_reg,
-                                     sync_bn=sync_bn, group=group)
+                                     sync_bn=sync_bn, group=group, fused=self.mode != "layerwise")
         self.sync = self.head.sync                 # SyncBatchNorm over the data-parallel group (config/backend/*.yaml: sync_bn)
         self.last_contexts = None
         # the trunk runs twice per step (template, search): each pass writes its parameter gradients into one flat buffer
@@ -697,16 +697,21 @@ class FEARNetTrainHIP:
                 xrows, xctx = ffwd(s)
             mark("trunk forward (search pass; template pass beside it)")
             z = self._new(B, 256, 8, 8)
-            x = self._new(B, 256, 16, 16)
             self._check(self.lib.fear_nhwc_to_nchw(_p(zrows), _p(z), B, 256, 64, 256, 0, st))
-            self._check(self.lib.fear_nhwc_to_nchw(_p(xrows), _p(x), B, 256, 256, 256, 0, st))
-            out = self.head.step(x, z, gt_reg, gt_cls, gt_weight)
+            # the head's weight gradients share the third stream with the trunk's (joined once, after the trunk's backward)
+            use_aux = side is not None and self.mode == "block"
+            if use_aux and self._aux is None:
+                self._aux = torch.cuda.Stream(device=dev)
+            self.head.aux_stream, self.head.aux_join = (self._aux, False) if use_aux else (None, True)
+            if use_aux:
+                self._aux.wait_stream(main)                         # (the gradient buffer's zeros)
+                gall.record_stream(self._aux)
+            out = self.head.step_rows(xrows, z, gt_reg, gt_cls, gt_weight)      # (the search features stay pixel rows both ways)
             grads = GradDict({"connect_model." + k: v for k, v in out["grads"].items()})
             grads.flat = gflat[0]
             mark("head forward + loss + backward")
-            dx = self._new(B * 256, 256)
+            dx = out["grad_search_rows"]
             dz = self._new(B * 64, 256)
-            self._check(self.lib.fear_nchw_to_nhwc(_p(out["grad_search"]), _p(dx), B, 256, 256, 256, 0, st))
             self._check(self.lib.fear_nchw_to_nhwc(_p(out["grad_template"].contiguous()), _p(dz), B, 256, 64, 256, 0, st))
             if side is not None:
                 side.wait_stream(main)                               # dz and the gradient buffer exist
@@ -720,13 +725,14 @@ class FEARNetTrainHIP:
                         self._lane = 0          # (a raising kernel check must not leave later steps on the side lane's workspace)
                 if self.mode == "block":
                     # third stream: the search pass's pointwise weight gradients, off the chain of input gradients
-                    if self._aux is None:
-                        self._aux = torch.cuda.Stream(device=dev)
                     fbwd(xctx, dx, gflat[0], aux=self._aux)
+                    mark("trunk backward: the search pass's chain of input gradients")
                     main.wait_stream(self._aux)
+                    mark("  ... waiting for the weight-gradient stream")
                 else:
                     fbwd(xctx, dx, gflat[0])
                 main.wait_stream(side)
+                mark("  ... waiting for the template pass")
             else:
                 fbwd(xctx, dx, gflat[0])
                 fbwd(zctx, dz, gflat[1])
@@ -741,7 +747,7 @@ class FEARNetTrainHIP:
                     grads[L.conv_key] = gw.reshape(L.cout, L.cin, 1, 1)
                 grads[L.bn_key + ".weight"] = self._gslot(gflat[0], L.bn_key + ".weight", L.cout)
                 grads[L.bn_key + ".bias"] = self._gslot(gflat[0], L.bn_key + ".bias", L.cout)
-            mark("trunk backward (search pass; template pass beside it)")
+            mark("trunk backward: sum of the two passes, gradient views")
             if marks is not None:
                 self.phase_marks = marks
             self.last_contexts = (zctx, xctx)          # saved activations of the two trunk passes (tests read the ReLU patterns)

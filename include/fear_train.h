@@ -235,6 +235,31 @@ int fear_pwbn_train_backward(const float* dy, const float* raw, const float* vec
                              const float* gamma, float* dw, float* dgamma, float* dbeta, float* dx, long M, int K, int N, float* workspace,
                              size_t ws_bytes, void* stream, void* wgrad_stream);
 
+/* SepConv (depthwise 3x3 + pointwise, both with bias) + BatchNorm + ReLU: the layer of the head's encoders and towers
+ * (SepConv + BatchNorm2d + ReLU: model_training/model/blocks.py:97-101 MatrixMobile, :115-119 MobileCorrelation, :151-161 BoxTower's towers), one call per direction.  Kernel layouts: depthwise taps
+ * [9][cin], pointwise [cout][cin].  The pointwise bias sits in front of the BatchNorm: it cancels in the normalisation (its gradient
+ * and the depthwise bias's are exactly zero and are not written) and only shifts the tracked running mean — `raw` is saved without it. */
+typedef struct FearSepLayer {
+    int cin, cout;
+    const float* w_dw;  const float* b_dw;        /* b_dw, b_pw may be NULL */
+    const float* w_pw;  const float* b_pw;
+    const float* gamma; const float* beta;
+    float* running_mean; float* running_var;      /* may be NULL: not tracked by this call */
+} FearSepLayer;
+typedef struct FearSepGrads { float* w_dw; float* w_pw; float* gamma; float* beta; } FearSepGrads;
+size_t fear_sepbn_workspace_bytes(const FearSepLayer* layer, int B, int H, int W);      /* 0: unsupported shape */
+/* x [B*H*W][ldx] -> saved d [M][cin], raw [M][cout], vec [4*cout] (mean | rstd | a | b) and out [M][ldo] = relu(a raw + b) */
+int fear_sepbn_train_forward(const FearSepLayer* layer, const float* x, int ldx, float* d, float* raw, float* vec, float* out, int ldo,
+                             int B, int H, int W, double momentum, double eps, float* workspace, size_t ws_bytes, void* stream);
+/* dy [M][cout] = gradient w.r.t. out -> dx [M][cin] and the four parameter gradients.  `dd` [M][cin] (the depthwise output's gradient)
+ * and `coef` [4*cout] are scratch PRIVATE to this call.  `wgrad_stream` (may be NULL = `stream`): the two weight gradients do not feed
+ * dx; given a second stream they are issued there, ordered behind the kernels that produce their operands.  The caller then makes
+ * whatever consumes the gradients — or reuses dd / coef / the tensors handed in — wait for that stream, and hands every call that
+ * shares this workspace the same weight-gradient stream (its partial sums live there). */
+int fear_sepbn_train_backward(const FearSepLayer* layer, const FearSepGrads* grads, const float* x, int ldx, const float* d,
+                              const float* raw, const float* vec, const float* dy, float* dd, float* coef, float* dx, int B, int H,
+                              int W, float* workspace, size_t ws_bytes, void* stream, void* wgrad_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -186,3 +186,69 @@ def test_pwbn_unit_forward_backward_vs_autograd(M, K, N, relu, need_dx):
     print({k_: f"{v:.1e}" for k_, v in errs.items()})
     bad = {k_: v for k_, v in errs.items() if not v < 2e-4}
     assert not bad, bad
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,cin,cout,bias,ldx_pad,ldo_pad", [(3, 16, 256, 256, True, 0, 0), (2, 16, 320, 256, True, 0, 64), (2, 8, 64, 48, False, 16, 0),
+                                                            (40, 16, 256, 256, True, 0, 0)])
+def test_sepbn_layer_forward_backward_vs_autograd(B, H, cin, cout, bias, ldx_pad, ldo_pad):
+    """The head's layer — SepConv (3x3 depthwise + pointwise, with or without biases) + BatchNorm + ReLU, model_training/model/
+    blocks.py:97-101 / 115-119 / 151-161 — as one call per direction; input / output rows with a pitch (the [encode | correlation]
+    concatenation); the weight gradients on a second stream are bit-identical to the in-line ones.  The last case's 10 240 rows reach
+    the row-sliced weight-gradient kernels of the full batch."""
+    from feartracker_amd.train_head import FearSepGrads, FearSepLayer, _p, load_train_library
+    lib = load_train_library()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11 + cin + cout + B)
+    M = B * H * H
+    R = lambda *s, scale=1.0: (torch.randn(*s, generator=g, dtype=torch.float64) * scale)
+    x = R(B, cin, H, H).requires_grad_(True)
+    taps = R(9, cin, scale=0.4).requires_grad_(True)
+    w = R(cout, cin, scale=(2.0 / cin) ** 0.5).requires_grad_(True)
+    b_dw = R(cin, scale=0.3).requires_grad_(True) if bias else None
+    b_pw = R(cout, scale=0.3).requires_grad_(True) if bias else None
+    gamma = (torch.rand(cout, generator=g, dtype=torch.float64) + 0.5).requires_grad_(True)
+    beta = R(cout, scale=0.3).requires_grad_(True)
+    rm_ref, rv_ref = torch.zeros(cout, dtype=torch.float64), torch.ones(cout, dtype=torch.float64)
+    d_ref = F.conv2d(x, taps.t().reshape(cin, 1, 3, 3), b_dw, padding=1, groups=cin)
+    y = F.relu(F.batch_norm(F.conv2d(d_ref, w.view(cout, cin, 1, 1), b_pw), rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5))
+    dy = R(B, cout, H, H)
+    y.backward(dy)
+    rows = lambda t: t.detach().permute(0, 2, 3, 1).reshape(M, -1)
+    D = lambda t: None if t is None else t.detach().to(dev, torch.float32).contiguous()
+    ldx, ldo = cin + ldx_pad, cout + ldo_pad
+    xd = torch.zeros(M, ldx, device=dev)
+    xd[:, :cin] = D(rows(x))
+    td, wd, bdw, bpw, gd, bd, dyd = D(taps), D(w), D(b_dw), D(b_pw), D(gamma), D(beta), D(rows(dy))
+    rm, rv = torch.zeros(cout, device=dev), torch.ones(cout, device=dev)
+    ptr = lambda t: None if t is None else t.data_ptr()
+    L = FearSepLayer(cin, cout, ptr(td), ptr(bdw), ptr(wd), ptr(bpw), ptr(gd), ptr(bd), ptr(rm), ptr(rv))
+    ws = torch.empty(int(lib.fear_sepbn_workspace_bytes(ctypes.byref(L), B, H, H)) // 4 + 64, device=dev)
+    d, raw, vec = torch.empty(M, cin, device=dev), torch.empty(M, cout, device=dev), torch.empty(4 * cout, device=dev)
+    out = torch.full((M, ldo), 7.0, device=dev)
+    assert lib.fear_sepbn_train_forward(ctypes.byref(L), _p(xd), ldx, _p(d), _p(raw), _p(vec), _p(out), ldo, B, H, H, 0.1, 1e-5, _p(ws),
+                                        ws.numel() * 4, None) == 0
+
+    def backward(aux):
+        gt, gw, gg, gb = torch.empty(9, cin, device=dev), torch.empty(cout, cin, device=dev), torch.empty(cout, device=dev), torch.empty(cout, device=dev)
+        dd, coef, dx = torch.empty(M, cin, device=dev), torch.empty(4 * cout, device=dev), torch.empty(M, cin, device=dev)
+        G = FearSepGrads(gt.data_ptr(), gw.data_ptr(), gg.data_ptr(), gb.data_ptr())
+        assert lib.fear_sepbn_train_backward(ctypes.byref(L), ctypes.byref(G), _p(xd), ldx, _p(d), _p(raw), _p(vec), _p(dyd), _p(dd), _p(coef),
+                                             _p(dx), B, H, H, _p(ws), ws.numel() * 4, None,
+                                             ctypes.c_void_p(aux.cuda_stream) if aux is not None else None) == 0
+        torch.cuda.synchronize()
+        return gt, gw, gg, gb, dx
+    gt, gw, gg, gb, dx = backward(None)
+    errs = {"out": _rel(out[:, :cout], rows(y)), "running_mean": _rel(rm, rm_ref), "running_var": _rel(rv, rv_ref), "d": _rel(d, rows(d_ref)),
+            "dtaps": _rel(gt, taps.grad), "dw": _rel(gw, w.grad), "dgamma": _rel(gg, gamma.grad), "dbeta": _rel(gb, beta.grad),
+            "dx": _rel(dx, rows(x.grad))}
+    print({k_: f"{v:.1e}" for k_, v in errs.items()})
+    bad = {k_: v for k_, v in errs.items() if not v < 2e-4}
+    assert not bad, bad
+    assert ldo_pad == 0 or bool((out[:, cout:] == 7.0).all())        # nothing written beyond the layer's own columns
+    if bias:                                                          # the biases' gradients vanish in front of the BatchNorm
+        assert float(b_pw.grad.abs().max()) < 1e-9 and float(b_dw.grad.abs().max()) < 1e-9
+    torch.cuda.synchronize()
+    again = backward(torch.cuda.Stream(device=dev))
+    for a, b in zip((gt, gw, gg, gb, dx), again):
+        assert torch.equal(a, b)
