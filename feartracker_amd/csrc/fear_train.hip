@@ -48,9 +48,16 @@ __device__ __forceinline__ f32x4 act4(const f32x4& x, const f32x4& a, const f32x
 // w.r.t. the BatchNorm's output, already masked by the ReLU behind it unless mask_a is given) and the BatchNorm's raw input E and
 // forms d(pre) in registers from four per-channel vectors: coef = [A | s1 | mu | Q] with A = gamma * rstd, s1 = sum(g) / count,
 // mu = mean, Q = rstd * sum(g * xhat) / count (col_finalize_kernel mode 4 writes them).
+//
+// Where the BatchNorm's input is itself LINEAR in something the consumer has (E = X W^T, an expansion's raw output), the E term
+// need not be read at all:  d(pre) = A (g - s1 + mu Q)  -  (A Q) E,  and the second part folds into the consumer's own algebra
+//     input gradient    d(pre) W   = [A (g - s1 + mu Q)] W  -  X (W^T diag(A Q) W)              (a cin x cin matrix)
+//     weight gradient   d(pre)^T X = [A (g - s1 + mu Q)]^T X  -  diag(A Q) W (X^T X)            (the input's Gram matrix)
+// — E = nullptr with coef given selects exactly the bracket (bnb4 with e = 0), fear_irb_train_backward supplies the rest: the
+// expansion's two consumers read g and the cin-channel block input instead of two cexp-channel tensors.
 struct BnbIn {
-    const float* E;        // [rows][lde] the BatchNorm's input (raw conv output); nullptr: the operand is used as loaded
-    const float* coef;     // [4][C]
+    const float* E;        // [rows][lde] the BatchNorm's input (raw conv output); nullptr with coef: see above
+    const float* coef;     // [4][C]; nullptr: the operand is used as loaded
     const float* mask_a;   // optional: g is first masked where fma(E, mask_a, mask_b) <= 0 (a ReLU between the BatchNorm and g)
     const float* mask_b;
     int lde, C;
@@ -394,14 +401,14 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs a) {
     const bool act = a.act_a != nullptr;
     f32x4 ia = zero, ib = zero;
     if (act && kv) { ia = *reinterpret_cast<const f32x4*>(a.act_a + k4); ib = *reinterpret_cast<const f32x4*>(a.act_b + k4); }
-    const bool bnb = a.bn.E != nullptr, bmask = a.bn.mask_a != nullptr;
+    const bool bnb = a.bn.coef != nullptr, bne = a.bn.E != nullptr, bmask = bne && a.bn.mask_a != nullptr;
     f32x4 cA = zero, cs1 = zero, cmu = zero, cQ = zero, cma = zero, cmb = zero;
     if (bnb && nv) {
         cA = *reinterpret_cast<const f32x4*>(a.bn.coef + n4); cs1 = *reinterpret_cast<const f32x4*>(a.bn.coef + a.bn.C + n4);
         cmu = *reinterpret_cast<const f32x4*>(a.bn.coef + 2 * a.bn.C + n4); cQ = *reinterpret_cast<const f32x4*>(a.bn.coef + 3 * a.bn.C + n4);
         if (bmask) { cma = *reinterpret_cast<const f32x4*>(a.bn.mask_a + n4); cmb = *reinterpret_cast<const f32x4*>(a.bn.mask_b + n4); }
     }
-    const float* eb = bnb ? a.bn.E + (nv ? n4 : 0) : nullptr;
+    const float* eb = bne ? a.bn.E + (nv ? n4 : 0) : nullptr;
     // row loop, software pipelined by hand: the 16 rows of step i + 1 are requested before the 64 MFMAs of step i are issued
     // (two register sets, ping-pong) — a wave otherwise waits out a memory round trip per step with nothing to issue
     auto load = [&](long m, f32x4 (&dv)[4], f32x4 (&xv)[4], f32x4 (&ev)[4]) {
@@ -411,7 +418,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs a) {
             const bool rv = r < m1;
             dv[u] = rv && nv ? *reinterpret_cast<const f32x4*>(dy + r * a.lddy) : zero;
             xv[u] = rv && kv ? *reinterpret_cast<const f32x4*>(x + r * a.ldx) : zero;
-            ev[u] = bnb && rv && nv ? *reinterpret_cast<const f32x4*>(eb + r * a.bn.lde) : zero;
+            ev[u] = bne && rv && nv ? *reinterpret_cast<const f32x4*>(eb + r * a.bn.lde) : zero;
         }
     };
     auto compute = [&](long m, f32x4 (&dv)[4], f32x4 (&xv)[4], const f32x4 (&ev)[4]) {
@@ -515,14 +522,14 @@ __global__ __launch_bounds__(256) void pw_wgrad_smallk_kernel(WgradArgs a) {
         ia[b] = act && kv[b] ? a.act_a[b * 16 + li] : 0.f;
         ib[b] = act && kv[b] ? a.act_b[b * 16 + li] : 0.f;
     }
-    const bool bnb = a.bn.E != nullptr, bmask = a.bn.mask_a != nullptr;
+    const bool bnb = a.bn.coef != nullptr, bne = a.bn.E != nullptr, bmask = bne && a.bn.mask_a != nullptr;
     f32x4 cA = zero, cs1 = zero, cmu = zero, cQ = zero, cma = zero, cmb = zero;
     if (bnb && nv) {
         cA = *reinterpret_cast<const f32x4*>(a.bn.coef + n4); cs1 = *reinterpret_cast<const f32x4*>(a.bn.coef + a.bn.C + n4);
         cmu = *reinterpret_cast<const f32x4*>(a.bn.coef + 2 * a.bn.C + n4); cQ = *reinterpret_cast<const f32x4*>(a.bn.coef + 3 * a.bn.C + n4);
         if (bmask) { cma = *reinterpret_cast<const f32x4*>(a.bn.mask_a + n4); cmb = *reinterpret_cast<const f32x4*>(a.bn.mask_b + n4); }
     }
-    const float* eb = bnb ? a.bn.E + (nv ? n4 : 0) : nullptr;
+    const float* eb = bne ? a.bn.E + (nv ? n4 : 0) : nullptr;
     for (long m = m0 + wave * 16; m < m1; m += 64) {
         f32x4 dv[4];
         float xs[4][KB];
@@ -532,7 +539,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_smallk_kernel(WgradArgs a) {
             const bool rv = r < m1;
             dv[u] = rv && nv ? *reinterpret_cast<const f32x4*>(dy + r * a.lddy) : zero;
             if (bnb && rv && nv) {
-                const f32x4 ev = *reinterpret_cast<const f32x4*>(eb + r * a.bn.lde);
+                const f32x4 ev = bne ? *reinterpret_cast<const f32x4*>(eb + r * a.bn.lde) : zero;
                 if (bmask) dv[u] = relu_mask4(dv[u], ev, cma, cmb);
                 dv[u] = bnb4(dv[u], ev, cA, cs1, cmu, cQ);
             }

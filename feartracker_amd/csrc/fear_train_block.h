@@ -32,14 +32,16 @@ namespace {
 struct PwBwdArgs {
     const float* G;
     BnbIn bn;
+    const float* X2;     // optional: the reduction's rows K1 ... Kred - 1 come from this second tensor [M][ldx2], as loaded (see BnbIn)
     const float* W;      // [Kred][Nout]
     const float* R;      // optional [M][ldr] added to Y (MS = false)
     float* Y;
     const float* D;      // MS: [M][ldd] raw tensor behind the ReLU
     const float* dvec;   // MS: [4][Nout] mean | rstd | a | b of D's BatchNorm
     double* partial;     // MS: [gridDim.x][2][Nout]
-    int ldg, ldr, ldy, ldd;
+    int ldg, ldx2, ldr, ldy, ldd;
     int M, Kred, Nout;
+    int K1;              // with X2: a multiple of 16
     int row_tiles;       // 128-row tiles per workgroup (0 = 1)
 };
 
@@ -51,7 +53,8 @@ __global__ __launch_bounds__(256) void pw_bwd_kernel(PwBwdArgs a) {
     const int wave = threadIdx.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int row_tiles = a.row_tiles > 0 ? a.row_tiles : 1;
-    const bool bnb = a.bn.E != nullptr, bmask = a.bn.mask_a != nullptr;
+    const bool bnb = a.bn.coef != nullptr, bne = a.bn.E != nullptr, bmask = bne && a.bn.mask_a != nullptr;
+    const bool two = a.X2 != nullptr;
     const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int n_tiles = (a.Nout + 15) >> 4;
     for (int nc = blockIdx.y * NT; nc < n_tiles; nc += NT * gridDim.y) {
@@ -74,6 +77,7 @@ __global__ __launch_bounds__(256) void pw_bwd_kernel(PwBwdArgs a) {
             if (m_wave >= a.M) break;      // (wave-uniform; no barrier inside this loop)
             const float* grow[MT];
             const float* erow[MT];
+            const float* x2row[MT];
             bool mvalid[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -81,7 +85,8 @@ __global__ __launch_bounds__(256) void pw_bwd_kernel(PwBwdArgs a) {
                 mvalid[mt] = m < a.M;
                 if (m >= a.M) m = a.M - 1;
                 grow[mt] = a.G + (long)m * a.ldg;
-                erow[mt] = bnb ? a.bn.E + (long)m * a.bn.lde : nullptr;
+                erow[mt] = bne ? a.bn.E + (long)m * a.bn.lde : nullptr;
+                x2row[mt] = two ? a.X2 + (long)m * a.ldx2 : nullptr;
             }
             f32x4 acc[MT][NT];
 #pragma unroll
@@ -94,13 +99,16 @@ __global__ __launch_bounds__(256) void pw_bwd_kernel(PwBwdArgs a) {
                 f32x4 xf[MT], wf[NT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) xf[mt] = zero;
-                if (kvalid) {
+                if (kvalid && two && kg >= a.K1) {          // (K1 is a multiple of 16: uniform over the wave)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) xf[mt] = *reinterpret_cast<const f32x4*>(x2row[mt] + (k - a.K1));
+                } else if (kvalid) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) xf[mt] = *reinterpret_cast<const f32x4*>(grow[mt] + k);
                     if (bnb) {
                         f32x4 ev[MT];
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) ev[mt] = *reinterpret_cast<const f32x4*>(erow[mt] + k);
+                        for (int mt = 0; mt < MT; ++mt) ev[mt] = bne ? *reinterpret_cast<const f32x4*>(erow[mt] + k) : zero;
                         const f32x4 cA = *reinterpret_cast<const f32x4*>(a.bn.coef + k), cs1 = *reinterpret_cast<const f32x4*>(a.bn.coef + a.bn.C + k);
                         const f32x4 cmu = *reinterpret_cast<const f32x4*>(a.bn.coef + 2 * a.bn.C + k), cQ = *reinterpret_cast<const f32x4*>(a.bn.coef + 3 * a.bn.C + k);
                         if (bmask) {
@@ -866,6 +874,43 @@ void bn_backward_sums(const float* dy, int lddy, const float* raw, int ldx, cons
     finalize_backward(col, blocks, C, (double)M, gamma, vec, dgamma, dbeta, coef, s);
 }
 
+// The E-free form of an expansion's backward (BnbIn, fear_train.hip): from BN1's coefficients [A | s1 | mu | Q] and the expansion
+// weights W1 [cexp][cin], the extended K-major weight matrix of the input-gradient GEMM
+//     Wext [cexp + cin][cin] = [ W1 ; -T ],   T = W1^T diag(A Q) W1
+// so that  dx = [A (g1 - s1 + mu Q) | x] Wext  (the GEMM's operand is g1 with BnbIn::E = nullptr, then the block input as loaded).
+// (one workgroup per row of T, the reduction over cexp dealt to 1024 / kp lanes per element, kp = cin rounded up to a power of two —
+// the kernel sits between BN1's coefficients and the input-gradient GEMM on the chain of input gradients; further workgroups copy W1)
+__global__ __launch_bounds__(1024) void irb_lin_weights_kernel(const float* coef, const float* W1, float* Wext, int cexp, int cin, int kp_log2) {
+    __shared__ double part[1024];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= cin) {
+        const int idx = ((int)blockIdx.x - cin) * 1024 + tid;
+        if (idx < cexp * cin) Wext[idx] = W1[idx];
+        return;
+    }
+    const int kp = 1 << kp_log2, J = 1024 >> kp_log2;
+    const int k1 = blockIdx.x, k = tid & (kp - 1), j = tid >> kp_log2;
+    double t = 0.0;
+    if (k < cin)
+        for (int c = j; c < cexp; c += J)
+            t += (double)W1[(long)c * cin + k1] * ((double)coef[c] * (double)coef[3 * cexp + c]) * (double)W1[(long)c * cin + k];
+    part[tid] = t;
+    __syncthreads();
+    if (j != 0 || k >= cin) return;
+    for (int l = 1; l < J; ++l) t += part[l * kp + k];      // fixed order
+    Wext[(long)(cexp + k1) * cin + k] = (float)-t;
+}
+
+// ... and of its weight gradient: dW1 [cexp][cin] (holding [A (g1 - s1 + mu Q)]^T x) -= diag(A Q) W1 G, G = x^T x [cin][cin]
+__global__ __launch_bounds__(256) void irb_lin_wgrad_fix_kernel(const float* coef, const float* W1, const float* G, float* dW1, int cexp, int cin) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= cexp * cin) return;
+    const int c = idx / cin, k = idx - c * cin;
+    double t = 0.0;
+    for (int k1 = 0; k1 < cin; ++k1) t += (double)W1[(long)c * cin + k1] * (double)G[(long)k1 * cin + k];
+    dW1[idx] = (float)((double)dW1[idx] - (double)coef[c] * (double)coef[3 * cexp + c] * t);
+}
+
 // running statistics of a BatchNorm from its saved vec = [mean | rstd | a | b] (the forward ran with running_mean = NULL so that
 // two passes of the shared trunk can overlap on two streams; torch's order — template pass first — is restored by applying the
 // search pass's update afterwards): biased variance = 1 / rstd^2 - eps, tracked unbiased
@@ -936,7 +981,9 @@ size_t fear_irb_scratch_floats(const FearIrbBlock* b, int B, int H, int W) {
     const long rows_in = (long)B * H * W, rows_out = rows_in / (b->stride * b->stride);
     // g2 | g1 | the three BatchNorms' backward coefficient vectors (3 x [4][cmax]; they must outlive the call when the weight
     // gradients run on their own stream, so they do not live in the shared workspace)
-    return (size_t)rows_out * b->cexp + (b->expand ? (size_t)rows_in * b->cexp : 0) + (size_t)12 * irb_cmax(b);
+    // | the extended weight matrix and the input's Gram matrix of the expansion's E-free backward (BnbIn)
+    return (size_t)rows_out * b->cexp + (b->expand ? (size_t)rows_in * b->cexp : 0) + (size_t)12 * irb_cmax(b) +
+           (b->expand ? (size_t)(b->cexp + 2 * b->cin) * b->cin : 0);
 }
 
 int fear_irb_train_forward(const FearIrbBlock* b, const FearIrbSaved* sv, const float* x, float* out, int B, int H, int W, double momentum,
@@ -1067,25 +1114,55 @@ int fear_irb_train_backward(const FearIrbBlock* b, const FearIrbSaved* sv, const
             finalize_backward(ws.col, a.wgs_per_slab, cexp, (double)rows_in, b->gamma[0], sv->vec[0], gr->gamma[0], gr->beta[0], coef1, s);
     }
     if (b->expand) {
+        // BN1's backward without its input: e = x W1^T is linear in the block input, so both consumers read g1 (cexp channels) and x
+        // (cin channels) instead of g1 and e — see BnbIn.  G = x^T x and the two small correction kernels are the price.
+        // where it pays — 16-32 input channels, the expansions of the 128 x 128 ... 32 x 32 maps: bandwidth-bound launches that read
+        // 0.1-0.8 GB less each (16.71 -> 16.49 ms per step).  With 64 / 112 input channels (the 16 x 16 maps) the T kernel on the
+        // chain, the Gram matrix and the correction cost more than the lighter loads save: 16.64 / 16.80 ms with those included.
+        // (cexp % 16: a GEMM stage of 16 reduction columns must not straddle g1 and x.)
+        const bool lin = cexp % 16 == 0 && cin <= 128 && !(b->flags & FEAR_IRB_NO_LINEAR_BN1) &&
+                         (cin <= 32 || (b->flags & FEAR_IRB_LINEAR_BN1));
         BnbIn bn1{};
-        bn1.E = sv->e; bn1.coef = coef1; bn1.lde = cexp; bn1.C = cexp;
-        if (dbg_skip() & 32) bn1 = BnbIn{};
+        bn1.coef = coef1; bn1.C = cexp;
+        if (!lin) { bn1.E = sv->e; bn1.lde = cexp; }
+        float* wext = coef1 + 12 * cmax;                       // [cexp + cin][cin]
+        float* gram = wext + (size_t)(cexp + cin) * cin;       // [cin][cin]
         if (sw != s && !stream_follow(sw, s)) return FEAR_TRAIN_ERR_HIP;          // g1 and coef1 exist
-        const int rc = wgrad_impl(g1, cexp, 0, x, cin, 0, gr->w_pw, ws.wg, ws.wg_bytes, rows_in, cin, cexp, 1, sw, nullptr, nullptr, 0, &bn1);
+        int rc = lin ? wgrad_impl(x, cin, 0, x, cin, 0, gram, ws.wg, ws.wg_bytes, rows_in, cin, cin, 1, sw) : FEAR_TRAIN_OK;
         if (rc != FEAR_TRAIN_OK) return rc;
-        if (dx && gemm_lds_applies(rows_in, cexp, cin)) {
-            GemmArgs g{};
-            g.X = g1; g.ldx = cexp; g.bn = bn1; g.W = b->w_pw; g.R = b->residual ? dout : nullptr; g.ldr = cout; g.Y = dx; g.ldy = cin;
-            g.M = (int)rows_in; g.K = cexp; g.N = cin;
-            if (dbg_skip() & 32) launch_gemm_lds<0, 0, true>(g, s, nullptr); else
-            launch_gemm_lds<2, 0, true>(g, s, nullptr);
-        } else if (dx) {
-            PwBwdArgs a{};
-            a.G = g1; a.ldg = cexp; a.bn = bn1; a.W = b->w_pw; a.R = b->residual ? dout : nullptr; a.ldr = cout; a.Y = dx; a.ldy = cin;
-            a.M = (int)rows_in; a.Kred = cexp; a.Nout = cin;
-            int nt = 1;
-            const dim3 grid = dgrad_grid(rows_in, cexp, cin, &nt);
-            launch_pw_bwd<false>(a, grid, nt, s);
+        rc = wgrad_impl(g1, cexp, 0, x, cin, 0, gr->w_pw, ws.wg, ws.wg_bytes, rows_in, cin, cexp, 1, sw, nullptr, nullptr, 0, &bn1);
+        if (rc != FEAR_TRAIN_OK) return rc;
+        if (lin)
+            hipLaunchKernelGGL(irb_lin_wgrad_fix_kernel, dim3((unsigned)((cexp * cin + 255) / 256)), dim3(256), 0, sw, coef1, b->w_pw, gram,
+                               gr->w_pw, cexp, cin);
+        if (dx) {
+            if (lin)
+            {
+                int kp_log2 = 4;
+                while ((1 << kp_log2) < cin) ++kp_log2;
+                hipLaunchKernelGGL(irb_lin_weights_kernel, dim3((unsigned)(cin + (cexp * cin + 1023) / 1024)), dim3(1024), 0, s, coef1, b->w_pw,
+                                   wext, cexp, cin, kp_log2);
+            }
+            const int kred = lin ? cexp + cin : cexp;
+            if (gemm_lds_applies(rows_in, kred, cin)) {
+                GemmArgs g{};
+                g.X = g1; g.ldx = cexp; g.bn = bn1; g.W = lin ? wext : b->w_pw; g.R = b->residual ? dout : nullptr; g.ldr = cout;
+                g.Y = dx; g.ldy = cin; g.M = (int)rows_in; g.K = kred; g.N = cin;
+                if (lin) {
+                    g.X2 = x; g.ldx2 = cin; g.K1 = cexp;
+                    launch_gemm_lds<3, 0, true>(g, s, nullptr);
+                } else {
+                    launch_gemm_lds<2, 0, true>(g, s, nullptr);
+                }
+            } else {
+                PwBwdArgs a{};
+                a.G = g1; a.ldg = cexp; a.bn = bn1; a.W = lin ? wext : b->w_pw; a.R = b->residual ? dout : nullptr; a.ldr = cout;
+                if (lin) { a.X2 = x; a.ldx2 = cin; a.K1 = cexp; }
+                a.Y = dx; a.ldy = cin; a.M = (int)rows_in; a.Kred = kred; a.Nout = cin;
+                int nt = 1;
+                const dim3 grid = dgrad_grid(rows_in, kred, cin, &nt);
+                launch_pw_bwd<false>(a, grid, nt, s);
+            }
         }
     }
     LAUNCH_CHECK();

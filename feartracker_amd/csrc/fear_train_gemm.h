@@ -15,7 +15,8 @@
 // loads per fragment.
 //
 // The fused prologues / epilogues are the first-generation kernels', applied where an element passes through registers anyway:
-//   XT  = 0 plain | 1 activation on load, max(fma(x, a, b), 0) (ActIn) | 2 BatchNorm backward on load (BnbIn)
+//   XT  = 0 plain | 1 activation on load, max(fma(x, a, b), 0) (ActIn) | 2 BatchNorm backward on load (BnbIn) | 3 its E-free
+//         bracket on load (bn.coef only), followed by plain columns of a second tensor X2 (an expansion's input gradient, see BnbIn)
 //   EPI = 0 (+ bias) (+ R) -> Y | 1 Y + column sums sum(y), sum(y^2) | 2 Y masked by act(D) > 0 + column sums sum(y), sum(y * dhat)
 // Same products in the same k order as those kernels (k ascending, four per MFMA).
 //
@@ -23,6 +24,7 @@
 
 struct GemmArgs {
     const float* X;      // [M][ldx]
+    const float* X2;     // XT 3: the reduction's columns K1 ... K - 1 come from this second tensor [M][ldx2], as loaded
     const float* W;      // WKN ? [K][N] row-major : [N][K] row-major
     const float* bias;   // EPI 0: [N] or nullptr
     const float* R;      // EPI 0: optional [M][ldr] added
@@ -32,8 +34,9 @@ struct GemmArgs {
     const float* D;      // EPI 2: [M][ldd] raw tensor behind the ReLU that masks Y
     const float* dvec;   // EPI 2: [4][N] mean | rstd | a | b of D's BatchNorm
     double* partial;     // EPI 1, 2: [gridDim.x][2][N]
-    int ldx, ldr, ldy, ldd;
+    int ldx, ldx2, ldr, ldy, ldd;
     int M, K, N;
+    int K1;              // XT 3: a multiple of 16 (a stage never straddles the two sources)
     int relu;            // EPI 0: max(., 0) on the way out
 };
 
@@ -57,7 +60,7 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs a) {
 
     // ---- staging registers: thread t stages k quad t & 3 of rows (t >> 2) + 64 j; the per-channel vectors of the prologue travel
     //      with the stage (requested with its loads, used when it is committed)
-    f32x4 xr[XL], er[XT == 2 ? XL : 1], wr[WL], pv[XT == 2 ? 6 : (XT == 1 ? 2 : 1)];
+    f32x4 xr[XL], er[XT == 2 ? XL : 1], wr[WL], pv[XT == 2 ? 6 : (XT == 1 || XT == 3 ? 2 : 1)];
     const int kq = tid & 3, row_t = tid >> 2;
     bool x_ok[XL];
 #pragma unroll
@@ -65,16 +68,25 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs a) {
     auto stage_load = [&](int k0) {
         const int k = k0 + 4 * kq;
         const bool kok = k < a.K;                        // K is a multiple of 4
+        const bool second = XT == 3 && k0 >= a.K1;      // (uniform over the workgroup)
 #pragma unroll
         for (int j = 0; j < XL; ++j) {
             const bool ok = x_ok[j] && kok;
             const long off = (long)(m0 + row_t + 64 * j);
-            xr[j] = ok ? *reinterpret_cast<const f32x4*>(a.X + off * a.ldx + k) : zero;
+            if (XT == 3 && second) xr[j] = ok ? *reinterpret_cast<const f32x4*>(a.X2 + off * a.ldx2 + (k - a.K1)) : zero;
+            else xr[j] = ok ? *reinterpret_cast<const f32x4*>(a.X + off * a.ldx + k) : zero;
             if (XT == 2) er[XT == 2 ? j : 0] = ok ? *reinterpret_cast<const f32x4*>(a.bn.E + off * a.bn.lde + k) : zero;
         }
         if (XT == 1 && xact && kok) {
             pv[0] = *reinterpret_cast<const f32x4*>(a.in.a + k);
             pv[XT == 1 ? 1 : 0] = *reinterpret_cast<const f32x4*>(a.in.b + k);
+        }
+        if (XT == 3 && kok && !second) {
+            // A | A (mu Q - s1): the E-free bracket of BnbIn as one fma per element
+            const f32x4 cA = *reinterpret_cast<const f32x4*>(a.bn.coef + k), cs1 = *reinterpret_cast<const f32x4*>(a.bn.coef + a.bn.C + k);
+            const f32x4 cmu = *reinterpret_cast<const f32x4*>(a.bn.coef + 2 * a.bn.C + k), cQ = *reinterpret_cast<const f32x4*>(a.bn.coef + 3 * a.bn.C + k);
+            pv[0] = cA;
+            pv[XT == 3 ? 1 : 0] = cA * (cmu * cQ - cs1);
         }
         if (XT == 2 && kok) {
 #pragma unroll
@@ -109,6 +121,8 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs a) {
             if (x_ok[j] && kok) {
                 if (XT == 1 && xact) {
                     v = act4(v, pv[0], pv[XT == 1 ? 1 : 0], a.in.relu != 0);
+                } else if (XT == 3) {
+                    if (k0 < a.K1) v = act4(v, pv[0], pv[XT == 3 ? 1 : 0], false);
                 } else if (XT == 2) {
                     const f32x4 e = er[XT == 2 ? j : 0];
                     if (bmask) v = relu_mask4(v, e, pv[XT == 2 ? 4 : 0], pv[XT == 2 ? 5 : 0]);
@@ -288,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(WgradArgs a) {
     const int c4 = tid & 31, r_t = tid >> 5;
     const int nch = n0 + 4 * c4, kch = k0 + 4 * c4;
     const bool nv = nch < a.N, kv = kch < a.K;
-    const bool act = a.act_a != nullptr, bnb = a.bn.E != nullptr, bmask = a.bn.mask_a != nullptr;
+    const bool act = a.act_a != nullptr, bnb = a.bn.coef != nullptr, bne = a.bn.E != nullptr, bmask = bne && a.bn.mask_a != nullptr;
     f32x4 ia = zero, ib = zero, cA = zero, cs1 = zero, cmu = zero, cQ = zero, cma = zero, cmb = zero;
     if (act && kv) { ia = *reinterpret_cast<const f32x4*>(a.act_a + kch); ib = *reinterpret_cast<const f32x4*>(a.act_b + kch); }
     if (bnb && nv) {
@@ -308,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(WgradArgs a) {
             const long r = m + r_t + 8 * j;
             const bool rv = r < m1;
             dr[set][j] = rv && nv ? *reinterpret_cast<const f32x4*>(a.dY + r * a.lddy + nch) : zero;
-            er[set][j] = bnb && rv && nv ? *reinterpret_cast<const f32x4*>(a.bn.E + r * a.bn.lde + nch) : zero;
+            er[set][j] = bne && rv && nv ? *reinterpret_cast<const f32x4*>(a.bn.E + r * a.bn.lde + nch) : zero;
             xr[set][j] = rv && kv ? *reinterpret_cast<const f32x4*>(a.X + r * a.ldx + kch) : zero;
         }
     };

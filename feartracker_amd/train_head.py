@@ -81,7 +81,7 @@ TRAIN_SYMBOLS = {
 
 class FearIrbBlock(ctypes.Structure):
     """include/fear_train.h: one inverted-residual block's shape and parameters (device pointers, kernel layouts)."""
-    _fields_ = [("cin", _i), ("cexp", _i), ("cout", _i), ("k", _i), ("stride", _i), ("expand", _i), ("residual", _i), ("reserved", _i),
+    _fields_ = [("cin", _i), ("cexp", _i), ("cout", _i), ("k", _i), ("stride", _i), ("expand", _i), ("residual", _i), ("flags", _i),
                 ("w_pw", _P), ("w_dw", _P), ("w_pwl", _P), ("gamma", _P * 3), ("beta", _P * 3), ("running_mean", _P * 3), ("running_var", _P * 3)]
 
 

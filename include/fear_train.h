@@ -184,8 +184,14 @@ int fear_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
  * backward: the BatchNorm backward applied on load from the pair (gradient, raw tensor)); what is written is the raw conv outputs
  * e / d / p (saved for the backward) and, in the backward, two masked gradients in `scratch`.  Same arithmetic as the operators
  * above composed unit by unit (tests/test_train_head.py pins both against autograd).  One rank (no SyncBatchNorm hook). */
+/* The expansion's backward without its raw output (e = x W1^T is linear in the block input: BatchNorm1's input gradient folds into
+ * the two consumers' own algebra, a cin x cin matrix each — csrc/fear_train.hip BnbIn): chosen by the call where it pays (up to 32
+ * input channels: the large maps); these flags force it wherever it applies (cexp % 16 == 0, cin <= 128) or forbid it. */
+#define FEAR_IRB_LINEAR_BN1 1
+#define FEAR_IRB_NO_LINEAR_BN1 2
 typedef struct FearIrbBlock {
-    int cin, cexp, cout, k, stride, expand, residual, reserved;
+    int cin, cexp, cout, k, stride, expand, residual;
+    int flags;                     /* 0 = let the call choose; FEAR_IRB_LINEAR_BN1 / FEAR_IRB_NO_LINEAR_BN1 (below) */
     const float* w_pw;             /* [cexp][cin]   (NULL without expansion) */
     const float* w_dw;             /* [k*k][cexp]   depthwise taps, tap-major */
     const float* w_pwl;            /* [cout][cexp] */

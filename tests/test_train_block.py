@@ -45,9 +45,16 @@ CASES = [
 ]
 
 
+# ... and the expansions of the large maps once more in the E-free form of BatchNorm1's backward (FEAR_IRB_LINEAR_BN1: the call
+# chooses it by itself from 10^5 rows up — the last case, whose 81 920 rows also take the first-generation GEMMs)
+LIN_CASES = [(c, b, h, 1) for c, b, h in CASES if c[5]] + [((16, 96, 24, 3, 2, 1, 0), 5, 128, 1), ((32, 192, 32, 5, 1, 1, 1), 2, 16, 2)]
+ALL_CASES = [(c, b, h, 0) for c, b, h in CASES] + LIN_CASES
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg,B,H", CASES, ids=[f"{c[0]}x{c[1]}x{c[2]}k{c[3]}s{c[4]}_b{b}h{h}" for c, b, h in CASES])
-def test_irb_block_forward_backward_vs_autograd(cfg, B, H):
+@pytest.mark.parametrize("cfg,B,H,flags", ALL_CASES,
+                         ids=[f"{c[0]}x{c[1]}x{c[2]}k{c[3]}s{c[4]}_b{b}h{h}" + ("", "_lin", "_nolin")[f] for c, b, h, f in ALL_CASES])
+def test_irb_block_forward_backward_vs_autograd(cfg, B, H, flags):
     from feartracker_amd.train_head import FearIrbBlock, FearIrbGrads, FearIrbSaved, _p, load_train_library
     lib = load_train_library()
     dev = torch.device("cuda:0")
@@ -82,6 +89,7 @@ def test_irb_block_forward_backward_vs_autograd(cfg, B, H):
     rows = lambda t: t.detach().permute(0, 2, 3, 1).reshape(-1, t.shape[1])
     blk = FearIrbBlock()
     blk.cin, blk.cexp, blk.cout, blk.k, blk.stride, blk.expand, blk.residual = cin, cexp, cout, k, stride, expand, residual
+    blk.flags = flags
     w_pw = D(p["w_pw"]) if expand else None
     w_dw, w_pwl = D(p["w_dw"]), D(p["w_pwl"])
     blk.w_pw, blk.w_dw, blk.w_pwl = (w_pw.data_ptr() if expand else None), w_dw.data_ptr(), w_pwl.data_ptr()
