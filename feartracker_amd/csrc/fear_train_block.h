@@ -194,6 +194,101 @@ __global__ __launch_bounds__(256) void pw_bwd_kernel(PwBwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The VIRTUAL expansion of a 16-channel block input (FEAR_IRB_VIRTUAL_E; the 16 -> 96 expansion of the 128 x 128 map is 0.8 GB per
+// 128 crops, written once and read three times): e = x W1^T is never stored.  Its two remaining consumers — the depthwise kernels;
+// the expansion's own backward reads g1 and x, see BnbIn — form their tile of it on the matrix pipe as the tile is staged: per 16
+// pixels one 16-byte load per lane (lane (pixel j, k quarter kk) holds x[j][4 kk ..]) and four MFMAs per 16 channels against the
+// W1 fragments a lane keeps (lane (channel i, kk): W1[i][4 kk ..]); the result lane (pixel j, q) is the float4 of channels 4 q ..
+// 4 q + 3 of pixel j — the (pixel, channel quad) unit both kernels work in.  The SAME products in the same order in both
+// directions, so the forward's activation and the backward's mask see the same numbers.
+// BatchNorm1's batch statistics follow from linearity as well: sum_m e = W1 (sum_m x), sum_m e^2 = diag(W1 G W1^T), G = x^T x.
+struct VirtE {
+    const float* X;       // [pixels][16] the block input
+    const float* W1;      // [C][16] the expansion's weights
+};
+
+// e[16 channels of column tile ct][16 pixels] from the fragments above: lane (pixel j, q) gets channels 4 q .. 4 q + 3
+__device__ __forceinline__ f32x4 virt_e_tile(const f32x4& wa, const f32x4& xb) {
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t], xb[t], acc, 0, 0, 0);
+    return acc;
+}
+
+// G = x^T x [16][16] and s = sum_m x [16] of a 16-channel tensor in one pass: a wave's load of 64 consecutive floats IS the MFMA
+// fragment of four rows — lane (channel i, row kk) — for both operands (D[i][j] += sum_kk x[kk][i] x[kk][j]); the column sums are the
+// same product against ones.  Per workgroup one partial [272] = G | s (+ 0-padding), summed by slice_sum_kernel in a fixed order.
+__global__ __launch_bounds__(256) void gram16_kernel(const float* X, long M, long rows_per_wg, float* P) {
+    __shared__ f32x4 red[3][2][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long m0 = (long)blockIdx.x * rows_per_wg;
+    const long m1 = m0 + rows_per_wg < M ? m0 + rows_per_wg : M;
+    const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 g = zero, sm = zero;
+    constexpr int U = 8;
+    const long ngroups = m1 > m0 ? (m1 - m0 + 3) / 4 : 0;      // groups of four rows, dealt to the waves U at a time
+    for (long g0 = (long)wave * U; g0 < ngroups; g0 += 4 * U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long r = m0 + (g0 + u) * 4 + (lane >> 4);
+            v[u] = (g0 + u < ngroups && r < m1) ? X[r * 16 + (lane & 15)] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            g = __builtin_amdgcn_mfma_f32_16x16x4f32(v[u], v[u], g, 0, 0, 0);
+            sm = __builtin_amdgcn_mfma_f32_16x16x4f32(v[u], 1.0f, sm, 0, 0, 0);
+        }
+    }
+    if (wave > 0) { red[wave - 1][0][lane] = g; red[wave - 1][1][lane] = sm; }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) { g += red[w][0][lane]; sm += red[w][1][lane]; }      // fixed order
+    float* out = P + (long)blockIdx.x * 272;
+    const int j = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[(4 * q + r) * 16 + j] = g[r];                      // lane (j, q), component r = G[4 q + r][j]
+    if (j == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[256 + 4 * q + r] = sm[r];
+    }
+}
+
+// BatchNorm1 of a virtual expansion from (G | s): mean, rstd, the affine a | b and the running statistics (col_finalize mode 0's)
+__global__ __launch_bounds__(256) void irb_virtual_stats_kernel(const float* GS, const float* W1, const float* gamma, const float* beta, float* vec,
+                                                              float* running_mean, float* running_var, int C, double M, double eps, double momentum) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double w[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) w[k] = (double)W1[(long)c * 16 + k];
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        s1 += w[k] * (double)GS[256 + k];
+        double t = 0.0;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) t += (double)GS[k * 16 + k2] * w[k2];
+        s2 += w[k] * t;
+    }
+    const double mean = s1 / M;
+    double var = s2 / M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float mf = (float)mean, rf = (float)(1.0 / sqrt(var + eps));
+    vec[c] = mf;
+    vec[C + c] = rf;
+    const float av = gamma[c] * rf;
+    vec[2 * C + c] = av;
+    vec[3 * C + c] = __builtin_fmaf(-mf, av, beta[c]);
+    if (running_mean) {
+        running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+        const double unbiased = M > 1.0 ? var * M / (M - 1.0) : var;
+        running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Backward through  ReLU o BN2 o depthwise o ReLU o BN1  in one pass (the middle of an inverted-residual block).
 //   inputs   G2 [B*Ho*Wo][C]  gradient w.r.t. the depthwise unit's activation, already masked by its ReLU (pw_bwd_kernel<MS>)
 //            D  [B*Ho*Wo][C]  raw depthwise output (BN2's input);  coef2 = BN2's BnbIn coefficients
@@ -223,10 +318,12 @@ struct DwBwdArgs {
     int ldo, lde, ldr, ldy;
     int B, H, W, Ho, Wo, C;
     int tiles_x, tiles_y, wgs_per_slab, nslab;
+    VirtE ve;             // VE: E is not read, e = ve.X ve.W1^T on the spot
 };
 
-template <int KS, int S, int SQ, bool BN1>
+template <int KS, int S, int SQ, bool BN1, bool VE = false>
 __global__ __launch_bounds__(256, 2) void dw_bwd_kernel(DwBwdArgs a) {
+    static_assert(!VE || (BN1 && S == 2), "the virtual expansion is built for the stride-2 kernels");
     constexpr int P = KS / 2, KK = KS * KS, TS = 16;
     constexpr int LO = P / S;                          // output rows / columns in front of the tile's first own one
     constexpr int OR = (TS - 1 + P) / S + LO + 1;      // side of the dd region a tile reads
@@ -261,6 +358,16 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_kernel(DwBwdArgs a) {
         if (BN1) {
             mu1 = *reinterpret_cast<const f32x4*>(a.act1 + c); rs1 = *reinterpret_cast<const f32x4*>(a.act1 + a.C + c);
             a1 = *reinterpret_cast<const f32x4*>(a.act1 + 2 * a.C + c); b1 = *reinterpret_cast<const f32x4*>(a.act1 + 3 * a.C + c);
+        }
+    }
+    // VE: the tile's raw expansion [256 pixels][SQ quads], formed on the matrix pipe while the dd region is staged
+    __shared__ f32x4 es[VE ? TS * TS * SQ : 1];
+    f32x4 wa[VE ? SQ / 4 : 1];
+    if (VE) {
+#pragma unroll
+        for (int ct = 0; ct < SQ / 4; ++ct) {
+            const int ch = slab * SQ * 4 + ct * 16 + (tid & 15);
+            wa[VE ? ct : 0] = ch < a.C ? *reinterpret_cast<const f32x4*>(a.ve.W1 + (long)ch * 16 + 4 * ((tid & 63) >> 4)) : zero;
         }
     }
     // this thread's parity class and the first tap it meets in each dimension
@@ -321,6 +428,18 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_kernel(DwBwdArgs a) {
                 const int pix = idx / SQ;
                 const int r = pix / OR, cc = pix - r * OR;
                 if (idx < NIDX) tile[r * PITCH + cc * SQ + cq_l] = in[u] ? bnb4(gv[u], dv[u], cA, cs1, cmu, cQ) : zero;
+            }
+        }
+        if constexpr (VE) {
+            const int wave = tid >> 6, j = tid & 15, kk = (tid & 63) >> 4;
+#pragma unroll 1
+            for (int rt = wave; rt < TS * TS / 16; rt += 4) {
+                const int p = rt * 16 + j;                       // tile pixel of this lane's column
+                const int iy = iy0 + p / TS, ix = ix0 + p % TS;
+                const bool inb = iy < a.H && ix < a.W;
+                const f32x4 xb = inb ? *reinterpret_cast<const f32x4*>(a.ve.X + (((long)b * a.H + iy) * a.W + ix) * 16 + 4 * kk) : zero;
+#pragma unroll
+                for (int ct = 0; ct < SQ / 4; ++ct) es[p * SQ + ct * 4 + kk] = virt_e_tile(wa[ct], xb);
             }
         }
         __syncthreads();
@@ -472,7 +591,11 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_kernel(DwBwdArgs a) {
                 const long prow = ((long)b * a.H + iy) * a.W + ix;
                 f32x4 e4 = zero, r4 = zero;
                 if (pin) {
-                    e4 = *reinterpret_cast<const f32x4*>(a.E + prow * a.lde + c);
+                    if constexpr (VE) {
+                        e4 = es[(iy_l * TS + ix_l) * SQ + cq_l];
+                    } else {
+                        e4 = *reinterpret_cast<const f32x4*>(a.E + prow * a.lde + c);
+                    }
                     if (!BN1 && a.R) r4 = *reinterpret_cast<const f32x4*>(a.R + prow * a.ldr + c);
                 }
                 f32x4 av = e4;                                 // the depthwise conv's operand at this pixel
@@ -565,9 +688,10 @@ struct DwFwdArgs {
     int ldx, ldy;
     int B, H, W, Ho, Wo, C;
     int tiles_x, tiles_y, wgs_per_slab, nslab;
+    VirtE ve;             // VE: X is not read, the operand is act(ve.X ve.W1^T)
 };
 
-template <int KS, int S, int SQ>
+template <int KS, int S, int SQ, bool VE = false>
 __global__ __launch_bounds__(256, 2) void dw_fwd_kernel(DwFwdArgs a) {
     constexpr int P = KS / 2, KK = KS * KS;
     constexpr int TO = S == 1 ? 16 : 8;                // output tile side
@@ -597,8 +721,20 @@ __global__ __launch_bounds__(256, 2) void dw_fwd_kernel(DwFwdArgs a) {
         for (int t = pl; t < KK; t += PL) wl[t * SQ + cq_l] = cv ? *reinterpret_cast<const f32x4*>(a.Wt + (long)t * a.C + c) : zero;
     }
     f64x4 S1 = (f64x4){0.0, 0.0, 0.0, 0.0}, S2 = S1;
-    const long xbytes = (long)a.B * a.H * a.W * a.ldx * 4;      // < 2^31: checked on the host
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X), 0, (int)xbytes, 0x00020000);
+    // VE: W1 fragments (lane (channel, k quarter)) and the activation of the two channel quads this lane's results belong to
+    f32x4 wa[VE ? SQ / 4 : 1], va[VE ? SQ / 4 : 1], vb[VE ? SQ / 4 : 1];
+    if (VE) {
+#pragma unroll
+        for (int ct = 0; ct < SQ / 4; ++ct) {
+            const int ch = slab * SQ * 4 + ct * 16 + (tid & 15);
+            wa[VE ? ct : 0] = ch < a.C ? *reinterpret_cast<const f32x4*>(a.ve.W1 + (long)ch * 16 + 4 * ((tid & 63) >> 4)) : zero;
+            const int c4 = (slab * SQ + ct * 4 + ((tid & 63) >> 4)) * 4;
+            va[VE ? ct : 0] = c4 < a.C ? *reinterpret_cast<const f32x4*>(a.in.a + c4) : zero;
+            vb[VE ? ct : 0] = c4 < a.C ? *reinterpret_cast<const f32x4*>(a.in.b + c4) : zero;
+        }
+    }
+    const long xbytes = (long)a.B * a.H * a.W * (VE ? 16 : a.ldx) * 4;      // < 2^31: checked on the host
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(VE ? a.ve.X : a.X), 0, (int)xbytes, 0x00020000);
     const int n_items = a.B * a.tiles_y * a.tiles_x;
     for (int item = wslot; item < n_items; item += a.wgs_per_slab) {
         const int tx = item % a.tiles_x, ty = (item / a.tiles_x) % a.tiles_y, b = item / (a.tiles_x * a.tiles_y);
@@ -608,6 +744,24 @@ __global__ __launch_bounds__(256, 2) void dw_fwd_kernel(DwFwdArgs a) {
         int wq = cq_l;
         asm volatile("" : "+v"(wq));        // (LDS weight index, opaque: see dw_bwd_kernel)
         constexpr int NIDX = IR * IR * SQ, U = 4;
+        if constexpr (VE) {
+            const int wave = tid >> 6, j = tid & 15, kk = (tid & 63) >> 4;
+#pragma unroll 1
+            for (int rt = wave; rt < (IR * IR + 15) / 16; rt += 4) {
+                const int pix = rt * 16 + j;                     // region pixel of this lane's column
+                const int r = pix / IR, cc = pix - r * IR;
+                const int y = iy0 + r, x = ix0 + cc;
+                const bool inb = pix < IR * IR && y >= 0 && y < a.H && x >= 0 && x < a.W;
+                const int off = inb ? ((b * a.H + y) * a.W + x) * 64 + 16 * kk : (int)0x80000000;
+                const f32x4 xb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
+#pragma unroll
+                for (int ct = 0; ct < SQ / 4; ++ct) {
+                    const f32x4 v = act4(virt_e_tile(wa[ct], xb), va[ct], vb[ct], a.in.relu != 0);
+                    const bool cok = (slab * SQ + ct * 4 + kk) * 4 < a.C;
+                    if (pix < IR * IR) tile[r * PITCH + cc * SQ + ct * 4 + kk] = inb && cok ? v : zero;
+                }
+            }
+        } else
         for (int i0 = 0; i0 < NIDX; i0 += 256 * U) {
             f32x4 xv[U];
             bool in[U];
@@ -966,6 +1120,12 @@ bool irb_shape_ok(const FearIrbBlock* b, int B, int H, int W) {
     return true;
 }
 
+// the shapes the virtual expansion is built for (FEAR-XS's 16 -> 96 expansion of the 128 x 128 map: 3 x 3 stride 2, 32-channel slabs)
+bool irb_virtual_shape(const FearIrbBlock* b) {
+    return b->expand && b->cin == 16 && b->k == 3 && b->stride == 2 && b->cexp >= 64 && b->cexp % 16 == 0 && !(b->flags & FEAR_IRB_NO_LINEAR_BN1);
+}
+bool irb_virtual(const FearIrbBlock* b) { return (b->flags & FEAR_IRB_VIRTUAL_E) != 0; }
+
 }  // namespace
 
 extern "C" {
@@ -975,6 +1135,8 @@ size_t fear_irb_workspace_bytes(const FearIrbBlock* b, int B, int H, int W) {
     const long rows_in = (long)B * H * W, rows_out = rows_in / (b->stride * b->stride);
     return block_ws(rows_in, rows_out, b->cin, b->cexp, b->cout, b->k, nullptr).total;
 }
+
+int fear_irb_virtual_ok(const FearIrbBlock* b) { return b && irb_virtual_shape(b) ? 1 : 0; }
 
 size_t fear_irb_scratch_floats(const FearIrbBlock* b, int B, int H, int W) {
     if (!b || !irb_shape_ok(b, B, H, W)) return 0;
@@ -989,17 +1151,29 @@ size_t fear_irb_scratch_floats(const FearIrbBlock* b, int B, int H, int W) {
 int fear_irb_train_forward(const FearIrbBlock* b, const FearIrbSaved* sv, const float* x, float* out, int B, int H, int W, double momentum,
                            double eps, float* workspace, size_t ws_bytes, void* stream) {
     if (!b || !sv || !x || !out || !workspace || !sv->d || !sv->p || !sv->vec[1] || !sv->vec[2] || !b->w_dw || !b->w_pwl) return FEAR_TRAIN_ERR_NULL;
-    if (b->expand && (!sv->e || !sv->vec[0] || !b->w_pw)) return FEAR_TRAIN_ERR_NULL;
+    if (b->expand && ((!sv->e && !irb_virtual(b)) || !sv->vec[0] || !b->w_pw)) return FEAR_TRAIN_ERR_NULL;
     for (int i = b->expand ? 0 : 1; i < 3; ++i)
         if (!b->gamma[i] || !b->beta[i]) return FEAR_TRAIN_ERR_NULL;
-    if (!irb_shape_ok(b, B, H, W)) return FEAR_TRAIN_ERR_SHAPE;
+    if (!irb_shape_ok(b, B, H, W) || (irb_virtual(b) && !irb_virtual_shape(b))) return FEAR_TRAIN_ERR_SHAPE;
     const long rows_in = (long)B * H * W, rows_out = rows_in / (b->stride * b->stride);
     const BlockWs ws = block_ws(rows_in, rows_out, b->cin, b->cexp, b->cout, b->k, workspace);
     if (ws_bytes < ws.total) return FEAR_TRAIN_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int Ho = H / b->stride, Wo = W / b->stride;
+    const bool virt = irb_virtual(b);
+    if (virt) {
+        // BatchNorm1's statistics of the expansion that is never written: G = x^T x and the column sums of x in one pass, then W1 on them
+        long rpw = (rows_in + 2047) / 2048;
+        rpw = (rpw + 127) / 128 * 128;
+        const int wgs = (int)((rows_in + rpw - 1) / rpw);
+        if ((size_t)wgs * 272 * sizeof(float) > ws.wg_bytes || ws.coef_bytes < 272 * sizeof(float)) return FEAR_TRAIN_ERR_WORKSPACE;
+        hipLaunchKernelGGL(gram16_kernel, dim3((unsigned)wgs), dim3(256), 0, s, x, rows_in, rpw, ws.wg);
+        launch_slice_sum(ws.wg, ws.coef, 272, wgs, s);
+        hipLaunchKernelGGL(irb_virtual_stats_kernel, dim3((unsigned)((b->cexp + 255) / 256)), dim3(256), 0, s, ws.coef, b->w_pw, b->gamma[0], b->beta[0],
+                           sv->vec[0], b->running_mean[0], b->running_var[0], b->cexp, (double)rows_in, eps, momentum);
+    }
     // expand 1x1 (+ statistics)
-    if (b->expand)
+    if (b->expand && !virt)
         pw_forward_unit(x, b->cin, nullptr, 0, b->w_pw, sv->e, rows_in, b->cin, b->cexp, b->gamma[0], b->beta[0], sv->vec[0], b->running_mean[0],
                         b->running_var[0], momentum, eps, ws.col, s);
     // depthwise over act1(e) (or over the block input) (+ statistics)
@@ -1015,7 +1189,10 @@ int fear_irb_train_forward(const FearIrbBlock* b, const FearIrbSaved* sv, const 
         a.wgs_per_slab = dw_bwd_wgs_per_slab(B * a.tiles_x * a.tiles_y, a.nslab);
         a.psums = ws.col;
         const dim3 grid((unsigned)(a.wgs_per_slab * a.nslab));
-        if (b->k == 3 && b->stride == 1) launch_dw_fwd_ks<3, 1>(a, sq, grid, s);
+        if (virt) {
+            a.X = nullptr; a.ve.X = x; a.ve.W1 = b->w_pw;
+            hipLaunchKernelGGL((dw_fwd_kernel<3, 2, 8, true>), grid, dim3(256), 0, s, a);
+        } else if (b->k == 3 && b->stride == 1) launch_dw_fwd_ks<3, 1>(a, sq, grid, s);
         else if (b->k == 3) launch_dw_fwd_ks<3, 2>(a, sq, grid, s);
         else if (b->stride == 1) launch_dw_fwd_ks<5, 1>(a, sq, grid, s);
         else launch_dw_fwd_ks<5, 2>(a, sq, grid, s);
@@ -1041,11 +1218,11 @@ int fear_irb_train_backward(const FearIrbBlock* b, const FearIrbSaved* sv, const
                             float* scratch, int B, int H, int W, float* workspace, size_t ws_bytes, void* stream, void* wgrad_stream) {
     if (!b || !sv || !gr || !x || !dout || !scratch || !workspace || !sv->d || !sv->p || !sv->vec[1] || !sv->vec[2] || !gr->w_dw || !gr->w_pwl)
         return FEAR_TRAIN_ERR_NULL;
-    if (b->expand && (!sv->e || !sv->vec[0] || !gr->w_pw)) return FEAR_TRAIN_ERR_NULL;
+    if (b->expand && ((!sv->e && !irb_virtual(b)) || !sv->vec[0] || !gr->w_pw)) return FEAR_TRAIN_ERR_NULL;
     if (!b->expand && !dx) return FEAR_TRAIN_ERR_NULL;
     for (int i = b->expand ? 0 : 1; i < 3; ++i)
         if (!gr->gamma[i] || !gr->beta[i] || !b->gamma[i]) return FEAR_TRAIN_ERR_NULL;
-    if (!irb_shape_ok(b, B, H, W)) return FEAR_TRAIN_ERR_SHAPE;
+    if (!irb_shape_ok(b, B, H, W) || (irb_virtual(b) && !irb_virtual_shape(b))) return FEAR_TRAIN_ERR_SHAPE;
     const long rows_in = (long)B * H * W, rows_out = rows_in / (b->stride * b->stride);
     const BlockWs ws = block_ws(rows_in, rows_out, b->cin, b->cexp, b->cout, b->k, workspace);
     if (ws_bytes < ws.total) return FEAR_TRAIN_ERR_WORKSPACE;
@@ -1105,7 +1282,10 @@ int fear_irb_train_backward(const FearIrbBlock* b, const FearIrbSaved* sv, const
         a.nslab = (cexp / 4 + sq - 1) / sq;
         a.wgs_per_slab = dw_bwd_wgs_per_slab(B * a.tiles_x * a.tiles_y, a.nslab);
         const dim3 grid((unsigned)(a.wgs_per_slab * a.nslab));
-        if (b->k == 3 && b->stride == 1) launch_dw_bwd_ks<3, 1>(a, sq, b->expand != 0, grid, s);
+        if (irb_virtual(b)) {
+            a.E = nullptr; a.ve.X = x; a.ve.W1 = b->w_pw;
+            hipLaunchKernelGGL((dw_bwd_kernel<3, 2, 8, true, true>), grid, dim3(256), 0, s, a);
+        } else if (b->k == 3 && b->stride == 1) launch_dw_bwd_ks<3, 1>(a, sq, b->expand != 0, grid, s);
         else if (b->k == 3) launch_dw_bwd_ks<3, 2>(a, sq, b->expand != 0, grid, s);
         else if (b->stride == 1) launch_dw_bwd_ks<5, 1>(a, sq, b->expand != 0, grid, s);
         else launch_dw_bwd_ks<5, 2>(a, sq, b->expand != 0, grid, s);
@@ -1121,7 +1301,7 @@ int fear_irb_train_backward(const FearIrbBlock* b, const FearIrbSaved* sv, const
         // chain, the Gram matrix and the correction cost more than the lighter loads save: 16.64 / 16.80 ms with those included.
         // (cexp % 16: a GEMM stage of 16 reduction columns must not straddle g1 and x.)
         const bool lin = cexp % 16 == 0 && cin <= 128 && !(b->flags & FEAR_IRB_NO_LINEAR_BN1) &&
-                         (cin <= 32 || (b->flags & FEAR_IRB_LINEAR_BN1));
+                         (cin <= 32 || (b->flags & FEAR_IRB_LINEAR_BN1));      // (always true for a virtual expansion: irb_virtual_shape)
         BnbIn bn1{};
         bn1.coef = coef1; bn1.C = cexp;
         if (!lin) { bn1.E = sv->e; bn1.lde = cexp; }

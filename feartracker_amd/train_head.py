@@ -66,6 +66,7 @@ TRAIN_SYMBOLS = {
     # block-fused trunk operators (structs below mirror include/fear_train.h)
     "fear_irb_workspace_bytes": ([_P, _i, _i, _i], _sz),
     "fear_irb_scratch_floats": ([_P, _i, _i, _i], _sz),
+    "fear_irb_virtual_ok": ([_P], _i),
     "fear_irb_train_forward": ([_P, _P, _P, _P, _i, _i, _i, _d, _d, _P, _sz, _P], _i),
     "fear_irb_train_backward": ([_P, _P, _P, _P, _P, _P, _P, _i, _i, _i, _P, _sz, _P, _P], _i),
     "fear_bn_running_update": ([_P, _d, _P, _P, _d, _d, _i, _P], _i),

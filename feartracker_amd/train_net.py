@@ -24,6 +24,7 @@ of one small float64 all-reduce per BatchNorm and direction; without it the stat
 """
 from __future__ import annotations
 
+import ctypes
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -111,10 +112,13 @@ class _ConvBN:
         self.running_var = sd[self.bn_key + ".running_var"].float().clone().to(dev)
 
 
+FEAR_IRB_VIRTUAL_E = 4        # include/fear_train.h
+
+
 class FEARNetTrainHIP:
     def __init__(self, state_dict: Dict[str, "np.ndarray | torch.Tensor"], device: int = 0, momentum: float = 0.1, eps: float = 1e-5,
                  coef_cls: float = 1.0, coef_reg: float = 1.0, sync_bn: bool = False, group=None, fused: Optional[bool] = None,
-                 two_streams: bool = True, mode: Optional[str] = None):
+                 two_streams: bool = True, mode: Optional[str] = None, virtual_expansion: bool = True):
         if not torch.cuda.is_available():
             raise RuntimeError("FEARNetTrainHIP needs a ROCm GPU; there is no CPU fallback")
         self.lib = load_train_library()
@@ -134,6 +138,9 @@ class FEARNetTrainHIP:
         if mode == "block" and sync_bn:
             raise ValueError("mode='block' has no SyncBatchNorm hook; use mode='layerwise' with sync_bn=True")
         self.mode = mode
+        # block mode: the 0.8 GB expansion of the 128 x 128 map is never written where the library has the kernels for it
+        # (FEAR_IRB_VIRTUAL_E, include/fear_train.h); False keeps every expansion saved
+        self.virtual_expansion = bool(virtual_expansion)
         fused = mode == "fused"
         # fused=True: the trunk runs on the fused conv + BatchNorm operators of include/fear_train.h — a BatchNorm'd activation
         # is never written, consumers apply it on load: 11 instead of 16 passes over every saved tensor and 13.7 instead of
@@ -451,6 +458,8 @@ class FEARNetTrainHIP:
                         continue
                     d.gamma[i], d.beta[i] = L.gamma.data_ptr(), L.beta.data_ptr()
                     d.running_mean[i], d.running_var[i] = L.running_mean.data_ptr(), L.running_var.data_ptr()
+                if self.virtual_expansion and self.lib.fear_irb_virtual_ok(ctypes.byref(d)):
+                    d.flags = FEAR_IRB_VIRTUAL_E          # the 16 -> 96 expansion of the 128 x 128 map: never written (include/fear_train.h)
                 descs.append(d)
             self._irb = descs
         return self._irb
@@ -507,7 +516,8 @@ class FEARNetTrainHIP:
         for d, blk in zip(descs, self.blocks):
             ho = h // d.stride
             sv = FearIrbSaved()
-            e = self._new(B * h * h, d.cexp) if d.expand else None
+            virt = bool(d.flags & FEAR_IRB_VIRTUAL_E)
+            e = self._new(B * h * h, d.cexp) if d.expand and not virt else None
             dd, pp = self._new(B * ho * ho, d.cexp), self._new(B * ho * ho, d.cout)
             vec = [self._new(4 * d.cexp) if d.expand else None, self._new(4 * d.cexp), self._new(4 * d.cout)]
             sv.e, sv.d, sv.p = (e.data_ptr() if e is not None else None), dd.data_ptr(), pp.data_ptr()
@@ -517,7 +527,8 @@ class FEARNetTrainHIP:
             self._check(lib.fear_irb_train_forward(ctypes.byref(d), ctypes.byref(sv), _p(x), _p(out), B, h, h, self.momentum, self.eps, ws, wsb, st))
             C = d.cexp
             if d.expand:
-                recs.append(dict(L=blk["pw"], pre=e, act=(vec[0][2 * C: 3 * C], vec[0][3 * C:], 1), B=B, H=h))
+                # (a virtual expansion has no saved pre-activation: relu_patterns forms x W1^T itself)
+                recs.append(dict(L=blk["pw"], pre=e if not virt else (x, blk["pw"].w), act=(vec[0][2 * C: 3 * C], vec[0][3 * C:], 1), B=B, H=h))
                 pending.append((vec[0], B * h * h, blk["pw"]))
             recs.append(dict(L=blk["dw"], pre=dd, act=(vec[1][2 * C: 3 * C], vec[1][3 * C:], 1), B=B, H=h))
             pending += [(vec[1], B * ho * ho, blk["dw"]), (vec[2], B * ho * ho, blk["pwl"])]
@@ -810,7 +821,10 @@ class FEARNetTrainHIP:
                     if not L.relu:
                         continue
                     a, b, _ = rec["act"]
-                    y = torch.from_numpy(np.float32(rec["pre"].cpu().numpy().astype(np.float64) * a.cpu().numpy().astype(np.float64)
+                    pre = rec["pre"]
+                    if isinstance(pre, tuple):               # virtual expansion: (block input rows, W1)
+                        pre = pre[0] @ pre[1].t()
+                    y = torch.from_numpy(np.float32(pre.cpu().numpy().astype(np.float64) * a.cpu().numpy().astype(np.float64)
                                                     + b.cpu().numpy().astype(np.float64)))      # fp32 fma: exact product, one rounding
                     act = y
                 else:

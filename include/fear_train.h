@@ -189,6 +189,11 @@ int fear_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
  * input channels: the large maps); these flags force it wherever it applies (cexp % 16 == 0, cin <= 128) or forbid it. */
 #define FEAR_IRB_LINEAR_BN1 1
 #define FEAR_IRB_NO_LINEAR_BN1 2
+/* ... and the expansion never written at all (FearIrbSaved.e may be NULL): the depthwise kernels of both directions form the channels
+ * they own from the pixel's 16 inputs on the spot, BatchNorm1's batch statistics come from the input's Gram matrix.  For the shapes
+ * fear_irb_virtual_ok() accepts (16 input channels, 3x3 stride 2, cexp a multiple of 16 from 64 up — FEAR-XS's 0.8 GB expansion of the
+ * 128 x 128 map); the same flag in the forward and the backward call. */
+#define FEAR_IRB_VIRTUAL_E 4
 typedef struct FearIrbBlock {
     int cin, cexp, cout, k, stride, expand, residual;
     int flags;                     /* 0 = let the call choose; FEAR_IRB_LINEAR_BN1 / FEAR_IRB_NO_LINEAR_BN1 (below) */
@@ -214,6 +219,7 @@ typedef struct FearIrbGrads {      /* parameter gradients, kernel layouts of Fea
     float* beta[3];
 } FearIrbGrads;
 size_t fear_irb_workspace_bytes(const FearIrbBlock* blk, int B, int H, int W);     /* 0: unsupported shape */
+int fear_irb_virtual_ok(const FearIrbBlock* blk);                                   /* 1: FEAR_IRB_VIRTUAL_E may be set for this block */
 size_t fear_irb_scratch_floats(const FearIrbBlock* blk, int B, int H, int W);      /* `scratch` of the backward */
 /* x [B*H*W][cin] -> out [B*(H/s)*(W/s)][cout] */
 int fear_irb_train_forward(const FearIrbBlock* blk, const FearIrbSaved* saved, const float* x, float* out, int B, int H, int W,

@@ -48,12 +48,14 @@ CASES = [
 # ... and the expansions of the large maps once more in the E-free form of BatchNorm1's backward (FEAR_IRB_LINEAR_BN1: the call
 # chooses it by itself from 10^5 rows up — the last case, whose 81 920 rows also take the first-generation GEMMs)
 LIN_CASES = [(c, b, h, 1) for c, b, h in CASES if c[5]] + [((16, 96, 24, 3, 2, 1, 0), 5, 128, 1), ((32, 192, 32, 5, 1, 1, 1), 2, 16, 2)]
+# ... and the 16 -> 96 expansion never written (FEAR_IRB_VIRTUAL_E): FearIrbSaved.e = NULL, BatchNorm1's statistics from the Gram matrix
+LIN_CASES += [((16, 96, 24, 3, 2, 1, 0), 3, 32, 4), ((16, 96, 24, 3, 2, 1, 0), 5, 128, 4), ((16, 64, 16, 3, 2, 1, 0), 2, 24, 4)]
 ALL_CASES = [(c, b, h, 0) for c, b, h in CASES] + LIN_CASES
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg,B,H,flags", ALL_CASES,
-                         ids=[f"{c[0]}x{c[1]}x{c[2]}k{c[3]}s{c[4]}_b{b}h{h}" + ("", "_lin", "_nolin")[f] for c, b, h, f in ALL_CASES])
+                         ids=[f"{c[0]}x{c[1]}x{c[2]}k{c[3]}s{c[4]}_b{b}h{h}" + {0: "", 1: "_lin", 2: "_nolin", 4: "_virtual"}[f] for c, b, h, f in ALL_CASES])
 def test_irb_block_forward_backward_vs_autograd(cfg, B, H, flags):
     from feartracker_amd.train_head import FearIrbBlock, FearIrbGrads, FearIrbSaved, _p, load_train_library
     lib = load_train_library()
@@ -103,10 +105,11 @@ def test_irb_block_forward_backward_vs_autograd(cfg, B, H, flags):
     ws = torch.empty(wsb // 4 + 64, device=dev)
     scratch = torch.empty(int(lib.fear_irb_scratch_floats(ctypes.byref(blk), B, H, H)) + 64, device=dev)
     sv = FearIrbSaved()
-    e = torch.empty(B * H * H, cexp, device=dev) if expand else None
+    e = torch.empty(B * H * H, cexp, device=dev) if expand and not flags & 4 else None
+    assert not flags & 4 or lib.fear_irb_virtual_ok(ctypes.byref(blk)) == 1
     d, pp = torch.empty(B * Ho * Ho, cexp, device=dev), torch.empty(B * Ho * Ho, cout, device=dev)
     vec = [torch.empty(4 * c, device=dev) for c in chans]
-    sv.e, sv.d, sv.p = (e.data_ptr() if expand else None), d.data_ptr(), pp.data_ptr()
+    sv.e, sv.d, sv.p = (e.data_ptr() if e is not None else None), d.data_ptr(), pp.data_ptr()
     for i in range(3):
         sv.vec[i] = vec[i].data_ptr()
     xd = D(rows(x))
