@@ -194,82 +194,121 @@ __global__ __launch_bounds__(256) void pw_bwd_kernel(PwBwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// The VIRTUAL expansion of a 16-channel block input (FEAR_IRB_VIRTUAL_E; the 16 -> 96 expansion of the 128 x 128 map is 0.8 GB per
+// The VIRTUAL expansion of a 16 ... 32-channel block input (FEAR_IRB_VIRTUAL_E; the 16 -> 96 expansion of the 128 x 128 map is 0.8 GB per
 // 128 crops, written once and read three times): e = x W1^T is never stored.  Its two remaining consumers — the depthwise kernels;
 // the expansion's own backward reads g1 and x, see BnbIn — form their tile of it on the matrix pipe as the tile is staged: per 16
-// pixels one 16-byte load per lane (lane (pixel j, k quarter kk) holds x[j][4 kk ..]) and four MFMAs per 16 channels against the
-// W1 fragments a lane keeps (lane (channel i, kk): W1[i][4 kk ..]); the result lane (pixel j, q) is the float4 of channels 4 q ..
+// pixels and 16 input channels one 16-byte load per lane (lane (pixel j, k quarter kk) holds x[j][4 kk ..]) and four MFMAs per 16
+// channels against the W1 fragments a lane keeps (lane (channel i, kk): W1[i][4 kk ..]); the result lane (pixel j, q) is the float4 of channels 4 q ..
 // 4 q + 3 of pixel j — the (pixel, channel quad) unit both kernels work in.  The SAME products in the same order in both
 // directions, so the forward's activation and the backward's mask see the same numbers.
 // BatchNorm1's batch statistics follow from linearity as well: sum_m e = W1 (sum_m x), sum_m e^2 = diag(W1 G W1^T), G = x^T x.
 struct VirtE {
-    const float* X;       // [pixels][16] the block input
-    const float* W1;      // [C][16] the expansion's weights
+    const float* X;       // [pixels][cin] the block input
+    const float* W1;      // [C][cin] the expansion's weights
+    int cin;              // 16 ... 32 (a multiple of 4): NC = ceil(cin / 16) chunks of 16 reduction columns, the last one zero-padded
 };
 
-// e[16 channels of column tile ct][16 pixels] from the fragments above: lane (pixel j, q) gets channels 4 q .. 4 q + 3
-__device__ __forceinline__ f32x4 virt_e_tile(const f32x4& wa, const f32x4& xb) {
+// e[16 channels][16 pixels] from the fragments above (NC chunks of 16 input channels): lane (pixel j, q) gets channels 4 q .. 4 q + 3
+template <int NC>
+__device__ __forceinline__ f32x4 virt_e_tile(const f32x4 (&wa)[NC], const f32x4 (&xb)[NC]) {
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t], xb[t], acc, 0, 0, 0);
+    for (int ci = 0; ci < NC; ++ci)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ci][t], xb[ci][t], acc, 0, 0, 0);
     return acc;
 }
 
-// G = x^T x [16][16] and s = sum_m x [16] of a 16-channel tensor in one pass: a wave's load of 64 consecutive floats IS the MFMA
-// fragment of four rows — lane (channel i, row kk) — for both operands (D[i][j] += sum_kk x[kk][i] x[kk][j]); the column sums are the
-// same product against ones.  Per workgroup one partial [272] = G | s (+ 0-padding), summed by slice_sum_kernel in a fixed order.
-__global__ __launch_bounds__(256) void gram16_kernel(const float* X, long M, long rows_per_wg, float* P) {
-    __shared__ f32x4 red[3][2][64];
+// G = x^T x [KP][KP] and s = sum_m x [KP] (KP = 16 NC >= cin, zero-padded) of a narrow tensor in one pass: lane (channel i, row kk)
+// loads x[row kk][16 ci + i] — with 16 channels a wave's load is 64 consecutive floats — and that one register is the MFMA fragment of
+// four rows for BOTH operands (D[i][j] += sum_kk x[kk][i] x[kk][j]); the column sums are the same product against ones.  Per
+// workgroup one partial [KP * KP + KP] = G | s, summed by slice_sum_kernel in a fixed order.
+template <int NC>
+__global__ __launch_bounds__(256) void gram_kernel(const float* X, long M, int cin, long rows_per_wg, float* P) {
+    __shared__ f32x4 red[3][NC * NC + NC][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long m0 = (long)blockIdx.x * rows_per_wg;
     const long m1 = m0 + rows_per_wg < M ? m0 + rows_per_wg : M;
     const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 g = zero, sm = zero;
-    constexpr int U = 8;
+    f32x4 g[NC][NC], sm[NC];
+#pragma unroll
+    for (int a_ = 0; a_ < NC; ++a_) {
+        sm[a_] = zero;
+#pragma unroll
+        for (int b_ = 0; b_ < NC; ++b_) g[a_][b_] = zero;
+    }
+    constexpr int U = NC == 1 ? 8 : 4;
     const long ngroups = m1 > m0 ? (m1 - m0 + 3) / 4 : 0;      // groups of four rows, dealt to the waves U at a time
+    bool cok[NC];
+#pragma unroll
+    for (int ci = 0; ci < NC; ++ci) cok[ci] = ci * 16 + (lane & 15) < cin;
     for (long g0 = (long)wave * U; g0 < ngroups; g0 += 4 * U) {
-        float v[U];
+        float v[U][NC];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long r = m0 + (g0 + u) * 4 + (lane >> 4);
-            v[u] = (g0 + u < ngroups && r < m1) ? X[r * 16 + (lane & 15)] : 0.f;
+            const bool rok = g0 + u < ngroups && r < m1;
+#pragma unroll
+            for (int ci = 0; ci < NC; ++ci) v[u][ci] = rok && cok[ci] ? X[r * cin + ci * 16 + (lane & 15)] : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            g = __builtin_amdgcn_mfma_f32_16x16x4f32(v[u], v[u], g, 0, 0, 0);
-            sm = __builtin_amdgcn_mfma_f32_16x16x4f32(v[u], 1.0f, sm, 0, 0, 0);
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int a_ = 0; a_ < NC; ++a_) {
+#pragma unroll
+                for (int b_ = 0; b_ < NC; ++b_) g[a_][b_] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[u][a_], v[u][b_], g[a_][b_], 0, 0, 0);
+                sm[a_] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[u][a_], 1.0f, sm[a_], 0, 0, 0);
+            }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int a_ = 0; a_ < NC; ++a_) {
+            red[wave - 1][NC * NC + a_][lane] = sm[a_];
+#pragma unroll
+            for (int b_ = 0; b_ < NC; ++b_) red[wave - 1][a_ * NC + b_][lane] = g[a_][b_];
         }
     }
-    if (wave > 0) { red[wave - 1][0][lane] = g; red[wave - 1][1][lane] = sm; }
     __syncthreads();
     if (wave != 0) return;
-#pragma unroll
-    for (int w = 0; w < 3; ++w) { g += red[w][0][lane]; sm += red[w][1][lane]; }      // fixed order
-    float* out = P + (long)blockIdx.x * 272;
+    constexpr int KP = 16 * NC;
+    float* out = P + (long)blockIdx.x * (KP * KP + KP);
     const int j = lane & 15, q = lane >> 4;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) out[(4 * q + r) * 16 + j] = g[r];                      // lane (j, q), component r = G[4 q + r][j]
-    if (j == 0) {
+    for (int a_ = 0; a_ < NC; ++a_) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out[256 + 4 * q + r] = sm[r];
+        for (int w = 0; w < 3; ++w) sm[a_] += red[w][NC * NC + a_][lane];      // fixed order
+#pragma unroll
+        for (int b_ = 0; b_ < NC; ++b_) {
+#pragma unroll
+            for (int w = 0; w < 3; ++w) g[a_][b_] += red[w][a_ * NC + b_][lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(a_ * 16 + 4 * q + r) * KP + b_ * 16 + j] = g[a_][b_][r];      // lane (j, q), component r
+        }
+        if (j == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[KP * KP + a_ * 16 + 4 * q + r] = sm[a_][r];
+        }
     }
 }
 
-// BatchNorm1 of a virtual expansion from (G | s): mean, rstd, the affine a | b and the running statistics (col_finalize mode 0's)
+// BatchNorm1 of a virtual expansion from (G | s) [KP * KP + KP]: mean, rstd, the affine a | b and the running statistics
+// (col_finalize mode 0's arithmetic on float64 sums)
+template <int KP>
 __global__ __launch_bounds__(256) void irb_virtual_stats_kernel(const float* GS, const float* W1, const float* gamma, const float* beta, float* vec,
-                                                              float* running_mean, float* running_var, int C, double M, double eps, double momentum) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+                                                              float* running_mean, float* running_var, int C, int cin, double M, double eps,
+                                                              double momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    double w[16];
+    double w[KP];                                   // (registers: every index below is a compile-time constant; G's are uniform loads)
 #pragma unroll
-    for (int k = 0; k < 16; ++k) w[k] = (double)W1[(long)c * 16 + k];
+    for (int k = 0; k < KP; ++k) w[k] = k < cin ? (double)W1[(long)c * cin + k] : 0.0;
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        s1 += w[k] * (double)GS[256 + k];
+    for (int k = 0; k < KP; ++k) {
+        s1 += w[k] * (double)GS[KP * KP + k];
         double t = 0.0;
 #pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) t += (double)GS[k * 16 + k2] * w[k2];
+        for (int k2 = 0; k2 < KP; ++k2) t += (double)GS[k * KP + k2] * w[k2];
         s2 += w[k] * t;
     }
     const double mean = s1 / M;
@@ -321,7 +360,7 @@ struct DwBwdArgs {
     VirtE ve;             // VE: E is not read, e = ve.X ve.W1^T on the spot
 };
 
-template <int KS, int S, int SQ, bool BN1, bool VE = false>
+template <int KS, int S, int SQ, bool BN1, int VE = 0>      // VE = NC chunks of 16 input channels of a virtual expansion (0: E is read)
 __global__ __launch_bounds__(256, 2) void dw_bwd_kernel(DwBwdArgs a) {
     static_assert(!VE || (BN1 && S == 2), "the virtual expansion is built for the stride-2 kernels");
     constexpr int P = KS / 2, KK = KS * KS, TS = 16;
@@ -362,13 +401,15 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_kernel(DwBwdArgs a) {
     }
     // VE: the tile's raw expansion [256 pixels][SQ quads], formed on the matrix pipe while the dd region is staged
     __shared__ f32x4 es[VE ? TS * TS * SQ : 1];
-    f32x4 wa[VE ? SQ / 4 : 1];
+    f32x4 wa[VE ? SQ / 4 : 1][VE ? VE : 1];
     if (VE) {
 #pragma unroll
-        for (int ct = 0; ct < SQ / 4; ++ct) {
-            const int ch = slab * SQ * 4 + ct * 16 + (tid & 15);
-            wa[VE ? ct : 0] = ch < a.C ? *reinterpret_cast<const f32x4*>(a.ve.W1 + (long)ch * 16 + 4 * ((tid & 63) >> 4)) : zero;
-        }
+        for (int ct = 0; ct < SQ / 4; ++ct)
+#pragma unroll
+            for (int ci = 0; ci < VE; ++ci) {
+                const int ch = slab * SQ * 4 + ct * 16 + (tid & 15), k = ci * 16 + 4 * ((tid & 63) >> 4);
+                wa[VE ? ct : 0][VE ? ci : 0] = ch < a.C && k < a.ve.cin ? *reinterpret_cast<const f32x4*>(a.ve.W1 + (long)ch * a.ve.cin + k) : zero;
+            }
     }
     // this thread's parity class and the first tap it meets in each dimension
     const int cls = S == 1 ? 0 : (pl & 3);
@@ -437,9 +478,13 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_kernel(DwBwdArgs a) {
                 const int p = rt * 16 + j;                       // tile pixel of this lane's column
                 const int iy = iy0 + p / TS, ix = ix0 + p % TS;
                 const bool inb = iy < a.H && ix < a.W;
-                const f32x4 xb = inb ? *reinterpret_cast<const f32x4*>(a.ve.X + (((long)b * a.H + iy) * a.W + ix) * 16 + 4 * kk) : zero;
+                f32x4 xb[VE ? VE : 1];
 #pragma unroll
-                for (int ct = 0; ct < SQ / 4; ++ct) es[p * SQ + ct * 4 + kk] = virt_e_tile(wa[ct], xb);
+                for (int ci = 0; ci < VE; ++ci)
+                    xb[ci] = inb && ci * 16 + 4 * kk < a.ve.cin
+                                 ? *reinterpret_cast<const f32x4*>(a.ve.X + (((long)b * a.H + iy) * a.W + ix) * a.ve.cin + ci * 16 + 4 * kk) : zero;
+#pragma unroll
+                for (int ct = 0; ct < SQ / 4; ++ct) es[p * SQ + ct * 4 + kk] = virt_e_tile<VE ? VE : 1>(wa[ct], xb);
             }
         }
         __syncthreads();
@@ -691,7 +736,7 @@ struct DwFwdArgs {
     VirtE ve;             // VE: X is not read, the operand is act(ve.X ve.W1^T)
 };
 
-template <int KS, int S, int SQ, bool VE = false>
+template <int KS, int S, int SQ, int VE = 0>      // VE = NC chunks of 16 input channels of a virtual expansion (0: X is read)
 __global__ __launch_bounds__(256, 2) void dw_fwd_kernel(DwFwdArgs a) {
     constexpr int P = KS / 2, KK = KS * KS;
     constexpr int TO = S == 1 ? 16 : 8;                // output tile side
@@ -722,18 +767,21 @@ __global__ __launch_bounds__(256, 2) void dw_fwd_kernel(DwFwdArgs a) {
     }
     f64x4 S1 = (f64x4){0.0, 0.0, 0.0, 0.0}, S2 = S1;
     // VE: W1 fragments (lane (channel, k quarter)) and the activation of the two channel quads this lane's results belong to
-    f32x4 wa[VE ? SQ / 4 : 1], va[VE ? SQ / 4 : 1], vb[VE ? SQ / 4 : 1];
+    f32x4 wa[VE ? SQ / 4 : 1][VE ? VE : 1], va[VE ? SQ / 4 : 1], vb[VE ? SQ / 4 : 1];
     if (VE) {
 #pragma unroll
         for (int ct = 0; ct < SQ / 4; ++ct) {
-            const int ch = slab * SQ * 4 + ct * 16 + (tid & 15);
-            wa[VE ? ct : 0] = ch < a.C ? *reinterpret_cast<const f32x4*>(a.ve.W1 + (long)ch * 16 + 4 * ((tid & 63) >> 4)) : zero;
+#pragma unroll
+            for (int ci = 0; ci < VE; ++ci) {
+                const int ch = slab * SQ * 4 + ct * 16 + (tid & 15), k = ci * 16 + 4 * ((tid & 63) >> 4);
+                wa[VE ? ct : 0][VE ? ci : 0] = ch < a.C && k < a.ve.cin ? *reinterpret_cast<const f32x4*>(a.ve.W1 + (long)ch * a.ve.cin + k) : zero;
+            }
             const int c4 = (slab * SQ + ct * 4 + ((tid & 63) >> 4)) * 4;
             va[VE ? ct : 0] = c4 < a.C ? *reinterpret_cast<const f32x4*>(a.in.a + c4) : zero;
             vb[VE ? ct : 0] = c4 < a.C ? *reinterpret_cast<const f32x4*>(a.in.b + c4) : zero;
         }
     }
-    const long xbytes = (long)a.B * a.H * a.W * (VE ? 16 : a.ldx) * 4;      // < 2^31: checked on the host
+    const long xbytes = (long)a.B * a.H * a.W * (VE ? a.ve.cin : a.ldx) * 4;      // < 2^31: checked on the host
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(VE ? a.ve.X : a.X), 0, (int)xbytes, 0x00020000);
     const int n_items = a.B * a.tiles_y * a.tiles_x;
     for (int item = wslot; item < n_items; item += a.wgs_per_slab) {
@@ -752,11 +800,15 @@ __global__ __launch_bounds__(256, 2) void dw_fwd_kernel(DwFwdArgs a) {
                 const int r = pix / IR, cc = pix - r * IR;
                 const int y = iy0 + r, x = ix0 + cc;
                 const bool inb = pix < IR * IR && y >= 0 && y < a.H && x >= 0 && x < a.W;
-                const int off = inb ? ((b * a.H + y) * a.W + x) * 64 + 16 * kk : (int)0x80000000;
-                const f32x4 xb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
+                f32x4 xb[VE ? VE : 1];
+#pragma unroll
+                for (int ci = 0; ci < VE; ++ci) {
+                    const int off = inb && ci * 16 + 4 * kk < a.ve.cin ? (((b * a.H + y) * a.W + x) * a.ve.cin + ci * 16 + 4 * kk) * 4 : (int)0x80000000;
+                    xb[ci] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
+                }
 #pragma unroll
                 for (int ct = 0; ct < SQ / 4; ++ct) {
-                    const f32x4 v = act4(virt_e_tile(wa[ct], xb), va[ct], vb[ct], a.in.relu != 0);
+                    const f32x4 v = act4(virt_e_tile<VE ? VE : 1>(wa[ct], xb), va[ct], vb[ct], a.in.relu != 0);
                     const bool cok = (slab * SQ + ct * 4 + kk) * 4 < a.C;
                     if (pix < IR * IR) tile[r * PITCH + cc * SQ + ct * 4 + kk] = inb && cok ? v : zero;
                 }
@@ -928,7 +980,8 @@ BlockWs block_ws(long rows_in, long rows_out, int cin, int cexp, int cout, int k
     const int nslab = (cexp / 4 + sq - 1) / sq;
     const int wps = 2048 / nslab > 1 ? 2048 / nslab : 1;                  // most workgroups per slab dw_bwd_wgs_per_slab hands out
     w.taps_bytes = align256((size_t)wps * k * k * cexp * sizeof(float));
-    w.coef_bytes = align256((size_t)3 * 4 * cmax * sizeof(float));
+    // (also the Gram matrix | column sums of a virtual expansion's input in the forward: up to 32 * 32 + 32 floats)
+    w.coef_bytes = align256((size_t)(3 * 4 * cmax > 1056 ? 3 * 4 * cmax : 1056) * sizeof(float));
     w.total = w.col_bytes + w.wg_bytes + w.taps_bytes + w.coef_bytes;
     char* p = reinterpret_cast<char*>(base);
     w.col = reinterpret_cast<double*>(p); p += w.col_bytes;
@@ -1056,12 +1109,12 @@ __global__ __launch_bounds__(1024) void irb_lin_weights_kernel(const float* coef
 }
 
 // ... and of its weight gradient: dW1 [cexp][cin] (holding [A (g1 - s1 + mu Q)]^T x) -= diag(A Q) W1 G, G = x^T x [cin][cin]
-__global__ __launch_bounds__(256) void irb_lin_wgrad_fix_kernel(const float* coef, const float* W1, const float* G, float* dW1, int cexp, int cin) {
+__global__ __launch_bounds__(256) void irb_lin_wgrad_fix_kernel(const float* coef, const float* W1, const float* G, int ldg, float* dW1, int cexp, int cin) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= cexp * cin) return;
     const int c = idx / cin, k = idx - c * cin;
     double t = 0.0;
-    for (int k1 = 0; k1 < cin; ++k1) t += (double)W1[(long)c * cin + k1] * (double)G[(long)k1 * cin + k];
+    for (int k1 = 0; k1 < cin; ++k1) t += (double)W1[(long)c * cin + k1] * (double)G[(long)k1 * ldg + k];
     dW1[idx] = (float)((double)dW1[idx] - (double)coef[c] * (double)coef[3 * cexp + c] * t);
 }
 
@@ -1120,9 +1173,10 @@ bool irb_shape_ok(const FearIrbBlock* b, int B, int H, int W) {
     return true;
 }
 
-// the shapes the virtual expansion is built for (FEAR-XS's 16 -> 96 expansion of the 128 x 128 map: 3 x 3 stride 2, 32-channel slabs)
+// the shapes the virtual expansion is built for: the stride-2 blocks with 16 ... 32 input channels and 32-channel slabs (FEAR-XS:
+// 16 -> 96 at 128 x 128, 24 -> 144 at 64 x 64, 32 -> 192 at 32 x 32); the stride-1 depthwise backward has no LDS left for the tile of e
 bool irb_virtual_shape(const FearIrbBlock* b) {
-    return b->expand && b->cin == 16 && b->k == 3 && b->stride == 2 && b->cexp >= 64 && b->cexp % 16 == 0 && !(b->flags & FEAR_IRB_NO_LINEAR_BN1);
+    return b->expand && b->cin >= 16 && b->cin <= 32 && b->stride == 2 && b->cexp >= 64 && b->cexp % 16 == 0 && !(b->flags & FEAR_IRB_NO_LINEAR_BN1);
 }
 bool irb_virtual(const FearIrbBlock* b) { return (b->flags & FEAR_IRB_VIRTUAL_E) != 0; }
 
@@ -1145,7 +1199,7 @@ size_t fear_irb_scratch_floats(const FearIrbBlock* b, int B, int H, int W) {
     // gradients run on their own stream, so they do not live in the shared workspace)
     // | the extended weight matrix and the input's Gram matrix of the expansion's E-free backward (BnbIn)
     return (size_t)rows_out * b->cexp + (b->expand ? (size_t)rows_in * b->cexp : 0) + (size_t)12 * irb_cmax(b) +
-           (b->expand ? (size_t)(b->cexp + 2 * b->cin) * b->cin : 0);
+           (b->expand ? (size_t)(b->cexp + b->cin) * b->cin + (b->cin * b->cin > 1056 ? b->cin * b->cin : 1056) : 0);
 }
 
 int fear_irb_train_forward(const FearIrbBlock* b, const FearIrbSaved* sv, const float* x, float* out, int B, int H, int W, double momentum,
@@ -1166,11 +1220,17 @@ int fear_irb_train_forward(const FearIrbBlock* b, const FearIrbSaved* sv, const 
         long rpw = (rows_in + 2047) / 2048;
         rpw = (rpw + 127) / 128 * 128;
         const int wgs = (int)((rows_in + rpw - 1) / rpw);
-        if ((size_t)wgs * 272 * sizeof(float) > ws.wg_bytes || ws.coef_bytes < 272 * sizeof(float)) return FEAR_TRAIN_ERR_WORKSPACE;
-        hipLaunchKernelGGL(gram16_kernel, dim3((unsigned)wgs), dim3(256), 0, s, x, rows_in, rpw, ws.wg);
-        launch_slice_sum(ws.wg, ws.coef, 272, wgs, s);
-        hipLaunchKernelGGL(irb_virtual_stats_kernel, dim3((unsigned)((b->cexp + 255) / 256)), dim3(256), 0, s, ws.coef, b->w_pw, b->gamma[0], b->beta[0],
-                           sv->vec[0], b->running_mean[0], b->running_var[0], b->cexp, (double)rows_in, eps, momentum);
+        const int nc = b->cin > 16 ? 2 : 1, kp = 16 * nc, per = kp * kp + kp;
+        if ((size_t)wgs * per * sizeof(float) > ws.wg_bytes || ws.coef_bytes < per * sizeof(float)) return FEAR_TRAIN_ERR_WORKSPACE;
+        if (nc == 1) hipLaunchKernelGGL(gram_kernel<1>, dim3((unsigned)wgs), dim3(256), 0, s, x, rows_in, b->cin, rpw, ws.wg);
+        else hipLaunchKernelGGL(gram_kernel<2>, dim3((unsigned)wgs), dim3(256), 0, s, x, rows_in, b->cin, rpw, ws.wg);
+        launch_slice_sum(ws.wg, ws.coef, per, wgs, s);
+        if (nc == 1)
+            hipLaunchKernelGGL(irb_virtual_stats_kernel<16>, dim3((unsigned)((b->cexp + 63) / 64)), dim3(64), 0, s, ws.coef, b->w_pw, b->gamma[0],
+                               b->beta[0], sv->vec[0], b->running_mean[0], b->running_var[0], b->cexp, b->cin, (double)rows_in, eps, momentum);
+        else
+            hipLaunchKernelGGL(irb_virtual_stats_kernel<32>, dim3((unsigned)((b->cexp + 63) / 64)), dim3(64), 0, s, ws.coef, b->w_pw, b->gamma[0],
+                               b->beta[0], sv->vec[0], b->running_mean[0], b->running_var[0], b->cexp, b->cin, (double)rows_in, eps, momentum);
     }
     // expand 1x1 (+ statistics)
     if (b->expand && !virt)
@@ -1190,8 +1250,11 @@ int fear_irb_train_forward(const FearIrbBlock* b, const FearIrbSaved* sv, const 
         a.psums = ws.col;
         const dim3 grid((unsigned)(a.wgs_per_slab * a.nslab));
         if (virt) {
-            a.X = nullptr; a.ve.X = x; a.ve.W1 = b->w_pw;
-            hipLaunchKernelGGL((dw_fwd_kernel<3, 2, 8, true>), grid, dim3(256), 0, s, a);
+            a.X = nullptr; a.ve.X = x; a.ve.W1 = b->w_pw; a.ve.cin = b->cin;
+            if (b->k == 3 && b->cin <= 16) hipLaunchKernelGGL((dw_fwd_kernel<3, 2, 8, 1>), grid, dim3(256), 0, s, a);
+            else if (b->k == 3) hipLaunchKernelGGL((dw_fwd_kernel<3, 2, 8, 2>), grid, dim3(256), 0, s, a);
+            else if (b->cin <= 16) hipLaunchKernelGGL((dw_fwd_kernel<5, 2, 8, 1>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((dw_fwd_kernel<5, 2, 8, 2>), grid, dim3(256), 0, s, a);
         } else if (b->k == 3 && b->stride == 1) launch_dw_fwd_ks<3, 1>(a, sq, grid, s);
         else if (b->k == 3) launch_dw_fwd_ks<3, 2>(a, sq, grid, s);
         else if (b->stride == 1) launch_dw_fwd_ks<5, 1>(a, sq, grid, s);
@@ -1283,8 +1346,11 @@ int fear_irb_train_backward(const FearIrbBlock* b, const FearIrbSaved* sv, const
         a.wgs_per_slab = dw_bwd_wgs_per_slab(B * a.tiles_x * a.tiles_y, a.nslab);
         const dim3 grid((unsigned)(a.wgs_per_slab * a.nslab));
         if (irb_virtual(b)) {
-            a.E = nullptr; a.ve.X = x; a.ve.W1 = b->w_pw;
-            hipLaunchKernelGGL((dw_bwd_kernel<3, 2, 8, true, true>), grid, dim3(256), 0, s, a);
+            a.E = nullptr; a.ve.X = x; a.ve.W1 = b->w_pw; a.ve.cin = cin;
+            if (b->k == 3 && cin <= 16) hipLaunchKernelGGL((dw_bwd_kernel<3, 2, 8, true, 1>), grid, dim3(256), 0, s, a);
+            else if (b->k == 3) hipLaunchKernelGGL((dw_bwd_kernel<3, 2, 8, true, 2>), grid, dim3(256), 0, s, a);
+            else if (cin <= 16) hipLaunchKernelGGL((dw_bwd_kernel<5, 2, 8, true, 1>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((dw_bwd_kernel<5, 2, 8, true, 2>), grid, dim3(256), 0, s, a);
         } else if (b->k == 3 && b->stride == 1) launch_dw_bwd_ks<3, 1>(a, sq, b->expand != 0, grid, s);
         else if (b->k == 3) launch_dw_bwd_ks<3, 2>(a, sq, b->expand != 0, grid, s);
         else if (b->stride == 1) launch_dw_bwd_ks<5, 1>(a, sq, b->expand != 0, grid, s);
@@ -1308,12 +1374,26 @@ int fear_irb_train_backward(const FearIrbBlock* b, const FearIrbSaved* sv, const
         float* wext = coef1 + 12 * cmax;                       // [cexp + cin][cin]
         float* gram = wext + (size_t)(cexp + cin) * cin;       // [cin][cin]
         if (sw != s && !stream_follow(sw, s)) return FEAR_TRAIN_ERR_HIP;          // g1 and coef1 exist
-        int rc = lin ? wgrad_impl(x, cin, 0, x, cin, 0, gram, ws.wg, ws.wg_bytes, rows_in, cin, cin, 1, sw) : FEAR_TRAIN_OK;
+        int rc = FEAR_TRAIN_OK, ldg = cin;
+        if (lin && cin <= 32) {
+            // (the one-load-per-four-rows Gram kernel of the virtual expansion's forward; its result is [KP][KP] | column sums)
+            long rpw = (rows_in + 2047) / 2048;
+            rpw = (rpw + 127) / 128 * 128;
+            const int wgs = (int)((rows_in + rpw - 1) / rpw);
+            const int nc = cin > 16 ? 2 : 1, per = 16 * nc * 16 * nc + 16 * nc;
+            ldg = 16 * nc;
+            if ((size_t)wgs * per * sizeof(float) > ws.wg_bytes) return FEAR_TRAIN_ERR_WORKSPACE;
+            if (nc == 1) hipLaunchKernelGGL(gram_kernel<1>, dim3((unsigned)wgs), dim3(256), 0, sw, x, rows_in, cin, rpw, ws.wg);
+            else hipLaunchKernelGGL(gram_kernel<2>, dim3((unsigned)wgs), dim3(256), 0, sw, x, rows_in, cin, rpw, ws.wg);
+            launch_slice_sum(ws.wg, gram, per, wgs, sw);
+        } else if (lin) {
+            rc = wgrad_impl(x, cin, 0, x, cin, 0, gram, ws.wg, ws.wg_bytes, rows_in, cin, cin, 1, sw);
+        }
         if (rc != FEAR_TRAIN_OK) return rc;
         rc = wgrad_impl(g1, cexp, 0, x, cin, 0, gr->w_pw, ws.wg, ws.wg_bytes, rows_in, cin, cexp, 1, sw, nullptr, nullptr, 0, &bn1);
         if (rc != FEAR_TRAIN_OK) return rc;
         if (lin)
-            hipLaunchKernelGGL(irb_lin_wgrad_fix_kernel, dim3((unsigned)((cexp * cin + 255) / 256)), dim3(256), 0, sw, coef1, b->w_pw, gram,
+            hipLaunchKernelGGL(irb_lin_wgrad_fix_kernel, dim3((unsigned)((cexp * cin + 255) / 256)), dim3(256), 0, sw, coef1, b->w_pw, gram, ldg,
                                gr->w_pw, cexp, cin);
         if (dx) {
             if (lin)

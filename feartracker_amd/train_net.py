@@ -118,7 +118,7 @@ FEAR_IRB_VIRTUAL_E = 4        # include/fear_train.h
 class FEARNetTrainHIP:
     def __init__(self, state_dict: Dict[str, "np.ndarray | torch.Tensor"], device: int = 0, momentum: float = 0.1, eps: float = 1e-5,
                  coef_cls: float = 1.0, coef_reg: float = 1.0, sync_bn: bool = False, group=None, fused: Optional[bool] = None,
-                 two_streams: bool = True, mode: Optional[str] = None, virtual_expansion: bool = True):
+                 two_streams: bool = True, mode: Optional[str] = None, virtual_expansion: int = 32):
         if not torch.cuda.is_available():
             raise RuntimeError("FEARNetTrainHIP needs a ROCm GPU; there is no CPU fallback")
         self.lib = load_train_library()
@@ -138,9 +138,9 @@ class FEARNetTrainHIP:
         if mode == "block" and sync_bn:
             raise ValueError("mode='block' has no SyncBatchNorm hook; use mode='layerwise' with sync_bn=True")
         self.mode = mode
-        # block mode: the 0.8 GB expansion of the 128 x 128 map is never written where the library has the kernels for it
-        # (FEAR_IRB_VIRTUAL_E, include/fear_train.h); False keeps every expansion saved
-        self.virtual_expansion = bool(virtual_expansion)
+        # block mode: expansions of up to this many input channels are never written where the library has the kernels for it
+        # (FEAR_IRB_VIRTUAL_E, include/fear_train.h: the stride-2 blocks); 0 keeps every expansion saved
+        self.virtual_expansion = int(virtual_expansion)
         fused = mode == "fused"
         # fused=True: the trunk runs on the fused conv + BatchNorm operators of include/fear_train.h — a BatchNorm'd activation
         # is never written, consumers apply it on load: 11 instead of 16 passes over every saved tensor and 13.7 instead of
@@ -458,7 +458,7 @@ class FEARNetTrainHIP:
                         continue
                     d.gamma[i], d.beta[i] = L.gamma.data_ptr(), L.beta.data_ptr()
                     d.running_mean[i], d.running_var[i] = L.running_mean.data_ptr(), L.running_var.data_ptr()
-                if self.virtual_expansion and self.lib.fear_irb_virtual_ok(ctypes.byref(d)):
+                if cin <= self.virtual_expansion and self.lib.fear_irb_virtual_ok(ctypes.byref(d)):
                     d.flags = FEAR_IRB_VIRTUAL_E          # the 16 -> 96 expansion of the 128 x 128 map: never written (include/fear_train.h)
                 descs.append(d)
             self._irb = descs

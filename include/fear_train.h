@@ -190,9 +190,9 @@ int fear_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
 #define FEAR_IRB_LINEAR_BN1 1
 #define FEAR_IRB_NO_LINEAR_BN1 2
 /* ... and the expansion never written at all (FearIrbSaved.e may be NULL): the depthwise kernels of both directions form the channels
- * they own from the pixel's 16 inputs on the spot, BatchNorm1's batch statistics come from the input's Gram matrix.  For the shapes
- * fear_irb_virtual_ok() accepts (16 input channels, 3x3 stride 2, cexp a multiple of 16 from 64 up — FEAR-XS's 0.8 GB expansion of the
- * 128 x 128 map); the same flag in the forward and the backward call. */
+ * they own from the pixel's inputs on the spot, BatchNorm1's batch statistics come from the input's Gram matrix.  For the shapes
+ * fear_irb_virtual_ok() accepts (16 ... 32 input channels, stride 2, cexp a multiple of 16 from 64 up — FEAR-XS's 16 -> 96 at 128 x 128
+ * (0.8 GB per 128 crops), 24 -> 144 at 64 x 64, 32 -> 192 at 32 x 32); the same flag in the forward and the backward call. */
 #define FEAR_IRB_VIRTUAL_E 4
 typedef struct FearIrbBlock {
     int cin, cexp, cout, k, stride, expand, residual;

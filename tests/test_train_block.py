@@ -49,7 +49,9 @@ CASES = [
 # chooses it by itself from 10^5 rows up — the last case, whose 81 920 rows also take the first-generation GEMMs)
 LIN_CASES = [(c, b, h, 1) for c, b, h in CASES if c[5]] + [((16, 96, 24, 3, 2, 1, 0), 5, 128, 1), ((32, 192, 32, 5, 1, 1, 1), 2, 16, 2)]
 # ... and the 16 -> 96 expansion never written (FEAR_IRB_VIRTUAL_E): FearIrbSaved.e = NULL, BatchNorm1's statistics from the Gram matrix
-LIN_CASES += [((16, 96, 24, 3, 2, 1, 0), 3, 32, 4), ((16, 96, 24, 3, 2, 1, 0), 5, 128, 4), ((16, 64, 16, 3, 2, 1, 0), 2, 24, 4)]
+LIN_CASES += [((16, 96, 24, 3, 2, 1, 0), 3, 32, 4), ((16, 96, 24, 3, 2, 1, 0), 5, 128, 4), ((16, 64, 16, 3, 2, 1, 0), 2, 24, 4),
+              ((24, 144, 32, 5, 2, 1, 0), 2, 32, 4), ((32, 192, 64, 5, 2, 1, 0), 2, 32, 4), ((32, 128, 48, 3, 2, 1, 0), 3, 16, 4),
+              ((20, 80, 24, 5, 2, 1, 0), 2, 24, 4)]
 ALL_CASES = [(c, b, h, 0) for c, b, h in CASES] + LIN_CASES
 
 

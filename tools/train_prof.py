@@ -1,7 +1,7 @@
 """The 128-pair training step (BASELINE configs[4], one rank's share) a few times, for rocprofv3:
     cd /tmp && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/trainprof -o p --output-format csv -- python $R/tools/train_prof.py
 (tools/profile_round.sh does it and tools/profile_fold.sh copies p_kernel_stats.csv to profiles/rNN_train_kernel_stats.csv).
-usage: train_prof.py [pairs=128] [steps=5] [mode=block|layerwise|fused (or 0 / 1 = layerwise / fused)] [two_streams=1]"""
+usage: train_prof.py [pairs=128] [steps=5] [mode=block|layerwise|fused (or 0 / 1 = layerwise / fused)] [two_streams=1] [virtual_expansion=32]"""
 import os
 import sys
 import time
@@ -16,9 +16,10 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 mode = sys.argv[3] if len(sys.argv) > 3 else "block"
 mode = {"0": "layerwise", "1": "fused"}.get(mode, mode)
 two = bool(int(sys.argv[4])) if len(sys.argv) > 4 else True
+virt = int(sys.argv[5]) if len(sys.argv) > 5 else 32
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(7)
-net = FEARNetTrainHIP(random_init_state(3), device=0, mode=mode, two_streams=two)
+net = FEARNetTrainHIP(random_init_state(3), device=0, mode=mode, two_streams=two, virtual_expansion=virt)
 tmpl = torch.randn(batch, 3, 128, 128, generator=g).to(dev)
 srch = torch.randn(batch, 3, 256, 256, generator=g).to(dev)
 gt_reg = (torch.rand(batch, 4, 16, 16, generator=g) * 60 + 1).to(dev)
