@@ -21,7 +21,6 @@
 #include "../../include/fear_train.h"
 
 namespace {
-static int dbg_skip() { static int v = getenv("FEAR_DBG_SKIP") ? atoi(getenv("FEAR_DBG_SKIP")) : 0; return v; }
 
 using namespace fear;
 
@@ -614,7 +613,6 @@ __global__ __launch_bounds__(256) void slice_sum_kernel(const float* P, float* o
 }
 
 void launch_slice_sum(const float* P, float* out, long count, int slices, hipStream_t s) {
-    if (dbg_skip() & 2) return;
     const int lanes = slices >= 64 ? 16 : 1;
     const int per = 256 / lanes;
     hipLaunchKernelGGL(slice_sum_kernel, dim3((unsigned)((count / 4 + per - 1) / per)), dim3(256), 0, s, P, out, count, slices, lanes);
@@ -1470,7 +1468,6 @@ int fear_pw_backward_data(const float* dy, int lddy, const float* w, const float
 static int wgrad_impl(const float* dy, int lddy, long dy_crop_stride, const float* x, int ldx, long x_crop_stride, float* dw,
                       float* workspace, size_t ws_bytes, long M, int K, int N, int crops, hipStream_t s, const float* act_a = nullptr,
                       const float* act_b = nullptr, int act_relu = 0, const BnbIn* bn = nullptr) {
-    if (dbg_skip() & 16) return FEAR_TRAIN_OK;
     WgradArgs a{};
     a.dY = dy; a.X = x; a.lddy = lddy; a.ldx = ldx; a.N = N; a.K = K; a.M = M; a.crops = crops;
     a.act_a = act_a; a.act_b = act_b; a.act_relu = act_relu;

@@ -998,7 +998,6 @@ void finalize_forward(const double* partial, int blocks, int C, double count, co
     f.mean_shift = mean_shift;
     f.partial = partial; f.out1 = vec; f.out2 = vec + C; f.out_a = vec + 2 * C; f.out_b = vec + 3 * C; f.gamma = gamma; f.beta = beta;
     f.running_mean = running_mean; f.running_var = running_var; f.blocks = blocks; f.C = C; f.mode = 0; f.M = count; f.eps = eps; f.momentum = momentum;
-    if (dbg_skip() & 1) return;
     hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, s, f);
 }
 
@@ -1008,7 +1007,6 @@ void finalize_backward(const double* partial, int blocks, int C, double count, c
     ColFinArgs f{};
     f.partial = partial; f.out1 = dbeta; f.out2 = dgamma; f.gamma = gamma; f.mean_in = vec; f.rstd_in = vec + C; f.coef = coef;
     f.blocks = blocks; f.C = C; f.mode = 4; f.M = count;
-    if (dbg_skip() & 1) return;
     hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, s, f);
 }
 
@@ -1077,7 +1075,7 @@ void bn_backward_sums(const float* dy, int lddy, const float* raw, int ldx, cons
     a.act_a = relu ? vec + 2 * C : nullptr; a.act_b = relu ? vec + 3 * C : nullptr;
     a.partial = col; a.M = M; a.C = C; a.rpb = col_rows_per_block(M);
     const int blocks = col_blocks(M);
-    if (!(dbg_skip() & 8)) hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(blocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(blocks), dim3(256), 0, s, a);
     finalize_backward(col, blocks, C, (double)M, gamma, vec, dgamma, dbeta, coef, s);
 }
 
@@ -1173,6 +1171,16 @@ bool irb_shape_ok(const FearIrbBlock* b, int B, int H, int W) {
     return true;
 }
 
+// floats of dw_bwd_kernel's tap-gradient partials [workgroups per slab][k * k][cexp] (block_ws's bound on the workgroups)
+size_t irb_taps_floats(const FearIrbBlock* b) {
+    const int sq = dw_bwd_sq(b->cexp), nslab = (b->cexp / 4 + sq - 1) / sq;
+    const int wps = 2048 / nslab > 1 ? 2048 / nslab : 1;
+    return (size_t)wps * b->k * b->k * b->cexp;
+}
+size_t irb_lin_floats(const FearIrbBlock* b) {
+    return b->expand ? (size_t)(b->cexp + b->cin) * b->cin + (b->cin * b->cin > 1056 ? b->cin * b->cin : 1056) : 0;
+}
+
 // the shapes the virtual expansion is built for: the stride-2 blocks with 16 ... 32 input channels and 32-channel slabs (FEAR-XS:
 // 16 -> 96 at 128 x 128, 24 -> 144 at 64 x 64, 32 -> 192 at 32 x 32); the stride-1 depthwise backward has no LDS left for the tile of e
 bool irb_virtual_shape(const FearIrbBlock* b) {
@@ -1198,8 +1206,9 @@ size_t fear_irb_scratch_floats(const FearIrbBlock* b, int B, int H, int W) {
     // g2 | g1 | the three BatchNorms' backward coefficient vectors (3 x [4][cmax]; they must outlive the call when the weight
     // gradients run on their own stream, so they do not live in the shared workspace)
     // | the extended weight matrix and the input's Gram matrix of the expansion's E-free backward (BnbIn)
-    return (size_t)rows_out * b->cexp + (b->expand ? (size_t)rows_in * b->cexp : 0) + (size_t)12 * irb_cmax(b) +
-           (b->expand ? (size_t)(b->cexp + b->cin) * b->cin + (b->cin * b->cin > 1056 ? b->cin * b->cin : 1056) : 0);
+    // | the depthwise tap gradients' per-workgroup partials (their final sum runs on the weight-gradient stream as well)
+    return (size_t)rows_out * b->cexp + (b->expand ? (size_t)rows_in * b->cexp : 0) + (size_t)12 * irb_cmax(b) + irb_lin_floats(b) +
+           irb_taps_floats(b);
 }
 
 int fear_irb_train_forward(const FearIrbBlock* b, const FearIrbSaved* sv, const float* x, float* out, int B, int H, int W, double momentum,
@@ -1338,7 +1347,8 @@ int fear_irb_train_backward(const FearIrbBlock* b, const FearIrbSaved* sv, const
         a.E = b->expand ? sv->e : x; a.lde = cexp; a.act1 = b->expand ? sv->vec[0] : nullptr;
         a.R = (!b->expand && b->residual) ? dout : nullptr; a.ldr = cout;
         a.Y = b->expand ? g1 : dx; a.ldy = cexp;
-        a.ptaps = ws.taps; a.psums = ws.col;
+        float* taps = coef1 + 12 * cmax + irb_lin_floats(b);
+        a.ptaps = taps; a.psums = ws.col;
         a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.C = cexp;
         a.tiles_x = (W + 15) / 16; a.tiles_y = (H + 15) / 16;
         const int sq = dw_bwd_sq(cexp);
@@ -1355,9 +1365,11 @@ int fear_irb_train_backward(const FearIrbBlock* b, const FearIrbSaved* sv, const
         else if (b->k == 3) launch_dw_bwd_ks<3, 2>(a, sq, b->expand != 0, grid, s);
         else if (b->stride == 1) launch_dw_bwd_ks<5, 1>(a, sq, b->expand != 0, grid, s);
         else launch_dw_bwd_ks<5, 2>(a, sq, b->expand != 0, grid, s);
-        launch_slice_sum(ws.taps, gr->w_dw, (long)b->k * b->k * cexp, a.wgs_per_slab, s);
         if (b->expand)
             finalize_backward(ws.col, a.wgs_per_slab, cexp, (double)rows_in, b->gamma[0], sv->vec[0], gr->gamma[0], gr->beta[0], coef1, s);
+        // the tap gradients' final sum is a weight gradient too: off the chain (the partials live in the call's private scratch)
+        if (sw != s && !stream_follow(sw, s)) return FEAR_TRAIN_ERR_HIP;          // the partials, g1 and coef1 exist
+        launch_slice_sum(taps, gr->w_dw, (long)b->k * b->k * cexp, a.wgs_per_slab, sw);
     }
     if (b->expand) {
         // BN1's backward without its input: e = x W1^T is linear in the block input, so both consumers read g1 (cexp channels) and x
@@ -1373,7 +1385,6 @@ int fear_irb_train_backward(const FearIrbBlock* b, const FearIrbSaved* sv, const
         if (!lin) { bn1.E = sv->e; bn1.lde = cexp; }
         float* wext = coef1 + 12 * cmax;                       // [cexp + cin][cin]
         float* gram = wext + (size_t)(cexp + cin) * cin;       // [cin][cin]
-        if (sw != s && !stream_follow(sw, s)) return FEAR_TRAIN_ERR_HIP;          // g1 and coef1 exist
         int rc = FEAR_TRAIN_OK, ldg = cin;
         if (lin && cin <= 32) {
             // (the one-load-per-four-rows Gram kernel of the virtual expansion's forward; its result is [KP][KP] | column sums)
@@ -1433,7 +1444,7 @@ int fear_bn_running_update(const float* vec, double count, float* running_mean, 
                            void* stream) {
     if (!vec || !running_mean || !running_var) return FEAR_TRAIN_ERR_NULL;
     if (C < 1 || !(count >= 1.0)) return FEAR_TRAIN_ERR_SHAPE;
-    if (!(dbg_skip() & 4)) hipLaunchKernelGGL(bn_running_update_kernel, dim3((C + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), vec, running_mean,
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3((C + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), vec, running_mean,
                        running_var, C, count, momentum, eps);
     LAUNCH_CHECK();
     return FEAR_TRAIN_OK;
