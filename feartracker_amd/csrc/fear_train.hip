@@ -367,6 +367,21 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
 // of loads, the row/column permutation undone at the store.  (The first version — one wave per 16 x 64 strip with scalar dY
 // loads — issued a load per two MFMAs and re-read X once per 16 output channels.)  The four waves' accumulators are added in
 // a fixed order through LDS: (w0 + w2) + (w1 + w3).
+// The stem's im2col row (fear_stem_im2col: k = (ci * 3 + ky) * 3 + kx of a 3 x 3 stride-2 pad-1 window, column 27 = 0) gathered from
+// the NCHW image instead of read from a materialised [pixels][28] tensor (0.24 GB per 128 search crops, written once and read by
+// the forward GEMM and by the weight gradient): the operand loaders of those two kernels take it element by element.
+struct StemIn {
+    const float* img;    // [n][3][H][W]; nullptr: the X operand is an ordinary row-major tensor
+    int H, W;
+};
+
+__device__ __forceinline__ float stem_tap(const StemIn& st, long bimg, int oy, int ox, int k) {
+    if (k >= 27) return 0.f;
+    const int ci = k / 9, ky = (k % 9) / 3, kx = k % 3;
+    const int y = oy * 2 - 1 + ky, x = ox * 2 - 1 + kx;
+    return (y >= 0 && y < st.H && x >= 0 && x < st.W) ? st.img[((bimg * 3 + ci) * st.H + y) * st.W + x] : 0.f;
+}
+
 struct WgradArgs {
     const float* dY;     // [M][lddy]   (per crop: + crop * dy_crop_stride)
     const float* X;      // [M][ldx]
@@ -378,6 +393,7 @@ struct WgradArgs {
     const float* act_b;
     int act_relu;
     BnbIn bn;            // block-fused step: the dY operand is the BatchNorm backward of (dY, bn.E), formed on load (crops == 1)
+    StemIn stem;         // pw_wgrad_smallk_kernel<2, true>: X = the stem's im2col rows, gathered (K = 28)
 };
 
 __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs a) {
@@ -491,7 +507,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs a) {
 // 64 (n) x 16 KB (k): the B operand of MFMA (p, b) is ONE float per lane, X[m + lk][16 b + li], so a launch issues
 // 4 KB instead of 16 MFMAs per four rows.  Rows are dealt to the waves and the partial tiles added exactly as in
 // pw_wgrad_kernel — every dW element sees the same products in the same order: the results are bit-identical.
-template <int KB>
+template <int KB, bool STEM = false>
 __global__ __launch_bounds__(256) void pw_wgrad_smallk_kernel(WgradArgs a) {
     __shared__ f32x4 red[2][4 * KB * 64];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
@@ -542,9 +558,17 @@ __global__ __launch_bounds__(256) void pw_wgrad_smallk_kernel(WgradArgs a) {
                 if (bmask) dv[u] = relu_mask4(dv[u], ev, cma, cmb);
                 dv[u] = bnb4(dv[u], ev, cA, cs1, cmu, cQ);
             }
+            long bimg = 0;
+            int oy = 0, ox = 0;
+            if (STEM) {
+                const int Wo = a.stem.W / 2, Ho = a.stem.H / 2;
+                ox = (int)(r % Wo); oy = (int)((r / Wo) % Ho); bimg = r / ((long)Wo * Ho);
+            }
 #pragma unroll
             for (int b = 0; b < KB; ++b) {
-                float v = rv && kv[b] ? x[b][r * a.ldx] : 0.f;
+                float v = 0.f;
+                if (STEM) { if (rv && kv[b]) v = stem_tap(a.stem, bimg, oy, ox, b * 16 + li); }
+                else v = rv && kv[b] ? x[b][r * a.ldx] : 0.f;
                 if (act && rv && kv[b]) {
                     v = __builtin_fmaf(v, ia[b], ib[b]);
                     if (a.act_relu) v = fmaxf(v, 0.f);
@@ -1103,6 +1127,8 @@ struct PwStatArgs {
     double* partial;     // [gridDim.x][2][N]
     int ldx, ldy, M, K, N;
     int row_tiles;       // 128-row tiles per workgroup (0 = 1): the large maps cut their millions of rows into <= ~2 048 partials
+    const float* stem_img;   // pw_stat_kernel<1, true>: X = the stem's im2col rows gathered from this NCHW image (K = 28), see StemIn
+    int stem_H, stem_W;
 };
 
 __device__ __forceinline__ float row16_sum(float v) {      // sum over the 16 lanes that share lane >> 4
@@ -1113,7 +1139,7 @@ __device__ __forceinline__ float row16_sum(float v) {      // sum over the 16 la
     return v;
 }
 
-template <int NT>
+template <int NT, bool STEM = false>
 __global__ __launch_bounds__(256) void pw_stat_kernel(PwStatArgs a) {
     constexpr int MT = 2;
     __shared__ double red[4][2][NT * 16];
@@ -1146,12 +1172,17 @@ __global__ __launch_bounds__(256) void pw_stat_kernel(PwStatArgs a) {
             if (m_wave >= a.M) break;      // (wave-uniform; no barrier inside this loop)
             const float* xrow[MT];
             bool mvalid[MT];
+            int sox[MT], soy[MT], sb[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 int m = m_wave + mt * 16 + li;
                 mvalid[mt] = m < a.M;
                 if (m >= a.M) m = a.M - 1;
-                xrow[mt] = a.X + (long)m * a.ldx;
+                xrow[mt] = STEM ? nullptr : a.X + (long)m * a.ldx;
+                if (STEM) {
+                    const int Wo = a.stem_W / 2, Ho = a.stem_H / 2;
+                    sox[mt] = m % Wo; soy[mt] = (m / Wo) % Ho; sb[mt] = m / (Wo * Ho);
+                }
             }
             f32x4 acc[MT][NT];
 #pragma unroll
@@ -1171,7 +1202,13 @@ __global__ __launch_bounds__(256) void pw_stat_kernel(PwStatArgs a) {
                 for (int mt = 0; mt < MT; ++mt) {
                     xf[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                     if (kvalid) {
-                        xf[mt] = *reinterpret_cast<const f32x4*>(xrow[mt] + k);
+                        if (STEM) {
+                            const StemIn st{a.stem_img, a.stem_H, a.stem_W};
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) xf[mt][i] = stem_tap(st, sb[mt], soy[mt], sox[mt], k + i);
+                        } else {
+                            xf[mt] = *reinterpret_cast<const f32x4*>(xrow[mt] + k);
+                        }
                         if (affine) xf[mt] = act4(xf[mt], ia, ib, a.in.relu != 0);
                     }
                 }
@@ -1467,8 +1504,12 @@ int fear_pw_backward_data(const float* dy, int lddy, const float* w, const float
 
 static int wgrad_impl(const float* dy, int lddy, long dy_crop_stride, const float* x, int ldx, long x_crop_stride, float* dw,
                       float* workspace, size_t ws_bytes, long M, int K, int N, int crops, hipStream_t s, const float* act_a = nullptr,
-                      const float* act_b = nullptr, int act_relu = 0, const BnbIn* bn = nullptr) {
+                      const float* act_b = nullptr, int act_relu = 0, const BnbIn* bn = nullptr, const StemIn* stem = nullptr) {
     WgradArgs a{};
+    if (stem) {
+        if (crops != 1 || K != 28) return FEAR_TRAIN_ERR_SHAPE;
+        a.stem = *stem;
+    }
     a.dY = dy; a.X = x; a.lddy = lddy; a.ldx = ldx; a.N = N; a.K = K; a.M = M; a.crops = crops;
     a.act_a = act_a; a.act_b = act_b; a.act_relu = act_relu;
     if (bn) {
@@ -1516,6 +1557,7 @@ static int wgrad_impl(const float* dy, int lddy, long dy_crop_stride, const floa
         a.P = workspace;
     }
     if (FEAR_WGRAD_SMALLK && K <= 16) hipLaunchKernelGGL(pw_wgrad_smallk_kernel<1>, dim3(a.n_tiles, slices, crops), dim3(256), 0, s, a);
+    else if (FEAR_WGRAD_SMALLK && K <= 32 && stem) hipLaunchKernelGGL((pw_wgrad_smallk_kernel<2, true>), dim3(a.n_tiles, slices, crops), dim3(256), 0, s, a);
     else if (FEAR_WGRAD_SMALLK && K <= 32) hipLaunchKernelGGL(pw_wgrad_smallk_kernel<2>, dim3(a.n_tiles, slices, crops), dim3(256), 0, s, a);
     else if (lds_tile) hipLaunchKernelGGL(wgrad_lds_kernel<0>, dim3(a.n_tiles * a.k_tiles, slices), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(pw_wgrad_kernel, dim3(a.n_tiles * a.k_tiles, slices, crops), dim3(256), 0, s, a);

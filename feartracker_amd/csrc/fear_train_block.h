@@ -1614,4 +1614,60 @@ int fear_sepbn_train_backward(const FearSepLayer* L, const FearSepGrads* gr, con
     return FEAR_TRAIN_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The stem (3 x 3 stride-2 conv 3 -> 16 + BatchNorm + ReLU, fbnet_c stages[0]) on the NCHW image: fear_pwbn_train_* over
+// fear_stem_im2col's rows with the rows never materialised — the forward GEMM and the weight gradient gather them (StemIn).
+static bool stem_shape_ok(long n, int H, int W) { return n >= 1 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0 && n * (H / 2) * (W / 2) < 0x7fffffffL / 28; }
+
+size_t fear_stem_workspace_bytes(long n, int H, int W) {
+    if (!stem_shape_ok(n, H, W)) return 0;
+    const long M = n * (H / 2) * (W / 2);
+    return block_ws(M, M, 28, 16, 16, 3, nullptr).total;
+}
+
+int fear_stem_train_forward(const float* x_nchw, const float* w, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                            float* raw, float* vec, float* out, long n, int H, int W, double momentum, double eps, float* workspace,
+                            size_t ws_bytes, void* stream) {
+    if (!x_nchw || !w || !gamma || !beta || !raw || !vec || !out || !workspace) return FEAR_TRAIN_ERR_NULL;
+    if (!stem_shape_ok(n, H, W)) return FEAR_TRAIN_ERR_SHAPE;
+    const long M = n * (H / 2) * (W / 2);
+    const BlockWs ws = block_ws(M, M, 28, 16, 16, 3, workspace);
+    if (ws_bytes < ws.total) return FEAR_TRAIN_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    PwStatArgs a{};
+    a.stem_img = x_nchw; a.stem_H = H; a.stem_W = W; a.W = w; a.Y = raw; a.ldy = 16; a.M = (int)M; a.K = 28; a.N = 16; a.partial = ws.col;
+    int nt = 1;
+    const dim3 grid = stat_grid(M, 28, 16, &nt, &a.row_tiles);      // (16 output channels: one column tile, nt = 1)
+    if (nt != 1 || (size_t)grid.x * 2 * 16 * sizeof(double) > ws.col_bytes) return FEAR_TRAIN_ERR_WORKSPACE;
+    hipLaunchKernelGGL((pw_stat_kernel<1, true>), grid, dim3(256), 0, s, a);
+    finalize_forward(ws.col, (int)grid.x, 16, (double)M, gamma, beta, vec, running_mean, running_var, momentum, eps, s);
+    BnActArgs k{};
+    k.X = raw; k.Y = out; k.in.a = vec + 2 * 16; k.in.b = vec + 3 * 16; k.in.relu = 1; k.M = M; k.C = 16; k.ldx = 16; k.ldy = 16;
+    hipLaunchKernelGGL(bn_act_kernel, dim3((unsigned)((M * 4 + 255) / 256)), dim3(256), 0, s, k);
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+int fear_stem_train_backward(const float* dy, const float* raw, const float* vec, const float* x_nchw, const float* gamma, float* dw,
+                             float* dgamma, float* dbeta, long n, int H, int W, float* workspace, size_t ws_bytes, void* stream,
+                             void* wgrad_stream) {
+    if (!dy || !raw || !vec || !x_nchw || !gamma || !dw || !dgamma || !dbeta || !workspace) return FEAR_TRAIN_ERR_NULL;
+    if (!stem_shape_ok(n, H, W)) return FEAR_TRAIN_ERR_SHAPE;
+    const long M = n * (H / 2) * (W / 2);
+    const BlockWs ws = block_ws(M, M, 28, 16, 16, 3, workspace);
+    if (ws_bytes < ws.total) return FEAR_TRAIN_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipStream_t sw = wgrad_stream ? static_cast<hipStream_t>(wgrad_stream) : s;
+    if (sw != s && !stream_follow(s, sw)) return FEAR_TRAIN_ERR_HIP;      // (the coefficient vectors live in the shared workspace, as in fear_pwbn_train_backward)
+    bn_backward_sums(dy, 16, raw, 16, vec, 1, gamma, dgamma, dbeta, ws.coef, M, 16, ws.col, s);
+    BnbIn bn{};
+    bn.E = raw; bn.coef = ws.coef; bn.lde = 16; bn.C = 16; bn.mask_a = vec + 2 * 16; bn.mask_b = vec + 3 * 16;
+    if (sw != s && !stream_follow(sw, s)) return FEAR_TRAIN_ERR_HIP;
+    const StemIn st{x_nchw, H, W};
+    const int rc = wgrad_impl(dy, 16, 0, nullptr, 28, 0, dw, ws.wg, ws.wg_bytes, M, 28, 16, 1, sw, nullptr, nullptr, 0, &bn, &st);
+    if (rc != FEAR_TRAIN_OK) return rc;
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
 }  // extern "C"

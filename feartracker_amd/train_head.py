@@ -73,6 +73,9 @@ TRAIN_SYMBOLS = {
     "fear_pwbn_workspace_bytes": ([_l, _i, _i], _sz),
     "fear_pwbn_train_forward": ([_P, _i, _P, _P, _P, _P, _P, _P, _P, _i, _P, _l, _i, _i, _d, _d, _P, _sz, _P], _i),
     "fear_pwbn_train_backward": ([_P, _P, _P, _i, _P, _i, _P, _P, _P, _P, _P, _P, _l, _i, _i, _P, _sz, _P, _P], _i),
+    "fear_stem_workspace_bytes": ([_l, _i, _i], _sz),
+    "fear_stem_train_forward": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _l, _i, _i, _d, _d, _P, _sz, _P], _i),
+    "fear_stem_train_backward": ([_P, _P, _P, _P, _P, _P, _P, _P, _l, _i, _i, _P, _sz, _P, _P], _i),
     # the head's SepConv + BatchNorm + ReLU layer, one call per direction
     "fear_sepbn_workspace_bytes": ([_P, _i, _i, _i], _sz),
     "fear_sepbn_train_forward": ([_P, _P, _i, _P, _P, _P, _P, _i, _i, _i, _i, _d, _d, _P, _sz, _P], _i),

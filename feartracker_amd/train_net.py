@@ -492,14 +492,13 @@ class FEARNetTrainHIP:
         B, H = img.shape[0], img.shape[2]
         ws, wsb, _ = self._block_buffers(B, H)
         h = H // 2
-        col = self._new(B * h * h, 28)
-        self._check(lib.fear_stem_im2col(_p(img), _p(col), B, H, H, st))
         S = self.stem
         run = (lambda L: (None, None)) if defer_running else (lambda L: (_p(L.running_mean), _p(L.running_var)))
         pending = []
         stem_raw, stem_vec, x = self._new(B * h * h, 16), self._new(4 * 16), self._new(B * h * h, 16)
-        self._check(lib.fear_pwbn_train_forward(_p(col), 28, _p(S.w), _p(S.gamma), _p(S.beta), *run(S), _p(stem_raw),
-                                                _p(stem_vec), 1, _p(x), B * h * h, 28, 16, self.momentum, self.eps, ws, wsb, st))
+        # (the stem's im2col rows are gathered from the image by the GEMM and, in the backward, by the weight gradient)
+        self._check(lib.fear_stem_train_forward(_p(img), _p(S.w), _p(S.gamma), _p(S.beta), *run(S), _p(stem_raw), _p(stem_vec), _p(x),
+                                                B, H, H, self.momentum, self.eps, ws, wsb, st))
         pending.append((stem_vec, B * h * h, S))
         recs = [dict(L=S, pre=stem_raw, act=(stem_vec[32:48], stem_vec[48:64], 1), B=B, H=h)]     # what relu_patterns reads
         blocks = []
@@ -539,7 +538,7 @@ class FEARNetTrainHIP:
         self._check(lib.fear_pwbn_train_forward(_p(x), 112, _p(N.w), _p(N.gamma), _p(N.beta), *run(N), _p(neck_raw),
                                                 _p(neck_vec), 0, _p(feats), B * h * h, 112, 256, self.momentum, self.eps, ws, wsb, st))
         pending.append((neck_vec, B * h * h, N))
-        return feats, (recs, dict(B=B, H=H, col=col, stem=(stem_raw, stem_vec), blocks=blocks, neck=(x, neck_raw, neck_vec, h),
+        return feats, (recs, dict(B=B, H=H, img=img, stem=(stem_raw, stem_vec), blocks=blocks, neck=(x, neck_raw, neck_vec, h),
                                   pending=pending if defer_running else []))
 
     def _apply_running(self, ctx) -> None:
@@ -609,11 +608,11 @@ class FEARNetTrainHIP:
         S = self.stem
         stem_raw, stem_vec = c["stem"]
         hs = H // 2
-        self._check(lib.fear_pwbn_train_backward(_p(d), _p(stem_raw), _p(stem_vec), 1, _p(c["col"]), 28, _p(S.w), _p(S.gamma),
-                                                 g(S.conv_key, 16 * 28), g(S.bn_key + ".weight", 16), g(S.bn_key + ".bias", 16), None,
-                                                 B * hs * hs, 28, 16, ws, wsb, st, aux_p))
+        self._check(lib.fear_stem_train_backward(_p(d), _p(stem_raw), _p(stem_vec), _p(c["img"]), _p(S.gamma), g(S.conv_key, 16 * 28),
+                                                 g(S.bn_key + ".weight", 16), g(S.bn_key + ".bias", 16), B, H, H, ws, wsb, st, aux_p))
         if aux is not None:
             d.record_stream(aux)
+            c["img"].record_stream(aux)
 
     # ------------------------------------------------------------------ trunk + neck
     def _features_forward(self, img: torch.Tensor):

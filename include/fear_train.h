@@ -247,6 +247,17 @@ int fear_pwbn_train_backward(const float* dy, const float* raw, const float* vec
                              const float* gamma, float* dw, float* dgamma, float* dbeta, float* dx, long M, int K, int N, float* workspace,
                              size_t ws_bytes, void* stream, void* wgrad_stream);
 
+/* the stem (3x3 stride-2 conv 3 -> 16 + BatchNorm + ReLU: the FBNet-C first stage behind model/fear_net.py:83-88) on the NCHW image —
+ * fear_pwbn_train_* over fear_stem_im2col's rows without ever materialising them (w [16][28]: k = (ci*3 + ky)*3 + kx, column 27 = 0;
+ * raw, out [n*(H/2)*(W/2)][16]; the image needs no gradient) */
+size_t fear_stem_workspace_bytes(long n, int H, int W);
+int fear_stem_train_forward(const float* x_nchw, const float* w, const float* gamma, const float* beta, float* running_mean,
+                            float* running_var, float* raw, float* vec, float* out, long n, int H, int W, double momentum, double eps,
+                            float* workspace, size_t ws_bytes, void* stream);
+int fear_stem_train_backward(const float* dy, const float* raw, const float* vec, const float* x_nchw, const float* gamma, float* dw,
+                             float* dgamma, float* dbeta, long n, int H, int W, float* workspace, size_t ws_bytes, void* stream,
+                             void* wgrad_stream);
+
 /* SepConv (depthwise 3x3 + pointwise, both with bias) + BatchNorm + ReLU: the layer of the head's encoders and towers
  * (SepConv + BatchNorm2d + ReLU: model_training/model/blocks.py:97-101 MatrixMobile, :115-119 MobileCorrelation, :151-161 BoxTower's towers), one call per direction.  Kernel layouts: depthwise taps
  * [9][cin], pointwise [cout][cin].  The pointwise bias sits in front of the BatchNorm: it cancels in the normalisation (its gradient

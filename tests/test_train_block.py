@@ -265,3 +265,58 @@ def test_sepbn_layer_forward_backward_vs_autograd(B, H, cin, cout, bias, ldx_pad
     again = backward(torch.cuda.Stream(device=dev))
     for a, b in zip((gt, gw, gg, gb, dx), again):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,H", [(3, 64), (2, 256), (5, 30)])
+def test_stem_on_the_image_forward_backward_vs_autograd(n, H):
+    """The stem — 3x3 stride-2 conv 3 -> 16 + BatchNorm + ReLU — with its im2col rows gathered from the NCHW image by the GEMM and by the
+    weight gradient (fear_stem_train_*): same numbers as the materialised rows (fear_stem_im2col + fear_pwbn_train_*), bit for bit
+    in the forward, and autograd's gradients."""
+    from feartracker_amd.train_head import _p, load_train_library
+    lib = load_train_library()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(21 + n + H)
+    x = torch.randn(n, 3, H, H, generator=g, dtype=torch.float64)
+    w = (torch.randn(16, 3, 3, 3, generator=g, dtype=torch.float64) * 0.3).requires_grad_(True)
+    gamma = (torch.rand(16, generator=g, dtype=torch.float64) + 0.5).requires_grad_(True)
+    beta = (torch.randn(16, generator=g, dtype=torch.float64) * 0.3).requires_grad_(True)
+    rm_ref, rv_ref = torch.zeros(16, dtype=torch.float64), torch.ones(16, dtype=torch.float64)
+    y = F.relu(F.batch_norm(F.conv2d(x, w, stride=2, padding=1), rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5))
+    Ho = H // 2
+    M = n * Ho * Ho
+    dy = torch.randn(n, 16, Ho, Ho, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    rows = lambda t: t.detach().permute(0, 2, 3, 1).reshape(M, -1)
+    D = lambda t: t.detach().to(dev, torch.float32).contiguous()
+    xd, gd, bd, dyd = D(x), D(gamma), D(beta), D(rows(dy))
+    w28 = torch.zeros(16, 28, device=dev)
+    w28[:, :27] = D(w).reshape(16, 27)
+    ws = torch.empty(int(lib.fear_stem_workspace_bytes(n, H, H)) // 4 + 64, device=dev)
+    rm, rv = torch.zeros(16, device=dev), torch.ones(16, device=dev)
+    raw, vec, out = torch.empty(M, 16, device=dev), torch.empty(64, device=dev), torch.empty(M, 16, device=dev)
+    assert lib.fear_stem_train_forward(_p(xd), _p(w28), _p(gd), _p(bd), _p(rm), _p(rv), _p(raw), _p(vec), _p(out), n, H, H, 0.1, 1e-5,
+                                       _p(ws), ws.numel() * 4, None) == 0
+    # the materialised form
+    col = torch.empty(M, 28, device=dev)
+    assert lib.fear_stem_im2col(_p(xd), _p(col), n, H, H, None) == 0
+    rm2, rv2 = torch.zeros(16, device=dev), torch.ones(16, device=dev)
+    raw2, vec2, out2 = torch.empty(M, 16, device=dev), torch.empty(64, device=dev), torch.empty(M, 16, device=dev)
+    assert lib.fear_pwbn_train_forward(_p(col), 28, _p(w28), _p(gd), _p(bd), _p(rm2), _p(rv2), _p(raw2), _p(vec2), 1, _p(out2), M, 28, 16,
+                                       0.1, 1e-5, _p(ws), ws.numel() * 4, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(raw, raw2) and torch.equal(out, out2) and torch.equal(vec, vec2)
+    dw, dg, db = torch.empty(16, 28, device=dev), torch.empty(16, device=dev), torch.empty(16, device=dev)
+    assert lib.fear_stem_train_backward(_p(dyd), _p(raw), _p(vec), _p(xd), _p(gd), _p(dw), _p(dg), _p(db), n, H, H, _p(ws), ws.numel() * 4,
+                                        None, None) == 0
+    dw2, dg2, db2 = torch.empty(16, 28, device=dev), torch.empty(16, device=dev), torch.empty(16, device=dev)
+    assert lib.fear_pwbn_train_backward(_p(dyd), _p(raw2), _p(vec2), 1, _p(col), 28, _p(w28), _p(gd), _p(dw2), _p(dg2), _p(db2), None, M, 28, 16,
+                                        _p(ws), ws.numel() * 4, None, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(dw, dw2) and torch.equal(dg, dg2) and torch.equal(db, db2)
+    errs = {"out": _rel(out, rows(y)), "running_mean": _rel(rm, rm_ref), "running_var": _rel(rv, rv_ref),
+            "dw": _rel(dw[:, :27].reshape(16, 3, 3, 3), w.grad), "dgamma": _rel(dg, gamma.grad), "dbeta": _rel(db, beta.grad)}
+    print({k_: f"{v:.1e}" for k_, v in errs.items()})
+    bad = {k_: v for k_, v in errs.items() if not v < 2e-4}
+    assert not bad, bad
+    assert float(dw[:, 27].abs().max()) == 0.0
