@@ -393,7 +393,7 @@ struct WgradArgs {
     const float* act_b;
     int act_relu;
     BnbIn bn;            // block-fused step: the dY operand is the BatchNorm backward of (dY, bn.E), formed on load (crops == 1)
-    StemIn stem;         // pw_wgrad_smallk_kernel<2, true>: X = the stem's im2col rows, gathered (K = 28)
+    StemIn stem;         // pw_wgrad_smallk_kernel<2, 1>: X = the stem's im2col rows, gathered (K = 28)
 };
 
 __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs a) {
@@ -507,8 +507,16 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs a) {
 // 64 (n) x 16 KB (k): the B operand of MFMA (p, b) is ONE float per lane, X[m + lk][16 b + li], so a launch issues
 // 4 KB instead of 16 MFMAs per four rows.  Rows are dealt to the waves and the partial tiles added exactly as in
 // pw_wgrad_kernel — every dW element sees the same products in the same order: the results are bit-identical.
-template <int KB, bool STEM = false>
+// MODE 0: as above | 1 (STEM): the X operand is the stem's im2col row, gathered from the image | 2 (SWAP): the two operands trade
+// places — for a NARROW dY (N <= 32: the projections' weight gradients, 24-32 output channels against 96-192 expanded ones) the
+// wide tensor takes the float4 side and the narrow one the per-lane side, so that a launch is N / 64 column tiles of streaming
+// rows instead of a 64 x 64 (or 128 x 128) tile that is three quarters padding (dW[24][96] over 524 288 rows: 518 us as a 64-wide
+// tile, 300 MB).  The prologues trade places with them (activation on the float4 side, BatchNorm backward — no mask — per lane)
+// and the tile is stored transposed: the caller passes (dY, N) := (the wide tensor, its width), (X, K) := (the narrow one, its
+// width) and still gets dW[K][N] row-major.
+template <int KB, int MODE = 0>
 __global__ __launch_bounds__(256) void pw_wgrad_smallk_kernel(WgradArgs a) {
+    constexpr bool STEM = MODE == 1, SWAP = MODE == 2;
     __shared__ f32x4 red[2][4 * KB * 64];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
     const int nt = blockIdx.x, slice = blockIdx.y, crop = blockIdx.z;
@@ -534,17 +542,31 @@ __global__ __launch_bounds__(256) void pw_wgrad_smallk_kernel(WgradArgs a) {
     float ia[KB], ib[KB];
 #pragma unroll
     for (int b = 0; b < KB; ++b) {
-        ia[b] = act && kv[b] ? a.act_a[b * 16 + li] : 0.f;
-        ib[b] = act && kv[b] ? a.act_b[b * 16 + li] : 0.f;
+        ia[b] = !SWAP && act && kv[b] ? a.act_a[b * 16 + li] : 0.f;
+        ib[b] = !SWAP && act && kv[b] ? a.act_b[b * 16 + li] : 0.f;
     }
-    const bool bnb = a.bn.coef != nullptr, bne = a.bn.E != nullptr, bmask = bne && a.bn.mask_a != nullptr;
+    const bool bnb = a.bn.coef != nullptr, bne = a.bn.E != nullptr, bmask = !SWAP && bne && a.bn.mask_a != nullptr;
     f32x4 cA = zero, cs1 = zero, cmu = zero, cQ = zero, cma = zero, cmb = zero;
-    if (bnb && nv) {
+    // SWAP: the activation's a | b of this lane's four dY-side columns, and the BatchNorm-backward coefficients of its X-side columns
+    f32x4 da = zero, db = zero;
+    float xA[KB], xs1[KB], xmu[KB], xQ[KB];
+#pragma unroll
+    for (int b = 0; b < KB; ++b) { xA[b] = 0.f; xs1[b] = 0.f; xmu[b] = 0.f; xQ[b] = 0.f; }
+    if (SWAP) {
+        if (act && nv) { da = *reinterpret_cast<const f32x4*>(a.act_a + n4); db = *reinterpret_cast<const f32x4*>(a.act_b + n4); }
+#pragma unroll
+        for (int b = 0; b < KB; ++b)
+            if (bnb && kv[b]) {
+                const int k = b * 16 + li;
+                xA[b] = a.bn.coef[k]; xs1[b] = a.bn.coef[a.bn.C + k]; xmu[b] = a.bn.coef[2 * a.bn.C + k]; xQ[b] = a.bn.coef[3 * a.bn.C + k];
+            }
+    }
+    if (!SWAP && bnb && nv) {
         cA = *reinterpret_cast<const f32x4*>(a.bn.coef + n4); cs1 = *reinterpret_cast<const f32x4*>(a.bn.coef + a.bn.C + n4);
         cmu = *reinterpret_cast<const f32x4*>(a.bn.coef + 2 * a.bn.C + n4); cQ = *reinterpret_cast<const f32x4*>(a.bn.coef + 3 * a.bn.C + n4);
         if (bmask) { cma = *reinterpret_cast<const f32x4*>(a.bn.mask_a + n4); cmb = *reinterpret_cast<const f32x4*>(a.bn.mask_b + n4); }
     }
-    const float* eb = bne ? a.bn.E + (nv ? n4 : 0) : nullptr;
+    const float* eb = !SWAP && bne ? a.bn.E + (nv ? n4 : 0) : nullptr;
     for (long m = m0 + wave * 16; m < m1; m += 64) {
         f32x4 dv[4];
         float xs[4][KB];
@@ -553,7 +575,8 @@ __global__ __launch_bounds__(256) void pw_wgrad_smallk_kernel(WgradArgs a) {
             const long r = m + u * 4 + lk;
             const bool rv = r < m1;
             dv[u] = rv && nv ? *reinterpret_cast<const f32x4*>(dy + r * a.lddy) : zero;
-            if (bnb && rv && nv) {
+            if (SWAP && act && rv && nv) dv[u] = act4(dv[u], da, db, a.act_relu != 0);
+            if (!SWAP && bnb && rv && nv) {
                 const f32x4 ev = bne ? *reinterpret_cast<const f32x4*>(eb + r * a.bn.lde) : zero;
                 if (bmask) dv[u] = relu_mask4(dv[u], ev, cma, cmb);
                 dv[u] = bnb4(dv[u], ev, cA, cs1, cmu, cQ);
@@ -569,9 +592,13 @@ __global__ __launch_bounds__(256) void pw_wgrad_smallk_kernel(WgradArgs a) {
                 float v = 0.f;
                 if (STEM) { if (rv && kv[b]) v = stem_tap(a.stem, bimg, oy, ox, b * 16 + li); }
                 else v = rv && kv[b] ? x[b][r * a.ldx] : 0.f;
-                if (act && rv && kv[b]) {
+                if (!SWAP && act && rv && kv[b]) {
                     v = __builtin_fmaf(v, ia[b], ib[b]);
                     if (a.act_relu) v = fmaxf(v, 0.f);
+                }
+                if (SWAP && bnb && rv && kv[b]) {
+                    const float e = bne ? a.bn.E[r * a.bn.lde + b * 16 + li] : 0.f;
+                    v = xA[b] * (v - xs1[b] - (e - xmu[b]) * xQ[b]);
                 }
                 xs[u][b] = v;
             }
@@ -612,7 +639,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_smallk_kernel(WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int nn = nt * 64 + lk * 16 + r * 4 + p;
-                if (nn < a.N) P[(long)nn * a.K + b * 16 + li] = acc[p][b][r];
+                if (nn < a.N) P[SWAP ? (long)(b * 16 + li) * a.N + nn : (long)nn * a.K + b * 16 + li] = acc[p][b][r];
             }
     }
 }
@@ -1517,6 +1544,34 @@ static int wgrad_impl(const float* dy, int lddy, long dy_crop_stride, const floa
         a.bn = *bn;
     }
     a.dy_crop_stride = dy_crop_stride; a.x_crop_stride = x_crop_stride;
+    // a narrow dY against a wide X (the projections of the large maps): the operands trade places in pw_wgrad_smallk_kernel<., 2>
+    if (FEAR_WGRAD_SMALLK && crops == 1 && N <= 32 && K > 32 && !stem && !(bn && bn->mask_a) && (!bn || bn->E)) {
+        a.dY = x; a.lddy = ldx; a.N = K; a.X = dy; a.ldx = lddy; a.K = N;
+        a.n_tiles = (K + 63) / 64; a.k_tiles = 1;
+        a.rows_per_slice = wgrad_rows_per_slice(M);
+        const long want = (768 + a.n_tiles - 1) / a.n_tiles;
+        long cap_ws = workspace ? (long)(ws_bytes / ((size_t)N * K * sizeof(float))) : 1;
+        if (cap_ws < 1) cap_ws = 1;
+        long sl = (M + a.rows_per_slice - 1) / a.rows_per_slice;
+        if (want > sl) sl = want;
+        if (sl > 1024) sl = 1024;
+        if (sl > cap_ws) sl = cap_ws;
+        long rps = ((M + sl - 1) / sl + 63) / 64 * 64;
+        if (rps < 256) rps = 256;
+        if (rps < a.rows_per_slice) a.rows_per_slice = rps;
+        const int slices = (int)((M + a.rows_per_slice - 1) / a.rows_per_slice);
+        if (slices == 1) {
+            a.P = dw;
+        } else {
+            if (!workspace || ws_bytes < (size_t)slices * N * K * sizeof(float)) return FEAR_TRAIN_ERR_WORKSPACE;
+            a.P = workspace;
+        }
+        if (N <= 16) hipLaunchKernelGGL((pw_wgrad_smallk_kernel<1, 2>), dim3(a.n_tiles, slices, 1), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((pw_wgrad_smallk_kernel<2, 2>), dim3(a.n_tiles, slices, 1), dim3(256), 0, s, a);
+        if (slices > 1) launch_slice_sum(workspace, dw, (long)N * K, slices, s);
+        LAUNCH_CHECK();
+        return FEAR_TRAIN_OK;
+    }
     a.n_tiles = (N + 63) / 64; a.k_tiles = (K + 63) / 64;
     // 128 x 128 tiles with the rows staged through LDS (wgrad_lds_kernel, fear_train_gemm.h) where both sides are wide enough for
     // the sharing to matter and the launch is one problem, not a batch of per-crop ones
@@ -1557,7 +1612,7 @@ static int wgrad_impl(const float* dy, int lddy, long dy_crop_stride, const floa
         a.P = workspace;
     }
     if (FEAR_WGRAD_SMALLK && K <= 16) hipLaunchKernelGGL(pw_wgrad_smallk_kernel<1>, dim3(a.n_tiles, slices, crops), dim3(256), 0, s, a);
-    else if (FEAR_WGRAD_SMALLK && K <= 32 && stem) hipLaunchKernelGGL((pw_wgrad_smallk_kernel<2, true>), dim3(a.n_tiles, slices, crops), dim3(256), 0, s, a);
+    else if (FEAR_WGRAD_SMALLK && K <= 32 && stem) hipLaunchKernelGGL((pw_wgrad_smallk_kernel<2, 1>), dim3(a.n_tiles, slices, crops), dim3(256), 0, s, a);
     else if (FEAR_WGRAD_SMALLK && K <= 32) hipLaunchKernelGGL(pw_wgrad_smallk_kernel<2>, dim3(a.n_tiles, slices, crops), dim3(256), 0, s, a);
     else if (lds_tile) hipLaunchKernelGGL(wgrad_lds_kernel<0>, dim3(a.n_tiles * a.k_tiles, slices), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(pw_wgrad_kernel, dim3(a.n_tiles * a.k_tiles, slices, crops), dim3(256), 0, s, a);
