@@ -360,10 +360,13 @@ struct DwBwdArgs {
     VirtE ve;             // VE: E is not read, e = ve.X ve.W1^T on the spot
 };
 
-template <int KS, int S, int SQ, bool BN1, int VE = 0>      // VE = NC chunks of 16 input channels of a virtual expansion (0: E is read)
+// TS: the tile side, 16 — or 8 for maps of at most 8 x 8 pixels (the template branch's stride-16 stage: a 16 x 16 tile would be three
+// quarters outside the map, dd region and sweeps alike; built for the 5 x 5 stride-1 kernels that stage consists of)
+template <int KS, int S, int SQ, bool BN1, int VE = 0, int TS = 16>      // VE = NC chunks of 16 input channels of a virtual expansion (0: E is read)
 __global__ __launch_bounds__(256, 2) void dw_bwd_kernel(DwBwdArgs a) {
     static_assert(!VE || (BN1 && S == 2), "the virtual expansion is built for the stride-2 kernels");
-    constexpr int P = KS / 2, KK = KS * KS, TS = 16;
+    static_assert(TS == 16 || (TS == 8 && S == 1 && KS == 5), "8 x 8 tiles: the 5 x 5 stride-1 kernels only");
+    constexpr int P = KS / 2, KK = KS * KS;
     constexpr int LO = P / S;                          // output rows / columns in front of the tile's first own one
     constexpr int OR = (TS - 1 + P) / S + LO + 1;      // side of the dd region a tile reads
     constexpr int PITCH = (OR + 1) * SQ;               // float4s per region row: one pixel of padding turns consecutive rows by half
@@ -736,14 +739,14 @@ struct DwFwdArgs {
     VirtE ve;             // VE: X is not read, the operand is act(ve.X ve.W1^T)
 };
 
-template <int KS, int S, int SQ, int VE = 0>      // VE = NC chunks of 16 input channels of a virtual expansion (0: X is read)
+template <int KS, int S, int SQ, int VE = 0, int TS1 = 16>      // VE = NC chunks of 16 input channels of a virtual expansion (0: X is read)
 __global__ __launch_bounds__(256, 2) void dw_fwd_kernel(DwFwdArgs a) {
     constexpr int P = KS / 2, KK = KS * KS;
-    constexpr int TO = S == 1 ? 16 : 8;                // output tile side
+    constexpr int TO = S == 1 ? TS1 : 8;               // output tile side (TS1 = 8: stride-1 maps of at most 8 x 8 pixels, see dw_bwd_kernel)
     constexpr int IR = (TO - 1) * S + KS;              // input region side
     constexpr int PITCH = (IR + 1) * SQ;
     constexpr int PL = 256 / SQ;
-    constexpr int T = S == 1 ? 4 : 1;                  // output pixels per thread and sweep (a run along x)
+    constexpr int T = S == 1 ? (TO == 8 ? 2 : 4) : 1;  // output pixels per thread and sweep (a run along x)
     constexpr int SMEM = IR * PITCH > 512 ? IR * PITCH : 512;
     __shared__ f32x4 tile[SMEM];
     f64x4* red64 = reinterpret_cast<f64x4*>(tile);
@@ -1251,9 +1254,10 @@ int fear_irb_train_forward(const FearIrbBlock* b, const FearIrbSaved* sv, const 
         a.X = b->expand ? sv->e : x; a.ldx = b->cexp; a.Wt = b->w_dw; a.Y = sv->d; a.ldy = b->cexp;
         a.B = B; a.H = H; a.W = W; a.C = b->cexp; a.Ho = Ho; a.Wo = Wo;
         if (b->expand) { a.in.a = sv->vec[0] + 2 * b->cexp; a.in.b = sv->vec[0] + 3 * b->cexp; a.in.relu = 1; }
-        const int to = b->stride == 1 ? 16 : 8;
-        a.tiles_x = (Wo + to - 1) / to; a.tiles_y = (Ho + to - 1) / to;
         const int sq = dw_bwd_sq(b->cexp);
+        const bool small_map = b->k == 5 && b->stride == 1 && sq == 8 && Ho <= 8 && Wo <= 8;      // 8 x 8 tiles (the template branch's last stage)
+        const int to = b->stride == 1 ? (small_map ? 8 : 16) : 8;
+        a.tiles_x = (Wo + to - 1) / to; a.tiles_y = (Ho + to - 1) / to;
         a.nslab = (b->cexp / 4 + sq - 1) / sq;
         a.wgs_per_slab = dw_bwd_wgs_per_slab(B * a.tiles_x * a.tiles_y, a.nslab);
         a.psums = ws.col;
@@ -1264,7 +1268,8 @@ int fear_irb_train_forward(const FearIrbBlock* b, const FearIrbSaved* sv, const 
             else if (b->k == 3) hipLaunchKernelGGL((dw_fwd_kernel<3, 2, 8, 2>), grid, dim3(256), 0, s, a);
             else if (b->cin <= 16) hipLaunchKernelGGL((dw_fwd_kernel<5, 2, 8, 1>), grid, dim3(256), 0, s, a);
             else hipLaunchKernelGGL((dw_fwd_kernel<5, 2, 8, 2>), grid, dim3(256), 0, s, a);
-        } else if (b->k == 3 && b->stride == 1) launch_dw_fwd_ks<3, 1>(a, sq, grid, s);
+        } else if (small_map) hipLaunchKernelGGL((dw_fwd_kernel<5, 1, 8, 0, 8>), grid, dim3(256), 0, s, a);
+        else if (b->k == 3 && b->stride == 1) launch_dw_fwd_ks<3, 1>(a, sq, grid, s);
         else if (b->k == 3) launch_dw_fwd_ks<3, 2>(a, sq, grid, s);
         else if (b->stride == 1) launch_dw_fwd_ks<5, 1>(a, sq, grid, s);
         else launch_dw_fwd_ks<5, 2>(a, sq, grid, s);
@@ -1350,8 +1355,10 @@ int fear_irb_train_backward(const FearIrbBlock* b, const FearIrbSaved* sv, const
         float* taps = coef1 + 12 * cmax + irb_lin_floats(b);
         a.ptaps = taps; a.psums = ws.col;
         a.B = B; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.C = cexp;
-        a.tiles_x = (W + 15) / 16; a.tiles_y = (H + 15) / 16;
         const int sq = dw_bwd_sq(cexp);
+        const bool small_map = b->k == 5 && b->stride == 1 && sq == 8 && b->expand && H <= 8 && W <= 8;      // 8 x 8 tiles
+        const int ts = small_map ? 8 : 16;
+        a.tiles_x = (W + ts - 1) / ts; a.tiles_y = (H + ts - 1) / ts;
         a.nslab = (cexp / 4 + sq - 1) / sq;
         a.wgs_per_slab = dw_bwd_wgs_per_slab(B * a.tiles_x * a.tiles_y, a.nslab);
         const dim3 grid((unsigned)(a.wgs_per_slab * a.nslab));
@@ -1361,7 +1368,8 @@ int fear_irb_train_backward(const FearIrbBlock* b, const FearIrbSaved* sv, const
             else if (b->k == 3) hipLaunchKernelGGL((dw_bwd_kernel<3, 2, 8, true, 2>), grid, dim3(256), 0, s, a);
             else if (cin <= 16) hipLaunchKernelGGL((dw_bwd_kernel<5, 2, 8, true, 1>), grid, dim3(256), 0, s, a);
             else hipLaunchKernelGGL((dw_bwd_kernel<5, 2, 8, true, 2>), grid, dim3(256), 0, s, a);
-        } else if (b->k == 3 && b->stride == 1) launch_dw_bwd_ks<3, 1>(a, sq, b->expand != 0, grid, s);
+        } else if (small_map) hipLaunchKernelGGL((dw_bwd_kernel<5, 1, 8, true, 0, 8>), grid, dim3(256), 0, s, a);
+        else if (b->k == 3 && b->stride == 1) launch_dw_bwd_ks<3, 1>(a, sq, b->expand != 0, grid, s);
         else if (b->k == 3) launch_dw_bwd_ks<3, 2>(a, sq, b->expand != 0, grid, s);
         else if (b->stride == 1) launch_dw_bwd_ks<5, 1>(a, sq, b->expand != 0, grid, s);
         else launch_dw_bwd_ks<5, 2>(a, sq, b->expand != 0, grid, s);
