@@ -968,7 +968,7 @@ BlockWs block_ws(long rows_in, long rows_out, int cin, int cexp, int cout, int k
     size_t col = fear_train_stats_workspace_bytes(rows, cmax);
     const size_t colr = (size_t)col_blocks(rows) * 2 * cmax * sizeof(double);
     if (colr > col) col = colr;
-    const size_t lds = rows <= 65536 ? (size_t)((rows + 63) / 64) * 2 * cmax * sizeof(double) : 0;      // gemm_lds_kernel: 64-row blocks
+    const size_t lds = rows <= FEAR_GEMM_LDS_MAX_ROWS ? (size_t)((rows + 63) / 64) * 2 * cmax * sizeof(double) : 0;      // gemm_lds_kernel: 64-row blocks
     if (lds > col) col = lds;
     const size_t dwp = (size_t)2048 * 2 * cmax * sizeof(double);           // dw_bwd_kernel's sums: <= 2048 workgroups per slab
     if (dwp > col) col = dwp;
@@ -1535,7 +1535,7 @@ static SepWs sep_ws(long M, int cin, int cout, float* base) {
     size_t col = fear_train_stats_workspace_bytes(M, cmax);
     const size_t colr = (size_t)col_blocks(M) * 2 * cmax * sizeof(double);
     if (colr > col) col = colr;
-    const size_t lds = M <= 65536 ? (size_t)((M + 63) / 64) * 2 * cmax * sizeof(double) : 0;
+    const size_t lds = M <= FEAR_GEMM_LDS_MAX_ROWS ? (size_t)((M + 63) / 64) * 2 * cmax * sizeof(double) : 0;
     if (lds > col) col = lds;
     w.col_bytes = align256(col);
     const size_t nk = (size_t)cin * cout;

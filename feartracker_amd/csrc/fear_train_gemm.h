@@ -1,6 +1,6 @@
 // fear_train_gemm.h — LDS-staged, double-buffered fp32 MFMA GEMM of the training step's small-map layers (round 5).
 //
-//     Y[m][n] = sum_k X'[m][k] W'[k][n]        M = pixels of a 16 x 16 / 8 x 8 map of a batch (8 192 ... 65 536 rows), K, N = 16 ... 672
+//     Y[m][n] = sum_k X'[m][k] W'[k][n]        M = pixels of a 32 x 32 ... 8 x 8 map of a batch (8 192 ... 131 072 rows), K, N = 16 ... 672
 //
 // The first-generation training GEMMs (pw_mfma_kernel, pw_stat_kernel, pw_bwd_kernel) fetch every MFMA fragment straight from
 // L1 / L2 right in front of the MFMAs that consume it: fine where a launch is thousands of workgroups deep and bandwidth bound (the
@@ -241,7 +241,13 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs a) {
 
 // which launches run on the LDS-staged kernel: few row blocks (the first-generation kernels are bandwidth bound and fine above
 // that) and a reduction long enough for the pipeline to matter
-bool gemm_lds_applies(long M, int K, int N) { return M <= 65536 && K >= 32 && N >= 16; }
+// (the 32 x 32 maps of a 128-pair batch — 131 072 rows — included: their first-generation kernels with a 32-channel reduction and six
+//  or twelve output tiles per pass sit at one wave per SIMD and 1.3 TB/s; measured 15.63 -> 15.45 ms per step.  From 524 288 rows up
+//  the first generation is as fast or faster: 15.53 / 15.72 ms with the 64 x 64 / 128 x 128 maps included.)
+#ifndef FEAR_GEMM_LDS_MAX_ROWS
+#define FEAR_GEMM_LDS_MAX_ROWS 131072
+#endif
+bool gemm_lds_applies(long M, int K, int N) { return M <= FEAR_GEMM_LDS_MAX_ROWS && K >= 32 && N >= 16; }
 
 // column tiles per workgroup: the widest of {8, 7, 6, 4} that divides the tile count, else 8 with a ragged last column block
 int gemm_lds_ntw(int n_tiles) {
