@@ -578,11 +578,11 @@ class FEARNetTrainHIP:
         N = self.neck
         x_neck, neck_raw, neck_vec, h = c["neck"]
         d = self._new(B * h * h, 112)
+        # (the neck's weight gradient stays in line: a lone unit's coefficient vectors live in the shared workspace, so a call with a
+        #  weight-gradient stream first waits for everything queued there — the head's weight gradients at this point)
         self._check(lib.fear_pwbn_train_backward(_p(dfeat), _p(neck_raw), _p(neck_vec), 0, _p(x_neck), 112, _p(N.w), _p(N.gamma),
                                                  g(N.conv_key, 256 * 112), g(N.bn_key + ".weight", 256), g(N.bn_key + ".bias", 256), _p(d),
-                                                 B * h * h, 112, 256, ws, wsb, st, aux_p))
-        if aux is not None:
-            dfeat.record_stream(aux)
+                                                 B * h * h, 112, 256, ws, wsb, st, None))
         for bi, ((desc, sv, x, hin, _keep), blk) in enumerate(zip(reversed(c["blocks"]), reversed(self.blocks))):
             gr = FearIrbGrads()
             units = (blk["pw"], blk["dw"], blk["pwl"])
@@ -608,11 +608,17 @@ class FEARNetTrainHIP:
         S = self.stem
         stem_raw, stem_vec = c["stem"]
         hs = H // 2
+        # the stem's weight gradient in line as well, on a workspace of its own: the last blocks' weight gradients are still running on
+        # the weight-gradient stream (on the shared workspace's row-slice region) when the chain of input gradients ends here — the
+        # pass's last kernel runs beside them instead of behind them
+        key = ("stem", self._lane)
+        need = int(lib.fear_stem_workspace_bytes(B, H, H))
+        sw = self._ws_lanes.get(key)
+        if sw is None or sw.numel() * 4 < need:
+            self._ws_lanes[key] = None
+            sw = self._ws_lanes[key] = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
         self._check(lib.fear_stem_train_backward(_p(d), _p(stem_raw), _p(stem_vec), _p(c["img"]), _p(S.gamma), g(S.conv_key, 16 * 28),
-                                                 g(S.bn_key + ".weight", 16), g(S.bn_key + ".bias", 16), B, H, H, ws, wsb, st, aux_p))
-        if aux is not None:
-            d.record_stream(aux)
-            c["img"].record_stream(aux)
+                                                 g(S.bn_key + ".weight", 16), g(S.bn_key + ".bias", 16), B, H, H, _p(sw), sw.numel() * 4, st, None))
 
     # ------------------------------------------------------------------ trunk + neck
     def _features_forward(self, img: torch.Tensor):
