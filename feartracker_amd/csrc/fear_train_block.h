@@ -358,14 +358,19 @@ struct DwBwdArgs {
     int B, H, W, Ho, Wo, C;
     int tiles_x, tiles_y, wgs_per_slab, nslab;
     VirtE ve;             // VE: E is not read, e = ve.X ve.W1^T on the spot
+    float* pw1;           // VE, optional: per-workgroup partials [wgs_per_slab][C][cin] of sum_m g1[m][c] x[m][k] — the expansion's weight
+                          // gradient before its BatchNorm1 algebra (irb_lin_wgrad_fix2_kernel), formed from the tile while g1 is on chip
 };
 
 // TS: the tile side, 16 — or 8 for maps of at most 8 x 8 pixels (the template branch's stride-16 stage: a 16 x 16 tile would be three
 // quarters outside the map, dd region and sweeps alike; built for the 5 x 5 stride-1 kernels that stage consists of)
-template <int KS, int S, int SQ, bool BN1, int VE = 0, int TS = 16>      // VE = NC chunks of 16 input channels of a virtual expansion (0: E is read)
+// W1G (with VE): the expansion's weight gradient is accumulated here as well (DwBwdArgs::pw1; built for the 3 x 3 kernels: the 5 x 5
+// ones have no registers left for its accumulators)
+template <int KS, int S, int SQ, bool BN1, int VE = 0, int TS = 16, bool W1G = false>      // VE = NC chunks of 16 input channels of a virtual expansion (0: E is read)
 __global__ __launch_bounds__(256, 2) void dw_bwd_kernel(DwBwdArgs a) {
     static_assert(!VE || (BN1 && S == 2), "the virtual expansion is built for the stride-2 kernels");
     static_assert(TS == 16 || (TS == 8 && S == 1 && KS == 5), "8 x 8 tiles: the 5 x 5 stride-1 kernels only");
+    static_assert(!W1G || VE != 0, "the in-kernel weight gradient belongs to the virtual expansion");
     constexpr int P = KS / 2, KK = KS * KS;
     constexpr int LO = P / S;                          // output rows / columns in front of the tile's first own one
     constexpr int OR = (TS - 1 + P) / S + LO + 1;      // side of the dd region a tile reads
@@ -414,6 +419,11 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_kernel(DwBwdArgs a) {
                 wa[VE ? ct : 0][VE ? ci : 0] = ch < a.C && k < a.ve.cin ? *reinterpret_cast<const f32x4*>(a.ve.W1 + (long)ch * a.ve.cin + k) : zero;
             }
     }
+    f32x4 acc1[W1G ? SQ / 4 : 1][W1G ? VE : 1];
+#pragma unroll
+    for (int ct = 0; ct < (W1G ? SQ / 4 : 1); ++ct)
+#pragma unroll
+        for (int ci = 0; ci < (W1G ? VE : 1); ++ci) acc1[ct][ci] = zero;
     // this thread's parity class and the first tap it meets in each dimension
     const int cls = S == 1 ? 0 : (pl & 3);
     const int py = S == 1 ? 0 : (cls >> 1), px = S == 1 ? 0 : (cls & 1);
@@ -671,14 +681,42 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_kernel(DwBwdArgs a) {
                         acc[j][i] += v * av;
                     }
                 }
+                f32x4 g1 = zero;
                 if (pin) {
                     if (BN1) {
-                        const f32x4 g1 = (f32x4){pre.x > 0.f ? de.x : 0.f, pre.y > 0.f ? de.y : 0.f, pre.z > 0.f ? de.z : 0.f, pre.w > 0.f ? de.w : 0.f};
+                        g1 = (f32x4){pre.x > 0.f ? de.x : 0.f, pre.y > 0.f ? de.y : 0.f, pre.z > 0.f ? de.z : 0.f, pre.w > 0.f ? de.w : 0.f};
                         *reinterpret_cast<f32x4*>(a.Y + prow * a.ldy + c) = g1;
                         s1f += g1;
                         s2f += g1 * ((e4 - mu1) * rs1);
                     } else {
                         *reinterpret_cast<f32x4*>(a.Y + prow * a.ldy + c) = de + r4;
+                    }
+                }
+                if constexpr (W1G) es[(iy_l * TS + ix_l) * SQ + cq_l] = g1;      // (this thread's own slot: e was read from it above)
+            }
+            if constexpr (W1G) {
+                // the expansion's weight gradient while g1 is on chip: sum over the tile's pixels of g1[p][c] x[p][k] — lane (channel i,
+                // pixel kk) reads g1 from LDS, lane (input channel j, pixel kk) reads x; four pixels per MFMA, the groups dealt to the waves
+                {
+                    __syncthreads();
+                    const int wave = tid >> 6, lj = tid & 15, kk = (tid & 63) >> 4;
+#pragma unroll 1
+                    for (int pg = wave; pg < TS * TS / 4; pg += 4) {
+                        const int p = pg * 4 + kk;
+                        const int iy = iy0 + p / TS, ix = ix0 + p % TS;
+                        const bool inb = iy < a.H && ix < a.W;
+                        float bx[VE];
+#pragma unroll
+                        for (int ci = 0; ci < VE; ++ci) {
+                            const int k = ci * 16 + lj;
+                            bx[ci] = inb && k < a.ve.cin ? a.ve.X[(((long)b * a.H + iy) * a.W + ix) * a.ve.cin + k] : 0.f;
+                        }
+#pragma unroll
+                        for (int ct = 0; ct < SQ / 4; ++ct) {
+                            const float gv = reinterpret_cast<const float*>(&es[p * SQ + ct * 4 + (lj >> 2)])[lj & 3];
+#pragma unroll
+                            for (int ci = 0; ci < VE; ++ci) acc1[ct][ci] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv, bx[ci], acc1[ct][ci], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -717,6 +755,30 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_kernel(DwBwdArgs a) {
                 const int cc = (slab * SQ + tid) * 4;
                 if (cc < a.C) *reinterpret_cast<f64x4*>(a.psums + ((long)wslot * 2 + which) * a.C + cc) = sum;
             }
+        }
+    }
+    if constexpr (W1G) {
+        {      // the four waves' shares added in wave order, one partial per workgroup
+            const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+            for (int ct = 0; ct < SQ / 4; ++ct)
+#pragma unroll
+                for (int ci = 0; ci < VE; ++ci) {
+                    __syncthreads();
+                    if (wave > 0) red[(wave - 1) * 64 + lane] = acc1[ct][ci];
+                    __syncthreads();
+                    if (wave == 0) {
+                        f32x4 v = acc1[ct][ci];
+#pragma unroll
+                        for (int w = 0; w < 3; ++w) v += red[w * 64 + lane];
+                        const int k = ci * 16 + (lane & 15);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int ch = slab * SQ * 4 + ct * 16 + 4 * (lane >> 4) + r;      // lane (k, q), component r = channel 4 q + r
+                            if (ch < a.C && k < a.ve.cin) a.pw1[((long)wslot * a.C + ch) * a.ve.cin + k] = v[r];
+                        }
+                    }
+                }
         }
     }
 }
@@ -1119,6 +1181,18 @@ __global__ __launch_bounds__(256) void irb_lin_wgrad_fix_kernel(const float* coe
     dW1[idx] = (float)((double)dW1[idx] - (double)coef[c] * (double)coef[3 * cexp + c] * t);
 }
 
+// ... and where dw_bwd_kernel<.., W1G> has already summed R[c][k] = sum_m g1[m][c] x[m][k] (dW1 holds it): the whole of BatchNorm1's algebra
+//     dW1 = A (R - (s1 - mu Q) Sx) - (A Q) W1 G,   Sx = column sums of x (gram_kernel's tail: G | Sx with row pitch ldg)
+__global__ __launch_bounds__(256) void irb_lin_wgrad_fix2_kernel(const float* coef, const float* W1, const float* G, int ldg, float* dW1, int cexp, int cin) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= cexp * cin) return;
+    const int c = idx / cin, k = idx - c * cin;
+    double t = 0.0;
+    for (int k1 = 0; k1 < cin; ++k1) t += (double)W1[(long)c * cin + k1] * (double)G[(long)k1 * ldg + k];
+    const double A = coef[c], s1 = coef[cexp + c], mu = coef[2 * cexp + c], Q = coef[3 * cexp + c];
+    dW1[idx] = (float)(A * ((double)dW1[idx] - (s1 - mu * Q) * (double)G[(long)ldg * ldg + k]) - A * Q * t);
+}
+
 // running statistics of a BatchNorm from its saved vec = [mean | rstd | a | b] (the forward ran with running_mean = NULL so that
 // two passes of the shared trunk can overlap on two streams; torch's order — template pass first — is restored by applying the
 // search pass's update afterwards): biased variance = 1 / rstd^2 - eps, tracked unbiased
@@ -1180,6 +1254,8 @@ size_t irb_taps_floats(const FearIrbBlock* b) {
     const int wps = 2048 / nslab > 1 ? 2048 / nslab : 1;
     return (size_t)wps * b->k * b->k * b->cexp;
 }
+bool irb_w1g(const FearIrbBlock* b) { return (b->flags & FEAR_IRB_VIRTUAL_E) && b->k == 3; }
+size_t irb_w1g_floats(const FearIrbBlock* b) { return irb_w1g(b) ? irb_taps_floats(b) / (b->k * b->k) * b->cin : 0; }      // [workgroups per slab][cexp][cin]
 size_t irb_lin_floats(const FearIrbBlock* b) {
     return b->expand ? (size_t)(b->cexp + b->cin) * b->cin + (b->cin * b->cin > 1056 ? b->cin * b->cin : 1056) : 0;
 }
@@ -1210,8 +1286,9 @@ size_t fear_irb_scratch_floats(const FearIrbBlock* b, int B, int H, int W) {
     // gradients run on their own stream, so they do not live in the shared workspace)
     // | the extended weight matrix and the input's Gram matrix of the expansion's E-free backward (BnbIn)
     // | the depthwise tap gradients' per-workgroup partials (their final sum runs on the weight-gradient stream as well)
+    // | (virtual 3 x 3 expansions) the per-workgroup partials of the expansion's weight gradient formed inside the depthwise backward
     return (size_t)rows_out * b->cexp + (b->expand ? (size_t)rows_in * b->cexp : 0) + (size_t)12 * irb_cmax(b) + irb_lin_floats(b) +
-           irb_taps_floats(b);
+           irb_taps_floats(b) + irb_w1g_floats(b);
 }
 
 int fear_irb_train_forward(const FearIrbBlock* b, const FearIrbSaved* sv, const float* x, float* out, int B, int H, int W, double momentum,
@@ -1364,8 +1441,9 @@ int fear_irb_train_backward(const FearIrbBlock* b, const FearIrbSaved* sv, const
         const dim3 grid((unsigned)(a.wgs_per_slab * a.nslab));
         if (irb_virtual(b)) {
             a.E = nullptr; a.ve.X = x; a.ve.W1 = b->w_pw; a.ve.cin = cin;
-            if (b->k == 3 && cin <= 16) hipLaunchKernelGGL((dw_bwd_kernel<3, 2, 8, true, 1>), grid, dim3(256), 0, s, a);
-            else if (b->k == 3) hipLaunchKernelGGL((dw_bwd_kernel<3, 2, 8, true, 2>), grid, dim3(256), 0, s, a);
+            if (irb_w1g(b)) a.pw1 = taps + irb_taps_floats(b);
+            if (b->k == 3 && cin <= 16) hipLaunchKernelGGL((dw_bwd_kernel<3, 2, 8, true, 1, 16, true>), grid, dim3(256), 0, s, a);
+            else if (b->k == 3) hipLaunchKernelGGL((dw_bwd_kernel<3, 2, 8, true, 2, 16, true>), grid, dim3(256), 0, s, a);
             else if (cin <= 16) hipLaunchKernelGGL((dw_bwd_kernel<5, 2, 8, true, 1>), grid, dim3(256), 0, s, a);
             else hipLaunchKernelGGL((dw_bwd_kernel<5, 2, 8, true, 2>), grid, dim3(256), 0, s, a);
         } else if (small_map) hipLaunchKernelGGL((dw_bwd_kernel<5, 1, 8, true, 0, 8>), grid, dim3(256), 0, s, a);
@@ -1378,6 +1456,7 @@ int fear_irb_train_backward(const FearIrbBlock* b, const FearIrbSaved* sv, const
         // the tap gradients' final sum is a weight gradient too: off the chain (the partials live in the call's private scratch)
         if (sw != s && !stream_follow(sw, s)) return FEAR_TRAIN_ERR_HIP;          // the partials, g1 and coef1 exist
         launch_slice_sum(taps, gr->w_dw, (long)b->k * b->k * cexp, a.wgs_per_slab, sw);
+        if (a.pw1) launch_slice_sum(a.pw1, gr->w_pw, (long)cexp * cin, a.wgs_per_slab, sw);      // R[c][k], completed below
     }
     if (b->expand) {
         // BN1's backward without its input: e = x W1^T is linear in the block input, so both consumers read g1 (cexp channels) and x
@@ -1409,9 +1488,13 @@ int fear_irb_train_backward(const FearIrbBlock* b, const FearIrbSaved* sv, const
             rc = wgrad_impl(x, cin, 0, x, cin, 0, gram, ws.wg, ws.wg_bytes, rows_in, cin, cin, 1, sw);
         }
         if (rc != FEAR_TRAIN_OK) return rc;
-        rc = wgrad_impl(g1, cexp, 0, x, cin, 0, gr->w_pw, ws.wg, ws.wg_bytes, rows_in, cin, cexp, 1, sw, nullptr, nullptr, 0, &bn1);
+        const bool w1g = irb_w1g(b);      // (then lin and cin <= 32: the Gram kernel's [KP][KP] | column sums above)
+        if (!w1g) rc = wgrad_impl(g1, cexp, 0, x, cin, 0, gr->w_pw, ws.wg, ws.wg_bytes, rows_in, cin, cexp, 1, sw, nullptr, nullptr, 0, &bn1);
         if (rc != FEAR_TRAIN_OK) return rc;
-        if (lin)
+        if (w1g)
+            hipLaunchKernelGGL(irb_lin_wgrad_fix2_kernel, dim3((unsigned)((cexp * cin + 255) / 256)), dim3(256), 0, sw, coef1, b->w_pw, gram, ldg,
+                               gr->w_pw, cexp, cin);
+        else if (lin)
             hipLaunchKernelGGL(irb_lin_wgrad_fix_kernel, dim3((unsigned)((cexp * cin + 255) / 256)), dim3(256), 0, sw, coef1, b->w_pw, gram, ldg,
                                gr->w_pw, cexp, cin);
         if (dx) {
