@@ -43,12 +43,24 @@ struct PwBwdArgs {
     int M, Kred, Nout;
     int K1;              // with X2: a multiple of 16
     int row_tiles;       // 128-row tiles per workgroup (0 = 1)
+    float* p3;           // W3G: per-workgroup partials [gridDim.x][Kred][Nout] of the projection's weight gradient, see pw_bwd_kernel
 };
 
-template <int NT, bool MS>
+// W3G (with MS, NT = all column tiles, Kred and Nout of the same tile count — the blocks without an expansion, 16 / 24 channels on the
+// 128 x 128 / 64 x 64 maps): the projection's weight gradient dW3[k][n] = sum_m bnb(G)[m][k] act(D)[m][n] is summed here as well — both
+// operands pass through this kernel anyway, a separate weight-gradient launch read three 134 MB tensors again for a 16 x 16 result.
+// Lane (k or n index li, row lk) re-reads its elements (L1 hits); one MFMA per four rows and tile; one partial per workgroup.
+template <int NT, bool MS, bool W3G = false>
 __global__ __launch_bounds__(256) void pw_bwd_kernel(PwBwdArgs a) {
     constexpr int MT = 2;
+    static_assert(!W3G || (MS && NT <= 2), "the in-kernel weight gradient: the narrow blocks' masked-gradient pass");
     __shared__ double red[MS ? 4 : 1][2][NT * 16];
+    __shared__ f32x4 red3[W3G ? 3 * 64 : 1];
+    f32x4 acc3[W3G ? NT : 1][W3G ? NT : 1];
+#pragma unroll
+    for (int kt = 0; kt < (W3G ? NT : 1); ++kt)
+#pragma unroll
+        for (int nt = 0; nt < (W3G ? NT : 1); ++nt) acc3[kt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
@@ -178,6 +190,35 @@ __global__ __launch_bounds__(256) void pw_bwd_kernel(PwBwdArgs a) {
                     }
                 }
             }
+            if constexpr (W3G) {
+                // (nc == 0: one pass over all column tiles)  this wave's 32 rows in groups of four
+                float cA[NT], cs[NT], cm[NT], cq[NT], da1[NT], db1[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int k = t * 16 + li;
+                    const bool kv = k < a.Kred, nv = k < a.Nout;
+                    cA[t] = kv ? a.bn.coef[k] : 0.f; cs[t] = kv ? a.bn.coef[a.bn.C + k] : 0.f;
+                    cm[t] = kv ? a.bn.coef[2 * a.bn.C + k] : 0.f; cq[t] = kv ? a.bn.coef[3 * a.bn.C + k] : 0.f;
+                    da1[t] = nv ? a.dvec[2 * a.Nout + k] : 0.f; db1[t] = nv ? a.dvec[3 * a.Nout + k] : 0.f;
+                }
+#pragma unroll 2
+                for (int g = 0; g < MT * 4; ++g) {
+                    const long m = (long)m_wave + g * 4 + lk;
+                    const bool mv = m < a.M;
+                    float av[NT], bv[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int k = t * 16 + li;
+                        av[t] = 0.f; bv[t] = 0.f;
+                        if (mv && k < a.Kred) av[t] = cA[t] * (a.G[m * a.ldg + k] - cs[t] - (a.bn.E[m * a.bn.lde + k] - cm[t]) * cq[t]);
+                        if (mv && k < a.Nout) bv[t] = fmaxf(__builtin_fmaf(a.D[m * a.ldd + k], da1[t], db1[t]), 0.f);
+                    }
+#pragma unroll
+                    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc3[kt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kt], bv[nt], acc3[kt][nt], 0, 0, 0);
+                }
+            }
         }
         if (MS) {
             __syncthreads();
@@ -190,6 +231,27 @@ __global__ __launch_bounds__(256) void pw_bwd_kernel(PwBwdArgs a) {
             }
             __syncthreads();
         }
+    }
+    if constexpr (W3G) {      // the four waves' shares in wave order, one partial [Kred][Nout] per workgroup
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                __syncthreads();
+                if (wave > 0) red3[(wave - 1) * 64 + lane] = acc3[kt][nt];
+                __syncthreads();
+                if (wave == 0) {
+                    f32x4 v = acc3[kt][nt];
+#pragma unroll
+                    for (int w = 0; w < 3; ++w) v += red3[w * 64 + lane];
+                    const int n = nt * 16 + li;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int k = kt * 16 + 4 * lk + r;      // lane (n, q), component r = row 4 q + r of the tile
+                        if (k < a.Kred && n < a.Nout) a.p3[((long)blockIdx.x * a.Kred + k) * a.Nout + n] = v[r];
+                    }
+                }
+            }
     }
 }
 
@@ -1254,6 +1316,8 @@ size_t irb_taps_floats(const FearIrbBlock* b) {
     const int wps = 2048 / nslab > 1 ? 2048 / nslab : 1;
     return (size_t)wps * b->k * b->k * b->cexp;
 }
+bool irb_w3g(const FearIrbBlock* b) { return b->cexp <= 32 && b->cout <= 32 && (b->cexp + 15) / 16 == (b->cout + 15) / 16; }
+size_t irb_w3g_floats(const FearIrbBlock* b) { return irb_w3g(b) ? (size_t)2048 * b->cout * b->cexp : 0; }
 bool irb_w1g(const FearIrbBlock* b) { return (b->flags & FEAR_IRB_VIRTUAL_E) && b->k == 3; }
 size_t irb_w1g_floats(const FearIrbBlock* b) { return irb_w1g(b) ? irb_taps_floats(b) / (b->k * b->k) * b->cin : 0; }      // [workgroups per slab][cexp][cin]
 size_t irb_lin_floats(const FearIrbBlock* b) {
@@ -1287,8 +1351,9 @@ size_t fear_irb_scratch_floats(const FearIrbBlock* b, int B, int H, int W) {
     // | the extended weight matrix and the input's Gram matrix of the expansion's E-free backward (BnbIn)
     // | the depthwise tap gradients' per-workgroup partials (their final sum runs on the weight-gradient stream as well)
     // | (virtual 3 x 3 expansions) the per-workgroup partials of the expansion's weight gradient formed inside the depthwise backward
+    // | (blocks of at most 32 channels throughout) those of the projection's weight gradient formed inside the masked-gradient pass
     return (size_t)rows_out * b->cexp + (b->expand ? (size_t)rows_in * b->cexp : 0) + (size_t)12 * irb_cmax(b) + irb_lin_floats(b) +
-           irb_taps_floats(b) + irb_w1g_floats(b);
+           irb_taps_floats(b) + irb_w1g_floats(b) + irb_w3g_floats(b);
 }
 
 int fear_irb_train_forward(const FearIrbBlock* b, const FearIrbSaved* sv, const float* x, float* out, int B, int H, int W, double momentum,
@@ -1396,6 +1461,9 @@ int fear_irb_train_backward(const FearIrbBlock* b, const FearIrbSaved* sv, const
     bn_backward_sums(dout, cout, sv->p, cout, sv->vec[2], 0, b->gamma[2], gr->gamma[2], gr->beta[2], coef3, rows_out, cout, ws.col, s);
     BnbIn bn3{};
     bn3.E = sv->p; bn3.coef = coef3; bn3.lde = cout; bn3.C = cout;
+    bool w3g = false;
+    int w3g_slices = 0;
+    float* w3g_part = coef1 + 12 * cmax + irb_lin_floats(b) + irb_taps_floats(b) + irb_w1g_floats(b);      // [<= 2048][cout][cexp]
     // g2 = (dp W3) masked by act2(d) > 0, + sums of (g2, dhat)
     if (gemm_lds_applies(rows_out, cout, cexp)) {
         GemmArgs g{};
@@ -1412,13 +1480,22 @@ int fear_irb_train_backward(const FearIrbBlock* b, const FearIrbSaved* sv, const
         int nt = 1;
         const dim3 grid = stat_grid(rows_out, cout, cexp, &nt, &a.row_tiles);
         if ((size_t)grid.x * 2 * cexp * sizeof(double) > ws.col_bytes) return FEAR_TRAIN_ERR_WORKSPACE;
-        launch_pw_bwd<true>(a, grid, nt, s);
+        // the narrow blocks (16 / 24 channels throughout, the 128 x 128 / 64 x 64 maps): the projection's weight gradient in the same pass
+        w3g = irb_w3g(b) && grid.y == 1 && nt == (cexp + 15) / 16 && grid.x <= 2048;
+        if (w3g) {
+            a.p3 = w3g_part; w3g_slices = (int)grid.x;
+            if (nt == 1) hipLaunchKernelGGL((pw_bwd_kernel<1, true, true>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((pw_bwd_kernel<2, true, true>), grid, dim3(256), 0, s, a);
+        } else {
+            launch_pw_bwd<true>(a, grid, nt, s);
+        }
         finalize_backward(ws.col, (int)grid.x, cexp, (double)rows_out, b->gamma[1], sv->vec[1], gr->gamma[1], gr->beta[1], coef2, s);
     }
     // dW3 = dp^T act2(d)
     {
         if (sw != s && !stream_follow(sw, s)) return FEAR_TRAIN_ERR_HIP;      // coef3 exists
-        const int rc = wgrad_impl(dout, cout, 0, sv->d, cexp, 0, gr->w_pwl, ws.wg, ws.wg_bytes, rows_out, cexp, cout, 1, sw, sv->vec[1] + 2 * cexp,
+        if (w3g) launch_slice_sum(w3g_part, gr->w_pwl, (long)cout * cexp, w3g_slices, sw);
+        const int rc = w3g ? FEAR_TRAIN_OK : wgrad_impl(dout, cout, 0, sv->d, cexp, 0, gr->w_pwl, ws.wg, ws.wg_bytes, rows_out, cexp, cout, 1, sw, sv->vec[1] + 2 * cexp,
                                   sv->vec[1] + 3 * cexp, 1, &bn3);
         if (rc != FEAR_TRAIN_OK) return rc;
     }

@@ -140,7 +140,7 @@ class FEARNetTrainHIP:
         self.mode = mode
         # block mode: expansions of up to this many input channels are never written where the library has the kernels for it
         # (FEAR_IRB_VIRTUAL_E, include/fear_train.h: the stride-2 blocks); 0 keeps every expansion saved
-        self.virtual_expansion = int(virtual_expansion)
+        self.virtual_expansion = 32 if virtual_expansion is True else int(virtual_expansion)
         fused = mode == "fused"
         # fused=True: the trunk runs on the fused conv + BatchNorm operators of include/fear_train.h — a BatchNorm'd activation
         # is never written, consumers apply it on load: 11 instead of 16 passes over every saved tensor and 13.7 instead of
