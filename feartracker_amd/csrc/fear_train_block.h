@@ -5,19 +5,29 @@
 // kernels on the device side of the boundary — the host issues ~70 calls per step instead of ~1 100 launches through ctypes —
 // and no BatchNorm'd activation, no BatchNorm input gradient and no ReLU mask is ever written to memory:
 //
-//   forward    e = W1 x            + column sums of e          (pw_stat_kernel)            saved: e
-//              d = DW act1(e)      + column sums of d          (dw_stat_kernel)            saved: d
-//              p = W3 act2(d)      + column sums of p          (pw_stat_kernel)            saved: p
+//   forward    e = W1 x            + column sums of e          (pw_stat_kernel / gemm_lds_kernel)   saved: e
+//              d = DW act1(e)      + column sums of d          (dw_fwd_kernel)                      saved: d
+//              p = W3 act2(d)      + column sums of p          (pw_stat_kernel / gemm_lds_kernel)   saved: p
 //              out = a3 p + b3 [+ x]                           (bn_act_kernel)
 //   backward   sums of (dout, p)                               (col_reduce_kernel<1>)      -> d gamma3, d beta3, coef3
-//              g2 = (dp W3) * [act2(d) > 0], dp = BN3'(dout, p) formed on load, + sums of (g2, dhat)   (pw_bwd_kernel<MS>)
-//              dW3 = dp^T act2(d), both operands formed on load                            (pw_wgrad_kernel)
+//              g2 = (dp W3) * [act2(d) > 0], dp = BN3'(dout, p) formed on load, + sums of (g2, dhat)   (pw_bwd_kernel<MS> / gemm_lds_kernel)
+//              dW3 = dp^T act2(d), both operands formed on load                            (weight-gradient stream)
 //              dd = BN2'(g2, d) formed on load into an LDS tile; g1 = (DW^T dd) * [act1(e) > 0]; d taps = sum dd (x) act1(e);
 //              sums of (g1, ehat) — one pass over g2, d, e                                 (dw_bwd_kernel)
-//              dx = de W1 [+ dout], de = BN1'(g1, e) formed on load                        (pw_bwd_kernel)
-//              dW1 = de^T x                                                                (pw_wgrad_kernel)
+//              dx = de W1 [+ dout], de = BN1'(g1, e) formed on load                        (pw_bwd_kernel / gemm_lds_kernel)
+//              dW1 = de^T x                                                                (weight-gradient stream)
 // where BNk'(g, x) = gamma rstd (g - mean(g) - xhat mean(g xhat)) (struct BnbIn).  Passes over the expanded tensors of a block,
 // forward + backward: e 8 (was 14 layer by layer), d 7 (was 14); launches 19 (was ~36).
+//
+// On top of that recipe, where the block's input is narrow (second half of round 5):
+//   * BN1' without e (cin <= 32): e = x W1^T is linear in the block input, so de folds into the two consumers' own algebra — dx from
+//     [A (g1 - s1 + mu Q) | x] [W1 ; -T], dW1 from [A (g1 - ...)]^T x - diag(A Q) W1 (x^T x) — see BnbIn (fear_train.hip), irb_lin_*;
+//   * the stride-2 expansions are never written (FEAR_IRB_VIRTUAL_E): the two depthwise kernels form their tile of e on the matrix
+//     pipe, BatchNorm1's statistics come from the input's Gram matrix (gram_kernel, irb_virtual_stats_kernel); the 3 x 3 ones also sum
+//     the expansion's weight gradient while g1 is on chip (dw_bwd_kernel<.., W1G>);
+//   * blocks of 16 / 24 channels throughout sum the projection's weight gradient inside the masked-gradient pass (pw_bwd_kernel<.., W3G>).
+// Also here: the head's SepConv + BatchNorm + ReLU layer (fear_sepbn_train_*), the lone conv + BatchNorm units (fear_pwbn_train_*:
+// the neck) and the stem on the NCHW image (fear_stem_train_*).
 //
 // Included at the end of fear_train.hip (same translation unit: it reuses that file's kernels and helpers).
 
