@@ -31,7 +31,11 @@ def load(c):
 
 F, W = load("FETCH_SIZE"), load("WRITE_SIZE")
 dur = collections.defaultdict(list)
-for r in csv.DictReader(open(f"{trace}/p_kernel_trace.csv")):
+trace_rows = sorted(csv.DictReader(open(f"{trace}/p_kernel_trace.csv")), key=lambda r: int(r["Start_Timestamp"]))
+# the steps begin with the stem's forward: what runs before it is the network's construction (one copy per parameter tensor into the
+# flat buffer, the random initialisation) and does not belong to a step
+first = next((i for i, r in enumerate(trace_rows) if "stem_im2col_kernel" in r["Kernel_Name"] or "pw_stat_kernel<1, true>" in r["Kernel_Name"]), 0)
+for r in trace_rows[first:]:
     dur[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 rows = []
 for n, (c, f) in F.items():
