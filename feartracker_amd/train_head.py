@@ -347,7 +347,9 @@ class BoxTowerTrainHIP:
     def _sep_backward(self, L: _Sep, dy: torch.Tensor, lddy: int, B: int, grads: Dict[str, torch.Tensor]) -> torch.Tensor:
         """dy = gradient w.r.t. the layer's output (after BN+ReLU when it has them); returns d(input) as [M][cin]."""
         lib, st, M = self.lib, self._stream(), B * self.S * self.S
-        if L.bn_prefix and self.fused and lddy == L.cout:
+        if L.bn_prefix and self.fused:
+            if lddy != L.cout:
+                raise TrainError(f"{L.prefix}: fear_sepbn_train_backward takes the output gradient as contiguous rows of {L.cout}, got pitch {lddy}")
             ws, wsb = self._sep_workspace(L, B)
             dd, coef, dx = self._new(M, L.cin), self._new(4 * L.cout), self._new(M, L.cin)
             dtaps, dw = self._gnew(L.prefix + ".depthwise.weight", 9, L.cin), self._gnew(L.prefix + ".pointwise.weight", L.n, L.cin)
