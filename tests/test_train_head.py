@@ -18,6 +18,57 @@ def _declared(header):
     return sorted(set(re.findall(r"\b(fear_[a-z0-9_]+)\s*\(", text)))
 
 
+def test_struct_mirrors_have_the_headers_layout(tmp_path):
+    """The ctypes mirrors of the structs in include/fear_train.h (block / layer descriptors handed across the C ABI by pointer) have the
+    size and field offsets the C compiler gives the header's own definitions, and the flag values agree; null / shape errors of the
+    struct-taking entry points need no GPU."""
+    import ctypes
+    import subprocess
+    from feartracker_amd import train_head as th
+    from feartracker_amd.train_net import FEAR_IRB_VIRTUAL_E
+    structs = {"FearIrbBlock": th.FearIrbBlock, "FearIrbSaved": th.FearIrbSaved, "FearIrbGrads": th.FearIrbGrads,
+               "FearSepLayer": th.FearSepLayer, "FearSepGrads": th.FearSepGrads}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{ROOT}/include/fear_train.h"', 'int main(void) {']
+    for name, cls in structs.items():
+        lines.append(f'  printf("{name} size %zu\\n", sizeof({name}));')
+        for field, _ in cls._fields_:
+            lines.append(f'  printf("{name} {field} %zu\\n", offsetof({name}, {field}));')
+    lines += ['  printf("FLAGS %d %d %d\\n", FEAR_IRB_LINEAR_BN1, FEAR_IRB_NO_LINEAR_BN1, FEAR_IRB_VIRTUAL_E);', '  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-o", str(exe), str(src)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    seen = 0
+    for line in out:
+        parts = line.split()
+        if len(parts) == 3 and parts[0] in structs:
+            cls = structs[parts[0]]
+            want = ctypes.sizeof(cls) if parts[1] == "size" else getattr(cls, parts[1]).offset
+            assert int(parts[2]) == want, line
+            seen += 1
+        elif parts[:1] == ["FLAGS"]:
+            assert [int(v) for v in parts[1:]] == [1, 2, FEAR_IRB_VIRTUAL_E]
+            seen += 1
+    assert seen == sum(len(c._fields_) + 1 for c in structs.values()) + 1
+    lib = th.load_train_library()
+    blk = th.FearIrbBlock()
+    assert lib.fear_irb_workspace_bytes(ctypes.byref(blk), 1, 16, 16) == 0            # all-zero descriptor: unsupported shape
+    assert lib.fear_irb_virtual_ok(ctypes.byref(blk)) == 0 and lib.fear_irb_virtual_ok(None) == 0
+    blk.cin, blk.cexp, blk.cout, blk.k, blk.stride, blk.expand = 16, 96, 24, 3, 2, 1
+    assert lib.fear_irb_virtual_ok(ctypes.byref(blk)) == 1 and lib.fear_irb_workspace_bytes(ctypes.byref(blk), 2, 32, 32) > 0
+    blk.stride = 1
+    assert lib.fear_irb_virtual_ok(ctypes.byref(blk)) == 0                             # (the stride-1 kernels keep their saved expansion)
+    assert lib.fear_irb_train_forward(ctypes.byref(blk), None, None, None, 2, 32, 32, 0.1, 1e-5, None, 0, None) == -1
+    sep = th.FearSepLayer()
+    assert lib.fear_sepbn_workspace_bytes(ctypes.byref(sep), 2, 16, 16) == 0
+    sep.cin, sep.cout = 320, 256
+    assert lib.fear_sepbn_workspace_bytes(ctypes.byref(sep), 2, 16, 16) > 0
+    assert lib.fear_sepbn_train_forward(ctypes.byref(sep), None, 320, None, None, None, None, 256, 2, 16, 16, 0.1, 1e-5, None, 0, None) == -1
+    assert lib.fear_stem_workspace_bytes(2, 255, 256) == 0 and lib.fear_stem_workspace_bytes(2, 256, 256) > 0
+    assert lib.fear_stem_train_forward(None, None, None, None, None, None, None, None, None, 2, 256, 256, 0.1, 1e-5, None, 0, None) == -1
+
+
 def test_training_operators_are_exported():
     """The C-ABI library exports every symbol include/fear_train.h declares, and the Python binding declares them all."""
     from feartracker_amd.train_head import TRAIN_SYMBOLS, load_train_library
