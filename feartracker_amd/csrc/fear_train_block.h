@@ -1084,8 +1084,13 @@ struct BlockWs {
 
 size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
+// persistent workgroups of the depthwise kernels, all slabs together: the 512 a device holds at two per CU — one round, no tail, and a
+// quarter of the partial rows of the 2 048 this started with (15.3 -> 15.0 ms per step; 384 / 768 / 1 024: 15.1)
+#ifndef FEAR_DW_WGS
+#define FEAR_DW_WGS 512
+#endif
 int dw_bwd_wgs_per_slab(int n_items, int nslab) {
-    int target = 2048 / nslab;
+    int target = FEAR_DW_WGS / nslab;
     if (target < 1) target = 1;
     if (target >= n_items) return n_items;
     const int per = (n_items + target - 1) / target;      // items per workgroup, then as few workgroups as that needs
@@ -1115,7 +1120,7 @@ BlockWs block_ws(long rows_in, long rows_out, int cin, int cexp, int cout, int k
     w.wg_bytes = align256(wg);
     const int sq = dw_bwd_sq(cexp);
     const int nslab = (cexp / 4 + sq - 1) / sq;
-    const int wps = 2048 / nslab > 1 ? 2048 / nslab : 1;                  // most workgroups per slab dw_bwd_wgs_per_slab hands out
+    const int wps = FEAR_DW_WGS / nslab > 1 ? FEAR_DW_WGS / nslab : 1;    // most workgroups per slab dw_bwd_wgs_per_slab hands out
     w.taps_bytes = align256((size_t)wps * k * k * cexp * sizeof(float));
     // (also the Gram matrix | column sums of a virtual expansion's input in the forward: up to 32 * 32 + 32 floats)
     w.coef_bytes = align256((size_t)(3 * 4 * cmax > 1056 ? 3 * 4 * cmax : 1056) * sizeof(float));
@@ -1323,7 +1328,7 @@ bool irb_shape_ok(const FearIrbBlock* b, int B, int H, int W) {
 // floats of dw_bwd_kernel's tap-gradient partials [workgroups per slab][k * k][cexp] (block_ws's bound on the workgroups)
 size_t irb_taps_floats(const FearIrbBlock* b) {
     const int sq = dw_bwd_sq(b->cexp), nslab = (b->cexp / 4 + sq - 1) / sq;
-    const int wps = 2048 / nslab > 1 ? 2048 / nslab : 1;
+    const int wps = FEAR_DW_WGS / nslab > 1 ? FEAR_DW_WGS / nslab : 1;
     return (size_t)wps * b->k * b->k * b->cexp;
 }
 bool irb_w3g(const FearIrbBlock* b) { return b->cexp <= 32 && b->cout <= 32 && (b->cexp + 15) / 16 == (b->cout + 15) / 16; }
