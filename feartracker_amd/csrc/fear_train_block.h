@@ -1386,7 +1386,7 @@ int fear_irb_train_forward(const FearIrbBlock* b, const FearIrbSaved* sv, const 
     const bool virt = irb_virtual(b);
     if (virt) {
         // BatchNorm1's statistics of the expansion that is never written: G = x^T x and the column sums of x in one pass, then W1 on them
-        long rpw = (rows_in + 2047) / 2048;
+        long rpw = (rows_in + 511) / 512;      // (512 workgroups: one round)
         rpw = (rpw + 127) / 128 * 128;
         const int wgs = (int)((rows_in + rpw - 1) / rpw);
         const int nc = b->cin > 16 ? 2 : 1, kp = 16 * nc, per = kp * kp + kp;
@@ -1567,7 +1567,7 @@ int fear_irb_train_backward(const FearIrbBlock* b, const FearIrbSaved* sv, const
         int rc = FEAR_TRAIN_OK, ldg = cin;
         if (lin && cin <= 32) {
             // (the one-load-per-four-rows Gram kernel of the virtual expansion's forward; its result is [KP][KP] | column sums)
-            long rpw = (rows_in + 2047) / 2048;
+            long rpw = (rows_in + 511) / 512;      // (512 workgroups: one round)
             rpw = (rpw + 127) / 128 * 128;
             const int wgs = (int)((rows_in + rpw - 1) / rpw);
             const int nc = cin > 16 ? 2 : 1, per = 16 * nc * 16 * nc + 16 * nc;
