@@ -1331,7 +1331,9 @@ size_t irb_taps_floats(const FearIrbBlock* b) {
     const int wps = FEAR_DW_WGS / nslab > 1 ? FEAR_DW_WGS / nslab : 1;
     return (size_t)wps * b->k * b->k * b->cexp;
 }
-bool irb_w3g(const FearIrbBlock* b) { return b->cexp <= 32 && b->cout <= 32 && (b->cexp + 15) / 16 == (b->cout + 15) / 16; }
+// (FEAR_IRB_FUSE_W3: on request only — with the virtual expansions' in-kernel weight gradient already on the chain of input gradients,
+//  this one as well makes that chain the longest of the three streams: 14.65 ms with either, 14.84 with both, 14.75 with neither)
+bool irb_w3g(const FearIrbBlock* b) { return (b->flags & FEAR_IRB_FUSE_W3) && b->cexp <= 32 && b->cout <= 32 && (b->cexp + 15) / 16 == (b->cout + 15) / 16; }
 size_t irb_w3g_floats(const FearIrbBlock* b) { return irb_w3g(b) ? (size_t)2048 * b->cout * b->cexp : 0; }
 bool irb_w1g(const FearIrbBlock* b) { return (b->flags & FEAR_IRB_VIRTUAL_E) && b->k == 3; }
 size_t irb_w1g_floats(const FearIrbBlock* b) { return irb_w1g(b) ? irb_taps_floats(b) / (b->k * b->k) * b->cin : 0; }      // [workgroups per slab][cexp][cin]
@@ -1534,8 +1536,10 @@ int fear_irb_train_backward(const FearIrbBlock* b, const FearIrbSaved* sv, const
         if (irb_virtual(b)) {
             a.E = nullptr; a.ve.X = x; a.ve.W1 = b->w_pw; a.ve.cin = cin;
             if (irb_w1g(b)) a.pw1 = taps + irb_taps_floats(b);
-            if (b->k == 3 && cin <= 16) hipLaunchKernelGGL((dw_bwd_kernel<3, 2, 8, true, 1, 16, true>), grid, dim3(256), 0, s, a);
-            else if (b->k == 3) hipLaunchKernelGGL((dw_bwd_kernel<3, 2, 8, true, 2, 16, true>), grid, dim3(256), 0, s, a);
+            if (b->k == 3 && cin <= 16 && a.pw1) hipLaunchKernelGGL((dw_bwd_kernel<3, 2, 8, true, 1, 16, true>), grid, dim3(256), 0, s, a);
+            else if (b->k == 3 && a.pw1) hipLaunchKernelGGL((dw_bwd_kernel<3, 2, 8, true, 2, 16, true>), grid, dim3(256), 0, s, a);
+            else if (b->k == 3 && cin <= 16) hipLaunchKernelGGL((dw_bwd_kernel<3, 2, 8, true, 1>), grid, dim3(256), 0, s, a);
+            else if (b->k == 3) hipLaunchKernelGGL((dw_bwd_kernel<3, 2, 8, true, 2>), grid, dim3(256), 0, s, a);
             else if (cin <= 16) hipLaunchKernelGGL((dw_bwd_kernel<5, 2, 8, true, 1>), grid, dim3(256), 0, s, a);
             else hipLaunchKernelGGL((dw_bwd_kernel<5, 2, 8, true, 2>), grid, dim3(256), 0, s, a);
         } else if (small_map) hipLaunchKernelGGL((dw_bwd_kernel<5, 1, 8, true, 0, 8>), grid, dim3(256), 0, s, a);

@@ -194,6 +194,10 @@ int fear_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
  * fear_irb_virtual_ok() accepts (16 ... 32 input channels, stride 2, cexp a multiple of 16 from 64 up — FEAR-XS's 16 -> 96 at 128 x 128
  * (0.8 GB per 128 crops), 24 -> 144 at 64 x 64, 32 -> 192 at 32 x 32); the same flag in the forward and the backward call. */
 #define FEAR_IRB_VIRTUAL_E 4
+/* blocks of at most 32 channels throughout: the projection's weight gradient is summed inside the masked-gradient pass that reads the
+ * same three tensors (0.9 GB less traffic per 128-pair step; off by default: it lengthens the chain of input gradients, see
+ * csrc/fear_train_block.h irb_w3g) */
+#define FEAR_IRB_FUSE_W3 8
 typedef struct FearIrbBlock {
     int cin, cexp, cout, k, stride, expand, residual;
     int flags;                     /* 0 = let the call choose; FEAR_IRB_LINEAR_BN1 / FEAR_IRB_NO_LINEAR_BN1 (below) */

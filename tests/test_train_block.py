@@ -52,12 +52,14 @@ LIN_CASES = [(c, b, h, 1) for c, b, h in CASES if c[5]] + [((16, 96, 24, 3, 2, 1
 LIN_CASES += [((16, 96, 24, 3, 2, 1, 0), 3, 32, 4), ((16, 96, 24, 3, 2, 1, 0), 5, 128, 4), ((16, 64, 16, 3, 2, 1, 0), 2, 24, 4),
               ((24, 144, 32, 5, 2, 1, 0), 2, 32, 4), ((32, 192, 64, 5, 2, 1, 0), 2, 32, 4), ((32, 128, 48, 3, 2, 1, 0), 3, 16, 4),
               ((20, 80, 24, 5, 2, 1, 0), 2, 24, 4)]
+# ... and the narrow blocks' projection weight gradient summed inside the masked-gradient pass (FEAR_IRB_FUSE_W3)
+LIN_CASES += [((16, 16, 16, 3, 1, 0, 1), 2, 64, 8), ((24, 24, 24, 3, 1, 0, 1), 2, 32, 8), ((24, 24, 24, 3, 1, 0, 1), 40, 64, 8)]
 ALL_CASES = [(c, b, h, 0) for c, b, h in CASES] + LIN_CASES
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg,B,H,flags", ALL_CASES,
-                         ids=[f"{c[0]}x{c[1]}x{c[2]}k{c[3]}s{c[4]}_b{b}h{h}" + {0: "", 1: "_lin", 2: "_nolin", 4: "_virtual"}[f] for c, b, h, f in ALL_CASES])
+                         ids=[f"{c[0]}x{c[1]}x{c[2]}k{c[3]}s{c[4]}_b{b}h{h}" + {0: "", 1: "_lin", 2: "_nolin", 4: "_virtual", 8: "_fusew3"}[f] for c, b, h, f in ALL_CASES])
 def test_irb_block_forward_backward_vs_autograd(cfg, B, H, flags):
     from feartracker_amd.train_head import FearIrbBlock, FearIrbGrads, FearIrbSaved, _p, load_train_library
     lib = load_train_library()
