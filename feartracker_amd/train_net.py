@@ -7,7 +7,9 @@ parameter — what `FEARLightningModel._training_step` + `loss.backward()` compu
 The head, the loss and their backward are `train_head.BoxTowerTrainHIP`; this module adds the trunk and the neck on the
 same hand-written HIP operators (include/fear_train.h): 1x1 convolutions as MFMA GEMMs (forward / dgrad / wgrad), the
 stem conv as im2col + the same GEMMs, depthwise 3x3 / 5x5 stride 1 / 2 forward, dgrad and wgrad, train-mode BatchNorm
-forward / backward with fixed-order reductions.  Host code only sequences kernels and owns the parameters.
+forward / backward with fixed-order reductions.  Host code only sequences kernels and owns the parameters.  The default on
+one rank (`mode="block"`) is one C-ABI call per inverted-residual block and direction (`fear_irb_train_*`; the stem on the
+image: `fear_stem_train_*`; the neck: `fear_pwbn_train_*`) on three streams — DESIGN.md §7 N3 has the recipe and its numbers.
 
 Trunk definition: the reference takes it from the un-vendored `mobile_cv` package (fbnet_c, model/blocks.py:22-35) and
 ships only the BatchNorm-folded inference trace, so the TRAINING form of the trunk is restated — block table of SURVEY.md
