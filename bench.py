@@ -333,10 +333,9 @@ def config5_train_step(dev, batch: int = 128, steps: int = 20, warmup: int = 4):
         opt.step(out["grads"])
     torch.cuda.synchronize()
     adam_ms = 1e3 * (time.perf_counter() - ta) / steps
-    # roofline of the step's dominant kernel symbol (pw_wgrad_kernel: 11 % of the kernel time, profiles/r05_train_kernel_stats.csv) on
-    # its heaviest shape in the step — the weight gradient of a 112 -> 672 expansion at 16 x 16 (32 768 rows per 128 pairs), whose dY
-    # operand is the BatchNorm backward formed on load in the block-fused step, i.e. three tensors are read — through the same C-ABI
-    # operator the step calls, bracketed with events on the stream it runs on
+    # a stand-alone measurement of one pointwise weight gradient (NOT the step's roofline: kept under its own key) — the heaviest
+    # shape of the step, dW[672][112] over the 32 768 rows of the 16 x 16 maps, through the C-ABI operator the layer-wise step calls
+    # (the block-fused step runs the same GEMM with the BatchNorm backward formed on its dY operand)
     from feartracker_amd.train_head import _p
     lib = net.lib
     Mw, Kw, Nw = batch * 256, 112, 672
@@ -357,28 +356,52 @@ def config5_train_step(dev, batch: int = 128, steps: int = 20, warmup: int = 4):
     wg_ms = e0.elapsed_time(e1) / reps          # (includes the fixed-order slice sum that follows every launch)
     wg_bytes = 4.0 * (Mw * Nw + Mw * Kw + Nw * Kw)
     wg_flops = 2.0 * Mw * Nw * Kw
-    ai = wg_flops / wg_bytes
-    bound = "mfma" if ai > PEAK_FP32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9) else "hbm"
-    ach = wg_flops / (wg_ms * 1e-3) / 1e12 if bound == "mfma" else wg_bytes / (wg_ms * 1e-3) / 1e9
-    peak = PEAK_FP32_MFMA_TFLOPS if bound == "mfma" else PEAK_HBM_GBS
-    train_roof = {"bound": bound, "achieved": ach, "peak": peak, "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": ach / peak,
-                  "traffic": None, "kernel": "pw_wgrad_kernel (pointwise-conv weight gradients; dominant symbol of the step)",
-                  "shape": f"dW[{Nw}][{Kw}] = sum over {Mw} rows", "avg_launch_ms": wg_ms,
-                  "arithmetic_intensity_flop_per_byte": ai,
-                  "note": "measured on the step's heaviest weight-gradient shape through the C-ABI operator; per-kernel times and PMC "
-                          "traffic of the whole step: profiles/r05_train_kernel_stats.csv, r05_train_traffic.txt"}
+    micro = {"operator": "fear_pw_backward_weight", "shape": f"dW[{Nw}][{Kw}] = sum over {Mw} rows", "avg_call_ms": wg_ms,
+             "tflops": wg_flops / (wg_ms * 1e-3) / 1e12, "frac_of_fp32_peak": wg_flops / (wg_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+             "algorithmic_gbs": wg_bytes / (wg_ms * 1e-3) / 1e9,
+             "note": "random operands, one shape, without the fused BatchNorm-backward operand of the block-fused step"}
+    # the step's own roofline: the whole step against both roofs (live time; FLOPs from the model, bytes from the committed PMC
+    # passes of the same step), and the symbol with the largest share of its kernel time under its real name with its PMC bytes per
+    # launch (profiles/rNN_train_traffic.txt: kernel trace + FETCH_SIZE / WRITE_SIZE passes of tools/train_prof.py)
+    prof = train_profile()
+    step_flops = 3 * 2 * (461_393_920 + 75_970_000) * batch
+    whole_frac_fp32 = step_flops / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS
+    whole_frac_hbm = (prof["pmc_gb_per_step"] / dt / PEAK_HBM_GBS) if prof else None
+    if prof:
+        d = prof["dominant"]
+        train_roof = {"bound": "hbm", "achieved": d["achieved_gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": d["achieved_gbs"] / PEAK_HBM_GBS,
+                      "traffic": d["traffic_bytes_per_launch"], "kernel": d["kernel"], "avg_launch_ms": d["avg_launch_us"] * 1e-3,
+                      "calls_per_step": d["calls_per_step"], "share_of_kernel_time": d["ms_per_step"] / max(prof["kernel_ms_per_step"], 1e-9),
+                      "source": prof["file"],
+                      "note": "the symbol with the largest share of the step's kernel time; duration and bytes are the profiled step's "
+                              "(rocprofv3 kernel trace and PMC passes of tools/train_prof.py, three streams in flight: the average duration "
+                              "is an upper bound) — `achieved` = PMC bytes per launch / that duration.  The step as a whole is bound by "
+                              "neither roof: see whole_step_*"}
+    else:
+        train_roof = None
     del dyw, xw, dww, wsw
     fwd_macs = 461_393_920 + 75_970_000           # search path + template path, forward MACs per pair
     nparams = sum(v.numel() for v in out["grads"].values())
+    loss_vals = [float(out["loss_cls"]), float(out["loss_reg"])]
+    ngrads = len(out["grads"])
+    peak_gb = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+    mode_name, two = net.mode, bool(net.two_streams)
+    adam_launches = 1 if getattr(net, "param_flat", None) is not None else ngrads
+    del out, opt, net
+    torch.cuda.empty_cache()
+    with _c_stdout_to_stderr():       # (RCCL prints its version banner to stdout from C: the line this script prints must stay the only one)
+        sync_one = sync_bn_one_rank_ms(dev, batch, max(steps // 2, 3), 2, (tmpl, srch, gt_reg, gt_cls, gt_w))
     return {"workload": f"FEARNet training step (trunk + neck on both crops, correlation head, FEARLoss; forward in train mode + "
                         f"backward), batch={batch} pairs per rank (configs[4]: 1024 over 8 ranks), fp32, random init, synthetic data",
             "value": batch / dt, "unit": "pairs/s per GPU", "ms_per_step": 1e3 * dt, "steps": steps, "warmup": warmup,
             "approx_tflops": 3 * 2 * fwd_macs * batch / dt / 1e12,
-            "loss": [float(out["loss_cls"]), float(out["loss_reg"])], "dtype": "f32",
-            "parameter_tensors_with_gradients": len(out["grads"]), "parameters": nparams, "adam_update_ms": adam_ms, "roofline": train_roof,
-            "host_issue_ms_per_step": host_issue_ms, "trunk_implementation": net.mode, "adam_launches": 1 if getattr(net, "param_flat", None) is not None else len(out["grads"]),
-            "two_streams": bool(net.two_streams),
-            "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30}
+            "loss": loss_vals, "dtype": "f32",
+            "parameter_tensors_with_gradients": ngrads, "parameters": nparams, "adam_update_ms": adam_ms, "roofline": train_roof,
+            "whole_step_frac_of_fp32_peak": whole_frac_fp32, "whole_step_hbm_frac": whole_frac_hbm,
+            "whole_step_pmc_gb": prof["pmc_gb_per_step"] if prof else None, "launches_per_step": prof["launches_per_step"] if prof else None,
+            "wgrad_microbenchmark": micro, "sync_bn_one_rank_ms": sync_one["ms_per_step"], "sync_bn_one_rank": sync_one,
+            "host_issue_ms_per_step": host_issue_ms, "trunk_implementation": mode_name, "adam_launches": adam_launches,
+            "two_streams": two, "peak_memory_gb": peak_gb}
 
 
 def clocks_under_load(step_fn, steps: int = 300):
@@ -572,6 +595,63 @@ def pmc_traffic(op_name: str, tag: str = ""):
         return (t[sym]["traffic_bytes_per_launch"], os.path.relpath(traffic, ROOT)) if sym in t else (None, None)
     except Exception:
         return None, None
+
+
+def train_profile():
+    """The training step's committed profile (profiles/rNN_train_traffic.txt, written by tools/train_traffic.py from the kernel
+    trace and the two PMC passes of tools/train_prof.py 128 ... block): per-step totals and the symbol with the largest share of
+    the kernel time, under its real name, with its PMC bytes per launch.  None when there is no such file."""
+    import glob
+    import re
+    try:
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_train_traffic.txt")))[-1]
+        txt = open(f).read()
+        m = re.search(r"per step: ([0-9.]+) GB of PMC traffic.*?, ([0-9]+) launches, ([0-9.]+) ms of kernel time", txt)
+        rows = re.findall(r"^\s*([0-9.]+)\s+(\S.*?)\s+([0-9]+)\s+([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s*$", txt, re.M)
+        if not m or not rows:
+            return None
+        ms, name, calls, avg_us, mb, tbs = rows[0]
+        return {"file": os.path.relpath(f, ROOT), "pmc_gb_per_step": float(m.group(1)), "launches_per_step": int(m.group(2)),
+                "kernel_ms_per_step": float(m.group(3)),
+                "dominant": {"kernel": name.strip(), "ms_per_step": float(ms), "calls_per_step": int(calls), "avg_launch_us": float(avg_us),
+                             "traffic_bytes_per_launch": float(mb) * 1e6, "achieved_gbs": float(tbs) * 1e3}}
+    except Exception:      # noqa: BLE001
+        return None
+
+
+def sync_bn_one_rank_ms(dev, batch, steps, warmup, data):
+    """The same training step as FEARNetTrainHIP(mode="block", sync_bn=True) in a torch.distributed group of the ONE rank a 1-GPU
+    run has: every BatchNorm's sums go through the library's all-reduce hook and RCCL (the reference's multi-GPU backends train
+    with sync_bn: True, config/backend/2gpu.yaml:5).  Best effort: None if no process group can be made here."""
+    import socket
+    import torch.distributed as dist
+    from feartracker_amd.train_net import FEARNetTrainHIP, random_init_state
+    made = False
+    try:
+        if not dist.is_initialized():
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+            made = True
+        net = FEARNetTrainHIP(random_init_state(3), device=dev.index, sync_bn=True)
+        for _ in range(warmup):
+            net.step(*data)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            net.step(*data)
+        torch.cuda.synchronize()
+        return {"ms_per_step": 1e3 * (time.perf_counter() - t0) / steps, "trunk_implementation": net.mode, "two_streams": bool(net.two_streams),
+                "ranks": dist.get_world_size()}
+    except Exception as exc:      # noqa: BLE001
+        return {"ms_per_step": None, "error": f"{type(exc).__name__}: {exc}"[:200]}
+    finally:
+        if made:
+            try:
+                dist.destroy_process_group()
+            except Exception:      # noqa: BLE001
+                pass
 
 
 @contextlib.contextmanager

@@ -18,10 +18,17 @@
 // LDS tiles are kept as six planes [channel quad][pixel][4 floats]: a wave's 16 pixels are 16 consecutive 16-byte units of a
 // plane (conflict free, MI355X_MICROARCH.md §LDS), the float2 reads of chunk 1 are the two halves of planes 4 and 5.
 #pragma once
+#include <type_traits>
 #include <vector>
 
 #ifndef E1P_ABL
 #define E1P_ABL 0      // tools/kbench ablations: 1 no block A, 2 no block B, 4 no input loads, 8 stamps
+#endif
+#ifndef E1P_NA
+#define E1P_NA 3       // of a thread's five prefetch loads, [0, E1P_NA) are in flight during block A and the rest during block B
+#endif
+#ifndef E1P_SKEW
+#define E1P_SKEW 8     // floats between the plane PAIRS of the input tile beyond a multiple of 256 B (E1PairGeom::xb); 0 = round 4's layout (tools/kbench A/B)
 #endif
 
 namespace fear {
@@ -31,11 +38,23 @@ struct E1PairArgs {
     float* Y;            // [crops][H][W][24]
     const float* Wpk;    // two blocks of E1PairGeom::WBLK floats (headchain-style host packing: e1pair_pack_block)
     int H, W, tiles_x, tiles_y;
+    int tpw;             // consecutive tiles per workgroup (0 = 1); launch with crops * tiles_x * tiles_y / tpw workgroups
 };
 
 struct E1PairGeom {
     static constexpr int C = 24, T = 16, XW = T + 4, MW = T + 2, NQ = C / 4;
     static constexpr int XPL = XW * XW * 4;                        // floats per plane of the input tile (1600 = 25 x 64)
+    // Plane q of the input tile starts xb(q) floats into it.  The tile fill stores the loads in their global order (channel quad
+    // fastest: a wave's 64 loads are 1 KB of consecutive addresses), so the 8 lanes of a ds_write_b128 service group hold the six
+    // quads of ONE pixel + two of the next; with every plane a multiple of 128 B apart those six land on the same four banks — a
+    // 6-way conflict on every group: 1 600 LDS cycles per fill against 300, the whole of the kernel's SQ_LDS_BANK_CONFLICT (0.27 of
+    // its LDS cycles, profiles/r05_sq_counters.txt).  The ds_read_b128 groups mix quads (0, 1) and (2, 3) — those pairs must stay a
+    // multiple of 256 B apart — and the float2 reads pair the halves of quad 4 and of quad 5; between the PAIRS the distance is free:
+    // 32 B more per pair leaves 2-way conflicts (600 cycles).
+    static constexpr int XSKEW = E1P_SKEW;
+    static constexpr int xb(int q) { return q * XPL + (q >> 1) * XSKEW; }
+    static constexpr int XT_FLOATS = NQ * XPL + 2 * XSKEW;
+    static constexpr int NSLOT = NQ * XW * XW, NIT = (NSLOT + 511) / 512;     // float4 slots of the input tile, per thread
     static constexpr int MPL = (MW * MW * 4 + 63) / 64 * 64;       // 1296 -> 1344
     static constexpr int NPIX_A = MW * MW, NMT_A = (NPIX_A + 15) / 16, MTA = (NMT_A + 7) / 8;
     // one block, packed: 4 projection fragments [chunk 0, out tile 0 | chunk 0, tile 1 | chunk 1, tile 0 | chunk 1, tile 1] of 256
@@ -44,8 +63,8 @@ struct E1PairGeom {
     static constexpr int FRAG = 4 * 256, TAP0 = FRAG, TAP1 = TAP0 + 9 * 16, BD = TAP1 + 9 * 8, BP = BD + 24, WBLK = BP + 32;
     static constexpr int WS = WBLK - FRAG;                         // the part that lives in LDS (taps and biases: 272 floats)
     static_assert(WS % 4 == 0 && WBLK % 4 == 0, "16-byte granules");
-    static constexpr int LDS_FLOATS = NQ * XPL + NQ * MPL + 2 * WS;
-    static constexpr int LDS_BYTES = LDS_FLOATS * 4;               // 72 832 B: two workgroups per CU
+    static constexpr int LDS_FLOATS = XT_FLOATS + NQ * MPL + 2 * WS;
+    static constexpr int LDS_BYTES = LDS_FLOATS * 4;               // 72 896 B: two workgroups per CU
 };
 
 // host side: dw = [24][9] depthwise weights, bd = [24] or nullptr, pw = [24][24] (out, in), bp = [24]
@@ -71,24 +90,6 @@ __device__ __forceinline__ void pk_fma2(f32x2& d, const f32x2& a, const f32x2& b
     asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
 }
 
-// The depthwise taps and bias of one block for this lane's channels (chunk 0: quad lk; chunk 1: channels 16 + 2 lk, + 1), read once
-// per phase into registers: re-read per m-tile they were half of the kernel's LDS traffic, and that traffic — not HBM, not the ALU —
-// was what bounded the first version (95 us against 108 for the two separate blocks).
-struct E1Taps {
-    f32x4 w0[9], b0;
-    f32x2 w1[9], b1;
-};
-__device__ __forceinline__ void e1_load_taps(E1Taps& t, const float* __restrict__ ws, int lk) {
-    using G = E1PairGeom;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        t.w0[k] = *reinterpret_cast<const f32x4*>(ws + (G::TAP0 - G::FRAG) + k * 16 + lk * 4);
-        t.w1[k] = *reinterpret_cast<const f32x2*>(ws + (G::TAP1 - G::FRAG) + k * 8 + lk * 2);
-    }
-    t.b0 = *reinterpret_cast<const f32x4*>(ws + (G::BD - G::FRAG) + lk * 4);
-    t.b1 = *reinterpret_cast<const f32x2*>(ws + (G::BD - G::FRAG) + 16 + lk * 2);
-}
-
 // ReLU of the depthwise result + the 24 -> 24 projection of the 16-pixel m-tile the wave's lanes form:
 // acc[nt] = channels 16 nt + 4 lk .. + 3 of pixel li; the accumulators start from the projection bias
 __device__ __forceinline__ void e1_project(f32x4 d4, f32x2 d2, const f32x4 (&wp)[4], const f32x4 (&bias)[2], f32x4 (&acc)[2]) {
@@ -105,149 +106,224 @@ __device__ __forceinline__ void e1_project(f32x4 d4, f32x2 d2, const f32x4 (&wp)
     }
 }
 
-// depthwise 3x3 of NR vertically adjacent pixels (centres cpix, cpix + SW, ...) of a plane-layout tile with SW pixels per row:
-// the (NR + 2) x 3 input reads are shared by the rows
-template <int SW, int SPL, int NR>
-__device__ __forceinline__ void e1_depthwise(const float* __restrict__ src, int cpix, const E1Taps& t, int lk, f32x4 (&d4)[NR], f32x2 (&d2)[NR]) {
-    const float* s0 = src + lk * SPL + cpix * 4;
-    const float* s1 = src + (4 + (lk >> 1)) * SPL + cpix * 4 + (lk & 1) * 2;
+// The input tile: six planes of 400 pixels, 2400 float4 slots over 512 threads (slots IT0 .. IT1 - 1 of each thread); a slot outside
+// the map reads zeros (the buffer load's out-of-range value: the depthwise's zero padding), all loads in flight together.
+// (Free functions on the register array, not lambdas: captured by reference in a closure that is called from two places, hipcc kept
+// the array in scratch memory.  The slot arithmetic is recomputed at every call — hoisted out of the tile loop it was ~70 registers
+// of offsets and predicates alive across both blocks; the empty asm makes the thread index opaque.)
+template <int IT0, int IT1>
+__device__ __forceinline__ void e1_issue_loads(const E1PairArgs& a, unsigned tix, int tid, f32x4 (&xv)[E1PairGeom::NIT]) {
+    using G = E1PairGeom;
+    constexpr int T = G::T, XW = G::XW, NQ = G::NQ, C = G::C;
+    const int tiles = a.tiles_x * a.tiles_y;
+    const long crop = tix / tiles;
+    const int tile = tix % tiles;
+    const int ox0 = (tile % a.tiles_x) * T, oy0 = (tile / a.tiles_x) * T;
+    const float* Xc = a.X + crop * a.H * a.W * C;
+    const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Xc), 0, a.H * a.W * C * 4, 0x00020000);
+    int t = tid;
+    asm volatile("" : "+v"(t));
 #pragma unroll
-    for (int r = 0; r < NR; ++r) { d4[r] = t.b0; d2[r] = t.b1; }
+    for (int it = IT0; it < IT1; ++it) {
+        const int s = it * 512 + t;                   // quad fastest: a wave's 64 loads are 1 KB of consecutive addresses
+        const int pix = s / NQ, q = s - pix * NQ;
+        const int py = pix / XW, px = pix - py * XW;
+        const int gy = oy0 - 2 + py, gx = ox0 - 2 + px;
+        const bool ok = s < G::NSLOT && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        if (E1P_ABL & 4) { xv[it] = (f32x4){1.f, 2.f, 3.f, 4.f}; continue; }
+        xv[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(img, ok ? ((gy * a.W + gx) * C + q * 4) * 4 : (int)0x80000000, 0, 0));
+    }
+}
+template <int IT0, int IT1>
+__device__ __forceinline__ void e1_commit_tile(float* Xt, int tid, const f32x4 (&xv)[E1PairGeom::NIT]) {
+    using G = E1PairGeom;
+    int t = tid;
+    asm volatile("" : "+v"(t));
 #pragma unroll
-    for (int iy = 0; iy < NR + 2; ++iy)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int off = ((iy - 1) * SW + (kx - 1)) * 4;
-            const f32x4 v4 = *reinterpret_cast<const f32x4*>(s0 + off);
-            const f32x2 v2 = *reinterpret_cast<const f32x2*>(s1 + off);
-#pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const int ky = iy - r;
-                if (ky >= 0 && ky < 3) {
-                    pk_fma4(d4[r], v4, t.w0[ky * 3 + kx]);
-                    pk_fma2(d2[r], v2, t.w1[ky * 3 + kx]);
-                }
-            }
-        }
+    for (int it = IT0; it < IT1; ++it) {
+        const int s = it * 512 + t;
+        const int pix = s / G::NQ, q = s - pix * G::NQ;
+        if (s < G::NSLOT) *reinterpret_cast<f32x4*>(Xt + q * G::XPL + (q >> 1) * G::XSKEW + pix * 4) = xv[it];
+    }
 }
 
 __global__ __launch_bounds__(512, 4) void e1pair_kernel(E1PairArgs a) {
     using G = E1PairGeom;
     constexpr int T = G::T, XW = G::XW, MW = G::MW, XPL = G::XPL, MPL = G::MPL, NQ = G::NQ, C = G::C;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* const Xt = lds;                   // [NQ][XPL]
-    float* const Mt = lds + NQ * XPL;        // [NQ][MPL]
+    float* const Xt = lds;                   // [NQ] planes at G::xb(q)
+    float* const Mt = lds + G::XT_FLOATS;    // [NQ][MPL]
     float* const WSl = Mt + NQ * MPL;        // [2][WS]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lk = lane >> 4;
     const int tiles = a.tiles_x * a.tiles_y;
-    const unsigned tix = xcd_tile_index(blockIdx.x, gridDim.x);
-    const long crop = tix / tiles;
-    const int tile = tix % tiles;
-    const int ox0 = (tile % a.tiles_x) * T, oy0 = (tile / a.tiles_x) * T;
-    const float* Xc = a.X + crop * a.H * a.W * C;
-    float* Yc = a.Y + crop * a.H * a.W * C;
+    // A workgroup can walk a.tpw consecutive tiles with the loads of tile t + 1 issued right after the barrier that publishes tile t
+    // (they land in registers while block A computes and go to LDS behind the A -> B barrier, in front of block B).  Built in round 6
+    // on the hypothesis that the workgroup's wait for its input tile (3 of its 10 us) was what kept the kernel at 0.25 of the fp32
+    // peak; measured (tools/kbench, profiles/r06_e1pair_kbench.txt): 94.8 us at one tile per workgroup, 95 / 96 / 97.5 / 121 us at
+    // 2 / 4 / 8 / 16 — the two resident workgroups already cover each other's loads, the kernel is bound by instruction issue.
+    // The engine launches one tile per workgroup (FEAR_E1PAIR_TPW_MAX).
+    const int tpw = a.tpw > 0 ? a.tpw : 1;
+    const unsigned t_first = xcd_tile_index(blockIdx.x, gridDim.x) * (unsigned)tpw;
 
     // ---- the input tile: six planes of 400 pixels, 2400 float4 slots over 512 threads; a slot outside the map reads zeros (the
     //      buffer load's out-of-range value: the depthwise's zero padding), all loads in flight together
-    constexpr int NSLOT = NQ * XW * XW, NIT = (NSLOT + 511) / 512;
-    f32x4 xv[NIT];
-    {
-        const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Xc), 0, a.H * a.W * C * 4, 0x00020000);
+    constexpr int NIT = G::NIT;
+    constexpr int NA = E1P_NA;                    // loads [0, NA) of the next tile are in flight during block A, [NA, NIT) during block B
+    f32x4 xv0[NIT];                          // (the first tile's registers are not the prefetch's: one live range over prologue and loop
+    e1_issue_loads<0, NIT>(a, t_first, tid, xv0);   //  was spilled as a whole)
+    // taps and biases go to LDS; a block's four projection fragments are fetched (L2-resident: every workgroup reads the same 4 KB)
+    // at the head of its phase — holding both blocks' across the tile loop did not fit beside the prefetched tile
+    auto load_wp = [&](int b, f32x4 (&wp)[4]) {
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int s = it * 512 + tid;                 // quad fastest: a wave's 64 loads are 1 KB of consecutive addresses
-            const int pix = s / NQ, q = s - pix * NQ;
-            const int py = pix / XW, px = pix - py * XW;
-            const int gy = oy0 - 2 + py, gx = ox0 - 2 + px;
-            const bool ok = s < NSLOT && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            if (E1P_ABL & 4) { xv[it] = (f32x4){1.f, 2.f, 3.f, 4.f}; continue; }
-            xv[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(img, ok ? ((gy * a.W + gx) * C + q * 4) * 4 : (int)0x80000000, 0, 0));
-        }
-    }
-    // the projection fragments of both blocks stay in registers, taps and biases go to LDS
-    f32x4 wp[2][4];
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int f = 0; f < 4; ++f) wp[b][f] = *reinterpret_cast<const f32x4*>(a.Wpk + b * G::WBLK + f * 256 + lane * 4);
+        for (int f = 0; f < 4; ++f) wp[f] = *reinterpret_cast<const f32x4*>(a.Wpk + b * G::WBLK + f * 256 + lane * 4);
+    };
     if (tid < 2 * G::WS / 4) {
         const int b = tid / (G::WS / 4), j = tid - b * (G::WS / 4);
         *reinterpret_cast<f32x4*>(WSl + b * G::WS + j * 4) = *reinterpret_cast<const f32x4*>(a.Wpk + b * G::WBLK + G::FRAG + j * 4);
     }
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int s = it * 512 + tid;
-        const int pix = s / NQ, q = s - pix * NQ;
-        if (s < NSLOT) *reinterpret_cast<f32x4*>(Xt + q * XPL + pix * 4) = xv[it];
-    }
-    __syncthreads();
+    e1_commit_tile<0, NIT>(Xt, tid, xv0);
 
-    // ---- block A on the 18x18 region around the tile -> Mt (zero outside the map: block B's depthwise pads with zeros)
-    if (!(E1P_ABL & 1)) {
-        const float* ws = WSl;
-        E1Taps taps;
-        e1_load_taps(taps, ws, lk);
-        f32x4 bpv[2];
+    for (int ti = 0; ti < tpw; ++ti) {
+        const unsigned tix = t_first + ti;
+        const long crop = tix / tiles;
+        const int tile = tix % tiles;
+        const int ox0 = (tile % a.tiles_x) * T, oy0 = (tile / a.tiles_x) * T;
+        float* Yc = a.Y + crop * a.H * a.W * C;
+        __syncthreads();                         // tile ti complete in Xt; every wave is through block B of tile ti - 1 (Mt is free)
+        f32x4 xv[NIT];
+        // (lane coordinates opaque per tile: hoisted out of the tile loop, the m-tiles' pixel offsets and masks were 26 spilled registers)
+        int li_o = li, lk_o = lk;
+        asm volatile("" : "+v"(li_o), "+v"(lk_o));
+        if (ti + 1 < tpw) e1_issue_loads<0, NA>(a, tix + 1, tid, xv);
+
+        // ---- block A on the 18x18 region around the tile -> Mt (zero outside the map: block B's depthwise pads with zeros)
+        // The wave's two or three m-tiles go through the depthwise TOGETHER, tap by tap: a tap's weights are read from LDS where
+        // they are used and dropped — the same number of LDS reads as loading all 54 tap registers once per phase, without
+        // holding them beside the prefetched tile (round 4's form, one m-tile at a time from register-resident taps, spilled the
+        // prefetch to scratch and waited for it on the spot).
+        if (!(E1P_ABL & 1)) {
+            const float* ws = WSl;
+            f32x4 wp[4];
+            load_wp(0, wp);
+            auto block_a = [&](auto nm_tag) {
+                constexpr int NM = decltype(nm_tag)::value;
+                // m-tiles 0 .. 17 are the first 16 columns of a row (16 consecutive 16-byte units of a plane: conflict-free LDS reads and
+                // stores), m-tiles 18 .. 20 the two remaining columns of the 18 rows, two pixels per row (row-major m-tiles over the
+                // 18-wide region straddled a row end in almost every m-tile: 35 % of the kernel's LDS cycles were bank conflicts)
+                int pc[NM], cpix[NM];
+                bool valid[NM];
+                float inside[NM];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) bpv[nt] = *reinterpret_cast<const f32x4*>(ws + (G::BP - G::FRAG) + (nt * 4 + lk) * 4);
+                for (int i = 0; i < NM; ++i) {
+                    const int mt = wave + 8 * i;
+                    const int j = (mt - MW) * 16 + li_o;                       // (mt >= 18)
+                    valid[i] = mt < MW || j < 2 * MW;
+                    const int my = mt < MW ? mt : (valid[i] ? j >> 1 : 0), mx = mt < MW ? li_o : 16 + (j & 1);
+                    pc[i] = my * MW + mx;
+                    cpix[i] = (my + 1) * XW + mx + 1;
+                    const int gy = oy0 - 1 + my, gx = ox0 - 1 + mx;
+                    inside[i] = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? 1.f : 0.f;
+                }
+                f32x4 d4[NM];
+                f32x2 d2[NM];
+                {
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(ws + (G::BD - G::FRAG) + lk_o * 4);
+                    const f32x2 b1 = *reinterpret_cast<const f32x2*>(ws + (G::BD - G::FRAG) + 16 + lk_o * 2);
 #pragma unroll
-        for (int i = 0; i < G::MTA; ++i) {
-            const int mt = wave + 8 * i;
-            if (mt >= G::NMT_A) break;                                 // wave-uniform
-            // m-tiles 0 .. 17 are the first 16 columns of a row (16 consecutive 16-byte units of a plane: conflict-free LDS reads and
-            // stores), m-tiles 18 .. 20 the two remaining columns of the 18 rows, two pixels per row (row-major m-tiles over the
-            // 18-wide region straddled a row end in almost every m-tile: 35 % of the kernel's LDS cycles were bank conflicts)
-            const int j = (mt - MW) * 16 + li;                         // (mt >= 18)
-            const bool valid = mt < MW || j < 2 * MW;
-            const int my = mt < MW ? mt : (valid ? j >> 1 : 0), mx = mt < MW ? li : 16 + (j & 1);
-            const int pc = my * MW + mx;
-            const int cpix = (my + 1) * XW + mx + 1;
-            f32x4 acc[2], d4[1];
-            f32x2 d2[1];
-            e1_depthwise<XW, XPL, 1>(Xt, cpix, taps, lk, d4, d2);
-            e1_project(d4[0], d2[0], wp[0], bpv, acc);
-            const int gy = oy0 - 1 + my, gx = ox0 - 1 + mx;
-            const float inside = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? 1.f : 0.f;
+                    for (int i = 0; i < NM; ++i) { d4[i] = b0; d2[i] = b1; }
+                }
+                const float* s0 = Xt + lk_o * XPL + (lk_o >> 1) * G::XSKEW;
+                const float* s1 = Xt + (4 + (lk_o >> 1)) * XPL + 2 * G::XSKEW + (lk_o & 1) * 2;
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                if (nt == 1 && lk >= 2) continue;                      // channels 24 .. 31 do not exist
-                const int qd = nt * 4 + lk;
-                const f32x4 v = (acc[nt] + *reinterpret_cast<const f32x4*>(Xt + qd * XPL + cpix * 4)) * inside;   // (finite values: x * 0 = 0)
-                if (valid) *reinterpret_cast<f32x4*>(Mt + qd * MPL + pc * 4) = v;
+                for (int k = 0; k < 9; ++k) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(ws + (G::TAP0 - G::FRAG) + k * 16 + lk_o * 4);
+                    const f32x2 w2 = *reinterpret_cast<const f32x2*>(ws + (G::TAP1 - G::FRAG) + k * 8 + lk_o * 2);
+                    const int off = ((k / 3 - 1) * XW + (k % 3 - 1)) * 4;
+#pragma unroll
+                    for (int i = 0; i < NM; ++i) {
+                        const f32x4 v4 = *reinterpret_cast<const f32x4*>(s0 + cpix[i] * 4 + off);
+                        const f32x2 v2 = *reinterpret_cast<const f32x2*>(s1 + cpix[i] * 4 + off);
+                        pk_fma4(d4[i], v4, w4);
+                        pk_fma2(d2[i], v2, w2);
+                    }
+                }
+                f32x4 bpv[2];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) bpv[nt] = *reinterpret_cast<const f32x4*>(ws + (G::BP - G::FRAG) + (nt * 4 + lk_o) * 4);
+#pragma unroll
+                for (int i = 0; i < NM; ++i) {
+                    f32x4 acc[2];
+                    e1_project(d4[i], d2[i], wp, bpv, acc);
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        if (nt == 1 && lk_o >= 2) continue;                    // channels 24 .. 31 do not exist
+                        const int qd = nt * 4 + lk_o;
+                        const f32x4 v = (acc[nt] + *reinterpret_cast<const f32x4*>(Xt + qd * XPL + (qd >> 1) * G::XSKEW + cpix[i] * 4)) * inside[i];   // (finite values: x * 0 = 0)
+                        if (valid[i]) *reinterpret_cast<f32x4*>(Mt + qd * MPL + pc[i] * 4) = v;
+                    }
+                }
+            };
+            if (wave + 16 < G::NMT_A) block_a(std::integral_constant<int, 3>{});      // wave-uniform: 21 m-tiles over 8 waves
+            else block_a(std::integral_constant<int, 2>{});
+        }
+        __syncthreads();                         // Mt complete; nobody reads Xt any more
+        if (ti + 1 < tpw) { e1_commit_tile<0, NA>(Xt, tid, xv); e1_issue_loads<NA, NIT>(a, tix + 1, tid, xv); }
+
+        // ---- block B on the tile's 16 rows (two per wave, sharing their depthwise reads) -> global
+        if (!(E1P_ABL & 2)) {
+            const float* ws = WSl + G::WS;
+            f32x4 wp[4];
+            load_wp(1, wp);
+            f32x4 bpv[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) bpv[nt] = *reinterpret_cast<const f32x4*>(ws + (G::BP - G::FRAG) + (nt * 4 + lk_o) * 4);
+            const int row0 = wave * 2;
+            const int cpix = (row0 + 1) * MW + li_o + 1;
+            // depthwise of the wave's two rows, input row by input row: a value feeds row 0 through tap row iy and row 1 through tap
+            // row iy - 1, so two tap rows (read from LDS as they come up) are live at a time instead of all nine taps
+            f32x4 d4[2];
+            f32x2 d2[2];
+            d4[0] = d4[1] = *reinterpret_cast<const f32x4*>(ws + (G::BD - G::FRAG) + lk_o * 4);
+            d2[0] = d2[1] = *reinterpret_cast<const f32x2*>(ws + (G::BD - G::FRAG) + 16 + lk_o * 2);
+            {
+                const float* s0 = Mt + lk_o * MPL + cpix * 4;
+                const float* s1 = Mt + (4 + (lk_o >> 1)) * MPL + cpix * 4 + (lk_o & 1) * 2;
+                f32x4 w4[2][3];
+                f32x2 w2[2][3];
+#pragma unroll
+                for (int iy = 0; iy < 4; ++iy) {
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        if (iy < 3) {
+                            w4[iy & 1][kx] = *reinterpret_cast<const f32x4*>(ws + (G::TAP0 - G::FRAG) + (iy * 3 + kx) * 16 + lk_o * 4);
+                            w2[iy & 1][kx] = *reinterpret_cast<const f32x2*>(ws + (G::TAP1 - G::FRAG) + (iy * 3 + kx) * 8 + lk_o * 2);
+                        }
+                        const int off = ((iy - 1) * MW + (kx - 1)) * 4;
+                        const f32x4 v4 = *reinterpret_cast<const f32x4*>(s0 + off);
+                        const f32x2 v2 = *reinterpret_cast<const f32x2*>(s1 + off);
+                        if (iy < 3) { pk_fma4(d4[0], v4, w4[iy & 1][kx]); pk_fma2(d2[0], v2, w2[iy & 1][kx]); }
+                        if (iy >= 1) { pk_fma4(d4[1], v4, w4[(iy - 1) & 1][kx]); pk_fma2(d2[1], v2, w2[(iy - 1) & 1][kx]); }
+                    }
+                }
+            }
+            const unsigned ylane = (unsigned)(li_o * C + lk_o * 4);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                f32x4 acc[2];
+                e1_project(d4[r], d2[r], wp, bpv, acc);
+                float* yrow = Yc + ((long)(oy0 + row0 + r) * a.W + ox0) * C;   // uniform
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    if (nt == 1 && lk_o >= 2) continue;
+                    const int qd = nt * 4 + lk_o;
+                    const f32x4 v = acc[nt] + *reinterpret_cast<const f32x4*>(Mt + qd * MPL + (cpix + r * MW) * 4);
+                    *reinterpret_cast<f32x4*>(yrow + (ylane + (unsigned)(nt * 16))) = v;
+                }
             }
         }
-    }
-    __syncthreads();
-
-    // ---- block B on the tile's 16 rows (two per wave, sharing their depthwise reads) -> global
-    if (!(E1P_ABL & 2)) {
-        const float* ws = WSl + G::WS;
-        E1Taps taps;
-        e1_load_taps(taps, ws, lk);
-        f32x4 bpv[2];
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) bpv[nt] = *reinterpret_cast<const f32x4*>(ws + (G::BP - G::FRAG) + (nt * 4 + lk) * 4);
-        const int row0 = wave * 2;
-        const int cpix = (row0 + 1) * MW + li + 1;
-        f32x4 d4[2];
-        f32x2 d2[2];
-        e1_depthwise<MW, MPL, 2>(Mt, cpix, taps, lk, d4, d2);
-        const unsigned ylane = (unsigned)(li * C + lk * 4);
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            f32x4 acc[2];
-            e1_project(d4[r], d2[r], wp[1], bpv, acc);
-            float* yrow = Yc + ((long)(oy0 + row0 + r) * a.W + ox0) * C;   // uniform
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                if (nt == 1 && lk >= 2) continue;
-                const int qd = nt * 4 + lk;
-                const f32x4 v = acc[nt] + *reinterpret_cast<const f32x4*>(Mt + qd * MPL + (cpix + r * MW) * 4);
-                *reinterpret_cast<f32x4*>(yrow + (ylane + (unsigned)(nt * 16))) = v;
-            }
-        }
+        if (ti + 1 < tpw) e1_commit_tile<NA, NIT>(Xt, tid, xv);
     }
 }
 

@@ -9,11 +9,13 @@
 // FBNet-style trunk (stem + inverted-residual blocks) with the FEAR head runs, not only FEAR-XS.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -23,6 +25,9 @@
 #include "fear_headchain.h"
 #include "fear_headchain_b.h"
 #include "fear_e1pair.h"
+#ifndef FEAR_E1PAIR_TPW_MAX
+#define FEAR_E1PAIR_TPW_MAX 1      // e1pair_kernel: at most this many consecutive tiles per workgroup (more measured no faster: fear_e1pair.h)
+#endif
 
 namespace {
 
@@ -1708,7 +1713,13 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main,
                 E1PairArgs a{};
                 a.X = buf(op.in_buf); a.Y = buf(op.out_buf); a.Wpk = op.d_packed;
                 a.H = op.H; a.W = op.W; a.tiles_x = op.W / E1PairGeom::T; a.tiles_y = op.H / E1PairGeom::T;
-                hipLaunchKernelGGL(e1pair_kernel, dim3((unsigned)n * a.tiles_x * a.tiles_y), dim3(512), E1PairGeom::LDS_BYTES, s, a);
+                // consecutive tiles per workgroup (the next tile's loads run under the current tile's arithmetic), never fewer than two
+                // workgroups for each of the 256 CUs; FEAR_E1PAIR_TPW_MAX = 1: one tile per workgroup
+                const unsigned total = (unsigned)n * a.tiles_x * a.tiles_y;
+                a.tpw = 1;
+                for (int t = FEAR_E1PAIR_TPW_MAX; t > 1; t >>= 1)
+                    if (total % t == 0 && total / t >= 512) { a.tpw = t; break; }
+                hipLaunchKernelGGL(e1pair_kernel, dim3(total / a.tpw), dim3(512), E1PairGeom::LDS_BYTES, s, a);
                 break;
             }
             case OP_CHAIN16: {

@@ -26,6 +26,8 @@
 #endif
 #ifndef HC_ABL
 #define HC_ABL 0       // timing ablations for tools/headchain_check only (bit mask); the product always builds with 0
+                       // 1: no scratch stores of the next layer's depthwise results, 2: no scratch reloads (1 | 2: the parking is
+                       // free), 4: no prologue fetch of the neck output, 8 / 128: time stamps
 #endif
 
 namespace fear {
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(512) void headchain_kernel(HeadChainArgs a) {
         for (int c = 0; c < C / 16; ++c) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
-                d[c][mt] = *reinterpret_cast<const f32x4*>(X0 + (long)((y0 + mt) * S + li) * a.ldx + c * 16 + lk * 4);
+                d[c][mt] = (HC_ABL & 4) ? (f32x4){0.5f, 0.25f, 1.f, 2.f} : *reinterpret_cast<const f32x4*>(X0 + (long)((y0 + mt) * S + li) * a.ldx + c * 16 + lk * 4);
             __builtin_amdgcn_sched_barrier(0);     // (in chunk order: hipcc would issue the first chunks last)
         }
         // zero fill done and weight blocks landed: everything but the youngest 32 operations (the input rows).
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(512) void headchain_kernel(HeadChainArgs a) {
         auto handoff_out = [&](int q, int nt, const f32x4& n0, const f32x4& n1, auto dst_tag) {
             constexpr int DST = decltype(dst_tag)::value;
             if (MODE != 2) {
-                if (DST < 0) { *dptr(2 * q + nt, 0) = n0; *dptr(2 * q + nt, 1) = n1; }
+                if (DST < 0) { if (!(HC_ABL & 1)) { *dptr(2 * q + nt, 0) = n0; *dptr(2 * q + nt, 1) = n1; } }
                 else { d[DST < 0 ? 0 : DST][0] = n0; d[DST < 0 ? 0 : DST][1] = n1; }
             } else {
                 // prediction SepConv's 1x1 to <= 4 channels on the depthwise of the finished chunk
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(512) void headchain_kernel(HeadChainArgs a) {
                     // (written to the scratch by this lane in the hand-over of pass c / 2 — the one of pass 6 a few groups ago; the
                     // last two chunks come straight from the hand-over below)
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) d[c][mt] = *dptr(c, mt);
+                    for (int mt = 0; mt < 2; ++mt) if (!(HC_ABL & 2)) d[c][mt] = *dptr(c, mt);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }

@@ -24,8 +24,12 @@ namespace {
 
 using namespace fear;
 
+// (sync_failed: a SyncBatchNorm all-reduce callback of this host thread reported an error since the last check — the finalize helpers
+//  that call it return nothing, fear_train_block.h)
+thread_local int sync_failed = 0;
 #define LAUNCH_CHECK()                                        \
     do {                                                      \
+        if (sync_failed) { sync_failed = 0; return FEAR_TRAIN_ERR_SYNC; } \
         if (hipGetLastError() != hipSuccess) return FEAR_TRAIN_ERR_HIP; \
     } while (0)
 
@@ -175,7 +179,10 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(ColArgs a) {
 
 // mode 0: mean / rstd (+ running statistics, torch semantics: biased variance normalises, unbiased one is tracked);
 // mode 1: the two sums as they are (sum g -> out1, sum g*xhat -> out2);  mode 2: out1 only;  mode 3: float64 sums;
-// mode 4: mode 1 + the BnbIn coefficient vectors
+// mode 4: mode 1 + the BnbIn coefficient vectors (out1 / out2 may be NULL: coefficients only);  mode 6: modes 1 and 3 together
+// SyncBatchNorm on the block-fused operators (fear_train_sync_bind): a finalize is then two launches around the caller's all-reduce —
+// mode 3 (forward) or 6 (backward: d beta / d gamma from the LOCAL sums) leave the float64 sums in the sync buffer, the second launch
+// is mode 0 / 4 over that buffer as its one partial row, with M = the rows of all ranks.
 struct ColFinArgs {
     const double* partial;
     float* out1;
@@ -235,13 +242,19 @@ __global__ __launch_bounds__(1024) void col_finalize_kernel(ColFinArgs a) {
             const double unbiased = a.M > 1.0 ? var * a.M / (a.M - 1.0) : var;
             a.running_var[c] = (float)((1.0 - a.momentum) * (double)a.running_var[c] + a.momentum * unbiased);
         }
-    } else if (a.mode == 3) {
+    } else if (a.mode == 3 || a.mode == 6) {
         a.dsum[c] = s1;
         a.dsum[a.C + c] = s2;
+        if (a.mode == 6) {
+            a.out1[c] = (float)s1;
+            a.out2[c] = (float)s2;
+        }
     } else if (a.mode == 4) {
         // BatchNorm backward: d beta = sum g, d gamma = sum g * xhat, and the coefficients its consumers apply on load
-        a.out1[c] = (float)s1;
-        a.out2[c] = (float)s2;
+        if (a.out1) {
+            a.out1[c] = (float)s1;
+            a.out2[c] = (float)s2;
+        }
         const float rs = a.rstd_in[c];
         a.coef[c] = a.gamma[c] * rs;
         a.coef[a.C + c] = (float)(s1 / a.M);

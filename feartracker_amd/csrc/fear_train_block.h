@@ -1133,6 +1133,22 @@ BlockWs block_ws(long rows_in, long rows_out, int cin, int cexp, int cout, int k
     return w;
 }
 
+// ---- SyncBatchNorm hook (include/fear_train.h, fear_train_sync_bind): streams bound to a FearSync.  A handful of entries, looked up
+// once per finalize under a mutex (the host side of a step is one thread per rank; the lock is for whoever drives two devices).
+struct SyncSlot { hipStream_t s; FearSync sy; bool used; };
+SyncSlot g_sync_slots[16];
+std::mutex g_sync_mutex;
+bool sync_of(hipStream_t s, FearSync* out) {
+    std::lock_guard<std::mutex> lock(g_sync_mutex);
+    for (const SyncSlot& e : g_sync_slots)
+        if (e.used && e.s == s) { *out = e.sy; return true; }
+    return false;
+}
+// the caller's all-reduce of n elements of the sync buffer; a failure is reported by the entry point's LAUNCH_CHECK
+void sync_all_reduce(const FearSync& sy, long n, int is_f32, hipStream_t s) {
+    if ((size_t)n * (is_f32 ? 4 : 8) > sy.buf_bytes || sy.all_reduce(sy.user, sy.buf, n, is_f32, s) != 0) sync_failed = 1;
+}
+
 // column-sum partials [blocks][2][C] -> mean | rstd | a | b (vec) + running statistics
 void finalize_forward(const double* partial, int blocks, int C, double count, const float* gamma, const float* beta, float* vec,
                       float* running_mean, float* running_var, double momentum, double eps, hipStream_t s, const float* mean_shift = nullptr) {
@@ -1140,6 +1156,15 @@ void finalize_forward(const double* partial, int blocks, int C, double count, co
     f.mean_shift = mean_shift;
     f.partial = partial; f.out1 = vec; f.out2 = vec + C; f.out_a = vec + 2 * C; f.out_b = vec + 3 * C; f.gamma = gamma; f.beta = beta;
     f.running_mean = running_mean; f.running_var = running_var; f.blocks = blocks; f.C = C; f.mode = 0; f.M = count; f.eps = eps; f.momentum = momentum;
+    FearSync sy;
+    if (sync_of(s, &sy)) {
+        // SyncBatchNorm: this rank's float64 sums -> the ranks' all-reduce -> statistics of all ranks' rows
+        ColFinArgs r{};
+        r.partial = partial; r.blocks = blocks; r.C = C; r.mode = 3; r.dsum = sy.buf;
+        hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, s, r);
+        sync_all_reduce(sy, 2L * C, 0, s);
+        f.partial = sy.buf; f.blocks = 1; f.M = count * sy.world;
+    }
     hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, s, f);
 }
 
@@ -1149,6 +1174,16 @@ void finalize_backward(const double* partial, int blocks, int C, double count, c
     ColFinArgs f{};
     f.partial = partial; f.out1 = dbeta; f.out2 = dgamma; f.gamma = gamma; f.mean_in = vec; f.rstd_in = vec + C; f.coef = coef;
     f.blocks = blocks; f.C = C; f.mode = 4; f.M = count;
+    FearSync sy;
+    if (sync_of(s, &sy)) {
+        // SyncBatchNorm: d beta / d gamma from this rank's sums (they are averaged with every other gradient), the input gradient's
+        // coefficients from all ranks' — the split torch.nn.SyncBatchNorm makes
+        ColFinArgs r = f;
+        r.mode = 6; r.dsum = sy.buf;
+        hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, s, r);
+        sync_all_reduce(sy, 2L * C, 0, s);
+        f.partial = sy.buf; f.blocks = 1; f.out1 = nullptr; f.out2 = nullptr; f.M = count * sy.world;
+    }
     hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, s, f);
 }
 
@@ -1299,10 +1334,18 @@ void launch_dw_bwd_ks(const DwBwdArgs& a, int sq, bool bn1, dim3 grid, hipStream
 // never destroyed (a wait refers to the record that preceded it, so re-recording an event later does not disturb waits already
 // enqueued; 512 is far more than a step has in flight)
 hipEvent_t ring_event() {
-    static hipEvent_t ring[512];
-    static unsigned pos = 0;
-    hipEvent_t& e = ring[pos++ % 512];
-    if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    // one ring per device (an event belongs to the device that was current when it was created), positions handed out atomically:
+    // two host threads may drive two networks at once
+    static hipEvent_t ring[16][512];
+    static std::atomic<unsigned> pos{0};
+    static std::mutex create;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    hipEvent_t& e = ring[dev][pos.fetch_add(1) % 512];
+    if (!e) {
+        std::lock_guard<std::mutex> lock(create);
+        if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    }
     return e;
 }
 // `to` waits for everything issued on `from` so far
@@ -1352,6 +1395,26 @@ bool irb_virtual(const FearIrbBlock* b) { return (b->flags & FEAR_IRB_VIRTUAL_E)
 
 extern "C" {
 
+int fear_train_sync_bind(void* stream, const FearSync* sync) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (sync && (!sync->all_reduce || !sync->buf)) return FEAR_TRAIN_ERR_NULL;
+    if (sync && (sync->world < 1 || sync->buf_bytes < FEAR_SYNC_BUF_BYTES)) return FEAR_TRAIN_ERR_SHAPE;
+    std::lock_guard<std::mutex> lock(g_sync_mutex);
+    SyncSlot* slot = nullptr;
+    for (SyncSlot& e : g_sync_slots)
+        if (e.used && e.s == s) slot = &e;
+    if (!sync) {
+        if (slot) slot->used = false;
+        return FEAR_TRAIN_OK;
+    }
+    if (!slot)
+        for (SyncSlot& e : g_sync_slots)
+            if (!e.used) { slot = &e; break; }
+    if (!slot) return FEAR_TRAIN_ERR_SHAPE;      // more than 16 streams bound
+    slot->s = s; slot->sy = *sync; slot->used = true;
+    return FEAR_TRAIN_OK;
+}
+
 size_t fear_irb_workspace_bytes(const FearIrbBlock* b, int B, int H, int W) {
     if (!b || !irb_shape_ok(b, B, H, W)) return 0;
     const long rows_in = (long)B * H * W, rows_out = rows_in / (b->stride * b->stride);
@@ -1396,12 +1459,21 @@ int fear_irb_train_forward(const FearIrbBlock* b, const FearIrbSaved* sv, const 
         if (nc == 1) hipLaunchKernelGGL(gram_kernel<1>, dim3((unsigned)wgs), dim3(256), 0, s, x, rows_in, b->cin, rpw, ws.wg);
         else hipLaunchKernelGGL(gram_kernel<2>, dim3((unsigned)wgs), dim3(256), 0, s, x, rows_in, b->cin, rpw, ws.wg);
         launch_slice_sum(ws.wg, ws.coef, per, wgs, s);
+        double count1 = (double)rows_in;
+        FearSync sy;
+        if (sync_of(s, &sy)) {
+            // SyncBatchNorm: the expansion's statistics are linear in (G, column sums) — those are what the ranks add up
+            if (hipMemcpyAsync(sy.buf, ws.coef, per * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return FEAR_TRAIN_ERR_HIP;
+            sync_all_reduce(sy, per, 1, s);
+            if (hipMemcpyAsync(ws.coef, sy.buf, per * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return FEAR_TRAIN_ERR_HIP;
+            count1 *= sy.world;
+        }
         if (nc == 1)
             hipLaunchKernelGGL(irb_virtual_stats_kernel<16>, dim3((unsigned)((b->cexp + 63) / 64)), dim3(64), 0, s, ws.coef, b->w_pw, b->gamma[0],
-                               b->beta[0], sv->vec[0], b->running_mean[0], b->running_var[0], b->cexp, b->cin, (double)rows_in, eps, momentum);
+                               b->beta[0], sv->vec[0], b->running_mean[0], b->running_var[0], b->cexp, b->cin, count1, eps, momentum);
         else
             hipLaunchKernelGGL(irb_virtual_stats_kernel<32>, dim3((unsigned)((b->cexp + 63) / 64)), dim3(64), 0, s, ws.coef, b->w_pw, b->gamma[0],
-                               b->beta[0], sv->vec[0], b->running_mean[0], b->running_var[0], b->cexp, b->cin, (double)rows_in, eps, momentum);
+                               b->beta[0], sv->vec[0], b->running_mean[0], b->running_var[0], b->cexp, b->cin, count1, eps, momentum);
     }
     // expand 1x1 (+ statistics)
     if (b->expand && !virt)

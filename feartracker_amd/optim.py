@@ -70,7 +70,8 @@ class AdamHIP:
         with torch.cuda.device(dev):
             st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             if self.flat is not None:
-                gflat = getattr(grads, "flat", None)
+                # (GradDict.current_flat: None once an entry was rebound or a re-laid-out copy edited — the dict's values then count)
+                gflat = grads.current_flat() if hasattr(grads, "current_flat") else getattr(grads, "flat", None)
                 if gflat is None or gflat.numel() != self.flat.numel() or gflat.device != self.flat.device:
                     # gradients from somewhere else: lay them out like the parameters (padding between slots stays zero)
                     if self._stage is None:

@@ -80,6 +80,8 @@ TRAIN_SYMBOLS = {
     "fear_sepbn_workspace_bytes": ([_P, _i, _i, _i], _sz),
     "fear_sepbn_train_forward": ([_P, _P, _i, _P, _P, _P, _P, _i, _i, _i, _i, _d, _d, _P, _sz, _P], _i),
     "fear_sepbn_train_backward": ([_P, _P, _P, _i, _P, _P, _P, _P, _P, _P, _P, _i, _i, _i, _P, _sz, _P, _P], _i),
+    # SyncBatchNorm hook of the block-fused operators: (stream, FearSync*)
+    "fear_train_sync_bind": ([_P, _P], _i),
 }
 
 
@@ -107,11 +109,50 @@ class FearSepGrads(ctypes.Structure):
     _fields_ = [("w_dw", _P), ("w_pw", _P), ("gamma", _P), ("beta", _P)]
 
 
+_ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_void_p)
+FEAR_SYNC_BUF_BYTES = 16384
+
+
+class FearSync(ctypes.Structure):
+    """include/fear_train.h: the all-reduce hook a stream is bound to (fear_train_sync_bind)."""
+    _fields_ = [("all_reduce", _ALLREDUCE_FN), ("user", _P), ("buf", _P), ("buf_bytes", _sz), ("world", _i)]
+
+
 class GradDict(dict):
     """{parameter name: gradient in the reference's layout} whose values are views of ONE flat buffer in the kernels' storage
     layout (`flat`, the layout of the network's `param_flat`): the all-reduce of several ranks and the optimiser work on `flat`
-    — one collective, one Adam launch — and the views follow."""
+    — one collective, one Adam launch — and the views follow.
+    Contract: `flat` is the truth only while the dict is what the step made it.  Most entries are views of `flat` (in-place edits
+    — `grads[k].mul_(c)`, the all-reduce — reach it); the depthwise and stem entries are re-laid-out COPIES.  `seal()` (called by
+    the step) records the state; `current_flat()` returns `flat` unless an entry was rebound (`grads[k] = grads[k] * c`, as
+    gradient clipping does) or a copy entry was edited in place — then None: `optim.AdamHIP.step` and `allreduce_gradients` fall
+    back to the dict's values, so such an edit is never silently dropped."""
     flat: Optional[torch.Tensor] = None
+    _sealed = None
+    _rebound = False
+
+    def seal(self) -> "GradDict":
+        base = self.flat.untyped_storage().data_ptr() if self.flat is not None else None
+        self._sealed = {k: v._version for k, v in self.items() if base is None or v.untyped_storage().data_ptr() != base}
+        self._rebound = False
+        return self
+
+    def __setitem__(self, key, value):
+        super().__setitem__(key, value)
+        if self._sealed is not None:
+            self._rebound = True
+
+    def __delitem__(self, key):
+        super().__delitem__(key)
+        if self._sealed is not None:
+            self._rebound = True
+
+    def current_flat(self) -> Optional[torch.Tensor]:
+        if self.flat is None or self._sealed is None:
+            return self.flat
+        if self._rebound or any(k not in self or self[k]._version != ver for k, ver in self._sealed.items()):
+            return None
+        return self.flat
 
 _bound = None
 
@@ -148,6 +189,65 @@ class SyncBN:
 
     def all_reduce(self, sums: torch.Tensor) -> None:
         self.dist.all_reduce(sums, op=self.dist.ReduceOp.SUM, group=self.group)
+
+
+class SyncHook:
+    """SyncBatchNorm for the block-fused operators (`fear_irb_train_*`, `fear_pwbn_*`, `fear_stem_train_*`, `fear_sepbn_*`): their
+    BatchNorm reductions sit inside one C call, so the ranks' all-reduce is a callback the library makes between a producer's
+    float64 sums and their finalize (include/fear_train.h, `fear_train_sync_bind`).  `bound(*torch streams)` binds each stream to a
+    buffer of its own for the duration of a step; the callback runs the group's all-reduce (`sync.all_reduce`: RCCL through
+    torch.distributed) on that stream's buffer, ordered on that stream.  Collectives of several streams reach the communicator in
+    the host's issue order — the same on every rank, because every rank runs the same Python.  `sync` is a `SyncBN` (or anything
+    with `.world` and `.all_reduce(tensor)`: the tests play two ranks on one GPU with it)."""
+
+    def __init__(self, lib, sync, device):
+        self.lib, self.sync, self.device = lib, sync, device
+        self._slots = {}                      # raw stream handle -> [torch stream, buffer, FearSync, depth]
+        self.error = None
+        self._cb = _ALLREDUCE_FN(self._all_reduce)      # (kept alive: the library holds the pointer while a stream is bound)
+
+    def _all_reduce(self, user, buf, n, is_f32, stream):
+        try:
+            stream_t, buffer = self._slots[int(stream or 0)][:2]
+            view = buffer.view(torch.float32)[:n] if is_f32 else buffer[:n]
+            with torch.cuda.stream(stream_t):
+                self.sync.all_reduce(view)
+            return 0
+        except BaseException as exc:          # noqa: BLE001 - must not unwind through the C frames; re-raised by the caller's _check
+            self.error = exc
+            return 1
+
+    def bound(self, *streams):
+        hook = self
+
+        class _Bound:
+            def __enter__(self_inner):
+                self_inner.handles = []
+                for st in streams:
+                    if st is None:
+                        continue
+                    h = int(st.cuda_stream)
+                    slot = hook._slots.get(h)
+                    if slot is None:
+                        buf = torch.zeros(FEAR_SYNC_BUF_BYTES // 8, dtype=torch.float64, device=hook.device)
+                        fs = FearSync(hook._cb, None, buf.data_ptr(), FEAR_SYNC_BUF_BYTES, int(hook.sync.world))
+                        slot = hook._slots[h] = [st, buf, fs, 0]
+                    if slot[3] == 0:
+                        rc = hook.lib.fear_train_sync_bind(ctypes.c_void_p(h), ctypes.byref(slot[2]))
+                        if rc != 0:
+                            raise TrainError(f"fear_train_sync_bind failed with status {rc}")
+                    slot[3] += 1
+                    self_inner.handles.append(h)
+                return hook
+
+            def __exit__(self_inner, *exc):
+                for h in self_inner.handles:
+                    slot = hook._slots[h]
+                    slot[3] -= 1
+                    if slot[3] == 0:
+                        hook.lib.fear_train_sync_bind(ctypes.c_void_p(h), None)
+                return False
+        return _Bound()
 
 
 def bn_forward(lib, st, ws, wsb, sync: Optional["SyncBN"], x, ldx, gamma, beta, out, ld_out, mean, rstd, running_mean, running_var,
@@ -215,13 +315,15 @@ class BoxTowerTrainHIP:
                  eps: float = 1e-5, coef_cls: float = 1.0, coef_reg: float = 1.0, sync_bn: bool = False, group=None,
                  fused: bool = True):
         """`fused` (default): every SepConv + BatchNorm + ReLU layer is one call per direction (`fear_sepbn_train_*`: statistics in
-        the GEMM's epilogue, the BatchNorm backward formed on load, weight gradients on `aux_stream`); False — and always with
-        SyncBatchNorm, whose collectives sit between the passes — one operator per pass, as rounds 2-4 ran it."""
+        the GEMM's epilogue, the BatchNorm backward formed on load, weight gradients on `aux_stream`) — with SyncBatchNorm the
+        ranks' all-reduces are made by the library's hook between a layer's sums and their finalize (`SyncHook`); False: one
+        operator per pass, as rounds 2-4 ran it (SyncBatchNorm: its collectives between the passes).
+        `sync_bn`: True (a `SyncBN` over `group`) or an object with `.world` and `.all_reduce(tensor)`."""
         if not torch.cuda.is_available():
             raise RuntimeError("BoxTowerTrainHIP needs a ROCm GPU; there is no CPU fallback")
-        self.fused = bool(fused) and not sync_bn
+        self.fused = bool(fused)
         self.lib = load_train_library()
-        self.sync = SyncBN(group) if sync_bn else None
+        self.sync = (SyncBN(group) if sync_bn is True else sync_bn) if sync_bn else None
         self.device = torch.device(f"cuda:{int(device)}")
         self.momentum, self.eps, self.coef_cls, self.coef_reg = momentum, eps, coef_cls, coef_reg
         sd = {k: torch.as_tensor(np.asarray(v)) if not isinstance(v, torch.Tensor) else v.detach().cpu() for k, v in state_dict.items()}
@@ -234,6 +336,7 @@ class BoxTowerTrainHIP:
                 pred=_Sep(self, pred, None, sd, pad_out_to=4))
         self.adjust = sd["adjust"].float().reshape(1).to(self.device)
         self.bias4 = sd["bias"].float().reshape(4).to(self.device)
+        self.hook = SyncHook(self.lib, self.sync, self.device) if (self.sync is not None and self.fused) else None
         self._ws = {}                # per stream lane
         self._lane = 0
         self._galloc = None          # set by FEARNetTrainHIP: gradient tensors are views of its flat gradient buffer
@@ -277,6 +380,10 @@ class BoxTowerTrainHIP:
     # ------------------------------------------------------------------ plumbing
     def _check(self, st: int) -> None:
         if st != 0:
+            err = self.hook.error if self.hook is not None else None
+            if st == -8 and err is not None:            # FEAR_TRAIN_ERR_SYNC: the all-reduce callback raised
+                self.hook.error = None
+                raise TrainError("the SyncBatchNorm all-reduce of a block-fused operator failed") from err
             raise TrainError(f"libfear_hip training operator failed with status {st}")
 
     def _stream(self):
@@ -443,6 +550,17 @@ class BoxTowerTrainHIP:
     @torch.no_grad()
     def step_rows(self, x: torch.Tensor, template_feats: torch.Tensor, gt_reg: torch.Tensor, gt_cls: torch.Tensor,
                   gt_weight: torch.Tensor) -> Dict[str, object]:
+        """`_step_rows`, with this stream and the side stream bound to the SyncBatchNorm hook when the head runs its one-call layers
+        in a data-parallel group (a binding the caller already holds is kept: `SyncHook.bound` counts)."""
+        if self.hook is None:
+            return self._step_rows(x, template_feats, gt_reg, gt_cls, gt_weight)
+        with torch.cuda.device(self.device):
+            with self.hook.bound(torch.cuda.current_stream(self.device), self.side_stream):
+                return self._step_rows(x, template_feats, gt_reg, gt_cls, gt_weight)
+
+    @torch.no_grad()
+    def _step_rows(self, x: torch.Tensor, template_feats: torch.Tensor, gt_reg: torch.Tensor, gt_cls: torch.Tensor,
+                   gt_weight: torch.Tensor) -> Dict[str, object]:
         """`step` on the search features as the trunk leaves them — pixel rows [B*256][256] (channels last) — returning
         "grad_search_rows" in the same layout instead of "grad_search": FEARNetTrainHIP's trunk works on rows on both sides of the
         head, and the two layout passes each way were 0.2 ms of its step.  The template features stay (B,256,8,8) NCHW: the
@@ -459,7 +577,7 @@ class BoxTowerTrainHIP:
             saved = {}
             pred_out = {}
             main = torch.cuda.current_stream(dev)
-            side = self.side_stream if self.sync is None else None
+            side = self.side_stream if (self.sync is None or self.hook is not None) else None
 
             def on_branch_streams(fn):
                 """fn(name, branch) for both towers: "reg" on the side stream (lane 1), "cls" on this one; joined on return."""
@@ -555,7 +673,7 @@ class BoxTowerTrainHIP:
         import torch.distributed as dist
         if not dist.is_initialized() or dist.get_world_size(group) == 1:
             return grads
-        flat = getattr(grads, "flat", None)
+        flat = grads.current_flat() if isinstance(grads, GradDict) else getattr(grads, "flat", None)
         if flat is not None:                       # FEARNetTrainHIP: the gradients ARE one buffer already; its views follow
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
             flat /= dist.get_world_size(group)

@@ -131,14 +131,16 @@ class FEARNetTrainHIP:
         #   "block"      (default on one rank) one C-ABI call per inverted-residual block and direction, csrc/fear_train_block.h:
         #                statistics in the producing pass, BatchNorm / its backward / ReLU masks formed on load, the two
         #                BatchNorms around the depthwise conv and its three gradients in one LDS-tiled pass
-        #   "layerwise"  (fused=False; SyncBatchNorm runs this one: its all-reduces sit between the reductions and the applies)
+        #                With SyncBatchNorm (round 6) the ranks' all-reduces are made by the library's hook between a producer's
+        #                float64 sums and their finalize (train_head.SyncHook, include/fear_train.h fear_train_sync_bind)
+        #   "layerwise"  (fused=False) one operator per layer and direction; SyncBatchNorm: all-reduces between the reductions and the applies
         #   "fused"      (fused=True) round 3's per-unit fused operators, the memory-saving form of "layerwise"
         if mode is None:
-            mode = "fused" if fused else ("layerwise" if (fused is False or sync_bn) else "block")
+            mode = "fused" if fused else ("layerwise" if fused is False else "block")
         if mode not in ("block", "layerwise", "fused"):
             raise ValueError(f"unknown mode {mode!r}")
-        if mode == "block" and sync_bn:
-            raise ValueError("mode='block' has no SyncBatchNorm hook; use mode='layerwise' with sync_bn=True")
+        if mode == "fused" and sync_bn:
+            raise ValueError("mode='fused' has no SyncBatchNorm form; use mode='block' (default) or 'layerwise' with sync_bn")
         self.mode = mode
         # block mode: expansions of up to this many input channels are never written where the library has the kernels for it
         # (FEAR_IRB_VIRTUAL_E, include/fear_train.h: the stride-2 blocks); 0 keeps every expansion saved
@@ -155,9 +157,10 @@ class FEARNetTrainHIP:
         self.fused = bool(fused)
         # two_streams: the BACKWARD of the template pass (a quarter of the search pass's work, the same launches) runs on a second
         # HIP stream next to the search pass's — the two are independent between the head and the final add of the shared
-        # parameters' gradients, and their small kernels fill each other's tails.  Each lane has its own workspace; SyncBatchNorm
-        # keeps one stream (its collectives must be issued in the same order on every rank).
-        self.two_streams = bool(two_streams) and not sync_bn
+        # parameters' gradients, and their small kernels fill each other's tails.  Each lane has its own workspace.  SyncBatchNorm:
+        # the layer-wise form keeps one stream; the block form keeps its streams — each is bound to a hook buffer of its own and
+        # the host issues the collectives of all of them in one order, the same on every rank (train_head.SyncHook).
+        self.two_streams = bool(two_streams) and (not sync_bn or mode == "block")
         self._side = None
         self._aux = None
         self._lane = 0
@@ -177,6 +180,7 @@ class FEARNetTrainHIP:
                                      device=device, momentum=momentum, eps=eps, coef_cls=coef_cls, coef_reg=coef_reg,
                                      sync_bn=sync_bn, group=group, fused=self.mode != "layerwise")
         self.sync = self.head.sync                 # SyncBatchNorm over the data-parallel group (config/backend/*.yaml: sync_bn)
+        self.hook = self.head.hook if self.mode == "block" else None      # block mode: the library's all-reduce hook (one per net: streams are bound once)
         self.last_contexts = None
         # the trunk runs twice per step (template, search): each pass writes its parameter gradients into one flat buffer
         # (kernel layouts, offsets below) and ONE add joins the two — not one add launch per parameter
@@ -217,7 +221,7 @@ class FEARNetTrainHIP:
     # ------------------------------------------------------------------ plumbing
     def _check(self, st: int) -> None:
         if st != 0:
-            raise TrainError(f"libfear_hip training operator failed with status {st}")
+            self.head._check(st)
 
     def _stream(self):
         import ctypes
@@ -546,9 +550,10 @@ class FEARNetTrainHIP:
     def _apply_running(self, ctx) -> None:
         """The deferred running-statistics updates of a `_features_forward_b(..., defer_running=True)` pass, on the current stream."""
         st = self._stream()
+        world = self.sync.world if self.sync is not None else 1      # (SyncBatchNorm: the statistics are those of all ranks' rows)
         for vec, rows, L in ctx[1]["pending"]:
             vec.record_stream(torch.cuda.current_stream(self.device))
-            self._check(self.lib.fear_bn_running_update(_p(vec), float(rows), _p(L.running_mean), _p(L.running_var), self.momentum, self.eps,
+            self._check(self.lib.fear_bn_running_update(_p(vec), float(rows) * world, _p(L.running_mean), _p(L.running_var), self.momentum, self.eps,
                                                         L.cout, st))
 
     def _features_backward_b(self, ctx, dfeat: torch.Tensor, gbuf: torch.Tensor, aux=None) -> None:
@@ -667,6 +672,20 @@ class FEARNetTrainHIP:
         if tuple(t.shape) != (B, 3, 128, 128) or tuple(s.shape) != (B, 3, 256, 256):
             raise ValueError("expected template (B,3,128,128) and search (B,3,256,256)")
         with torch.cuda.device(dev):
+            if self.two_streams and self._side is None:
+                self._side = torch.cuda.Stream(device=dev)
+                self.head.side_stream = self._side         # the head runs its two towers on the two streams as well
+            # SyncBatchNorm in block mode: the streams that carry BatchNorms are bound to the library's all-reduce hook for the step
+            # (the third stream has weight gradients only)
+            import contextlib
+            bound = self.hook.bound(torch.cuda.current_stream(dev), self._side if self.two_streams else None) if self.hook is not None else contextlib.nullcontext()
+            with bound:
+                out, grads = self._step_on_device(t, s, B, gt_reg, gt_cls, gt_weight)
+        return {"loss_cls": out["loss_cls"], "loss_reg": out["loss_reg"], "bbox": out["bbox"], "cls": out["cls"], "grads": grads}
+
+    def _step_on_device(self, t, s, B, gt_reg, gt_cls, gt_weight):
+        dev = self.device
+        if True:
             st = self._stream()
             ffwd = {"block": self._features_forward_b, "fused": self._features_forward_f, "layerwise": self._features_forward}[self.mode]
             fbwd = {"block": self._features_backward_b, "fused": self._features_backward_f, "layerwise": self._features_backward}[self.mode]
@@ -675,9 +694,6 @@ class FEARNetTrainHIP:
             gflat = (gall[: self._ptotal], gall[self._ptotal:])
             self._gcur = gflat[0]
             main = torch.cuda.current_stream(dev)
-            if self.two_streams and self._side is None:
-                self._side = torch.cuda.Stream(device=dev)
-                self.head.side_stream = self._side         # the head runs its two towers on the two streams as well
             side = self._side if self.two_streams else None
             marks = [] if self.phase_marks is not None else None      # (tools/train_prof.py: where the step's time goes)
 
@@ -765,11 +781,12 @@ class FEARNetTrainHIP:
                     grads[L.conv_key] = gw.reshape(L.cout, L.cin, 1, 1)
                 grads[L.bn_key + ".weight"] = self._gslot(gflat[0], L.bn_key + ".weight", L.cout)
                 grads[L.bn_key + ".bias"] = self._gslot(gflat[0], L.bn_key + ".bias", L.cout)
+            grads.seal()
             mark("trunk backward: sum of the two passes, gradient views")
             if marks is not None:
                 self.phase_marks = marks
             self.last_contexts = (zctx, xctx)          # saved activations of the two trunk passes (tests read the ReLU patterns)
-        return {"loss_cls": out["loss_cls"], "loss_reg": out["loss_reg"], "bbox": out["bbox"], "cls": out["cls"], "grads": grads}
+        return out, grads
 
     allreduce_gradients = staticmethod(BoxTowerTrainHIP.allreduce_gradients)
 

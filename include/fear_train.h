@@ -32,6 +32,7 @@ extern "C" {
 #define FEAR_TRAIN_ERR_SHAPE (-2)
 #define FEAR_TRAIN_ERR_HIP (-4)
 #define FEAR_TRAIN_ERR_WORKSPACE (-7)   /* workspace missing or too small */
+#define FEAR_TRAIN_ERR_SYNC (-8)        /* the SyncBatchNorm all-reduce callback failed, or its buffer is too small (fear_train_sync_bind) */
 
 size_t fear_train_workspace_bytes(long rows, int max_channels);
 
@@ -183,7 +184,7 @@ int fear_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
  * in registers by whichever kernel needs them (forward: statistics in the producing pass, normalisation on load in the consumer;
  * backward: the BatchNorm backward applied on load from the pair (gradient, raw tensor)); what is written is the raw conv outputs
  * e / d / p (saved for the backward) and, in the backward, two masked gradients in `scratch`.  Same arithmetic as the operators
- * above composed unit by unit (tests/test_train_head.py pins both against autograd).  One rank (no SyncBatchNorm hook). */
+ * above composed unit by unit (tests/test_train_head.py pins both against autograd).  SyncBatchNorm: fear_train_sync_bind below. */
 /* The expansion's backward without its raw output (e = x W1^T is linear in the block input: BatchNorm1's input gradient folds into
  * the two consumers' own algebra, a cin x cin matrix each — csrc/fear_train.hip BnbIn): chosen by the call where it pays (up to 32
  * input channels: the large maps); these flags force it wherever it applies (cexp % 16 == 0, cin <= 128) or forbid it. */
@@ -261,6 +262,32 @@ int fear_stem_train_forward(const float* x_nchw, const float* w, const float* ga
 int fear_stem_train_backward(const float* dy, const float* raw, const float* vec, const float* x_nchw, const float* gamma, float* dw,
                              float* dgamma, float* dbeta, long n, int H, int W, float* workspace, size_t ws_bytes, void* stream,
                              void* wgrad_stream);
+
+/* ---- SyncBatchNorm for the block-fused operators (round 6) -----------------------------------------------------------------------
+ * The reference's multi-GPU backends train with `sync_bn: True` (model_training/config/backend/2gpu.yaml:5, 4gpu.yaml:5 ->
+ * train/trainer.py:50-52).  In fear_irb_train_* / fear_pwbn_train_* / fear_stem_train_* / fear_sepbn_train_* a BatchNorm's two
+ * reductions sit INSIDE one call (producer -> float64 column sums -> finalize -> consumer), so the ranks' all-reduce is a hook:
+ * a stream is bound to a FearSync, and every BatchNorm finalize enqueued on that stream becomes
+ *     local float64 sums [2][C] -> sync.buf        (forward: sum y | sum y^2;  backward: sum g | sum g * xhat, with d gamma / d beta
+ *                                                    taken from the LOCAL sums — they are averaged with every other gradient)
+ *     sync.all_reduce(user, buf, 2 C, 0, stream)   the caller's collective (RCCL through torch.distributed in feartracker_amd/train_net.py),
+ *                                                    in place, ordered on `stream`; returns 0 on success
+ *     finalize from the summed buffer with count = local rows * sync.world
+ * (a virtual expansion's BatchNorm1 — statistics from the input's Gram matrix — all-reduces that fp32 matrix instead: is_f32 = 1).
+ * Every rank must enqueue the same sequence of operators with the same row counts (DDP's equal batches), and a FearSync serves ONE
+ * stream: two passes on two streams bind two of them (two buffers); their collectives then reach the communicator in the host's
+ * issue order, which is the same on every rank.  Streams without a binding run the one-rank form; with world = 1 the bound form gives
+ * the same numbers bit for bit.  Binding copies *sync; NULL unbinds.  At most 16 streams are bound at a time. */
+typedef int (*fear_allreduce_fn)(void* user, void* buf, long n, int is_f32, void* stream);
+typedef struct FearSync {
+    fear_allreduce_fn all_reduce;
+    void* user;
+    double* buf;                   /* device scratch of this binding alone, >= FEAR_SYNC_BUF_BYTES */
+    size_t buf_bytes;
+    int world;                     /* ranks of the group (>= 1) */
+} FearSync;
+#define FEAR_SYNC_BUF_BYTES 16384  /* 2 x 1024 channels x 8 bytes */
+int fear_train_sync_bind(void* stream, const FearSync* sync);
 
 /* SepConv (depthwise 3x3 + pointwise, both with bias) + BatchNorm + ReLU: the layer of the head's encoders and towers
  * (SepConv + BatchNorm2d + ReLU: model_training/model/blocks.py:97-101 MatrixMobile, :115-119 MobileCorrelation, :151-161 BoxTower's towers), one call per direction.  Kernel layouts: depthwise taps

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #ifndef KHDR
@@ -13,6 +14,9 @@
 #endif
 #include KHDR
 #include "../feartracker_amd/csrc/fear_e1pair.h"
+#ifdef FEAR_E1PAIR_REF
+#include FEAR_E1PAIR_REF        // round 5's kernel with its symbols renamed (tools/_kb/e1pair_r5.h, made by: git show <rev>:...fear_e1pair.h | sed ...)
+#endif
 
 using namespace fear;
 
@@ -314,22 +318,64 @@ static void bench_e1pair(int crops, int iters) {
     E1PairArgs a{};
     a.X = dev_rand((size_t)crops * hw * hw * 24, 2.f);
     a.Wpk = dev_rand(2 * G::WBLK, 0.2f);
+    const size_t ny = (size_t)crops * hw * hw * 24;
     float* y;
-    CK(hipMalloc(&y, (size_t)crops * hw * hw * 24 * sizeof(float)));
+    CK(hipMalloc(&y, ny * sizeof(float)));
     a.Y = y; a.H = hw; a.W = hw; a.tiles_x = hw / 16; a.tiles_y = hw / 16;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(e1pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const dim3 grid((unsigned)crops * 16);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(e1pair_kernel, grid, dim3(512), G::LDS_BYTES, 0, a);
-    CK(hipDeviceSynchronize());
-    CK(hipEventRecord(e0));
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(e1pair_kernel, grid, dim3(512), G::LDS_BYTES, 0, a);
-    CK(hipEventRecord(e1));
-    CK(hipEventSynchronize(e1));
-    float ms;
-    CK(hipEventElapsedTime(&ms, e0, e1));
-    printf("e1pair 24ch hw64 (E1P_ABL=%d)  %8.1f us  (LDS %d B)\n", E1P_ABL, 1e3 * ms / iters, G::LDS_BYTES);
+    std::vector<float> ref(ny), out(ny);
+#ifdef FEAR_E1PAIR_REF
+    std::vector<float> r5(ny);
+    {
+        E1PairR5Args b{};
+        b.X = a.X; b.Wpk = a.Wpk; b.Y = y; b.H = hw; b.W = hw; b.tiles_x = a.tiles_x; b.tiles_y = a.tiles_y;
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(e1pair_r5_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, E1PairR5Geom::LDS_BYTES));
+        const dim3 grid((unsigned)crops * 16);
+        for (int rep = 0; rep < 2; ++rep) {
+            for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(e1pair_r5_kernel, grid, dim3(512), E1PairR5Geom::LDS_BYTES, 0, b);
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(e1pair_r5_kernel, grid, dim3(512), E1PairR5Geom::LDS_BYTES, 0, b);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("e1pair round-5 kernel                                         %8.1f us\n", 1e3 * ms / iters);
+        }
+        CK(hipMemcpy(r5.data(), y, ny * sizeof(float), hipMemcpyDeviceToHost));
+    }
+#endif
+    // tiles per workgroup: 1 = one launch slot per tile (round 4's form), 8 = 512 workgroups at 256 crops
+    for (int rep = 0; rep < 2; ++rep)
+        for (int tpw : {1, 2, 4, 8, 16}) {
+            if ((crops * 16) % tpw) continue;
+            a.tpw = tpw;
+            const dim3 grid((unsigned)crops * 16 / tpw);
+            CK(hipMemset(y, 0xff, ny * sizeof(float)));
+            for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(e1pair_kernel, grid, dim3(512), G::LDS_BYTES, 0, a);
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(e1pair_kernel, grid, dim3(512), G::LDS_BYTES, 0, a);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            CK(hipMemcpy(out.data(), y, ny * sizeof(float), hipMemcpyDeviceToHost));
+            size_t bad = 0;
+            if (tpw == 1) {
+                ref = out;
+#ifdef FEAR_E1PAIR_REF
+                size_t b5 = 0;
+                for (size_t i = 0; i < ny; ++i) b5 += memcmp(&r5[i], &out[i], 4) != 0;
+                if (rep == 0) printf("   against the round-5 kernel: %s (%zu of %zu differ)\n", b5 ? "MISMATCH" : "bit-identical", b5, ny);
+#endif
+            }
+            else for (size_t i = 0; i < ny; ++i) bad += memcmp(&ref[i], &out[i], 4) != 0;
+            printf("e1pair 24ch hw64 (E1P_ABL=%d, E1P_SKEW=%d, E1P_NA=%d) tiles/workgroup %2d  %8.1f us  (LDS %d B)  %s\n", E1P_ABL, E1P_SKEW, E1P_NA, tpw, 1e3 * ms / iters,
+                   G::LDS_BYTES, tpw == 1 ? "" : bad ? "MISMATCH vs 1 tile/workgroup" : "bit-identical to 1 tile/workgroup");
+        }
 }
 
 static void bench_stem(int crops, int iters) {
@@ -379,6 +425,14 @@ int main(int argc, char** argv) {
     // the product's tile table (fear_engine.hip kFusedTile), in plan order
 #ifdef FEAR_E1PAIR_ONLY
     bench_e1pair(crops, iters);
+    return 0;
+#endif
+#ifdef FEAR_IR16_ONLY
+    printf("IR16_GS=%d IR16_D=%d\n", IR16_GS, IR16_D);
+    for (int rep = 0; rep < 2; ++rep) {
+        bench<112, 672, 112, 5, true>("ir16_112x672x112_k5", crops, iters);
+        bench<64, 384, 64, 5, true>("ir16_64x384x64_k5", crops, iters);
+    }
     return 0;
 #endif
     bench_stem(crops, iters);

@@ -20,6 +20,7 @@ python tools/pmc_to_traffic.py $O/fear_m_pmc_FETCH_SIZE/p_counter_collection.csv
 cp $O/train_trace/p_kernel_stats.csv $P/r${N}_train_kernel_stats.csv
 { grep -h "mode=\|ms  " $O/train_plain.err; python tools/train_traffic.py $O $O/train_trace 7 4; } > $P/r${N}_train_traffic.txt
 python tools/pmc_summary.py $O/sq_pass1 $O/sq_pass2 $O/sq_pass3 > $P/r${N}_sq_counters.txt
+python tools/pmc_summary.py --all $O/train_sq_pass1 $O/train_sq_pass2 $O/train_sq_pass3 > $P/r${N}_train_sq_counters.txt
 python -c "import json,sys; print(json.dumps(json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])['latency_batch1']))" $P/r${N}_bench.json > $P/r${N}_latency_batch1.json
 tail -1 $O/bench_force_dist.json > $P/r${N}_bench_force_dist_1gpu.json
 ls -la $P

@@ -43,6 +43,14 @@ for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU
   rocprofv3 --kernel-trace --pmc $set -d "$O/sq_pass$i" -o p --output-format csv -- \
     python "$R/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-other-math --no-pipelined --no-latency --no-fear-m --no-train > "$O/sq_pass$i.json" 2> "$O/sq_pass$i.err"
 done
+# ... and of the training step's (tools/pmc_summary.py --all -> profiles/rNN_train_sq_counters.txt)
+i=0
+for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32" \
+           "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" \
+           "SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $set -d "$O/train_sq_pass$i" -o p --output-format csv -- python "$R/tools/train_prof.py" 128 1 block > "$O/train_sq_pass$i.out" 2> "$O/train_sq_pass$i.err"
+done
 # the distributed code path (RCCL process group, barriers, fear_track_packed + all-gather) with the one rank a 1-GPU box has
 FEAR_BENCH_FORCE_DIST=1 python "$R/bench.py" --no-cpu-baseline --no-other-math > "$O/bench_force_dist.json" 2> "$O/bench_force_dist.err"
 tail -c 600 "$O/bench.json"
