@@ -2055,18 +2055,22 @@ static int track_impl(fear_handle* h, const float* search, const float* tmpl, co
             HIP_TRY(h, hipEventRecord(h->split_fork, s_main));               // inputs ready, the workspace free
             HIP_TRY(h, hipStreamWaitEvent(h->split_stream, h->split_fork, 0));
             st = run_plan(h, *p, nA, ext, s_main, 0, true);
-            if (st != FEAR_OK) return st;
-            Ext eb = ext;
-            eb.img = ext.img + (size_t)nA * 3 * hw * hw;
-            eb.tmpl = ext.tmpl + (size_t)nA * tz;
-            eb.tmpl_cls = ext.tmpl_cls ? ext.tmpl_cls + (size_t)nA * tz : nullptr;
-            eb.bbox_out = ext.bbox_out + (size_t)nA * bbox_stride;
-            eb.cls_out = ext.cls_out + (size_t)nA * cls_stride;
-            st = run_plan(h, *p, nB, eb, h->split_stream, (size_t)nA, true);
-            if (st != FEAR_OK) return st;
+            int st_b = FEAR_OK;
+            if (st == FEAR_OK) {
+                Ext eb = ext;
+                eb.img = ext.img + (size_t)nA * 3 * hw * hw;
+                eb.tmpl = ext.tmpl + (size_t)nA * tz;
+                eb.tmpl_cls = ext.tmpl_cls ? ext.tmpl_cls + (size_t)nA * tz : nullptr;
+                eb.bbox_out = ext.bbox_out + (size_t)nA * bbox_stride;
+                eb.cls_out = ext.cls_out + (size_t)nA * cls_stride;
+                st_b = run_plan(h, *p, nB, eb, h->split_stream, (size_t)nA, true);
+            }
+            // join even when a half failed: whatever it did enqueue on the handle's stream still uses the shared workspace, and a
+            // later call must not start before it has drained
             HIP_TRY(h, hipEventRecord(h->split_join, h->split_stream));      // the caller's stream continues once both halves are done
             HIP_TRY(h, hipStreamWaitEvent(s_main, h->split_join, 0));
             HIP_TRY(h, hipEventRecord(h->stream_switch, s_main));
+            if (st == FEAR_OK) st = st_b;
         } else {
             st = run_plan(h, *p, nb, ext, s_main);
         }

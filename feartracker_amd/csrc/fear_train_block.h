@@ -1319,6 +1319,22 @@ __global__ __launch_bounds__(256) void bn_running_update_kernel(const float* vec
     rv[c] = (float)((1.0 - momentum) * (double)rv[c] + momentum * unbiased);
 }
 
+// the same update for up to 64 BatchNorms in one launch (block = one BatchNorm): the deferred updates of a trunk pass were 47 launches
+struct BnRunMulti { const float* vec[64]; float* rm[64]; float* rv[64]; int C[64]; double count[64]; };
+__global__ __launch_bounds__(256) void bn_running_update_multi_kernel(BnRunMulti t, double momentum, double eps) {
+    const int e = blockIdx.x, C = t.C[e];
+    const float* vec = t.vec[e];
+    const double count = t.count[e];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const double mean = (double)vec[c], rs = (double)vec[C + c];
+        double var = 1.0 / (rs * rs) - eps;
+        if (var < 0.0) var = 0.0;
+        t.rm[e][c] = (float)((1.0 - momentum) * (double)t.rm[e][c] + momentum * mean);
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        t.rv[e][c] = (float)((1.0 - momentum) * (double)t.rv[e][c] + momentum * unbiased);
+    }
+}
+
 template <int KS, int S>
 void launch_dw_bwd_ks(const DwBwdArgs& a, int sq, bool bn1, dim3 grid, hipStream_t s) {
     if (sq == 8) {
@@ -1559,8 +1575,9 @@ int fear_irb_train_backward(const FearIrbBlock* b, const FearIrbSaved* sv, const
         g.X = dout; g.ldx = cout; g.bn = bn3; g.W = b->w_pwl; g.Y = g2; g.ldy = cexp; g.D = sv->d; g.ldd = cexp; g.dvec = sv->vec[1];
         g.partial = ws.col; g.M = (int)rows_out; g.K = cout; g.N = cexp;
         int blocks = 0;
+        // (checked before the launch that writes them: at most one partial row per 64 output rows)
+        if ((size_t)((rows_out + 63) / 64) * 2 * cexp * sizeof(double) > ws.col_bytes) return FEAR_TRAIN_ERR_WORKSPACE;
         launch_gemm_lds<2, 2, true>(g, s, &blocks);
-        if ((size_t)blocks * 2 * cexp * sizeof(double) > ws.col_bytes) return FEAR_TRAIN_ERR_WORKSPACE;
         finalize_backward(ws.col, blocks, cexp, (double)rows_out, b->gamma[1], sv->vec[1], gr->gamma[1], gr->beta[1], coef2, s);
     } else {
         PwBwdArgs a{};
@@ -1705,6 +1722,24 @@ int fear_bn_running_update(const float* vec, double count, float* running_mean, 
     if (C < 1 || !(count >= 1.0)) return FEAR_TRAIN_ERR_SHAPE;
     hipLaunchKernelGGL(bn_running_update_kernel, dim3((C + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), vec, running_mean,
                        running_var, C, count, momentum, eps);
+    LAUNCH_CHECK();
+    return FEAR_TRAIN_OK;
+}
+
+int fear_bn_running_update_multi(const FearBnRunning* items, int n, double momentum, double eps, void* stream) {
+    if (!items || n < 0) return FEAR_TRAIN_ERR_NULL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        BnRunMulti t{};
+        const int m = n - i0 < 64 ? n - i0 : 64;
+        for (int i = 0; i < m; ++i) {
+            const FearBnRunning& it = items[i0 + i];
+            if (!it.vec || !it.running_mean || !it.running_var) return FEAR_TRAIN_ERR_NULL;
+            if (it.C < 1 || !(it.count >= 1.0)) return FEAR_TRAIN_ERR_SHAPE;
+            t.vec[i] = it.vec; t.rm[i] = it.running_mean; t.rv[i] = it.running_var; t.C[i] = it.C; t.count[i] = it.count;
+        }
+        hipLaunchKernelGGL(bn_running_update_multi_kernel, dim3((unsigned)m), dim3(256), 0, s, t, momentum, eps);
+    }
     LAUNCH_CHECK();
     return FEAR_TRAIN_OK;
 }

@@ -70,6 +70,7 @@ TRAIN_SYMBOLS = {
     "fear_irb_train_forward": ([_P, _P, _P, _P, _i, _i, _i, _d, _d, _P, _sz, _P], _i),
     "fear_irb_train_backward": ([_P, _P, _P, _P, _P, _P, _P, _i, _i, _i, _P, _sz, _P, _P], _i),
     "fear_bn_running_update": ([_P, _d, _P, _P, _d, _d, _i, _P], _i),
+    "fear_bn_running_update_multi": ([_P, _i, _d, _d, _P], _i),
     "fear_pwbn_workspace_bytes": ([_l, _i, _i], _sz),
     "fear_pwbn_train_forward": ([_P, _i, _P, _P, _P, _P, _P, _P, _P, _i, _P, _l, _i, _i, _d, _d, _P, _sz, _P], _i),
     "fear_pwbn_train_backward": ([_P, _P, _P, _i, _P, _i, _P, _P, _P, _P, _P, _P, _l, _i, _i, _P, _sz, _P, _P], _i),
@@ -97,6 +98,10 @@ class FearIrbSaved(ctypes.Structure):
 
 class FearIrbGrads(ctypes.Structure):
     _fields_ = [("w_pw", _P), ("w_dw", _P), ("w_pwl", _P), ("gamma", _P * 3), ("beta", _P * 3)]
+
+
+class FearBnRunning(ctypes.Structure):
+    _fields_ = [("vec", _P), ("running_mean", _P), ("running_var", _P), ("C", _i), ("count", _d)]
 
 
 class FearSepLayer(ctypes.Structure):

@@ -32,7 +32,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
-from .train_head import (BoxTowerTrainHIP, FearIrbBlock, FearIrbGrads, FearIrbSaved, GradDict, SyncBN, TrainError, _p,
+from .train_head import (BoxTowerTrainHIP, FearBnRunning, FearIrbBlock, FearIrbGrads, FearIrbSaved, GradDict, SyncBN, TrainError, _p,
                          load_train_library)
 
 # (cin, cexp, cout, k, stride, expand, residual): fbnet_c stages[1:18]
@@ -165,7 +165,7 @@ class FEARNetTrainHIP:
         self._aux = None
         self._lane = 0
         self._ws_lanes = {}
-        self.timing = None        # a list: every pointwise weight-gradient launch is bracketed with events and appended (bench.py's roofline)
+        self.timing = None        # layerwise / fused modes: a list — every pointwise weight-gradient launch is bracketed with events and appended (no effect in block mode: its weight gradients are issued by the C side)
         sd = {k: torch.as_tensor(np.asarray(v)) if not isinstance(v, torch.Tensor) else v.detach().cpu() for k, v in state_dict.items()}
         dev = self.device
         self.stem = _ConvBN("stem", "stem", sd, dev, k=3, stride=2)
@@ -476,9 +476,14 @@ class FEARNetTrainHIP:
         lib = self.lib
         need, scratch = int(lib.fear_pwbn_workspace_bytes(B * (H // 2) ** 2, 28, 16)), 0
         h = H // 2
-        for d in self._irb_descriptors():
-            need = max(need, int(lib.fear_irb_workspace_bytes(ctypes.byref(d), B, h, h)))
-            scratch = max(scratch, int(lib.fear_irb_scratch_floats(ctypes.byref(d), B, h, h)))
+        for i, d in enumerate(self._irb_descriptors()):
+            nb, ns = int(lib.fear_irb_workspace_bytes(ctypes.byref(d), B, h, h)), int(lib.fear_irb_scratch_floats(ctypes.byref(d), B, h, h))
+            if nb == 0 or ns == 0:
+                # (the block operators index their tensors with 32-bit offsets: B * H * W * cexp * 4 bytes < 2^31, i.e. up to
+                #  341 pairs per rank on the 96-channel 128 x 128 map)
+                raise TrainError(f"trunk block {i} ({d.cin}->{d.cexp}->{d.cout} at {h}x{h}) does not support {B} crops per pass in mode='block'; "
+                                 "use a smaller per-rank batch or mode='layerwise'")
+            need, scratch = max(need, nb), max(scratch, ns)
             h //= d.stride
         need = max(need, int(lib.fear_pwbn_workspace_bytes(B * h * h, 112, 256)))
         ws, wsb = self._lane_workspace(need)
@@ -551,10 +556,14 @@ class FEARNetTrainHIP:
         """The deferred running-statistics updates of a `_features_forward_b(..., defer_running=True)` pass, on the current stream."""
         st = self._stream()
         world = self.sync.world if self.sync is not None else 1      # (SyncBatchNorm: the statistics are those of all ranks' rows)
-        for vec, rows, L in ctx[1]["pending"]:
+        pending = ctx[1]["pending"]
+        if not pending:
+            return
+        items = (FearBnRunning * len(pending))()
+        for it, (vec, rows, L) in zip(items, pending):
             vec.record_stream(torch.cuda.current_stream(self.device))
-            self._check(self.lib.fear_bn_running_update(_p(vec), float(rows) * world, _p(L.running_mean), _p(L.running_var), self.momentum, self.eps,
-                                                        L.cout, st))
+            it.vec, it.running_mean, it.running_var, it.C, it.count = vec.data_ptr(), L.running_mean.data_ptr(), L.running_var.data_ptr(), L.cout, float(rows) * world
+        self._check(self.lib.fear_bn_running_update_multi(items, len(pending), self.momentum, self.eps, st))      # one launch for all of them
 
     def _features_backward_b(self, ctx, dfeat: torch.Tensor, gbuf: torch.Tensor, aux=None) -> None:
         """`aux`: a torch stream for the pointwise weight gradients (they do not feed the chain of input gradients): every block

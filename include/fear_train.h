@@ -242,6 +242,9 @@ int fear_irb_train_backward(const FearIrbBlock* blk, const FearIrbSaved* saved, 
  * and torch's update order — template pass first — is restored by applying the search pass's update afterwards. */
 int fear_bn_running_update(const float* vec, double count, float* running_mean, float* running_var, double momentum, double eps, int C,
                            void* stream);
+/* ... for a whole pass's BatchNorms in ONE launch (n items; the search pass's 47 deferred updates were 47 launches) */
+typedef struct FearBnRunning { const float* vec; float* running_mean; float* running_var; int C; double count; } FearBnRunning;
+int fear_bn_running_update_multi(const FearBnRunning* items, int n, double momentum, double eps, void* stream);
 /* a lone pointwise conv + BatchNorm [+ ReLU] in the same style (the stem on its im2col rows, the AdjustLayer neck blocks.py:75-88):
  * raw = x w^T, vec as above, out = act(raw) materialised;  backward from dy = gradient w.r.t. out */
 size_t fear_pwbn_workspace_bytes(long M, int K, int N);

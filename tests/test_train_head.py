@@ -628,3 +628,32 @@ def test_training_step_at_the_config_size_is_finite_and_reproducible():
     np.testing.assert_allclose((h0 + h1).cpu().numpy(), full.cpu().numpy(), rtol=1e-12)
     yd = y[: 1 << 16].double()
     assert torch.isfinite(full).all() and float(full[N:].min()) > 0 and abs(float(yd.sum())) < 1e12
+
+
+
+@pytest.mark.gpu
+def test_deferred_running_statistics_in_one_launch_equal_the_per_batchnorm_updates():
+    """fear_bn_running_update_multi (the search pass's 47 deferred running-statistics updates as one launch) against
+    fear_bn_running_update item by item."""
+    import ctypes
+    from feartracker_amd.train_head import FearBnRunning, _p, load_train_library
+    lib = load_train_library()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(12)
+    Cs = [16, 96, 24, 672, 256, 112, 4] * 11          # 77 items: more than one launch's table of 64
+    vecs = [torch.cat([torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5, torch.zeros(2 * C)]).to(dev) for C in Cs]
+    rm = [torch.randn(C, generator=g).to(dev) for C in Cs]
+    rv = [(torch.rand(C, generator=g) + 0.5).to(dev) for C in Cs]
+    rm2, rv2 = [t.clone() for t in rm], [t.clone() for t in rv]
+    counts = [float(100 + 7 * i) for i in range(len(Cs))]
+    items = (FearBnRunning * len(Cs))()
+    for it, v, a, b, C, n in zip(items, vecs, rm, rv, Cs, counts):
+        it.vec, it.running_mean, it.running_var, it.C, it.count = v.data_ptr(), a.data_ptr(), b.data_ptr(), C, n
+    assert lib.fear_bn_running_update_multi(items, len(Cs), 0.1, 1e-5, None) == 0
+    for v, a, b, C, n in zip(vecs, rm2, rv2, Cs, counts):
+        assert lib.fear_bn_running_update(_p(v), n, _p(a), _p(b), 0.1, 1e-5, C, None) == 0
+    torch.cuda.synchronize()
+    for a, a2, b, b2 in zip(rm, rm2, rv, rv2):
+        assert torch.equal(a, a2) and torch.equal(b, b2)
+    items[3].count = 0.0
+    assert lib.fear_bn_running_update_multi(items, len(Cs), 0.1, 1e-5, None) == -2
