@@ -57,7 +57,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         # spill STORM (hundreds) in these, is what a compiler regression looks like
         known = next((cap for key, cap in KNOWN_SPILLS.items() if key in name), None)
         if known is not None and n <= known:
-            print(f"note: {name} spills {n} VGPRs to scratch (known, outside its loops)")
+            print(f"note: {name} spills {n} VGPRs to scratch (known and priced: KNOWN_SPILLS)")
         else:
             print(f"WARNING: {name} spills {n} VGPRs to scratch (hipcc scheduling is fragile around the fused kernels; "
                   "a spilling build is several times slower)")

@@ -27,8 +27,13 @@
 #ifndef E1P_NA
 #define E1P_NA 3       // of a thread's five prefetch loads, [0, E1P_NA) are in flight during block A and the rest during block B
 #endif
+#ifndef E1P_PERM
+#define E1P_PERM 1     // 1: a wave's 64 fill slots are dealt to its lanes with stride 9 (lane 8g + j takes slot 8 ((g + j) mod 8) + j) and the plane
+                       // pairs sit 48 B beyond a multiple of 256 B apart: every 8-lane store group then hits 8 different 16-byte bank slots
+                       // (conflict free; a wave's loads are still one contiguous 1 KB).  0: slots in lane order, pairs 32 B apart: 2-way
+#endif
 #ifndef E1P_SKEW
-#define E1P_SKEW 8     // floats between the plane PAIRS of the input tile beyond a multiple of 256 B (E1PairGeom::xb); 0 = round 4's layout (tools/kbench A/B)
+#define E1P_SKEW (E1P_PERM ? 12 : 8)     // floats between the plane PAIRS of the input tile beyond a multiple of 256 B (E1PairGeom::xb); 0 = round 4's layout (tools/kbench A/B)
 #endif
 
 namespace fear {
@@ -106,6 +111,13 @@ __device__ __forceinline__ void e1_project(f32x4 d4, f32x2 d2, const f32x4 (&wp)
     }
 }
 
+// which of its wave's 64 consecutive fill slots a thread takes (E1P_PERM)
+__device__ __forceinline__ int e1_fill_slot(int tid) {
+    if (!E1P_PERM) return tid;
+    const int l = tid & 63, g = l >> 3, j = l & 7;
+    return (tid & ~63) | (8 * ((g + j) & 7) + j);
+}
+
 // The input tile: six planes of 400 pixels, 2400 float4 slots over 512 threads (slots IT0 .. IT1 - 1 of each thread); a slot outside
 // the map reads zeros (the buffer load's out-of-range value: the depthwise's zero padding), all loads in flight together.
 // (Free functions on the register array, not lambdas: captured by reference in a closure that is called from two places, hipcc kept
@@ -121,7 +133,7 @@ __device__ __forceinline__ void e1_issue_loads(const E1PairArgs& a, unsigned tix
     const int ox0 = (tile % a.tiles_x) * T, oy0 = (tile / a.tiles_x) * T;
     const float* Xc = a.X + crop * a.H * a.W * C;
     const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Xc), 0, a.H * a.W * C * 4, 0x00020000);
-    int t = tid;
+    int t = e1_fill_slot(tid);
     asm volatile("" : "+v"(t));
 #pragma unroll
     for (int it = IT0; it < IT1; ++it) {
@@ -137,7 +149,7 @@ __device__ __forceinline__ void e1_issue_loads(const E1PairArgs& a, unsigned tix
 template <int IT0, int IT1>
 __device__ __forceinline__ void e1_commit_tile(float* Xt, int tid, const f32x4 (&xv)[E1PairGeom::NIT]) {
     using G = E1PairGeom;
-    int t = tid;
+    int t = e1_fill_slot(tid);
     asm volatile("" : "+v"(t));
 #pragma unroll
     for (int it = IT0; it < IT1; ++it) {

@@ -47,8 +47,18 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs a) {
     constexpr int WQ = BN * 4;                 // float4s of a W stage
     constexpr int XL = MT;                     // X float4s per thread and stage
     constexpr int WL = (WQ + 255) / 256;       // W float4s per thread and stage
+    // W stage: [buffer][k quad][column] float4s (a fragment = one ds_read_b128) — or, for a K-major weight matrix (WKN), the rows as
+    // they are loaded: [buffer][k][BN + 4] floats (round 6).  The K-major form used to be transposed on its way into LDS with four
+    // ds_write_b32 per float4, 64 B between consecutive lanes: a 16-way bank conflict on every store, ~900 LDS cycles per k-group
+    // against the ~900 cycles of MFMAs a SIMD has per k-group — those launches were LDS-bound (conflict share 0.76, MFMA pipe 0.30:
+    // profiles/r06_train_sq_counters.txt).  Now its float4s go in with one conflict-free ds_write_b128 and a fragment is four
+    // ds_read_b32 (lane group lk reads rows 4 lk .. 4 lk + 3; the row pitch BN + 4 puts the two lane groups of a 32-lane read on
+    // disjoint banks).
+    constexpr int WTP = BN + 4;                // floats per k row of the K-major stage
     __shared__ f32x4 Xs[2][4][BM];             // [buffer][k quad][row]
-    __shared__ f32x4 Ws[2][4][BN];             // [buffer][k quad][column]
+    __shared__ f32x4 Wraw[2 * 4 * WTP];        // >= 2 x 4 x BN float4s either way
+    f32x4 (*Ws)[4][BN] = reinterpret_cast<f32x4 (*)[4][BN]>(Wraw);
+    float (*Wt)[16][WTP] = reinterpret_cast<float (*)[16][WTP]>(Wraw);
     __shared__ double red[EPI ? 4 : 1][2][EPI ? BN : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
@@ -59,7 +69,13 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs a) {
     const bool bmask = XT == 2 && a.bn.mask_a != nullptr;
 
     // ---- staging registers: thread t stages k quad t & 3 of rows (t >> 2) + 64 j; the per-channel vectors of the prologue travel
-    //      with the stage (requested with its loads, used when it is committed)
+    //      with the stage (requested with its loads, used when it is committed).
+    //      (The four quads of a row sit in planes a multiple of 128 B apart, so the eight lanes of a ds_write_b128 service group —
+    //      two rows x four quads — meet 4-way on the banks: the 0.35 conflict share of the forward GEMMs in
+    //      profiles/r06_train_sq_counters.txt.  Dealing eight consecutive lanes eight consecutive rows of ONE quad makes the stores
+    //      conflict free and was measured SLOWER, 84.7 -> 90.4 us for 32 768 x 672 -> 112 with statistics: a quad of lanes then
+    //      loads 16 bytes from each of four rows instead of 64 contiguous bytes, and the global side costs more than the LDS side
+    //      gains — tools/gemm_ab.py, profiles/r06_gemm_ab.txt.)
     f32x4 xr[XL], er[XT == 2 ? XL : 1], wr[WL], pv[XT == 2 ? 6 : (XT == 1 || XT == 3 ? 2 : 1)];
     const int kq = tid & 3, row_t = tid >> 2;
     bool x_ok[XL];
@@ -137,8 +153,7 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs a) {
             if (idx < WQ) {
                 if (WKN) {
                     const int kk = idx / (BN / 4), n4 = idx - kk * (BN / 4);
-                    float* dst = reinterpret_cast<float*>(&Ws[buf][kk >> 2][4 * n4]) + (kk & 3);      // column 4 n4 + c, component kk & 3
-                    dst[0] = wr[j].x; dst[4] = wr[j].y; dst[8] = wr[j].z; dst[12] = wr[j].w;
+                    *reinterpret_cast<f32x4*>(&Wt[buf][kk][4 * n4]) = wr[j];
                 } else {
                     Ws[buf][kq][idx >> 2] = wr[j];
                 }
@@ -163,7 +178,14 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs a) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) xf[mt] = Xs[buf][lk][wave * 16 * MT + mt * 16 + li];
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) wf[nt] = Ws[buf][lk][nt * 16 + li];
+        for (int nt = 0; nt < NTW; ++nt) {
+            if (WKN) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wf[nt][i] = Wt[buf][4 * lk + i][nt * 16 + li];
+            } else {
+                wf[nt] = Ws[buf][lk][nt * 16 + li];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll

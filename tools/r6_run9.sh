@@ -1,0 +1,10 @@
+#!/bin/bash
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r6i
+rm -rf "$O"; mkdir -p "$O"
+cd "$R"
+timeout 1200 python -m pytest tests/test_train_block.py tests/test_train_head.py tests/test_train_syncbn.py -m gpu -x -q > "$O/gputests.txt" 2>&1
+echo "pytest rc $?" >> "$O/gputests.txt"
+grep -n "passed\|failed\|FAILED\|rc \|Error" "$O/gputests.txt" | head
+for i in 1 2 3; do python tools/train_prof.py 128 8 block 2>&1 | grep "mode="; done
