@@ -61,13 +61,35 @@ ALL_CASES = [(c, b, h, 0) for c, b, h in CASES] + LIN_CASES
 @pytest.mark.parametrize("cfg,B,H,flags", ALL_CASES,
                          ids=[f"{c[0]}x{c[1]}x{c[2]}k{c[3]}s{c[4]}_b{b}h{h}" + {0: "", 1: "_lin", 2: "_nolin", 4: "_virtual", 8: "_fusew3"}[f] for c, b, h, f in ALL_CASES])
 def test_irb_block_forward_backward_vs_autograd(cfg, B, H, flags):
+    _irb_case(cfg, B, H, flags, biased=False)
+
+
+BIASED_CASES = [((16, 96, 24, 3, 2, 1, 0), 3, 32, 4), ((24, 144, 32, 5, 2, 1, 0), 2, 32, 4), ((32, 192, 64, 5, 2, 1, 0), 2, 32, 4),
+                ((32, 192, 32, 5, 1, 1, 1), 2, 16, 0), ((16, 96, 24, 3, 2, 1, 0), 3, 32, 1)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,B,H,flags", BIASED_CASES, ids=[f"{c[0]}x{c[1]}x{c[2]}k{c[3]}s{c[4]}_flags{f}" for c, b, h, f in BIASED_CASES])
+def test_irb_block_on_biased_correlated_inputs(cfg, B, H, flags):
+    """a virtual expansion's BatchNorm1 variance is w^T G w / M - mean^2 with G = x^T x accumulated in fp32; the cases
+    above feed zero-mean uncorrelated inputs, the benign case.  Real block inputs are post-ReLU / residual: here every channel is
+    relu(noise) + 3 plus a component shared by all channels (mean ~ 4 x the spread, channels correlated at 0.5), on the virtual
+    blocks, an E-free one and a plain one — the same 2e-4 against float64 autograd, running statistics included."""
+    _irb_case(cfg, B, H, flags, biased=True)
+
+
+def _irb_case(cfg, B, H, flags, biased):
     from feartracker_amd.train_head import FearIrbBlock, FearIrbGrads, FearIrbSaved, _p, load_train_library
     lib = load_train_library()
     dev = torch.device("cuda:0")
     cin, cexp, cout, k, stride, expand, residual = cfg
     g = torch.Generator().manual_seed(100 + cin + cexp + k + stride + H)
     Ho = H // stride
-    x = torch.randn(B, cin, H, H, generator=g, dtype=torch.float64, requires_grad=True)
+    x = torch.randn(B, cin, H, H, generator=g, dtype=torch.float64)
+    if biased:
+        shared = torch.randn(B, 1, H, H, generator=g, dtype=torch.float64)
+        x = (torch.relu(x) * 0.7 + shared * 0.7 + 3.0)
+    x.requires_grad_(True)
     p = {"w_dw": torch.randn(k * k, cexp, generator=g, dtype=torch.float64) * (2.0 / (k * k)) ** 0.5,
          "w_pwl": torch.randn(cout, cexp, generator=g, dtype=torch.float64) * (2.0 / cexp) ** 0.5}
     if expand:
