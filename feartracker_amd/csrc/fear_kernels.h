@@ -22,6 +22,9 @@
 #ifndef IR16_D
 #define IR16_D 4       // LDS read-ahead of ir16_interval, in tap steps
 #endif
+#ifndef IR16H_D
+#define IR16H_D 4      // LDS read-ahead of ir16h_fused_kernel's depthwise, in tap steps (two reads per step and channel half)
+#endif
 #ifndef FEAR_V4_GS
 #define FEAR_V4_GS 2      // tap steps per scheduling group of ir_tile_v4_kernel
 #endif
@@ -2566,7 +2569,17 @@ __global__ __launch_bounds__(512) void ir16h_fused_kernel(Ir2Args a) {
     const float* Xc = a.X + crop * 256 * a.ldx;
     const int y0 = wave * 2;
 
-    for (int i = tid * 4; i < 2 * EBUF; i += 512 * 4) *reinterpret_cast<f32x4*>(lds + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // the tile's zero ring (= the convolution's padding): the P rows above and below the map, the P gutter columns of every row and
+    // the tail — 106 of the 362 pixel slots at k = 5.  The 256 interior pixels are written by every chunk before they are read
+    // (all 32 channels of a chunk: padded channels carry zero weights), so they are not cleared: the full clear was 14 LDS stores
+    // per thread at the head of every launch, 5 us of an 83 us workgroup in the bf16 mode.
+    constexpr int NPE = (S + 2 * P) * PW + P, ES4 = ES / 4;
+    for (int i = tid; i < 2 * NPE * ES4; i += 512) {
+        const int b = i / (NPE * ES4), r = i - b * (NPE * ES4);
+        const int pe = r / ES4, row = pe / PW, col = pe - row * PW;
+        if (row >= P && row < P + S && col >= P) continue;          // interior
+        *reinterpret_cast<f32x4*>(lds + b * EBUF + r * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 
     // activation fragments (hi / lo halves) of this wave's two pixel rows, resident for every chunk
     V8 xhi[EXPAND ? 2 : 1][EXPAND ? KG : 1], xlo[EXPAND ? 2 : 1][EXPAND ? KG : 1];
@@ -2655,6 +2668,7 @@ __global__ __launch_bounds__(512) void ir16h_fused_kernel(Ir2Args a) {
                 const V8 wf = *reinterpret_cast<const V8*>(wa + (nt * KG + kg) * 256 + lane * 4);
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
+                    if (FEAR_ABL & 8) { acc[mt][nt].x += (float)wf[0]; continue; }
                     acc[mt][nt] = MX::mma(wf, xhi[mt][kg], xlo[mt][kg], acc[mt][nt]);
                 }
             }
@@ -2679,43 +2693,103 @@ __global__ __launch_bounds__(512) void ir16h_fused_kernel(Ir2Args a) {
         const float* E = Ebuf + (c & 1) * EBUF;
         const float* wb = WB + (c & 1) * BP;
         const float* wd = wb + NTP * 256 + lk * 8;
-        // Both output rows of a lane are carried in ONE 8-wide accumulator per channel half ({row0 x4, row1 x4}):
-        // an input row iy feeds row 0 with tap row iy and row 1 with tap row iy-1, i.e. one 8-wide FMA with the
-        // activation duplicated.  (Written as two float4 chains, hipcc computes the chains in two passes and spills
-        // every LDS value in between: ~500 VGPRs of scratch traffic.)
-        f32x8 d8[2];
+        f32x4 d0[2], d1[2];
+        if constexpr (MM == 2 && EXPAND) {      // (the head's SepConvs carry 16 output tiles of accumulators: no room for the rings)
+            // The depthwise as ir16_interval runs it (round 6): a chain of KS (KS + 1) tap steps (kx outer, input row inner: the weight of
+            // (iy, kx) feeds row 0 now and row 1 in the next step), both channel halves of the lane side by side, the two LDS reads of a
+            // step and half — activation and tap — issued IR16H_D steps ahead of the packed FMAs that consume them, sched_barrier(0)
+            // after every step so that hipcc keeps the order.  Round 2's form (an 8-wide accumulator per half, hipcc's own schedule:
+            // read -> wait -> FMAs, tap weights re-read per column) ran the 112 -> 672 -> 112 block at 177 us per 512 crops against
+            // 28 us of packed FMAs and ~60 us of LDS reads: latency-bound at two waves per SIMD.  Same products in the same
+            // order: the block's output is the same bits.
+            constexpr int NS = KS * (KS + 1), D = IR16H_D;
+            static_assert(NS >= D, "read-ahead");
+            f32x4 wprev[2];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const f32x4 bd = *reinterpret_cast<const f32x4*>(wd + KS * KS * 32 + h * 4);
-            d8[h] = __builtin_shufflevector(bd, bd, 0, 1, 2, 3, 4, 5, 6, 7);
-        }
-        const float* e0 = E + (y0 * PW + li) * ES + lk * 4;
-        const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // column-outer; the two channel halves are two independent 8-wide chains interleaved for ILP
+            for (int h = 0; h < 2; ++h) {
+                d0[h] = *reinterpret_cast<const f32x4*>(wd + KS * KS * 32 + h * 4);
+                d1[h] = d0[h];
+                wprev[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            const float* e0 = E + (y0 * PW + li) * ES + lk * 4;
+            f32x4 ev[D][2], wv[D][2];
 #pragma unroll
-        for (int kx = 0; kx < KS; ++kx) {
-            f32x4 w[2][KS];
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int ky = 0; ky < KS; ++ky) w[h][ky] = *reinterpret_cast<const f32x4*>(wd + (ky * KS + kx) * 32 + h * 4);
-#pragma unroll
-            for (int iy = 0; iy < KS + 1; ++iy) {
+            for (int t = 0; t < D; ++t) {
+                const int kx = t / (KS + 1), iy = t % (KS + 1);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(e0 + (iy * PW + kx) * ES + h * 16);
-                    const f32x8 v8 = __builtin_shufflevector(v, v, 0, 1, 2, 3, 4, 5, 6, 7);
-                    const f32x8 w8 = __builtin_shufflevector(iy < KS ? w[h][iy < KS ? iy : 0] : zero4,
-                                                             iy >= 1 ? w[h][iy >= 1 ? iy - 1 : 0] : zero4, 0, 1, 2, 3, 4, 5, 6, 7);
-                    d8[h] += v8 * w8;
+                    ev[t][h] = *reinterpret_cast<const f32x4*>(e0 + (iy * PW + kx) * ES + h * 16);
+                    if (iy < KS) wv[t][h] = *reinterpret_cast<const f32x4*>(wd + (iy * KS + kx) * 32 + h * 4);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+                const int iy = t % (KS + 1);
+                f32x4 e[2], w[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    e[h] = ev[t % D][h];
+                    w[h] = wv[t % D][h];
+                    if (t + D < NS && !(FEAR_ABL & 4)) {
+                        const int kx2 = (t + D) / (KS + 1), iy2 = (t + D) % (KS + 1);
+                        ev[t % D][h] = *reinterpret_cast<const f32x4*>(e0 + (iy2 * PW + kx2) * ES + h * 16);
+                        if (iy2 < KS) wv[t % D][h] = *reinterpret_cast<const f32x4*>(wd + (iy2 * KS + kx2) * 32 + h * 4);
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (FEAR_ABL & 32) { d0[h].x += e[h].x + w[h].x; continue; }
+                    if (iy < KS) pk_fma4(d0[h], e[h], w[h]);
+                    if (iy >= 1) pk_fma4(d1[h], e[h], wprev[h]);
+                    wprev[h] = w[h];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_nop 7" : "+v"(d0[0]), "+v"(d0[1]), "+v"(d1[0]), "+v"(d1[1]));      // (inline-asm FMA results feed conversions / MFMAs: pk_fma_settle)
+        } else {
+            // (the fp16-split mode keeps round 2's form: with the lo halves of every operand resident it sits at 254 registers, and the
+            //  read-ahead rings of the pipelined form cost it 3 % — 147.0 k -> 143.0 k crops/s on FEAR-XS, same box)
+            // Both output rows of a lane are carried in ONE 8-wide accumulator per channel half ({row0 x4, row1 x4}):
+            // an input row iy feeds row 0 with tap row iy and row 1 with tap row iy-1, i.e. one 8-wide FMA with the
+            // activation duplicated.  (Written as two float4 chains, hipcc computes the chains in two passes and spills
+            // every LDS value in between: ~500 VGPRs of scratch traffic.)
+            f32x8 d8[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 bd = *reinterpret_cast<const f32x4*>(wd + KS * KS * 32 + h * 4);
+                d8[h] = __builtin_shufflevector(bd, bd, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+            const float* e0 = E + (y0 * PW + li) * ES + lk * 4;
+            const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // column-outer; the two channel halves are two independent 8-wide chains interleaved for ILP
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+                f32x4 w[2][KS];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int ky = 0; ky < KS; ++ky) w[h][ky] = *reinterpret_cast<const f32x4*>(wd + (ky * KS + kx) * 32 + h * 4);
+#pragma unroll
+                for (int iy = 0; iy < KS + 1; ++iy) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(e0 + (iy * PW + kx) * ES + h * 16);
+                        const f32x8 v8 = __builtin_shufflevector(v, v, 0, 1, 2, 3, 4, 5, 6, 7);
+                        const f32x8 w8 = __builtin_shufflevector(iy < KS ? w[h][iy < KS ? iy : 0] : zero4,
+                                                                 iy >= 1 ? w[h][iy >= 1 ? iy - 1 : 0] : zero4, 0, 1, 2, 3, 4, 5, 6, 7);
+                        d8[h] += v8 * w8;
+                    }
+                }
+            }
+            d0[0] = __builtin_shufflevector(d8[0], d8[0], 0, 1, 2, 3); d1[0] = __builtin_shufflevector(d8[0], d8[0], 4, 5, 6, 7);
+            d0[1] = __builtin_shufflevector(d8[1], d8[1], 0, 1, 2, 3); d1[1] = __builtin_shufflevector(d8[1], d8[1], 4, 5, 6, 7);
         }
         V8 dhi[2], dlo[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            f32x4 q0 = r == 0 ? __builtin_shufflevector(d8[0], d8[0], 0, 1, 2, 3) : __builtin_shufflevector(d8[0], d8[0], 4, 5, 6, 7);
-            f32x4 q1 = r == 0 ? __builtin_shufflevector(d8[1], d8[1], 0, 1, 2, 3) : __builtin_shufflevector(d8[1], d8[1], 4, 5, 6, 7);
+            f32x4 q0 = r == 0 ? d0[0] : d1[0];
+            f32x4 q1 = r == 0 ? d0[1] : d1[1];
             if (a.relu_dw) {
                 q0.x = fmaxf(q0.x, 0.f); q0.y = fmaxf(q0.y, 0.f); q0.z = fmaxf(q0.z, 0.f); q0.w = fmaxf(q0.w, 0.f);
                 q1.x = fmaxf(q1.x, 0.f); q1.y = fmaxf(q1.y, 0.f); q1.z = fmaxf(q1.z, 0.f); q1.w = fmaxf(q1.w, 0.f);
@@ -2727,6 +2801,7 @@ __global__ __launch_bounds__(512) void ir16h_fused_kernel(Ir2Args a) {
             const V8 wp = *reinterpret_cast<const V8*>(wb + nt * 256 + lane * 4);
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
+                if (FEAR_ABL & 16) { accp[r][nt].x += (float)wp[0] + (float)dhi[r][0]; continue; }
                 accp[r][nt] = MX::mma(wp, dhi[r], dlo[r], accp[r][nt]);
             }
         }

@@ -427,6 +427,24 @@ int main(int argc, char** argv) {
     bench_e1pair(crops, iters);
     return 0;
 #endif
+#ifdef FEAR_IR16H_ONLY
+    // the bf16 matrix-pipe form of the two heaviest stride-16 blocks (FEAR-M's stage; 512 crops = configs[3])
+    for (int rep = 0; rep < 2; ++rep) {
+        {
+            using G = IrHGeom<112, 672, 112, 5, true>;
+            Ir2Args a = make_args<112, 112>(crops, (size_t)G::NCHUNK * (G::AP + G::BP));
+            const double us = time_kernel(ir16h_fused_kernel<112, 672, 112, 5, true, 2>, G::LDS_BYTES, crops, iters, a);
+            printf("ir16h_112x672x112_k5 bf16 (FEAR_ABL=%d, IR16H_D=%d)  %8.1f us per %d crops\n", FEAR_ABL, IR16H_D, us, crops);
+        }
+        {
+            using G = IrHGeom<64, 384, 64, 5, true>;
+            Ir2Args a = make_args<64, 64>(crops, (size_t)G::NCHUNK * (G::AP + G::BP));
+            const double us = time_kernel(ir16h_fused_kernel<64, 384, 64, 5, true, 2>, G::LDS_BYTES, crops, iters, a);
+            printf("ir16h_64x384x64_k5   bf16 (FEAR_ABL=%d, IR16H_D=%d)  %8.1f us per %d crops\n", FEAR_ABL, IR16H_D, us, crops);
+        }
+    }
+    return 0;
+#endif
 #ifdef FEAR_IR16_ONLY
     printf("IR16_GS=%d IR16_D=%d\n", IR16_GS, IR16_D);
     for (int rep = 0; rep < 2; ++rep) {
