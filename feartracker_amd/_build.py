@@ -12,7 +12,7 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(PKG_DIR, "csrc", "fear_engine.hip")
 SRC_TRAIN = os.path.join(PKG_DIR, "csrc", "fear_train.hip")       # head training-step operators, #included by fear_engine.hip
-DEPS = [SRC, SRC_TRAIN, os.path.join(PKG_DIR, "csrc", "fear_train_block.h"), os.path.join(PKG_DIR, "csrc", "fear_train_gemm.h"),
+DEPS = [SRC, SRC_TRAIN, os.path.join(PKG_DIR, "csrc", "fear_chain32.h"), os.path.join(PKG_DIR, "csrc", "fear_train_block.h"), os.path.join(PKG_DIR, "csrc", "fear_train_gemm.h"),
         os.path.join(PKG_DIR, "csrc", "fear_kernels.h"), os.path.join(PKG_DIR, "csrc", "fear_headchain.h"), os.path.join(PKG_DIR, "csrc", "fear_headchain_b.h"), os.path.join(PKG_DIR, "csrc", "fear_e1pair.h"),
         os.path.join(os.path.dirname(PKG_DIR), "include", "fear_hip.h"),
         os.path.join(os.path.dirname(PKG_DIR), "include", "fear_train.h"),

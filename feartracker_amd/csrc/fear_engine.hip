@@ -25,6 +25,7 @@
 #include "fear_headchain.h"
 #include "fear_headchain_b.h"
 #include "fear_e1pair.h"
+#include "fear_chain32.h"
 #ifndef FEAR_E1PAIR_TPW_MAX
 #define FEAR_E1PAIR_TPW_MAX 1      // e1pair_kernel: at most this many consecutive tiles per workgroup (more measured no faster: fear_e1pair.h)
 #endif
@@ -100,7 +101,7 @@ struct Conv {
     bool is_pw() const { return groups == 1 && k == 1; }
 };
 
-enum OpType { OP_STEM, OP_PW, OP_DW, OP_CORR, OP_PW_SMALL, OP_IR16, OP_IRTILE, OP_CHAIN16, OP_HEADCHAIN, OP_E1PAIR };
+enum OpType { OP_STEM, OP_PW, OP_DW, OP_CORR, OP_PW_SMALL, OP_IR16, OP_IRTILE, OP_CHAIN16, OP_HEADCHAIN, OP_E1PAIR, OP_CHAIN32 };
 
 struct Op {
     OpType type;
@@ -182,6 +183,7 @@ struct fear_handle {
     int tile_v4 = 1;       // FEAR_OPT_TILE_V4: 1 = phase-overlapped tile kernel for the blocks of kFusedTileV4 (throughput plan)
     int chain = 1;         // 1: run the stride-16 trunk stage as one register-resident chain kernel (fp32 mode)
     int bf16_store = 1;    // FEAR_OPT_BF16_STORE: math 2 keeps the activations of the trunk's HBM-bound front in bf16 between kernels
+    int chain32 = 1;       // FEAR_OPT_CHAIN32: 1 = the 32 x 32 trunk stage (four blocks) as one register-resident chain kernel (chain32_kernel; fp32 mode, throughput plan)
     int e1_pair = 1;       // FEAR_OPT_E1_PAIR: 1 = two consecutive 24-channel e1 blocks as one launch (e1pair_kernel; fp32 mode, throughput plan)
     int head_chain = 1;    // FEAR_OPT_HEAD_CHAIN: 1 = the whole BoxTower as one launch (headchain_kernel; fp32 mode, throughput plan)
     int small_pass = 96;   // passes of at most this many crops run the small-batch plan (FEAR_OPT_SMALL_PASS; 0: never);
@@ -676,6 +678,13 @@ auto* const kChainXSKernel =
 constexpr int kChainXSLds =
     Chain16Lds<5, Ir2Geom<112, 672, 112, 5, true>::AP, Ir2Geom<112, 672, 112, 5, true>::BP>::FLOATS * 4;
 
+// The 32 x 32 trunk stage of FEAR-XS (fbnet_c stage 3 + the stride-2 block that opens stage 4) as one register-resident chain
+// kernel (fear_chain32.h).
+struct Chain32Shape { int cin, cexp, cout, ks, stride, res; };
+const Chain32Shape kChain32XS[4] = {{32, 96, 32, 5, 1, 1}, {32, 192, 32, 5, 1, 1}, {32, 192, 32, 3, 1, 1}, {32, 192, 64, 5, 2, 0}};
+auto* const kChain32XSKernel = chain32_kernel<C32Blk<32, 96, 32, 5, 1, true>, C32Blk<32, 192, 32, 5, 1, true>,
+                                              C32Blk<32, 192, 32, 3, 1, true>, C32Blk<32, 192, 64, 5, 2, false>>;
+
 // the whole BoxTower as one launch (fear_headchain.h): 3x3 SepConvs, 256 channels, 64 template positions
 auto* const kHeadChainKernel = headchain_kernel<3>;
 using HeadChainG = HeadChainGeom<3>;
@@ -1011,6 +1020,51 @@ int build_plan_uncached(fear_handle* h, int hw, bool with_head, int mode, Plan**
                     cur = o;
                     bi += 8;
                     break;      // the neck is consumed: continue with the head
+                }
+            }
+        }
+        // ---- the whole 32 x 32 stage (three blocks + the stride-2 block down to 16 x 16) as one chain kernel (fp32, search branch)
+        if (h->fuse && h->chain32 && !h->math && !small && with_head && b.kind == FEARW_IR && cur.H == 32 && cur.W == 32 && cur.off == 0 &&
+            bi + 3 < h->blocks.size()) {
+            bool match = cur.C == kChain32XS[0].cin;
+            for (int j = 0; j < 4 && match; ++j) {
+                const FearwBlock& bj = h->blocks[bi + j];
+                if (bj.kind != FEARW_IR || bj.conv[0] < 0) { match = false; break; }
+                const Conv& e = h->convs[bj.conv[0]];
+                const Conv& d = h->convs[bj.conv[1]];
+                const Conv& p = h->convs[bj.conv[2]];
+                const Chain32Shape& cs = kChain32XS[j];
+                match = e.cin_g == cs.cin && d.cout == cs.cexp && p.cout == cs.cout && d.k == cs.ks && d.stride == cs.stride &&
+                        (int)bj.residual == cs.res && e.has_bias && p.has_bias && e.relu && d.relu && !p.relu;
+            }
+            if (match) {
+                Op op{};
+                op.type = OP_CHAIN32;
+                bool ok = true;
+                double fl = 0;
+                for (int j = 0; j < 4 && ok; ++j) {
+                    const FearwBlock& bj = h->blocks[bi + j];
+                    ok = pack_fused16(h, bj.conv[0], bj.conv[1], bj.conv[2], &op.chain_pk[j]) == FEAR_OK;
+                    op.chain_cp[j] = bj.conv[2];
+                    const Chain32Shape& cs = kChain32XS[j];
+                    const double po = 1024.0 / (cs.stride * cs.stride);
+                    fl += 2.0 * (1024.0 * cs.cin * cs.cexp + po * cs.ks * cs.ks * cs.cexp + po * cs.cexp * cs.cout);
+                }
+                if (ok) {
+                    op.in_buf = cur.buf; op.in_ld = cur.ld; op.in_off = 0;
+                    op.H = 32; op.W = 32; op.Ho = 16; op.Wo = 16; op.C = kChain32XS[0].cin; op.N = kChain32XS[3].cout;
+                    T o;
+                    o.buf = pool.acquire(); o.ld = op.N; o.off = 0; o.C = op.N; o.H = 16; o.W = 16;
+                    op.out_buf = o.buf; op.out_ld = o.ld;
+                    snprintf(op.name, sizeof(op.name), "chain32_4blocks_%dx%d_hw32", op.C, op.N);
+                    op.flops = fl;
+                    op.bytes = 4.0 * (1024.0 * op.C + 256.0 * op.N);
+                    ops.push_back(op);
+                    track(o);
+                    pool.release(cur.buf);
+                    cur = o;
+                    bi += 3;        // four blocks consumed (the loop adds the fourth)
+                    continue;
                 }
             }
         }
@@ -1497,6 +1551,8 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kSep16CorrLds));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kChainXSKernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kChainXSLds));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kChain32XSKernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, C32Geom::LDS_BYTES));
         for (const TileBf16& tb : kTileBf16) {
             const int lds = tb.stem ? kStemTile.lds_bytes : (tb.id == 1 || tb.id == 3) ? kFusedTileB[tb.id].lds_bytes : kFusedTile[tb.id].lds_bytes;
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(tb.kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -1731,6 +1787,14 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main,
                 hipLaunchKernelGGL(kChainXSKernel, dim3(n), dim3(512), kChainXSLds, s, a);
                 break;
             }
+            case OP_CHAIN32: {
+                Chain32Args a{};
+                a.X = buf(op.in_buf) + op.in_off; a.ldx = op.in_ld;
+                a.Y = buf(op.out_buf); a.ldy = op.out_ld;
+                for (int j = 0; j < 4; ++j) { a.Wpk[j] = op.chain_pk[j]; a.bp[j] = h->convs[op.chain_cp[j]].d_b; }
+                hipLaunchKernelGGL(kChain32XSKernel, dim3(n), dim3(512), C32Geom::LDS_BYTES, s, a);
+                break;
+            }
             case OP_HEADCHAIN: {
                 if (op.math == 2) {
                     HeadChainBArgs a{};
@@ -1940,6 +2004,10 @@ int fear_set_option(fear_handle* h, int option, int64_t value) {
             if (value != 0 && value != 1) return FEAR_ERR_SHAPE;
             if (h->e1_pair != (int)value) { h->e1_pair = (int)value; return drop_plans(h); }
             return FEAR_OK;
+        case FEAR_OPT_CHAIN32:
+            if (value != 0 && value != 1) return FEAR_ERR_SHAPE;
+            if (h->chain32 != (int)value) { h->chain32 = (int)value; return drop_plans(h); }
+            return FEAR_OK;
         case FEAR_OPT_BF16_STORE:
             if (value != 0 && value != 1) return FEAR_ERR_SHAPE;
             if (h->bf16_store != (int)value) { h->bf16_store = (int)value; return drop_plans(h); }
@@ -1969,6 +2037,7 @@ int64_t fear_get_option(fear_handle* h, int option) {
         case FEAR_OPT_TINY_SEP: return h->tiny_sep;
         case FEAR_OPT_HEAD_CHAIN: return h->head_chain;
         case FEAR_OPT_E1_PAIR: return h->e1_pair;
+        case FEAR_OPT_CHAIN32: return h->chain32;
         case FEAR_OPT_BF16_STORE: return h->bf16_store;
         case FEAR_OPT_SPLIT_STREAMS: return h->split_streams;
         default: return FEAR_ERR_SHAPE;

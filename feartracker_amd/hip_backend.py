@@ -43,6 +43,7 @@ FEAR_OPT_HEAD_CHAIN = 13
 FEAR_OPT_BF16_STORE = 14
 FEAR_OPT_E1_PAIR = 15
 FEAR_OPT_SPLIT_STREAMS = 16
+FEAR_OPT_CHAIN32 = 17
 
 _lib = None
 
@@ -229,6 +230,11 @@ class FEARNetHIP:
         """A/B switch (FEAR_OPT_E1_PAIR, default on; fp32 mode, throughput plan): two consecutive 24-channel e1 blocks as one launch
         (the map between them stays in LDS) vs one tile-kernel launch per block."""
         self._check(self._lib.fear_set_option(self._h, FEAR_OPT_E1_PAIR, 1 if on else 0))
+
+    def set_chain32(self, on: bool) -> None:
+        """A/B switch (FEAR_OPT_CHAIN32, default on; fp32 mode, throughput plan): the four blocks of the 32 x 32 trunk stage as one
+        register-resident launch (chain32_kernel) vs one tile-kernel launch per block."""
+        self._check(self._lib.fear_set_option(self._h, FEAR_OPT_CHAIN32, 1 if on else 0))
 
     def set_split_streams(self, on: bool) -> None:
         """FEAR_OPT_SPLIT_STREAMS (default off): a throughput pass of `track` / `track_maps` runs as two half-batches on two HIP

@@ -47,7 +47,8 @@ def test_option_ids_match_header():
     assert ids == {"FEAR_OPT_MAX_BATCH": "1", "FEAR_OPT_PROFILE": "2", "FEAR_OPT_PROFILE_OP": "3", "FEAR_OPT_FUSE": "4",
                    "FEAR_OPT_MATH": "5", "FEAR_OPT_CHAIN": "6", "FEAR_OPT_SMALL_PASS": "7", "FEAR_OPT_PLAN_CROPS": "8",
                    "FEAR_OPT_DUAL_HEAD": "9", "FEAR_OPT_HEAD_STAGGER": "10", "FEAR_OPT_TILE_V4": "11", "FEAR_OPT_TINY_SEP": "12",
-                   "FEAR_OPT_HEAD_CHAIN": "13", "FEAR_OPT_BF16_STORE": "14", "FEAR_OPT_E1_PAIR": "15", "FEAR_OPT_SPLIT_STREAMS": "16"}
+                   "FEAR_OPT_HEAD_CHAIN": "13", "FEAR_OPT_BF16_STORE": "14", "FEAR_OPT_E1_PAIR": "15", "FEAR_OPT_SPLIT_STREAMS": "16",
+                   "FEAR_OPT_CHAIN32": "17"}
     for name, val in ids.items():
         assert getattr(hip_backend, name) == int(val)
 

@@ -500,6 +500,40 @@ def test_e1_pair_kernel_against_the_two_tile_launches_and_the_oracle(oracle_net)
     assert torch.equal(b3, b1) and torch.equal(c3, c1)
 
 
+@pytest.mark.gpu
+def test_chain32_kernel_against_the_four_tile_launches_and_the_oracle(oracle_net):
+    """FEAR_OPT_CHAIN32: the 32 x 32 trunk stage (three inverted-residual blocks of 32 channels, 5x5 / 5x5 / 3x3, + the stride-2
+    5x5 block down to the 16 x 16 map — model/blocks.py:8-42 from the fbnet_c table) as ONE launch whose map stays in registers
+    between blocks, vs one tile launch per block.  Same products per output, another order of the additions (no halo tiles, the
+    bias and residual first): fp32 rounding apart.  Search crops only; ragged crop counts; against the oracle at 5 crops."""
+    from feartracker_amd import FEARNetHIP
+    from conftest import WEIGHTS
+    one = FEARNetHIP(WEIGHTS, device=0, max_batch=32)
+    one.set_small_pass(0)
+    four = FEARNetHIP(WEIGHTS, device=0, max_batch=32)
+    four.set_small_pass(0)
+    four.set_chain32(False)
+    names_one = [n for n, _, _ in one.plan(256, True)]
+    names_four = [n for n, _, _ in four.plan(256, True)]
+    assert sum(n.startswith("chain32") for n in names_one) == 1 and not any(n.startswith("chain32") for n in names_four)
+    assert len(names_four) == len(names_one) + 3, (names_one, names_four)
+    assert not any(n.startswith("chain32") for n, _, _ in one.plan(128, False))      # the template branch keeps its kernels
+    g = torch.Generator().manual_seed(79)
+    for n in (1, 5, 32, 33):
+        x = norm_u8(torch.randint(0, 256, (n, 3, 256, 256), dtype=torch.uint8, generator=g)).cuda()
+        t = norm_u8(torch.randint(0, 256, (n, 3, 128, 128), dtype=torch.uint8, generator=g)).cuda()
+        z1, z2 = one.get_features(t), four.get_features(t)
+        assert torch.equal(z1, z2), n
+        b1, c1 = one.track_maps(x, z2)
+        b2, c2 = four.track_maps(x, z2)
+        assert_maps_close(b1, c1, b2.cpu().numpy(), c2.cpu().numpy())
+        if n == 5:
+            ref = oracle_net.track(x.cpu(), z2.cpu())
+            assert_maps_close(b1, c1, ref["TARGET_REGRESSION_LABEL_KEY"], ref["TARGET_CLASSIFICATION_KEY"])
+    b3, c3 = one.track_maps(x, z2)
+    assert torch.equal(b3, b1) and torch.equal(c3, c1)
+
+
 def test_head_chain_bf16_mode_against_the_bf16_sepconv_launches_and_fp32():
     """FEAR_OPT_MATH = 2 (BASELINE configs[3]): the one-launch head on v_mfma_f32_16x16x32_bf16 (headchain_b_kernel) rounds the same
     values to bf16 as the sep16 `*_h` launches it replaces — depthwise outputs, template features, weights — so the two agree far

@@ -14,6 +14,7 @@
 #endif
 #include KHDR
 #include "../feartracker_amd/csrc/fear_e1pair.h"
+#include "../feartracker_amd/csrc/fear_chain32.h"
 #ifdef FEAR_E1PAIR_REF
 #include FEAR_E1PAIR_REF        // round 5's kernel with its symbols renamed (tools/_kb/e1pair_r5.h, made by: git show <rev>:...fear_e1pair.h | sed ...)
 #endif
@@ -425,6 +426,38 @@ int main(int argc, char** argv) {
     // the product's tile table (fear_engine.hip kFusedTile), in plan order
 #ifdef FEAR_E1PAIR_ONLY
     bench_e1pair(crops, iters);
+    return 0;
+#endif
+#ifdef FEAR_C32_ONLY
+    {   // the 32 x 32 stage as one chain kernel (random weights: timing only; 25.3 GFLOP per 256 crops)
+        Chain32Args a{};
+        a.ldx = 32; a.ldy = 64;
+        a.X = dev_rand((size_t)crops * 1024 * 32, 2.f);
+        float* y;
+        CK(hipMalloc(&y, (size_t)crops * 256 * 64 * sizeof(float)));
+        a.Y = y;
+        a.Wpk[0] = dev_rand((size_t)Ir2Geom<32, 96, 32, 5, true>::NCHUNK * (Ir2Geom<32, 96, 32, 5, true>::AP + Ir2Geom<32, 96, 32, 5, true>::BP), 0.01f);
+        a.Wpk[1] = dev_rand((size_t)Ir2Geom<32, 192, 32, 5, true>::NCHUNK * (Ir2Geom<32, 192, 32, 5, true>::AP + Ir2Geom<32, 192, 32, 5, true>::BP), 0.01f);
+        a.Wpk[2] = dev_rand((size_t)Ir2Geom<32, 192, 32, 3, true>::NCHUNK * (Ir2Geom<32, 192, 32, 3, true>::AP + Ir2Geom<32, 192, 32, 3, true>::BP), 0.01f);
+        a.Wpk[3] = dev_rand((size_t)Ir2Geom<32, 192, 64, 5, true>::NCHUNK * (Ir2Geom<32, 192, 64, 5, true>::AP + Ir2Geom<32, 192, 64, 5, true>::BP), 0.01f);
+        for (int j = 0; j < 4; ++j) a.bp[j] = dev_rand(64, 0.2f);
+        auto k = chain32_kernel<C32Blk<32, 96, 32, 5, 1, true>, C32Blk<32, 192, 32, 5, 1, true>, C32Blk<32, 192, 32, 3, 1, true>, C32Blk<32, 192, 64, 5, 2, false>>;
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, C32Geom::LDS_BYTES));
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        for (int rep = 0; rep < 2; ++rep) {
+            for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(crops), dim3(512), C32Geom::LDS_BYTES, 0, a);
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k, dim3(crops), dim3(512), C32Geom::LDS_BYTES, 0, a);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            const double us = 1e3 * ms / iters, gf = 25.3 * crops / 256.0;
+            printf("chain32 (C32_D=%d D2=%d GS2=%d ABL=%d)  %8.1f us per %d crops  %6.1f TF/s\n", C32_D, C32_D2, C32_GS2, C32_ABL, us, crops, gf / us * 1e-3);
+        }
+    }
     return 0;
 #endif
 #ifdef FEAR_IR16H_ONLY
