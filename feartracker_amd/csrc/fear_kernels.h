@@ -25,6 +25,9 @@
 #ifndef IR16H_D
 #define IR16H_D 4      // LDS read-ahead of ir16h_fused_kernel's depthwise, in tap steps (two reads per step and channel half)
 #endif
+#ifndef CHAIN16_PEEL
+#define CHAIN16_PEEL 1     // chain16_block: the last chunk peeled out of the chunk loop (0: a run-time branch inside the loop, rounds 1-5)
+#endif
 #ifndef FEAR_V4_GS
 #define FEAR_V4_GS 2      // tap steps per scheduling group of ir_tile_v4_kernel
 #endif
@@ -2249,6 +2252,7 @@ __global__ __launch_bounds__(512, MINW) void ir_tile_v4_kernel(IrT2Args t) {
         if (nt * 16 + lk * 4 < COUT) bpv[nt] = *reinterpret_cast<const f32x4*>(a.bp + nt * 16 + lk * 4);
     }
 
+    // (peeling the last chunk, which pays in chain16 / chain32, measured neutral here: 116.4 k -> 116.1 k crops/s, profiles/r06_peel_ab.txt)
     for (int c = 0; c < NCHUNK; ++c) {
         const bool more = c + 1 < NCHUNK;
         if (c + 2 < NCHUNK) stage_a(c + 2);
@@ -3236,6 +3240,26 @@ __device__ __forceinline__ void chain16_block(const f32x4 (&xin)[2][B::CIN / 16]
     __syncthreads();
     phase_a(0);
     __syncthreads();
+#if CHAIN16_PEEL
+    // (the last chunk — nothing left to expand — is peeled instead of branching around two instantiations of the interval inside
+    //  the loop: chain32's A/B of the same change, profiles/r06_chain32_kbench.txt)
+    for (int c = 0; c < NCHUNK - 1; ++c) {
+        if (c + 2 < NCHUNK) stage_a(c + 2);
+        stage_b(c + 1);
+        const float* Ec = Ebuf + (c & 1) * EBUF;
+        float* En = Ebuf + ((c + 1) & 1) * EBUF;
+        const float* wa = WA + ((c + 1) & 1) * AP_MAX;
+        const float* wb = WB + (c & 1) * BP_MAX;
+        ir16_interval<B::KS, PW, ES, KG, NTP, true>(Ec, En, wa, wb, xin, accp, y0, li, lk, lane, true);
+        __syncthreads();
+    }
+    {
+        constexpr int c = NCHUNK - 1;
+        ir16_interval<B::KS, PW, ES, KG, NTP, false>(Ebuf + (c & 1) * EBUF, Ebuf + ((c + 1) & 1) * EBUF, WA + ((c + 1) & 1) * AP_MAX,
+                                                     WB + (c & 1) * BP_MAX, xin, accp, y0, li, lk, lane, true);
+        __syncthreads();
+    }
+#else
     for (int c = 0; c < NCHUNK; ++c) {
         if (c + 2 < NCHUNK) stage_a(c + 2);
         if (c + 1 < NCHUNK) stage_b(c + 1);
@@ -3247,6 +3271,7 @@ __device__ __forceinline__ void chain16_block(const f32x4 (&xin)[2][B::CIN / 16]
         else ir16_interval<B::KS, PW, ES, KG, NTP, false>(Ec, En, wa, wb, xin, accp, y0, li, lk, lane, true);
         __syncthreads();
     }
+#endif
 }
 
 // FEAR-XS stride-16 stage: 7 blocks + neck.  (The engine matches the model's block table against this chain.)
