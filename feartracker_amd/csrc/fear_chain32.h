@@ -344,15 +344,15 @@ __device__ __forceinline__ void chain32_block(const f32x4 (&xin)[8][B::CIN / 16]
     interval(NCHUNK - 1, std::false_type{});
 }
 
+// chain32_body: from the crop's 32 x 32 x 32 map in global memory to the output fragments of the stride-2 block (wave w: rows
+// 2w, 2w + 1 of the 16 x 16 map — chain16's input fragments).
 template <class B0, class B1, class B2, class B3>
-__global__ __launch_bounds__(512) void chain32_kernel(Chain32Args a) {
+__device__ __forceinline__ void chain32_body(const Chain32Args& a, float* lds, long crop, f32x4 (&y4)[2][B3::COUT / 16]) {
     using L = C32Geom;
     static_assert(B0::STRIDE == 1 && B1::STRIDE == 1 && B2::STRIDE == 1 && B3::STRIDE == 2, "three blocks on the 32 x 32 map, then the stride-2 block");
     static_assert(B0::COUT == B1::CIN && B1::COUT == B2::CIN && B2::COUT == B3::CIN, "chain");
-    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    const long crop = blockIdx.x;
     // the whole tile once: its zero ring is the padding of every chunk of every block (the interior is rewritten per chunk)
     for (int i = tid * 4; i < L::EBUF; i += 512 * 4) *reinterpret_cast<f32x4*>(lds + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -379,13 +379,41 @@ __global__ __launch_bounds__(512) void chain32_kernel(Chain32Args a) {
         const int pl = tid / (L::PW * 2), r = tid % (L::PW * 2);
         *reinterpret_cast<f32x4*>(lds + pl * L::PLANE + ((r >> 1) * L::PW + L::HALF - 1 + (r & 1)) * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    f32x4 y4[2][B3::COUT / 16];
     chain32_block<B3>(x3, y4, a.Wpk[3], a.bp[3], lds);
+}
+
+template <class B0, class B1, class B2, class B3>
+__global__ __launch_bounds__(512) void chain32_kernel(Chain32Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const long crop = blockIdx.x;
+    f32x4 y4[2][B3::COUT / 16];
+    chain32_body<B0, B1, B2, B3>(a, lds, crop, y4);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < B3::COUT / 16; ++nt)
             *reinterpret_cast<f32x4*>(a.Y + (crop * 256 + (wave * 2 + mt) * 16 + li) * (long)a.ldy + nt * 16 + lk * 4) = y4[mt][nt];
+}
+
+// chain32 + chain16 + neck as ONE launch: the output fragments of the stride-2 block ARE chain16's input fragments (wave w: rows
+// 2w, 2w + 1 of the 16 x 16 map), so the 64-channel map between the two stages never leaves the registers either; what
+// disappears is a launch boundary at which 256 CUs wait for the slowest workgroup of the first kernel, chain16's prologue (its
+// first loads) and a 16.8 MB round trip.  LDS: the larger of the two carves; chain16's two E tiles are zero-filled behind the
+// last barrier of the stride-2 block (their readers come after the barrier in chain16's first block prologue).
+template <class A0, class A1, class A2, class A3, class B0, class B1, class B2, class B3, class B4, class B5, class B6, int CNECK>
+__global__ __launch_bounds__(512) void chain32_16_kernel(Chain32Args a32, Chain16Args a16) {
+    static_assert(A3::COUT == B0::CIN, "the stride-2 block feeds the stride-16 stage");
+    constexpr int KS = B0::KS;
+    using L16 = Chain16Lds<KS, Ir2Geom<B4::CIN, B4::CEXP, B4::COUT, KS, true>::AP, Ir2Geom<B4::CIN, B4::CEXP, B4::COUT, KS, true>::BP>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const long crop = blockIdx.x;
+    f32x4 x0[2][B0::CIN / 16];
+    chain32_body<A0, A1, A2, A3>(a32, lds, crop, x0);
+    for (int i = tid * 4; i < 2 * L16::EBUF; i += 512 * 4) *reinterpret_cast<f32x4*>(lds + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    chain16_body<B0, B1, B2, B3, B4, B5, B6, CNECK>(x0, a16, lds, crop);
 }
 
 }  // namespace fear

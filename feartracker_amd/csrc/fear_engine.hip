@@ -101,7 +101,7 @@ struct Conv {
     bool is_pw() const { return groups == 1 && k == 1; }
 };
 
-enum OpType { OP_STEM, OP_PW, OP_DW, OP_CORR, OP_PW_SMALL, OP_IR16, OP_IRTILE, OP_CHAIN16, OP_HEADCHAIN, OP_E1PAIR, OP_CHAIN32 };
+enum OpType { OP_STEM, OP_PW, OP_DW, OP_CORR, OP_PW_SMALL, OP_IR16, OP_IRTILE, OP_CHAIN16, OP_HEADCHAIN, OP_E1PAIR, OP_CHAIN32, OP_CHAIN32_16 };
 
 struct Op {
     OpType type;
@@ -138,6 +138,9 @@ struct Op {
     // OP_CHAIN16: per-block packed weights / projection convs, neck fragments
     float* chain_pk[8] = {nullptr};
     int chain_cp[8] = {0};
+    // OP_CHAIN32_16: chain_pk / chain_cp hold the four 32 x 32 blocks, these the seven stride-16 blocks
+    float* chain16_pk[8] = {nullptr};
+    int chain16_cp[8] = {0};
     float* neck_pk = nullptr;
     int neck_conv = -1;
     // OP_HEADCHAIN (headchain_kernel): per branch (0 = classification, 1 = regression) the pass-major weights of its four SepConvs,
@@ -183,7 +186,7 @@ struct fear_handle {
     int tile_v4 = 1;       // FEAR_OPT_TILE_V4: 1 = phase-overlapped tile kernel for the blocks of kFusedTileV4 (throughput plan)
     int chain = 1;         // 1: run the stride-16 trunk stage as one register-resident chain kernel (fp32 mode)
     int bf16_store = 1;    // FEAR_OPT_BF16_STORE: math 2 keeps the activations of the trunk's HBM-bound front in bf16 between kernels
-    int chain32 = 1;       // FEAR_OPT_CHAIN32: 1 = the 32 x 32 trunk stage (four blocks) as one register-resident chain kernel (chain32_kernel; fp32 mode, throughput plan)
+    int chain32 = 2;       // FEAR_OPT_CHAIN32: 1 = the 32 x 32 trunk stage (four blocks) as one register-resident chain kernel (chain32_kernel; fp32 mode, throughput plan), 2 = in one launch with the stride-16 stage + neck (chain32_16_kernel) when FEAR_OPT_CHAIN is on as well
     int e1_pair = 1;       // FEAR_OPT_E1_PAIR: 1 = two consecutive 24-channel e1 blocks as one launch (e1pair_kernel; fp32 mode, throughput plan)
     int head_chain = 1;    // FEAR_OPT_HEAD_CHAIN: 1 = the whole BoxTower as one launch (headchain_kernel; fp32 mode, throughput plan)
     int small_pass = 96;   // passes of at most this many crops run the small-batch plan (FEAR_OPT_SMALL_PASS; 0: never);
@@ -684,6 +687,12 @@ struct Chain32Shape { int cin, cexp, cout, ks, stride, res; };
 const Chain32Shape kChain32XS[4] = {{32, 96, 32, 5, 1, 1}, {32, 192, 32, 5, 1, 1}, {32, 192, 32, 3, 1, 1}, {32, 192, 64, 5, 2, 0}};
 auto* const kChain32XSKernel = chain32_kernel<C32Blk<32, 96, 32, 5, 1, true>, C32Blk<32, 192, 32, 5, 1, true>,
                                               C32Blk<32, 192, 32, 3, 1, true>, C32Blk<32, 192, 64, 5, 2, false>>;
+auto* const kChain32_16XSKernel =
+    chain32_16_kernel<C32Blk<32, 96, 32, 5, 1, true>, C32Blk<32, 192, 32, 5, 1, true>, C32Blk<32, 192, 32, 3, 1, true>, C32Blk<32, 192, 64, 5, 2, false>,
+                      ChainBlk<64, 192, 64, 5, true>, ChainBlk<64, 384, 64, 5, true>, ChainBlk<64, 384, 64, 5, true>,
+                      ChainBlk<64, 384, 112, 5, false>, ChainBlk<112, 672, 112, 5, true>, ChainBlk<112, 672, 112, 5, true>,
+                      ChainBlk<112, 336, 112, 5, true>, kChainNeckOut>;
+constexpr int kChain32_16Lds = kChainXSLds > C32Geom::LDS_BYTES ? kChainXSLds : C32Geom::LDS_BYTES;
 
 // the whole BoxTower as one launch (fear_headchain.h): 3x3 SepConvs, 256 channels, 64 template positions
 auto* const kHeadChainKernel = headchain_kernel<3>;
@@ -1014,7 +1023,21 @@ int build_plan_uncached(fear_handle* h, int hw, bool with_head, int mode, Plan**
                     snprintf(op.name, sizeof(op.name), "chain16_7blocks_neck_%dx%d", op.C, op.N);
                     op.flops = fl + 2.0 * 256 * kChainXS[6].cout * kChainNeckOut;
                     op.bytes = 4.0 * 256 * (op.C + op.N);
-                    ops.push_back(op);
+                    if (h->chain32 == 2 && !ops.empty() && ops.back().type == OP_CHAIN32 && ops.back().out_buf == op.in_buf && op.in_off == 0) {
+                        // the 32 x 32 stage in front of it is a chain kernel too: one launch for both (chain32_16_kernel), the
+                        // 16 x 16 x 64 map between them stays in registers
+                        Op& f = ops.back();
+                        f.type = OP_CHAIN32_16;
+                        for (int j = 0; j < 7; ++j) { f.chain16_pk[j] = op.chain_pk[j]; f.chain16_cp[j] = op.chain_cp[j]; }
+                        f.neck_conv = op.neck_conv; f.neck_pk = op.neck_pk;
+                        f.out_buf = op.out_buf; f.out_ld = op.out_ld;
+                        f.N = op.N;
+                        snprintf(f.name, sizeof(f.name), "chain32_16_11blocks_neck_%dx%d", f.C, f.N);
+                        f.flops += op.flops;
+                        f.bytes = 4.0 * (1024.0 * f.C + 256.0 * f.N);
+                    } else {
+                        ops.push_back(op);
+                    }
                     track(o);
                     pool.release(cur.buf);
                     cur = o;
@@ -1553,6 +1576,8 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kChainXSLds));
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kChain32XSKernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, C32Geom::LDS_BYTES));
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kChain32_16XSKernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kChain32_16Lds));
         for (const TileBf16& tb : kTileBf16) {
             const int lds = tb.stem ? kStemTile.lds_bytes : (tb.id == 1 || tb.id == 3) ? kFusedTileB[tb.id].lds_bytes : kFusedTile[tb.id].lds_bytes;
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(tb.kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -1795,6 +1820,19 @@ int run_plan(fear_handle* h, Plan& p, int n, const Ext& ext, hipStream_t s_main,
                 hipLaunchKernelGGL(kChain32XSKernel, dim3(n), dim3(512), C32Geom::LDS_BYTES, s, a);
                 break;
             }
+            case OP_CHAIN32_16: {
+                Chain32Args a{};
+                a.X = buf(op.in_buf) + op.in_off; a.ldx = op.in_ld;
+                a.Y = nullptr; a.ldy = 0;
+                for (int j = 0; j < 4; ++j) { a.Wpk[j] = op.chain_pk[j]; a.bp[j] = h->convs[op.chain_cp[j]].d_b; }
+                Chain16Args b{};
+                b.X = nullptr; b.ldx = 0;
+                b.Y = buf(op.out_buf); b.ldy = op.out_ld;
+                for (int j = 0; j < 7; ++j) { b.Wpk[j] = op.chain16_pk[j]; b.bp[j] = h->convs[op.chain16_cp[j]].d_b; }
+                b.neck_pk = op.neck_pk; b.neck_b = h->convs[op.neck_conv].d_b;
+                hipLaunchKernelGGL(kChain32_16XSKernel, dim3(n), dim3(512), kChain32_16Lds, s, a, b);
+                break;
+            }
             case OP_HEADCHAIN: {
                 if (op.math == 2) {
                     HeadChainBArgs a{};
@@ -2005,7 +2043,7 @@ int fear_set_option(fear_handle* h, int option, int64_t value) {
             if (h->e1_pair != (int)value) { h->e1_pair = (int)value; return drop_plans(h); }
             return FEAR_OK;
         case FEAR_OPT_CHAIN32:
-            if (value != 0 && value != 1) return FEAR_ERR_SHAPE;
+            if (value < 0 || value > 2) return FEAR_ERR_SHAPE;
             if (h->chain32 != (int)value) { h->chain32 = (int)value; return drop_plans(h); }
             return FEAR_OK;
         case FEAR_OPT_BF16_STORE:

@@ -3275,27 +3275,18 @@ __device__ __forceinline__ void chain16_block(const f32x4 (&xin)[2][B::CIN / 16]
 }
 
 // FEAR-XS stride-16 stage: 7 blocks + neck.  (The engine matches the model's block table against this chain.)
+// chain16_body: from the first block's input fragments (x0: wave w holds map rows 2w, 2w + 1) to the neck's output in global
+// memory; the caller has zero-filled the two E tiles (Chain16Lds: the first 2 * EBUF floats of `lds`) — no barrier needed in
+// between, the first block's prologue has one.  Shared by chain16_kernel and the fused chain32_16_kernel (fear_chain32.h).
 template <class B0, class B1, class B2, class B3, class B4, class B5, class B6, int CNECK>
-__global__ __launch_bounds__(512) void chain16_kernel(Chain16Args a) {
+__device__ __forceinline__ void chain16_body(const f32x4 (&x0)[2][B0::CIN / 16], const Chain16Args& a, float* lds, long crop) {
     constexpr int KS = B0::KS;
     constexpr int APM = Ir2Geom<B4::CIN, B4::CEXP, B4::COUT, KS, true>::AP;      // widest expand fragments (CIN = 112)
     constexpr int BPM = Ir2Geom<B4::CIN, B4::CEXP, B4::COUT, KS, true>::BP;
     using L = Chain16Lds<KS, APM, BPM>;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    const long crop = blockIdx.x;
     const int y0 = wave * 2;
-    for (int i = tid * 4; i < 2 * L::EBUF; i += 512 * 4) *reinterpret_cast<f32x4*>(lds + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    f32x4 x0[2][B0::CIN / 16];
-    const float* Xc = a.X + crop * 256 * a.ldx;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int kg = 0; kg < B0::CIN / 16; ++kg)
-            x0[mt][kg] = *reinterpret_cast<const f32x4*>(Xc + (long)((y0 + mt) * 16 + li) * a.ldx + kg * 16 + lk * 4);
-    __syncthreads();
 
     f32x4 x1[2][B0::COUT / 16];
     chain16_block<B0, KS, APM, BPM>(x0, x1, a.Wpk[0], a.bp[0], lds);
@@ -3367,6 +3358,31 @@ __global__ __launch_bounds__(512) void chain16_kernel(Chain16Args a) {
         if (g + 1 < NTN / GRP) store_g(g + 1);
         __syncthreads();
     }
+}
+
+
+template <class B0, class B1, class B2, class B3, class B4, class B5, class B6, int CNECK>
+__global__ __launch_bounds__(512) void chain16_kernel(Chain16Args a) {
+    constexpr int KS = B0::KS;
+    constexpr int APM = Ir2Geom<B4::CIN, B4::CEXP, B4::COUT, KS, true>::AP;
+    constexpr int BPM = Ir2Geom<B4::CIN, B4::CEXP, B4::COUT, KS, true>::BP;
+    using L = Chain16Lds<KS, APM, BPM>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const long crop = blockIdx.x;
+    const int y0 = wave * 2;
+    for (int i = tid * 4; i < 2 * L::EBUF; i += 512 * 4) *reinterpret_cast<f32x4*>(lds + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 x0[2][B0::CIN / 16];
+    const float* Xc = a.X + crop * 256 * a.ldx;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int kg = 0; kg < B0::CIN / 16; ++kg)
+            x0[mt][kg] = *reinterpret_cast<const f32x4*>(Xc + (long)((y0 + mt) * 16 + li) * a.ldx + kg * 16 + lk * 4);
+    __syncthreads();
+    chain16_body<B0, B1, B2, B3, B4, B5, B6, CNECK>(x0, a, lds, crop);
 }
 
 }  // namespace fear

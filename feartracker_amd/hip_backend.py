@@ -231,10 +231,12 @@ class FEARNetHIP:
         (the map between them stays in LDS) vs one tile-kernel launch per block."""
         self._check(self._lib.fear_set_option(self._h, FEAR_OPT_E1_PAIR, 1 if on else 0))
 
-    def set_chain32(self, on: bool) -> None:
-        """A/B switch (FEAR_OPT_CHAIN32, default on; fp32 mode, throughput plan): the four blocks of the 32 x 32 trunk stage as one
-        register-resident launch (chain32_kernel) vs one tile-kernel launch per block."""
-        self._check(self._lib.fear_set_option(self._h, FEAR_OPT_CHAIN32, 1 if on else 0))
+    def set_chain32(self, mode) -> None:
+        """A/B switch (FEAR_OPT_CHAIN32; fp32 mode, throughput plan): the four blocks of the 32 x 32 trunk stage as a register-resident
+        chain — 2 (default, also True): in one launch with the stride-16 stage + neck (chain32_16_kernel), 1: a launch of its own
+        (chain32_kernel), 0 / False: one tile-kernel launch per block."""
+        mode = 2 if mode is True else int(mode)
+        self._check(self._lib.fear_set_option(self._h, FEAR_OPT_CHAIN32, mode))
 
     def set_split_streams(self, on: bool) -> None:
         """FEAR_OPT_SPLIT_STREAMS (default off): a throughput pass of `track` / `track_maps` runs as two half-batches on two HIP

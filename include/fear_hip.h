@@ -160,9 +160,10 @@ int fear_crop_normalize(fear_handle* h, const uint8_t* frame_u8, int frame_h, in
                                /*   Same plans, same kernels per crop: bit-identical maps.  0 (default): one stream — every per-kernel      */
                                /*   figure of bench.py (the roofline object first of all) is then a full-grid launch.  Only when both        */
                                /*   halves still exceed FEAR_OPT_SMALL_PASS; ignored while FEAR_OPT_PROFILE is on.                           */
-#define FEAR_OPT_CHAIN32 17    /* 1 (default): fp32 mode, throughput plan — the 32 x 32 trunk stage (three inverted-residual blocks of 32       */
-                               /*   channels + the stride-2 block down to the 16 x 16 map; model/blocks.py:8-42) runs as ONE launch whose map  */
-                               /*   stays in registers between blocks (chain32_kernel); 0: one tile kernel per block (A/B).                    */
+#define FEAR_OPT_CHAIN32 17    /* fp32 mode, throughput plan — the 32 x 32 trunk stage (three inverted-residual blocks of 32 channels + the     */
+                               /*   stride-2 block down to the 16 x 16 map; model/blocks.py:8-42) as a register-resident chain:                  */
+                               /*   2 (default): in ONE launch with the stride-16 stage + neck when FEAR_OPT_CHAIN is on (chain32_16_kernel);    */
+                               /*   1: a launch of its own (chain32_kernel); 0: one tile kernel per block (A/B).                                 */
 int fear_set_option(fear_handle* h, int option, int64_t value);
 int64_t fear_get_option(fear_handle* h, int option);
 

@@ -405,10 +405,13 @@ def test_chain_kernel_matches_per_block_kernels(hip_net):
     from feartracker_amd import FEARNetHIP
     from conftest import WEIGHTS
     # (throughput plan forced: passes of <= FEAR_OPT_SMALL_PASS crops would take the small-batch plan instead)
+    # (FEAR_OPT_CHAIN32 = 1: the 32 x 32 stage as a launch of its own in both plans — by default it shares chain16's launch)
     chained = FEARNetHIP(WEIGHTS, device=0, max_batch=64)
     chained.set_small_pass(0)
+    chained.set_chain32(1)
     per_block = FEARNetHIP(WEIGHTS, device=0, max_batch=64)
     per_block.set_small_pass(0)
+    per_block.set_chain32(1)
     per_block.set_chain(False)
     names_chain = [n for n, _, _ in chained.plan(256, True)]
     names_blocks = [n for n, _, _ in per_block.plan(256, True)]
@@ -504,19 +507,26 @@ def test_e1_pair_kernel_against_the_two_tile_launches_and_the_oracle(oracle_net)
 def test_chain32_kernel_against_the_four_tile_launches_and_the_oracle(oracle_net):
     """FEAR_OPT_CHAIN32: the 32 x 32 trunk stage (three inverted-residual blocks of 32 channels, 5x5 / 5x5 / 3x3, + the stride-2
     5x5 block down to the 16 x 16 map — model/blocks.py:8-42 from the fbnet_c table) as ONE launch whose map stays in registers
-    between blocks, vs one tile launch per block.  Same products per output, another order of the additions (no halo tiles, the
+    between blocks — by default the same launch as the stride-16 stage + neck (chain32_16_kernel), with FEAR_OPT_CHAIN32 = 1 a
+    launch of its own (bit-identical) — vs one tile launch per block.  Same products per output, another order of the additions (no halo tiles, the
     bias and residual first): fp32 rounding apart.  Search crops only; ragged crop counts; against the oracle at 5 crops."""
     from feartracker_amd import FEARNetHIP
     from conftest import WEIGHTS
-    one = FEARNetHIP(WEIGHTS, device=0, max_batch=32)
+    one = FEARNetHIP(WEIGHTS, device=0, max_batch=32)          # default: chain32 + chain16 + neck as one launch
     one.set_small_pass(0)
+    own = FEARNetHIP(WEIGHTS, device=0, max_batch=32)          # chain32 as a launch of its own
+    own.set_small_pass(0)
+    own.set_chain32(1)
     four = FEARNetHIP(WEIGHTS, device=0, max_batch=32)
     four.set_small_pass(0)
     four.set_chain32(False)
     names_one = [n for n, _, _ in one.plan(256, True)]
+    names_own = [n for n, _, _ in own.plan(256, True)]
     names_four = [n for n, _, _ in four.plan(256, True)]
-    assert sum(n.startswith("chain32") for n in names_one) == 1 and not any(n.startswith("chain32") for n in names_four)
-    assert len(names_four) == len(names_one) + 3, (names_one, names_four)
+    assert sum(n.startswith("chain32_16_") for n in names_one) == 1 and not any(n.startswith("chain16") for n in names_one)
+    assert sum(n.startswith("chain32_4blocks") for n in names_own) == 1 and sum(n.startswith("chain16") for n in names_own) == 1
+    assert not any(n.startswith("chain32") for n in names_four)
+    assert len(names_four) == len(names_own) + 3 == len(names_one) + 4, (names_one, names_own, names_four)
     assert not any(n.startswith("chain32") for n, _, _ in one.plan(128, False))      # the template branch keeps its kernels
     g = torch.Generator().manual_seed(79)
     for n in (1, 5, 32, 33):
@@ -527,6 +537,8 @@ def test_chain32_kernel_against_the_four_tile_launches_and_the_oracle(oracle_net
         b1, c1 = one.track_maps(x, z2)
         b2, c2 = four.track_maps(x, z2)
         assert_maps_close(b1, c1, b2.cpu().numpy(), c2.cpu().numpy())
+        b4, c4 = own.track_maps(x, z2)
+        assert torch.equal(b4, b1) and torch.equal(c4, c1), n      # the same arithmetic in the same order, with or without the launch boundary
         if n == 5:
             ref = oracle_net.track(x.cpu(), z2.cpu())
             assert_maps_close(b1, c1, ref["TARGET_REGRESSION_LABEL_KEY"], ref["TARGET_CLASSIFICATION_KEY"])
@@ -813,10 +825,10 @@ def test_plan_introspection_follows_the_pass_size():
     from conftest import WEIGHTS
     net = FEARNetHIP(WEIGHTS, device=0, max_batch=256)
     full = [n for n, _, _ in net.plan(256, True)]
-    assert any(n.startswith("chain16") for n in full)
+    assert any(n.startswith(("chain16", "chain32_16")) for n in full)
     net.set_plan_crops(1)
     one = [n for n, _, _ in net.plan(256, True)]
-    assert any("splitk" in n for n in one) and not any(n.startswith("chain16") for n in one)
+    assert any("splitk" in n for n in one) and not any(n.startswith(("chain16", "chain32")) for n in one)
     g = torch.Generator().manual_seed(8)
     x = norm_u8(torch.randint(0, 256, (1, 3, 256, 256), dtype=torch.uint8, generator=g)).cuda()
     z = net.get_features(norm_u8(torch.randint(0, 256, (1, 3, 128, 128), dtype=torch.uint8, generator=g)).cuda())
