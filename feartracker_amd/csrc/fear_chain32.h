@@ -163,6 +163,101 @@ __device__ __forceinline__ void c32_sub(const float* __restrict__ e0, const floa
     }
 }
 
+#ifndef C32_ROWS4
+#define C32_ROWS4 1    // 1: the stride-1 depthwise as ONE chain over the wave's four rows per column half (c32_half4) instead of two row-pair chains
+#endif
+#ifndef C32_D4
+#define C32_D4 4       // read-ahead of that chain, in tap steps
+#endif
+// The first D steps' reads of a four-row chain (KS + 3 input rows per column).
+template <int KS, int D>
+__device__ __forceinline__ void c32_prime4(const float* __restrict__ e0, const float* __restrict__ wd, f32x4 (&ev)[D], f32x4 (&wv)[D], f32x4& dbias) {
+    constexpr int PW = C32Geom::PW, NR = KS + 3;
+    dbias = *reinterpret_cast<const f32x4*>(wd + KS * KS * 16);
+#pragma unroll
+    for (int t = 0; t < D; ++t) {
+        const int kx = t / NR, iy = t % NR;
+        ev[t] = *reinterpret_cast<const f32x4*>(e0 + (iy * PW + kx) * 4);
+        if (iy < KS) wv[t] = *reinterpret_cast<const f32x4*>(wd + (iy * KS + kx) * 16);
+    }
+}
+
+// One column half of a stride-1 chunk interval as ONE depthwise chain over the wave's four rows: KS (KS + 3) tap steps (column kx
+// outer, input row iy inner); the activation read of a step feeds up to four output rows (row r with tap row iy - r), the tap weight
+// read at step iy stays in a four-deep window until row 3 has used it: 8 + 5 LDS reads per column instead of 2 x (6 + 5) —
+// each ds_read_b128 costs ~5 issue cycles of a kernel that is issue-bound (profiles/r06_chain32_kbench.txt).
+template <int KS, int KG, int NTP, bool HAS_A>
+__device__ __forceinline__ void c32_half4(const float* __restrict__ e0, const float* __restrict__ wa, const float* __restrict__ wb,
+                                          const f32x4 (&x0)[KG], const f32x4 (&x1)[KG], const f32x4 (&x2)[KG], const f32x4 (&x3)[KG],
+                                          f32x4& a0, f32x4& a1, f32x4& a2, f32x4& a3, f32x4 (&p0)[NTP], f32x4 (&p1)[NTP], f32x4 (&p2)[NTP],
+                                          f32x4 (&p3)[NTP], int lk, int lane, f32x4 (&ev)[C32_D4], f32x4 (&wv)[C32_D4], f32x4& dbias,
+                                          const float* enext) {
+    constexpr int PW = C32Geom::PW, NR = KS + 3, NS = KS * NR, D = C32_D4;
+    constexpr int NU = HAS_A ? KG * 4 : 0;
+    static_assert(NS >= D + 1, "read-ahead");
+    const float* wd = wb + NTP * 256 + lk * 4;
+    f32x4 wfq[2];
+    if (HAS_A) {
+        a0 = a1 = a2 = a3 = *reinterpret_cast<const f32x4*>(wa + KG * 256 + lk * 4);      // expansion bias
+        wfq[0] = *reinterpret_cast<const f32x4*>(wa + lane * 4);
+    }
+    f32x4 d0 = dbias, d1 = dbias, d2 = dbias, d3 = dbias;
+    f32x4 wwin[4], wpq[2];
+    // (static_for, not `#pragma unroll`: past ~30 steps of this size hipcc leaves the loop rolled — ring and window become
+    //  scratch arrays, 575-2000 us)
+    static_for<0, NS>([&](auto T) {
+        constexpr int t = decltype(T)::value, iy = t % NR;
+        const f32x4 e = ev[t % D];
+        if constexpr (iy < KS) wwin[iy & 3] = wv[t % D];
+        if constexpr (t == NS - 1) wpq[0] = *reinterpret_cast<const f32x4*>(wb + lane * 4);      // the projection's first A fragment, a step ahead
+        if constexpr (t + D < NS && !(C32_ABL & 8)) {
+            constexpr int kx2 = (t + D) / NR, iy2 = (t + D) % NR;
+            ev[t % D] = *reinterpret_cast<const f32x4*>(e0 + (iy2 * PW + kx2) * 4);
+            if constexpr (iy2 < KS) wv[t % D] = *reinterpret_cast<const f32x4*>(wd + (iy2 * KS + kx2) * 16);
+        }
+        if constexpr (HAS_A) {
+            static_for<t * NU / NS, (t + 1) * NU / NS>([&](auto U) {
+                constexpr int u = decltype(U)::value, kg = u / 4, i = u % 4;
+                if constexpr (i == 0 && kg + 1 < KG) wfq[(kg + 1) & 1] = *reinterpret_cast<const f32x4*>(wa + (kg + 1) * 256 + lane * 4);
+                if constexpr (!(C32_ABL & 2)) {
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wfq[kg & 1][i], x0[kg][i], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wfq[kg & 1][i], x1[kg][i], a1, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wfq[kg & 1][i], x2[kg][i], a2, 0, 0, 0);
+                    a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(wfq[kg & 1][i], x3[kg][i], a3, 0, 0, 0);
+                }
+            });
+        }
+        if constexpr (C32_ABL & 1) {
+            asm volatile("" :: "v"(e));
+        } else {
+            if constexpr (iy < KS) pk_fma4(d0, e, wwin[iy & 3]);
+            if constexpr (iy >= 1 && iy - 1 < KS) pk_fma4(d1, e, wwin[(iy - 1) & 3]);
+            if constexpr (iy >= 2 && iy - 2 < KS) pk_fma4(d2, e, wwin[(iy - 2) & 3]);
+            if constexpr (iy >= 3) pk_fma4(d3, e, wwin[(iy - 3) & 3]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    asm volatile("s_nop 7" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));      // (pk_fma_settle: inline-asm FMA results feed MFMAs)
+    d0 = c32_relu(d0);
+    d1 = c32_relu(d1);
+    d2 = c32_relu(d2);
+    d3 = c32_relu(d3);
+    if (enext) c32_prime4<KS, D>(enext, wd, ev, wv, dbias);
+#pragma unroll
+    for (int nt = 0; nt < NTP; ++nt) {
+        if (nt + 1 < NTP) wpq[(nt + 1) & 1] = *reinterpret_cast<const f32x4*>(wb + (nt + 1) * 256 + lane * 4);
+        if (C32_ABL & 4) { p0[nt] += d0 * wpq[nt & 1]; p1[nt] += d1 * wpq[nt & 1]; p2[nt] += d2 * wpq[nt & 1]; p3[nt] += d3 * wpq[nt & 1]; continue; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            p0[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wpq[nt & 1][i], d0[i], p0[nt], 0, 0, 0);
+            p1[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wpq[nt & 1][i], d1[i], p1[nt], 0, 0, 0);
+            p2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wpq[nt & 1][i], d2[i], p2[nt], 0, 0, 0);
+            p3[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wpq[nt & 1][i], d3[i], p3[nt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // The chunk interval of the stride-2 block (5 x 5): output rows 2w, 2w + 1 of the 16 x 16 map are two m-tiles per wave.  Output
 // row 0 reads input rows rr = 0..4 of the wave's seven (4w - 2 .. 4w + 4) with tap row rr, output row 1 rows rr = 2..6 with tap
 // row rr - 2: 35 steps (column outer), the tap weight of a step feeds row 0 now and row 1 two steps later.  The tile is column-
@@ -323,6 +418,17 @@ __device__ __forceinline__ void chain32_block(const f32x4 (&xin)[8][B::CIN / 16]
             const float* e0 = E + lk * L::PLANE + (wave * 4 * PW + li) * 4;
             c32_interval_s2<KG, NTP, MORE>(e0, wa, wb, xin, park, accp, lk, lane);
         } else {
+#if C32_ROWS4
+            f32x4 ev[C32_D4], wv[C32_D4], dbias;
+            const float* eb = E + lk * L::PLANE + ((wave * 4 + PT - P) * PW + li + PT - P) * 4;
+            c32_prime4<KS, C32_D4>(eb, wb + NTP * 256 + lk * 4, ev, wv, dbias);
+            __builtin_amdgcn_sched_barrier(0);
+            c32_half4<KS, KG, NTP, MORE>(eb, wa, wb, xin[0], xin[1], xin[2], xin[3], park[0], park[1], park[2], park[3], accp[0], accp[1], accp[2],
+                                         accp[3], lk, lane, ev, wv, dbias, eb + 64);
+            c32_half4<KS, KG, NTP, MORE>(eb + 64, wa, wb, xin[4], xin[5], xin[6], xin[7], park[4], park[5], park[6], park[7], accp[4], accp[5],
+                                         accp[6], accp[7], lk, lane, ev, wv, dbias, nullptr);
+        }
+#else
             f32x4 ev[C32_D], wv[C32_D], dbias;
             const float* eb = E + lk * L::PLANE + ((wave * 4 + PT - P) * PW + li + PT - P) * 4;
             c32_prime<KS, C32_D>(eb, wb + NTP * 256 + lk * 4, ev, wv, dbias);
@@ -334,6 +440,7 @@ __device__ __forceinline__ void chain32_block(const f32x4 (&xin)[8][B::CIN / 16]
                 c32_sub<KS, KG, NTP, MORE>(e0, wa, wb, xin[2 * q], xin[2 * q + 1], park[2 * q], park[2 * q + 1], accp[2 * q], accp[2 * q + 1], lk, lane, ev, wv, dbias, q < 3 ? en : nullptr);
             }
         }
+#endif
         if (!(C32_ABL & 16)) __syncthreads();
         if constexpr (MORE) {
             if (!(C32_ABL & 32)) store_park();
