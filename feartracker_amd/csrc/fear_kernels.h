@@ -1081,12 +1081,15 @@ __global__ __launch_bounds__(512) void ir16v2_fused_kernel(Ir2Args a) {
     }
     __syncthreads();
 
-    for (int c = 0; c < NCHUNK; ++c) {
+    // (the last chunk — nothing left to expand — is peeled, as in chain16_block: no run-time branch around two instantiations of
+    //  the interval inside the loop)
+    auto chunk = [&](int c, auto more_c) {
+        constexpr bool MORE = decltype(more_c)::value;
         // prefetch (registers only): EXPAND: A-part two chunks ahead; !EXPAND: next chunk's activations
         const int ca = EXPAND ? c + 2 : c + 1;
         if (!(FEAR_ABL & 2)) {
             if (ca < NCHUNK) load_a(ca);
-            if (c + 1 < NCHUNK) load_b(c + 1);
+            if (MORE) load_b(c + 1);
         }
         // (fp32 MFMA executes on the vector ALUs on gfx950 — tools/coexec.hip: an MFMA wave and a VALU wave on one
         //  SIMD take the SUM of their times — so staggering phases between waves buys nothing; what matters is that
@@ -1095,14 +1098,15 @@ __global__ __launch_bounds__(512) void ir16v2_fused_kernel(Ir2Args a) {
         float* En = Ebuf + ((c + 1) & 1) * EBUF;
         const float* wa = WA + ((c + 1) & 1) * AP;
         const float* wb = WB + (c & 1) * BP;
-        if (EXPAND && c + 1 < NCHUNK) ir16_interval<KS, PW, ES, KG, NTP, EXPAND>(Ec, En, wa, wb, xf, accp, y0, li, lk, lane, a.relu_dw);
-        else ir16_interval<KS, PW, ES, KG, NTP, false>(Ec, En, wa, wb, xf, accp, y0, li, lk, lane, a.relu_dw);
+        ir16_interval<KS, PW, ES, KG, NTP, EXPAND && MORE>(Ec, En, wa, wb, xf, accp, y0, li, lk, lane, a.relu_dw);
         if (!(FEAR_ABL & 2)) {
             if (ca < NCHUNK) store_a(ca);
-            if (c + 1 < NCHUNK) store_b(c + 1);
+            if (MORE) store_b(c + 1);
         }
         if (!(FEAR_ABL & 1)) __syncthreads();
-    }
+    };
+    for (int c = 0; c < NCHUNK - 1; ++c) chunk(c, std::true_type{});
+    chunk(NCHUNK - 1, std::false_type{});
 
     if (SPLITK) {                   // raw partial sums; bias, residual and activation belong to splitk_reduce_kernel
         float* Yp = a.Y + (long)blockIdx.y * a.kc_part_stride;
@@ -2824,16 +2828,19 @@ __global__ __launch_bounds__(512) void ir16h_fused_kernel(Ir2Args a) {
     }
     __syncthreads();
 
-    for (int c = 0; c < NCHUNK; ++c) {
+    // (the last chunk is peeled: no run-time branch around the expansion phase inside the loop — chain16_block's change)
+    for (int c = 0; c < NCHUNK - 1; ++c) {
         const int ca = EXPAND ? c + 2 : c + 1;
         if (ca < NCHUNK) load_a(ca);
-        if (c + 1 < NCHUNK) load_b(c + 1);
-        if (EXPAND && c + 1 < NCHUNK) phase_a(c + 1);
+        load_b(c + 1);
+        if (EXPAND) phase_a(c + 1);
         phase_bc(c);
         if (ca < NCHUNK) store_a(ca);
-        if (c + 1 < NCHUNK) store_b(c + 1);
+        store_b(c + 1);
         __syncthreads();
     }
+    phase_bc(NCHUNK - 1);
+    __syncthreads();
 
     if (a.pred_cout > 0) {          // prediction head: lanes lk == 0 hold channels 0..3 of their pixel
         if (lk == 0) {

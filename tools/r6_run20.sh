@@ -1,0 +1,5 @@
+#!/bin/bash
+cd ${GRAFT_REPO_ROOT:-.}
+mkdir -p gpurun_out/r6n
+timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/r6n/gputests.txt 2>&1; echo "pytest rc $?" >> gpurun_out/r6n/gputests.txt
+tail -4 gpurun_out/r6n/gputests.txt
