@@ -51,6 +51,14 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     res = subprocess.run(cmd, check=True, capture_output=True, text=True)
     os.replace(LIB + ".tmp", LIB)
     spills = check_spills(res.stderr)
+    spilled = {name for name, _ in spills}
+    for name, nbytes in check_scratch(res.stderr):
+        # scratch WITHOUT spilled registers = a private array hipcc could not keep in registers — in this code base that has always
+        # been a `#pragma unroll` loop left rolled (its ring / window arrays indexed by a run-time counter): chain32's four-row chain
+        # ran at 575-2000 us instead of 250 that way (profiles/r06_chain32_kbench.txt); write such loops with static_for
+        if name not in spilled:
+            print(f"WARNING: {name} uses {nbytes} B of scratch per lane without spilling registers (a loop left rolled? "
+                  "index arrays by compile-time constants: static_for)")
     for name, n in spills:
         # the two chained head kernels are known to carry a handful of spilled registers outside their loops (ten scratch
         # instructions per launch); the tolerance is theirs alone, by name and count — a new spill in any other fused kernel, or a
@@ -73,6 +81,20 @@ def check_spills(remarks: str):
         if m:
             name = m.group(1)
         m = re.search(r"VGPRs Spill: (\d+)", line)
+        if m and name and int(m.group(1)) > 0:
+            out.append((name, int(m.group(1))))
+    return out
+
+
+def check_scratch(remarks: str):
+    """[(kernel symbol, scratch bytes per lane)] for kernels with a non-zero ScratchSize."""
+    import re
+    out, name = [], None
+    for line in remarks.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
         if m and name and int(m.group(1)) > 0:
             out.append((name, int(m.group(1))))
     return out
