@@ -22,6 +22,9 @@
 #ifndef IR16_D
 #define IR16_D 4       // LDS read-ahead of ir16_interval, in tap steps
 #endif
+#ifndef IR16H_ASYNC
+#define IR16H_ASYNC 1  // ir16h_fused_kernel (blocks with expansion): packed weights global -> LDS by asynchronous copies (0: through registers, rounds 2-5)
+#endif
 #ifndef IR16H_D
 #define IR16H_D 4      // LDS read-ahead of ir16h_fused_kernel's depthwise, in tap steps (two reads per step and channel half)
 #endif
@@ -2815,6 +2818,30 @@ __global__ __launch_bounds__(512) void ir16h_fused_kernel(Ir2Args a) {
         }
     };
 
+    if constexpr (EXPAND && IR16H_ASYNC) {
+        // The packed weights go global -> LDS by asynchronous copies (global_load_lds_dwordx4: no staging registers, no ds_write),
+        // as in chain16_block: issued at the top of an interval into the stage the previous interval read last, complete at the
+        // interval's barrier.  (Round 2's form — two or three loads and ds_write_b128 per thread and chunk through `ra` / `rb` —
+        // stays for the blocks without expansion, whose A part is the activation itself.)
+        const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+        auto stage_a = [&](int c) { lds_copy_async<AP>(a.Wpk + (long)c * CST, WA + (c & 1) * AP, wave_s, lane); };
+        auto stage_b = [&](int c) { lds_copy_async<BP>(a.Wpk + (long)c * CST + AP, WB + (c & 1) * BP, wave_s, lane); };
+        stage_a(0);
+        stage_b(0);
+        if (NCHUNK > 1) stage_a(1);
+        __syncthreads();                   // (also: the zero ring is in place)
+        phase_a(0);
+        __syncthreads();
+        for (int c = 0; c < NCHUNK - 1; ++c) {
+            if (c + 2 < NCHUNK) stage_a(c + 2);
+            stage_b(c + 1);
+            phase_a(c + 1);
+            phase_bc(c);
+            __syncthreads();
+        }
+        phase_bc(NCHUNK - 1);
+        __syncthreads();
+    } else {
     // ---- prologue: stage A(0), A(1), BC(0); produce E[0]
     load_a(0);
     load_b(0);
@@ -2841,6 +2868,7 @@ __global__ __launch_bounds__(512) void ir16h_fused_kernel(Ir2Args a) {
     }
     phase_bc(NCHUNK - 1);
     __syncthreads();
+    }
 
     if (a.pred_cout > 0) {          // prediction head: lanes lk == 0 hold channels 0..3 of their pixel
         if (lk == 0) {
