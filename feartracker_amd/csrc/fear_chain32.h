@@ -346,9 +346,11 @@ __device__ __forceinline__ void c32_interval_s2(const float* __restrict__ e0, co
 }
 
 // one block of the chain: xin (registers, 8 m-tiles) -> yout (registers: 8 m-tiles, or the wave's 2 of the 16 x 16 map)
-template <class B>
+// (NB / WpkNext / PRE: the next block's first weight stages copied during this block's last interval — see chain16_block)
+template <class B, class NB = void, bool PRE = false>
 __device__ __forceinline__ void chain32_block(const f32x4 (&xin)[8][B::CIN / 16], f32x4 (&yout)[B::MO][B::COUT / 16],
-                                              const float* __restrict__ Wpk, const float* __restrict__ bp, float* lds) {
+                                              const float* __restrict__ Wpk, const float* __restrict__ bp, float* lds,
+                                              const float* __restrict__ WpkNext = nullptr) {
     using G = Ir2Geom<B::CIN, B::CEXP, B::COUT, B::KS, true>;      // the packed chunk layout (AP | BP), nothing else
     using L = C32Geom;
     constexpr int KS = B::KS, P = KS / 2, PT = L::PT, PW = L::PW, NCHUNK = G::NCHUNK, NTP = G::NTP, KG = G::KG;
@@ -386,10 +388,12 @@ __device__ __forceinline__ void chain32_block(const f32x4 (&xin)[8][B::CIN / 16]
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-    stage_a(0);
-    stage_b(0);
-    if (NCHUNK > 1) stage_a(1);
-    __syncthreads();
+    if constexpr (!PRE) {
+        stage_a(0);
+        stage_b(0);
+        if (NCHUNK > 1) stage_a(1);
+        __syncthreads();
+    }
     {   // chunk 0's expansion: nothing to overlap it with
         const float* wa = WA;
         const f32x4 b = *reinterpret_cast<const f32x4*>(wa + KG * 256 + lk * 4);
@@ -448,6 +452,13 @@ __device__ __forceinline__ void chain32_block(const f32x4 (&xin)[8][B::CIN / 16]
         }
     };
     for (int c = 0; c < NCHUNK - 1; ++c) interval(c, std::true_type{});
+    if constexpr (!std::is_void<NB>::value) {
+        using GN = Ir2Geom<NB::CIN, NB::CEXP, NB::COUT, NB::KS, true>;
+        static_assert(NCHUNK % 2 == 0 && GN::AP <= L::AP_MAX && GN::BP <= L::BP_MAX, "the last interval reads stage 1 of B only");
+        lds_copy_async<GN::AP>(WpkNext, WA, wave_s, lane);
+        lds_copy_async<GN::BP>(WpkNext + GN::AP, WB, wave_s, lane);
+        if (GN::NCHUNK > 1) lds_copy_async<GN::AP>(WpkNext + (GN::AP + GN::BP), WA + L::AP_MAX, wave_s, lane);
+    }
     interval(NCHUNK - 1, std::false_type{});
 }
 
@@ -475,18 +486,18 @@ __device__ __forceinline__ void chain32_body(const Chain32Args& a, float* lds, l
     __syncthreads();
 
     f32x4 x1[8][B0::COUT / 16];
-    chain32_block<B0>(x0, x1, a.Wpk[0], a.bp[0], lds);
+    chain32_block<B0, B1, false>(x0, x1, a.Wpk[0], a.bp[0], lds, a.Wpk[1]);
     f32x4 x2[8][B1::COUT / 16];
-    chain32_block<B1>(x1, x2, a.Wpk[1], a.bp[1], lds);
+    chain32_block<B1, B2, true>(x1, x2, a.Wpk[1], a.bp[1], lds, a.Wpk[2]);
     f32x4 x3[8][B2::COUT / 16];
-    chain32_block<B2>(x2, x3, a.Wpk[2], a.bp[2], lds);
+    chain32_block<B2, B3, true>(x2, x3, a.Wpk[2], a.bp[2], lds, a.Wpk[3]);
     // the stride-2 block's tile is column-de-interleaved: slots 17 and 18 of a row (interior so far) become its padding
     // (the last barrier of B2 is behind us; B3 stores after its first barrier)
     if (tid < 4 * L::PW * 2) {
         const int pl = tid / (L::PW * 2), r = tid % (L::PW * 2);
         *reinterpret_cast<f32x4*>(lds + pl * L::PLANE + ((r >> 1) * L::PW + L::HALF - 1 + (r & 1)) * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    chain32_block<B3>(x3, y4, a.Wpk[3], a.bp[3], lds);
+    chain32_block<B3, void, true>(x3, y4, a.Wpk[3], a.bp[3], lds);
 }
 
 template <class B0, class B1, class B2, class B3>

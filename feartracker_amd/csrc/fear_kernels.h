@@ -3212,9 +3212,14 @@ struct Chain16Lds {
 };
 
 // one block of the chain: xin (registers) -> yout (registers)
-template <class B, int KS_LDS, int AP_MAX, int BP_MAX>
+// NB / WpkNext: the block that follows (void: none) — its first weight stages A(0), B(0), A(1) are copied during THIS block's last
+// interval (an even chunk count leaves exactly those three stages unread there), and it is then instantiated with PRE = true: no
+// staging and no barrier of its own in front of its first expansion.  (At a block boundary the copies' latency was exposed: issue,
+// barrier, nothing in between — ~1 us per block, 10 boundaries in the chained launch.)
+template <class B, int KS_LDS, int AP_MAX, int BP_MAX, class NB = void, bool PRE = false>
 __device__ __forceinline__ void chain16_block(const f32x4 (&xin)[2][B::CIN / 16], f32x4 (&yout)[2][B::COUT / 16],
-                                              const float* __restrict__ Wpk, const float* __restrict__ bp, float* lds) {
+                                              const float* __restrict__ Wpk, const float* __restrict__ bp, float* lds,
+                                              const float* __restrict__ WpkNext = nullptr) {
     using G = Ir2Geom<B::CIN, B::CEXP, B::COUT, B::KS, true>;
     using L = Chain16Lds<KS_LDS, AP_MAX, BP_MAX>;
     static_assert(B::KS == KS_LDS, "all blocks of a chain share the depthwise kernel size (LDS tile geometry)");
@@ -3269,10 +3274,12 @@ __device__ __forceinline__ void chain16_block(const f32x4 (&xin)[2][B::CIN / 16]
     }
     // prologue (the previous block / the kernel prologue ended with a barrier: stages and E are free)
     __builtin_amdgcn_sched_barrier(0);      // keep the scheduler from moving code across block boundaries
-    stage_a(0);
-    stage_b(0);
-    if (NCHUNK > 1) stage_a(1);
-    __syncthreads();
+    if constexpr (!PRE) {
+        stage_a(0);
+        stage_b(0);
+        if (NCHUNK > 1) stage_a(1);
+        __syncthreads();
+    }
     phase_a(0);
     __syncthreads();
 #if CHAIN16_PEEL
@@ -3290,6 +3297,13 @@ __device__ __forceinline__ void chain16_block(const f32x4 (&xin)[2][B::CIN / 16]
     }
     {
         constexpr int c = NCHUNK - 1;
+        if constexpr (!std::is_void<NB>::value) {
+            using GN = Ir2Geom<NB::CIN, NB::CEXP, NB::COUT, NB::KS, true>;
+            static_assert(NCHUNK % 2 == 0 && GN::AP <= AP_MAX && GN::BP <= BP_MAX, "the last interval reads stage 1 of B only");
+            lds_copy_async<GN::AP>(WpkNext, WA, wave_s, lane);
+            lds_copy_async<GN::BP>(WpkNext + GN::AP, WB, wave_s, lane);
+            if (GN::NCHUNK > 1) lds_copy_async<GN::AP>(WpkNext + (GN::AP + GN::BP), WA + AP_MAX, wave_s, lane);
+        }
         ir16_interval<B::KS, PW, ES, KG, NTP, false>(Ebuf + (c & 1) * EBUF, Ebuf + ((c + 1) & 1) * EBUF, WA + ((c + 1) & 1) * AP_MAX,
                                                      WB + (c & 1) * BP_MAX, xin, accp, y0, li, lk, lane, true);
         __syncthreads();
@@ -3324,19 +3338,19 @@ __device__ __forceinline__ void chain16_body(const f32x4 (&x0)[2][B0::CIN / 16],
     const int y0 = wave * 2;
 
     f32x4 x1[2][B0::COUT / 16];
-    chain16_block<B0, KS, APM, BPM>(x0, x1, a.Wpk[0], a.bp[0], lds);
+    chain16_block<B0, KS, APM, BPM, B1, false>(x0, x1, a.Wpk[0], a.bp[0], lds, a.Wpk[1]);
     f32x4 x2[2][B1::COUT / 16];
-    chain16_block<B1, KS, APM, BPM>(x1, x2, a.Wpk[1], a.bp[1], lds);
+    chain16_block<B1, KS, APM, BPM, B2, true>(x1, x2, a.Wpk[1], a.bp[1], lds, a.Wpk[2]);
     f32x4 x3[2][B2::COUT / 16];
-    chain16_block<B2, KS, APM, BPM>(x2, x3, a.Wpk[2], a.bp[2], lds);
+    chain16_block<B2, KS, APM, BPM, B3, true>(x2, x3, a.Wpk[2], a.bp[2], lds, a.Wpk[3]);
     f32x4 x4[2][B3::COUT / 16];
-    chain16_block<B3, KS, APM, BPM>(x3, x4, a.Wpk[3], a.bp[3], lds);
+    chain16_block<B3, KS, APM, BPM, B4, true>(x3, x4, a.Wpk[3], a.bp[3], lds, a.Wpk[4]);
     f32x4 x5[2][B4::COUT / 16];
-    chain16_block<B4, KS, APM, BPM>(x4, x5, a.Wpk[4], a.bp[4], lds);
+    chain16_block<B4, KS, APM, BPM, B5, true>(x4, x5, a.Wpk[4], a.bp[4], lds, a.Wpk[5]);
     f32x4 x6[2][B5::COUT / 16];
-    chain16_block<B5, KS, APM, BPM>(x5, x6, a.Wpk[5], a.bp[5], lds);
+    chain16_block<B5, KS, APM, BPM, B6, true>(x5, x6, a.Wpk[5], a.bp[5], lds, a.Wpk[6]);
     f32x4 x7[2][B6::COUT / 16];
-    chain16_block<B6, KS, APM, BPM>(x6, x7, a.Wpk[6], a.bp[6], lds);
+    chain16_block<B6, KS, APM, BPM, void, true>(x6, x7, a.Wpk[6], a.bp[6], lds);
 
     // ---- neck: Y = Wn . x7 + bn, 16 output tiles in groups of 4; fragments [nt][kg][256] staged through the (now
     //      free) E area in two 4-tile slots
