@@ -1125,11 +1125,16 @@ BlockWs block_ws(long rows_in, long rows_out, int cin, int cexp, int cout, int k
     // (also the Gram matrix | column sums of a virtual expansion's input in the forward: up to 32 * 32 + 32 floats)
     w.coef_bytes = align256((size_t)(3 * 4 * cmax > 1056 ? 3 * 4 * cmax : 1056) * sizeof(float));
     w.total = w.col_bytes + w.wg_bytes + w.taps_bytes + w.coef_bytes;
-    char* p = reinterpret_cast<char*>(base);
-    w.col = reinterpret_cast<double*>(p); p += w.col_bytes;
-    w.wg = reinterpret_cast<float*>(p); p += w.wg_bytes;
-    w.taps = reinterpret_cast<float*>(p); p += w.taps_bytes;
-    w.coef = reinterpret_cast<float*>(p);
+    // (a size query passes base = nullptr: no arithmetic on it — an offset applied to a null pointer is undefined behaviour and traps
+    //  in the UBSan build, libfear_hip_debug.so)
+    w.col = nullptr; w.wg = nullptr; w.taps = nullptr; w.coef = nullptr;
+    if (base) {
+        char* p = reinterpret_cast<char*>(base);
+        w.col = reinterpret_cast<double*>(p); p += w.col_bytes;
+        w.wg = reinterpret_cast<float*>(p); p += w.wg_bytes;
+        w.taps = reinterpret_cast<float*>(p); p += w.taps_bytes;
+        w.coef = reinterpret_cast<float*>(p);
+    }
     return w;
 }
 
@@ -1832,10 +1837,13 @@ static SepWs sep_ws(long M, int cin, int cout, float* base) {
     w.wg_bytes = align256(wg);
     w.taps_bytes = align256((size_t)col_blocks(M) * 9 * cin * sizeof(float));
     w.total = w.col_bytes + w.wg_bytes + w.taps_bytes;
-    char* p = reinterpret_cast<char*>(base);
-    w.col = reinterpret_cast<double*>(p); p += w.col_bytes;
-    w.wg = reinterpret_cast<float*>(p); p += w.wg_bytes;
-    w.taps = reinterpret_cast<float*>(p);
+    w.col = nullptr; w.wg = nullptr; w.taps = nullptr;
+    if (base) {                    // (nullptr: a size query — see block_ws)
+        char* p = reinterpret_cast<char*>(base);
+        w.col = reinterpret_cast<double*>(p); p += w.col_bytes;
+        w.wg = reinterpret_cast<float*>(p); p += w.wg_bytes;
+        w.taps = reinterpret_cast<float*>(p);
+    }
     return w;
 }
 

@@ -1,4 +1,3 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-.}
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "chain or plan or hip_net" 2>&1 | tail -2
-bash tools/ab_libs.sh
+FEAR_LIB=feartracker_amd/libfear_hip_debug.so timeout 2000 python -X faulthandler -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|Fatal|File \"/root/repo/tests" | tail -8
