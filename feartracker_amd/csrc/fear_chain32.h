@@ -10,7 +10,8 @@
 // (fragment identity of the 16x16x4 MFMA, see chain16), no halo is ever recomputed, and only the first block reads and the
 // last block writes global memory.
 //
-// Work split: wave w owns map rows 4w .. 4w+3, i.e. 8 m-tiles of 16 pixels (column half ch, row r: m = 4 ch + r); lane (li, lk) holds channels 4 lk .. 4 lk + 3 of each 16-channel tile of pixel li, as everywhere.
+// Work split: wave w owns map rows 4w .. 4w+3, i.e. 8 m-tiles of 16 pixels (column half ch, row r: m = 4 ch + r); lane (li, lk)
+// holds channels 4 lk .. 4 lk + 3 of each 16-channel tile of pixel li, as everywhere.
 //
 // LDS: ONE tile of the expanded 16-channel chunk, 36 x 36 pixel slots (2-pixel zero ring: the 5 x 5 blocks' padding; the 3 x 3
 // block reads it one pixel in), kept as four channel-quad planes [lk][slot][4 floats] of 20 736 B (a multiple of 256 B: the 16
@@ -18,7 +19,13 @@
 // MI355X_MICROARCH.md §LDS — hit 16 distinct 16-byte slots): 82 944 B.  Two such tiles do not fit beside the weight stages, so
 // the chunk pipeline is ir_tile_v4's: the expansion of chunk c + 1 runs on the matrix pipe BETWEEN the depthwise steps of
 // chunk c (ir16_interval's interleaving) into 32 parked registers, and is stored after the barrier that ends the reads of chunk
-// c: two barriers per chunk around eight ds_write_b128 per lane, ~3 % of a ~6 us interval.
+// c: two barriers per chunk around eight ds_write_b128 per lane (measured: the barriers cost nothing, profiles/r06_chain32_kbench.txt).
+// The depthwise of a column half is ONE chain over the wave's four rows (c32_half4; C32_ROWS4 = 0 keeps the two row-pair chains of
+// the first form, c32_sub, for A/Bs); the last chunk of a block is peeled out of the chunk loop; the next block's first weight
+// stages are copied during the current block's last interval.  What each of these is worth: the same file.
+//
+// chain32_kernel is the stage as a launch of its own, chain32_16_kernel the stage + chain16's seven blocks + the neck in one launch
+// (the engine's default): the stride-2 block's output fragments are chain16's input fragments.
 //
 // The stride-2 block reads every other column: its tile is stored column-de-interleaved (even padded columns in slots 0..17,
 // odd ones in 18..35 of a row), so that the 16 output pixels of an m-tile read 16 consecutive slots for every tap.
