@@ -755,7 +755,7 @@ int build_plan(fear_handle* h, int hw, bool with_head, int mode, Plan** out) {
 }
 
 int build_plan_uncached(fear_handle* h, int hw, bool with_head, int mode, Plan** out) {
-    const bool small = mode != 0;
+    const bool small = mode == 1 || mode == 2;      // (mode 3: the throughput plan of a mid-size pass — no 32 x 32 chain, see plan_mode)
     // chunks of a 16x16 block are dealt to at most this many workgroups per crop: every workgroup writes a full partial
     // output map, so a deep split only pays while the crops are few (batch 1: 0.545 -> 0.512 ms per track call)
     const int splitk_max = mode == 2 ? 24 : 8;
@@ -1047,7 +1047,7 @@ int build_plan_uncached(fear_handle* h, int hw, bool with_head, int mode, Plan**
             }
         }
         // ---- the whole 32 x 32 stage (three blocks + the stride-2 block down to 16 x 16) as one chain kernel (fp32, search branch)
-        if (h->fuse && h->chain32 && !h->math && !small && with_head && b.kind == FEARW_IR && cur.H == 32 && cur.W == 32 && cur.off == 0 &&
+        if (h->fuse && h->chain32 && mode != 3 && !h->math && !small && with_head && b.kind == FEARW_IR && cur.H == 32 && cur.W == 32 && cur.off == 0 &&
             bi + 3 < h->blocks.size()) {
             bool match = cur.C == kChain32XS[0].cin;
             for (int j = 0; j < 4 && match; ++j) {
@@ -2091,8 +2091,24 @@ int64_t fear_get_option(fear_handle* h, int option) {
 constexpr int kTinyPass = FEAR_TINY_PASS;
 static int small_pass(const fear_handle* h, int nb) { return h->fuse && nb <= h->small_pass ? (nb <= kTinyPass ? 2 : 1) : 0; }
 
+// build_plan's mode for a pass of nb crops: small_pass's, or 3 for a MID-SIZE pass of the throughput plan — the chained 32 x 32 stage
+// is one workgroup per crop for ~250 us whatever the crop count, while the four tile launches it replaces scale with it: up to 128
+// crops the tiles win (1.507 vs 1.523 ms at 104 crops, 1.558 vs 1.572 at 128; 1.983 vs 1.940 at 143 / 144, 2.008 vs 1.964 at 160, 2.226 vs 2.167 at 256:
+// profiles/r06_chain32_midsize.txt).  Only while the automatic plan selection is on (FEAR_OPT_SMALL_PASS > 0): with 0 the caller
+// asks for THE throughput plan at every size (A/Bs, tests).
+#ifndef FEAR_CHAIN32_MIN_CROPS
+#define FEAR_CHAIN32_MIN_CROPS 129
+#endif
+static int plan_mode(const fear_handle* h, int nb) {
+    const int sm = small_pass(h, nb);
+    return sm == 0 && h->small_pass > 0 && h->chain32 && nb < FEAR_CHAIN32_MIN_CROPS ? 3 : sm;
+}
+
 // the plan fear_plan_* / fear_profile_read describe: that of a pass of FEAR_OPT_PLAN_CROPS crops (default: a full pass)
-static int introspected_small(const fear_handle* h) { return small_pass(h, h->plan_crops > 0 ? h->plan_crops : h->max_batch); }
+static int introspected_small(const fear_handle* h, bool with_head = true) {
+    const int nb = h->plan_crops > 0 ? h->plan_crops : h->max_batch;
+    return with_head ? plan_mode(h, nb) : small_pass(h, nb);
+}
 
 int fear_features(fear_handle* h, const float* img, int n, int hw, float* out, void* stream) {
     if (!h) return FEAR_ERR_NULL;
@@ -2104,7 +2120,7 @@ int fear_features(fear_handle* h, const float* img, int n, int hw, float* out, v
     for (int b0 = 0; b0 < n; b0 += h->max_batch) {
         const int nb = n - b0 < h->max_batch ? n - b0 : h->max_batch;
         Plan* p = nullptr;
-        int st = build_plan(h, hw, false, small_pass(h, nb), &p);
+        int st = build_plan(h, hw, false, small_pass(h, nb), &p);      // (the template branch has no mid-size variant)
         if (st != FEAR_OK) return st;
         st = ensure_workspace(h, *p);
         if (st != FEAR_OK) return st;
@@ -2129,7 +2145,7 @@ static int track_impl(fear_handle* h, const float* search, const float* tmpl, co
     for (int b0 = 0; b0 < n; b0 += h->max_batch) {
         const int nb = n - b0 < h->max_batch ? n - b0 : h->max_batch;
         Plan* p = nullptr;
-        int st = build_plan(h, hw, true, small_pass(h, nb), &p);
+        int st = build_plan(h, hw, true, plan_mode(h, nb), &p);
         if (st != FEAR_OK) return st;
         st = ensure_workspace(h, *p);
         if (st != FEAR_OK) return st;
@@ -2268,7 +2284,7 @@ int fear_crop_normalize(fear_handle* h, const uint8_t* frame_u8, int frame_h, in
 int fear_plan_size(fear_handle* h, int hw, int with_head) {
     if (!h) return FEAR_ERR_NULL;
     Plan* p = nullptr;
-    int st = build_plan(h, hw, with_head != 0, introspected_small(h), &p);
+    int st = build_plan(h, hw, with_head != 0, introspected_small(h, with_head != 0), &p);
     if (st != FEAR_OK) return st;
     return (int)p->ops.size();
 }
@@ -2277,7 +2293,7 @@ int fear_plan_op(fear_handle* h, int hw, int with_head, int i, char* name64, dou
                  double* bytes_per_crop) {
     if (!h) return FEAR_ERR_NULL;
     Plan* p = nullptr;
-    int st = build_plan(h, hw, with_head != 0, introspected_small(h), &p);
+    int st = build_plan(h, hw, with_head != 0, introspected_small(h, with_head != 0), &p);
     if (st != FEAR_OK) return st;
     if (i < 0 || i >= (int)p->ops.size()) return FEAR_ERR_SHAPE;
     const Op& op = p->ops[i];
@@ -2290,7 +2306,7 @@ int fear_plan_op(fear_handle* h, int hw, int with_head, int i, char* name64, dou
 int fear_profile_read(fear_handle* h, int hw, int with_head, int i, double* total_ms, int64_t* launches) {
     if (!h) return FEAR_ERR_NULL;
     Plan* p = nullptr;
-    int st = build_plan(h, hw, with_head != 0, introspected_small(h), &p);
+    int st = build_plan(h, hw, with_head != 0, introspected_small(h, with_head != 0), &p);
     if (st != FEAR_OK) return st;
     if (i < 0 || i >= (int)p->ops.size()) return FEAR_ERR_SHAPE;
     st = drain_events(h);

@@ -164,6 +164,8 @@ int fear_crop_normalize(fear_handle* h, const uint8_t* frame_u8, int frame_h, in
                                /*   stride-2 block down to the 16 x 16 map; model/blocks.py:8-42) as a register-resident chain:                  */
                                /*   2 (default): in ONE launch with the stride-16 stage + neck when FEAR_OPT_CHAIN is on (chain32_16_kernel);    */
                                /*   1: a launch of its own (chain32_kernel); 0: one tile kernel per block (A/B).                                 */
+                               /*   With the automatic plan selection on (FEAR_OPT_SMALL_PASS > 0) a pass of at most 128 crops keeps the tile    */
+                               /*   kernels for this stage: one workgroup per crop on half the CUs is slower than tiles there.                    */
 int fear_set_option(fear_handle* h, int option, int64_t value);
 int64_t fear_get_option(fear_handle* h, int option);
 

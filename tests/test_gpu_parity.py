@@ -546,6 +546,35 @@ def test_chain32_kernel_against_the_four_tile_launches_and_the_oracle(oracle_net
     assert torch.equal(b3, b1) and torch.equal(c3, c1)
 
 
+def test_mid_size_passes_run_the_tile_kernels_instead_of_the_32x32_chain():
+    """The chained 32 x 32 stage is one workgroup per crop for ~250 us whatever the crop count; up to 128 crops (half the CUs) the four tile
+    launches it replaces are faster (profiles/r06_chain32_midsize.txt).  With the automatic plan selection on (the default), a pass
+    of 97 .. 128 crops therefore runs the throughput plan WITHOUT it — same maps to fp32 rounding — and a pass of >= 129 crops with
+    it; FEAR_OPT_SMALL_PASS = 0 asks for THE throughput plan (with the chain) at every size."""
+    from feartracker_amd import FEARNetHIP
+    from conftest import WEIGHTS
+    net = FEARNetHIP(WEIGHTS, device=0, max_batch=256)
+    names = lambda: [n for n, _, _ in net.plan(256, True)]
+    assert any(n.startswith("chain32_16") for n in names())
+    net.set_plan_crops(128)
+    assert not any(n.startswith("chain32") for n in names()) and any(n.startswith("chain16") for n in names())
+    net.set_plan_crops(129)
+    assert any(n.startswith("chain32_16") for n in names())
+    net.set_plan_crops(100)
+    net.set_small_pass(0)
+    assert any(n.startswith("chain32_16") for n in names())
+    net.set_small_pass(96)
+    net.set_plan_crops(0)
+    g = torch.Generator().manual_seed(81)
+    x = norm_u8(torch.randint(0, 256, (120, 3, 256, 256), dtype=torch.uint8, generator=g)).cuda()
+    z = net.get_features(norm_u8(torch.randint(0, 256, (120, 3, 128, 128), dtype=torch.uint8, generator=g)).cuda())
+    b_mid, c_mid = net.track_maps(x, z)                       # one pass of 120 crops: the mid-size plan
+    forced = FEARNetHIP(WEIGHTS, device=0, max_batch=256)
+    forced.set_small_pass(0)                                  # the same crops through the chained plan
+    b_ch, c_ch = forced.track_maps(x, z)
+    assert_maps_close(b_mid, c_mid, b_ch.cpu().numpy(), c_ch.cpu().numpy())
+
+
 def test_head_chain_bf16_mode_against_the_bf16_sepconv_launches_and_fp32():
     """FEAR_OPT_MATH = 2 (BASELINE configs[3]): the one-launch head on v_mfma_f32_16x16x32_bf16 (headchain_b_kernel) rounds the same
     values to bf16 as the sep16 `*_h` launches it replaces — depthwise outputs, template features, weights — so the two agree far

@@ -1,5 +1,16 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-.}
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -1
-python bench.py 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['kernel'], d['roofline']['frac'], d['roofline']['traffic'], d['cpu_baseline']['value'], d['config4_fear_m_bf16']['value'], d['config5_train_step']['ms_per_step'])"
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "mid_size or chain or plan or ragged or toggles" 2>&1 | tail -3
+python - <<'PY'
+import torch, time
+from feartracker_amd import FEARNetHIP
+from tests.conftest import WEIGHTS
+for nb in (104, 128, 143, 144, 160, 256):
+    n = FEARNetHIP(WEIGHTS, device=0, max_batch=nb)
+    x = torch.randn(nb,3,256,256,device='cuda'); z = n.get_features(torch.randn(nb,3,128,128,device='cuda'))
+    for _ in range(5): n.track_maps(x,z)
+    torch.cuda.synchronize(); t=time.time()
+    for _ in range(30): n.track_maps(x,z)
+    torch.cuda.synchronize(); dt=(time.time()-t)/30
+    print('crops', nb, 'default ms', round(dt*1e3,4), [nm for nm,_,_ in n.plan(256, True)][3:5], flush=True)
+PY
