@@ -687,6 +687,9 @@ def main() -> None:
     ap.add_argument("--no-tile-v4", action="store_true", help="A/B: every tiled block on ir_tile_v2 (no phase-overlapped kernel)")
     ap.add_argument("--no-head-chain", action="store_true", help="A/B: the BoxTower as eight sep16 launches instead of one headchain launch")
     ap.add_argument("--no-e1-pair", action="store_true", help="A/B: the two 24-channel e1 blocks as one tile-kernel launch each instead of one e1pair launch")
+    ap.add_argument("--chain32", type=int, default=-1, choices=[-1, 0, 1, 2],
+                    help="A/B (FEAR_OPT_CHAIN32): the 32 x 32 stage as four tile launches (0), a chain launch of its own (1), one launch with "
+                         "the stride-16 stage + neck (2, the engine's default); -1: leave the default")
     ap.add_argument("--no-chain", action="store_true", help="A/B: one fused kernel per stride-16 block instead of the chain kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-math", action="store_true",
@@ -773,6 +776,8 @@ def main() -> None:
         net.set_head_chain(False)
     if args.no_e1_pair:
         net.set_e1_pair(False)
+    if args.chain32 >= 0:
+        net.set_chain32(args.chain32)
     search_u8, tmpl_u8 = synth_batch(B, rank)
     search = norm_u8(search_u8.to(dev)).contiguous()
     tmpl_feats = net.get_features(norm_u8(tmpl_u8.to(dev)).contiguous())
