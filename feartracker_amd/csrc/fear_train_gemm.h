@@ -171,9 +171,10 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs a) {
     stage_load(0);
     stage_store(0, 0);
     __syncthreads();
-    for (int kg = 0; kg < nk; ++kg) {
+    auto kstep = [&](int kg, auto more_c) {
+        constexpr bool MORE = decltype(more_c)::value;
         const int buf = kg & 1;
-        if (kg + 1 < nk) stage_load((kg + 1) * 16);
+        if (MORE) stage_load((kg + 1) * 16);
         f32x4 xf[MT], wf[NTW];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) xf[mt] = Xs[buf][lk][wave * 16 * MT + mt * 16 + li];
@@ -193,9 +194,11 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(GemmArgs a) {
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][i], xf[mt][i], acc[mt][nt], 0, 0, 0);
-        if (kg + 1 < nk) stage_store((kg + 1) * 16, buf ^ 1);
+        if (MORE) stage_store((kg + 1) * 16, buf ^ 1);
         __syncthreads();
-    }
+    };
+    for (int kg = 0; kg < nk - 1; ++kg) kstep(kg, std::true_type{});      // (the last k-group peeled: no prefetch branches in the loop)
+    kstep(nk - 1, std::false_type{});
 
     // ---- epilogue: lane holds columns n0 + nt * 16 + 4 lk + {0..3} of rows m0 + wave * 16 MT + mt * 16 + li
     const int mw = m0 + wave * 16 * MT;
@@ -399,10 +402,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(WgradArgs a) {
         if (st + 1 < nst) stage_store(m0 + (st + 1) * R, buf ^ 1, set_cur ^ 1);
         __syncthreads();
     };
-    for (long st = 0; st < nst; st += 2) {
+    // (pairs without a branch between the two instantiations of the step, the odd tail peeled: chain16_block's lesson)
+    long st = 0;
+    for (; st + 1 < nst; st += 2) {
         step(st, 0);
-        if (st + 1 < nst) step(st + 1, 1);
+        step(st + 1, 1);
     }
+    if (st < nst) step(st, 0);
     if (!live) return;
     // acc[p][q] lane (li, lk), component r  =  dW[n0 + 64 wn + 16 lk + 4 r + p][k0 + 64 wk + 4 li + q]
     float* P = a.P + (long)slice * a.N * a.K;
